@@ -1,0 +1,207 @@
+/*
+ * tfkaldi_hip.h -- C ABI of the MI355X (gfx950) DNN acoustic-model training engine.
+ *
+ * This is the drop-in boundary for the hot path of vrenkens/tfkaldi: everything the reference runs
+ * inside `tf.Session.run()` for neuralNetworks/trainer.py (Trainer / CrossEnthropyTrainer),
+ * neuralNetworks/decoder.py (Decoder) and neuralNetworks/classifiers/{dnn,layer,activation}.py.
+ * The reference has no FFI of its own (its "native layer" is TensorFlow); each entry point below names
+ * the TensorFlow graph fetch (reference file:line) it replaces.  A Python host binds it with ctypes
+ * (tfkaldi_amd/_lib.py); see INTEGRATION.md.
+ *
+ * Conventions: plain C, every call returns 0 on success or a non-zero status (tfk_last_error() gives
+ * the message, thread-local).  Host buffers are caller-owned and only read/written during the call.
+ * One engine per GPU; calls on one engine must be serialised by the caller; all device work is
+ * stream-ordered on the engine's HIP stream.  Matrices are dense row-major fp32 unless a leading
+ * dimension is given.
+ */
+#ifndef TFKALDI_HIP_H
+#define TFKALDI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFK_ABI_VERSION 1
+
+typedef struct tfk_engine tfk_engine;
+
+/* nonlinearity of the hidden layers: neuralNetworks/nnet.py:48-65 */
+enum { TFK_NONLIN_RELU = 0, TFK_NONLIN_SIGMOID = 1, TFK_NONLIN_TANH = 2, TFK_NONLIN_LINEAR = 3 };
+
+/*
+ * Network + optimiser description: the `[nnet]` hyper-parameters that reach the TF graph
+ * (config/config_AURORA4.cfg:102-153 via neuralNetworks/nnet.py:17-78 and trainer.py:13-15).
+ * Hidden layer = affine -> Batchnorm -> nonlin -> L2Norm -> Dropout (activation.py:22-42 order).
+ */
+typedef struct tfk_config {
+  int32_t struct_size;         /* = sizeof(tfk_config) */
+  int32_t device;              /* HIP device ordinal */
+  int32_t input_dim;           /* F: spliced feature dimension (nnet.py:39) */
+  int32_t num_layers;          /* L: hidden layers (dnn.py:28) */
+  int32_t num_units;           /* H (dnn.py:29) */
+  int32_t output_dim;          /* O: pdf-ids (classifier.py:13) */
+  int32_t nonlin;              /* TFK_NONLIN_* */
+  int32_t batch_norm;          /* activation.py:145-161 */
+  int32_t l2_norm;             /* activation.py:87-111 */
+  float keep_prob;             /* activation.py:113-143; >= 1 disables dropout */
+  int32_t layerwise_init;      /* dnn.py:81-122 */
+  float init_learning_rate;    /* trainer.py:110-112 */
+  float learning_rate_decay;   /* trainer.py:110-112 */
+  int32_t num_steps;           /* trainer.py:88 */
+  int32_t max_frames;          /* initial frame capacity of one accumulate call (grows on demand) */
+  uint64_t seed;               /* dropout RNG seed */
+  /* TF-0.1x defaults that live outside the reference tree; 0 selects the default in brackets */
+  float bn_decay;              /* [0.999] tf.contrib.layers.batch_norm decay */
+  float bn_epsilon;            /* [1e-3] */
+  float adam_beta1;            /* [0.9]   tf.train.AdamOptimizer */
+  float adam_beta2;            /* [0.999] */
+  float adam_epsilon;          /* [1e-8] */
+} tfk_config;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* Bytes of persistent state (parameters, gradient sums, Adam moments, BN moving statistics) an
+ * engine of this shape keeps in HBM. */
+int tfk_state_bytes(const tfk_config* cfg, size_t* bytes);
+
+/* Build the engine: replaces Trainer.__init__ graph construction (trainer.py:37-215) and
+ * Decoder.__init__ (decoder.py:11-47).  Parameters start as the reference initialises them EXCEPT the
+ * random hidden weights, which the host injects with tfk_tensor_set (layer.py:39-48: hidden W ~
+ * N(0, 1/sqrt(d_in)), biases 0; dnn.py:67-68: output W = 0). */
+int tfk_create(const tfk_config* cfg, tfk_engine** out);
+
+/* As tfk_create, but the persistent state lives in caller-provided device memory (e.g. a torch
+ * tensor, so torch.distributed can all-reduce views of it) and work is enqueued on `stream`
+ * (a hipStream_t; NULL = the engine creates its own).  `state` must be 256-byte aligned, hold
+ * tfk_state_bytes() bytes, and outlive the engine. */
+int tfk_create_ex(const tfk_config* cfg, void* state, size_t state_bytes, void* stream, tfk_engine** out);
+
+int tfk_destroy(tfk_engine* e);
+
+const char* tfk_last_error(void);
+int tfk_abi_version(void);
+
+/* ---- state access (checkpointing, weight injection, parity tests) ------------------------------ */
+
+enum { /* tensor kind */
+  TFK_WEIGHTS = 0,         /* layer l in [0, L]: [d_in, d_out] row-major (layer.py:42-44) */
+  TFK_BIASES = 1,          /* [d_out]                                  (layer.py:46-48) */
+  TFK_BN_BETA = 2,         /* layer l in [0, L): [H]   (batch_norm center=True, scale=False) */
+  TFK_BN_MOVING_MEAN = 3,  /* [H] init 0 */
+  TFK_BN_MOVING_VAR = 4    /* [H] init 1 */
+};
+enum { /* tensor slot */
+  TFK_SLOT_PARAM = 0,
+  TFK_SLOT_GRAD = 1,       /* the `gradients/...` accumulators G (trainer.py:118-122) */
+  TFK_SLOT_ADAM_M = 2,
+  TFK_SLOT_ADAM_V = 3
+};
+int tfk_tensor_count(tfk_engine* e, int kind, int layer, size_t* count);
+int tfk_tensor_get(tfk_engine* e, int kind, int slot, int layer, float* host, size_t count);
+int tfk_tensor_set(tfk_engine* e, int kind, int slot, int layer, const float* host, size_t count);
+
+enum { /* scalars */
+  TFK_GLOBAL_STEP = 0,          /* trainer.py:98-100 */
+  TFK_LEARNING_RATE_FACT = 1,   /* trainer.py:104-106 */
+  TFK_INITIALISED_LAYERS = 2,   /* dnn.py:85-89 */
+  TFK_ADAM_STEPS = 3,           /* Adam's own step count t (beta powers); NOT checkpointed by the reference */
+  TFK_BATCH_LOSS = 4,           /* trainer.py:91-93  (read-only) */
+  TFK_NUM_FRAMES = 5,           /* trainer.py:126-128 (read-only) */
+  TFK_LEARNING_RATE = 6         /* current decayed rate (read-only) */
+};
+int tfk_scalar_get(tfk_engine* e, int which, double* value);
+int tfk_scalar_set(tfk_engine* e, int which, double value);
+
+/* ---- training: one micro-batch --------------------------------------------------------------- */
+
+enum { /* flags */
+  TFK_DEVICE_PTRS = 1,     /* X / y / out are device pointers (already resident in HBM) */
+  TFK_LAST_MICROBATCH = 2, /* last accumulate before tfk_apply: fire the bucket callback per layer */
+  TFK_LOG_DIV_PRIOR = 4    /* tfk_posteriors: write log(posterior / prior) (nnet.py:280-286) */
+};
+
+/* Replaces `update_gradients_op.run(feed_dict)` (trainer.py:160-169, 325-332) for ONE micro-batch,
+ * already flattened utterance-major as seq2nonseq would (seq_convertors.py:12-39):
+ *   X [T, ldx] fp32 spliced frames, y [T] int32 pdf-ids.
+ * Forward (train mode) + softmax cross-entropy (trainer.py:526-531) + backward;
+ * G += g, batch_loss += loss, num_frames += T, BN moving-average updates (UPDATE_OPS). */
+int tfk_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags);
+
+/* Replaces `[average_loss, apply_gradients_op]` + the three re-initialisations (trainer.py:336-352):
+ * g = clip(G / num_frames, -1, 1); Adam; global_step += 1; returns batch_loss / num_frames (the
+ * pre-update, train-mode loss); zeroes G, batch_loss, num_frames.  With data parallelism the host
+ * all-reduces the reduce region (below) between the last tfk_accumulate and tfk_apply. */
+int tfk_apply(tfk_engine* e, float* average_loss);
+
+/* Replaces `update_valid_loss.run(feed_dict)` (trainer.py:188-195, 433): eval-mode forward + loss. */
+int tfk_eval_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags);
+/* Replaces `average_loss.eval()` + re-initialisation (trainer.py:436-441). */
+int tfk_eval_finish(tfk_engine* e, float* average_loss);
+
+int tfk_halve_learning_rate(tfk_engine* e); /* trainer.py:141-142 */
+int tfk_add_layer(tfk_engine* e);           /* control_ops['add']  (dnn.py:92) */
+int tfk_init_last_layer(tfk_engine* e);     /* control_ops['init'] (dnn.py:114-120) */
+
+/* ---- decoding -------------------------------------------------------------------------------- */
+
+/* Replaces `Decoder.outputs.eval` (decoder.py:41-44, 70-71): eval-mode forward + softmax.
+ * X [N, ldx] -> out [N, ldo] posteriors (or log(posterior/prior) with TFK_LOG_DIV_PRIOR). */
+int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags);
+int tfk_set_prior(tfk_engine* e, const float* prior, size_t count); /* prior.npy (nnet.py:241-244) */
+
+/* ---- data parallelism (one engine per rank; the host owns the collective) --------------------- */
+
+/* The reduce region is one contiguous fp32 span of the state: [ G (all layers) | batch_loss,
+ * num_frames, num_microbatches, pad | BN moving-average increments ].  A SUM all-reduce of it across
+ * ranks before tfk_apply makes B/U serial micro-batches on one GPU (trainer.py:310-332) and
+ * one micro-batch on each of B/U GPUs the same computation.  Buckets: b in [0, L] is the
+ * gradient span of layer L - b (the order backward produces them), bucket L + 1 the scalars + BN tail. */
+int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
+int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* num_floats);
+int tfk_num_buckets(tfk_engine* e, int* n);
+
+/* Called on the host from tfk_accumulate(TFK_LAST_MICROBATCH) right after the kernels that finish a
+ * bucket have been enqueued, so the host can launch that bucket's all-reduce behind them while the
+ * remaining backward keeps the GPU busy. */
+typedef void (*tfk_bucket_fn)(void* user, int bucket);
+int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user);
+
+/* Number of micro-batches of this optimiser step that ranks AFTER this one process: weights this
+ * rank's BN moving-average increment by bn_decay^later so the all-reduced result equals the
+ * reference's sequential per-micro-batch EMA updates. */
+int tfk_set_later_microbatches(tfk_engine* e, int32_t later);
+
+/* ---- streams, profiling, debugging ------------------------------------------------------------- */
+
+int tfk_synchronize(tfk_engine* e);
+int tfk_stream(tfk_engine* e, void** hip_stream);
+
+typedef struct tfk_kernel_stat {
+  char name[48];
+  int64_t launches;
+  double total_ms;  /* HIP-event time on the engine stream */
+  double flops;     /* algorithmic FLOPs of those launches */
+  double bytes;     /* algorithmic bytes of those launches */
+} tfk_kernel_stat;
+/* Bracket every kernel launch with HIP events (on the engine stream) until tfk_profile_end. */
+int tfk_profile_begin(tfk_engine* e);
+int tfk_profile_end(tfk_engine* e, tfk_kernel_stat* stats, int capacity, int* count);
+
+enum { /* debug tensors of the LAST accumulate / eval / posteriors call */
+  TFK_DBG_LOGITS = 0,      /* [T, O] logits; after tfk_accumulate: dLogits = softmax - onehot */
+  TFK_DBG_HIDDEN = 1,      /* [T, H] output of hidden layer `layer` */
+  TFK_DBG_DROPOUT_MASK = 2 /* [T, H] 0/1 keep mask of hidden layer `layer` (regenerated) */
+};
+int tfk_debug_fetch(tfk_engine* e, int what, int layer, float* host, size_t count);
+
+/* Stand-alone fp32 GEMM on device pointers (tests / tools): layout 0 NN, 1 NT, 2 TN (gemm_f32.h). */
+int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 int M, int N, int K, const float* bias, int epi, int tile_config);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFKALDI_HIP_H */

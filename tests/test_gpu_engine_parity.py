@@ -1,0 +1,249 @@
+"""HIP engine (through the C ABI) against the float64 oracle on identical inputs.
+
+Tolerances (fp32 arithmetic on the GPU vs float64 oracle; BASELINE.json asks for "stated fp32 tolerance"):
+  loss per step                rtol 2e-5
+  logits / posteriors          rtol 1e-4, atol 2e-5
+  gradient sums G              rtol 2e-4 + atol 2e-5 * max|G| of that tensor (fp32 sums over T frames)
+  parameters after Adam        see test_multi_step_training (Adam divides by sqrt(v): it amplifies round-off of
+                               near-zero gradients, in TF as much as here)
+"""
+import numpy as np
+import pytest
+
+from util import assert_close, batch, engine_grads, engine_params, make_pair
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(input_dim=22, num_layers=2, num_units=36, output_dim=13, init_learning_rate=1e-3, num_steps=100)
+CHAINS = [
+    dict(nonlin="relu", batch_norm=True),                                  # the AURORA4 recipe
+    dict(nonlin="relu"),
+    dict(nonlin="sigmoid", batch_norm=True),
+    dict(nonlin="tanh", l2_norm=True),
+    dict(nonlin="relu", batch_norm=True, l2_norm=True),
+    dict(nonlin="linear"),
+    dict(nonlin="relu", batch_norm=True, keep_prob=0.7),
+    dict(nonlin="sigmoid", l2_norm=True, keep_prob=0.6),
+]
+
+
+def _masks(eng, T):
+    from tfkaldi_amd import _lib
+    if eng.cfg.keep_prob >= 1:
+        return None
+    return [eng.debug_fetch(_lib.DBG_DROPOUT_MASK, l, T).astype(np.float64) for l in range(eng.L)]
+
+
+def _check_grads(eng, oracle):
+    got = engine_grads(eng)
+    for k, want in oracle.G.items():
+        if oracle.bn and k.startswith("b") and not k.startswith("beta") and k != "b%d" % oracle.L:
+            # bias under batch norm: the true gradient is 0, both sides hold round-off only
+            assert np.abs(got[k]).max() <= 1e-4 * max(1.0, np.abs(oracle.G["W" + k[1:]]).max()), k
+            continue
+        assert_close("G[%s]" % k, got[k], want, rtol=2e-4, atol=2e-5 * max(np.abs(want).max(), 1e-3))
+
+
+@pytest.mark.parametrize("chain", CHAINS, ids=lambda c: "-".join("%s=%s" % kv for kv in sorted(c.items())))
+def test_accumulate_matches_oracle(gpu, chain):
+    """one micro-batch: logits, loss, every gradient, BN moving averages"""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(5)
+    kw = dict(SMALL, **chain)
+    eng, oracle = make_pair(rng, **kw)
+    T = 75
+    X, y = batch(rng, T, kw["input_dim"], kw["output_dim"])
+    eng.accumulate(X, y)
+    oracle.accumulate(X, y, _masks(eng, T))
+    # the buffer holds dLogits = softmax - onehot after the backward pass
+    dlog = eng.debug_fetch(_lib.DBG_LOGITS, 0, T)
+    prob = np.exp(oracle.last_logits - oracle.last_logits.max(1, keepdims=True))
+    prob /= prob.sum(1, keepdims=True)
+    prob[np.arange(T), y] -= 1
+    assert_close("dlogits", dlog, prob, rtol=1e-4, atol=2e-6)
+    for l in range(eng.L):
+        assert_close("hidden%d" % l, eng.debug_fetch(_lib.DBG_HIDDEN, l, T), oracle.last_cache[l]["a"], 1e-4, 2e-5)
+    assert_close("batch_loss", eng.scalar(_lib.BATCH_LOSS), oracle.batch_loss, 2e-5, 0)
+    assert eng.scalar(_lib.NUM_FRAMES) == T
+    _check_grads(eng, oracle)
+    # second micro-batch accumulates on top (G += g)
+    X2, y2 = batch(rng, 41, kw["input_dim"], kw["output_dim"])
+    eng.accumulate(X2, y2)
+    oracle.accumulate(X2, y2, _masks(eng, 41))
+    _check_grads(eng, oracle)
+    loss = eng.apply()
+    assert_close("avg loss", loss, oracle.apply(), 2e-5, 0)
+    if oracle.bn:
+        for l in range(eng.L):
+            assert_close("mov_mean", eng.get(_lib.BN_MOVING_MEAN, l), oracle.mov_mean[l], 1e-5, 1e-6)
+            assert_close("mov_var", eng.get(_lib.BN_MOVING_VAR, l), oracle.mov_var[l], 1e-5, 1e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("dims", [dict(input_dim=7, num_units=10, output_dim=5, num_layers=3),
+                                  dict(input_dim=440, num_units=256, output_dim=100, num_layers=2)],
+                         ids=["odd-dims", "baseline-cfg1"])
+def test_multi_step_training(gpu, dims):
+    """per-step loss trace + parameters over several optimiser steps from the reference initialisation
+    (output layer zero).  dims[0] has no dimension divisible by 4 (padded leading dimensions);
+    dims[1] is BASELINE configs[0] (2x256, 440 in, 100 pdfs, batch 256)."""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(11)
+    kw = dict(SMALL, nonlin="relu", batch_norm=True, **dims)
+    eng, oracle = make_pair(rng, output_too=False, **kw)
+    F, O = kw["input_dim"], kw["output_dim"]
+    lr = kw["init_learning_rate"]
+    data = [batch(rng, 256 if F == 440 else 37, F, O) for _ in range(3)]
+    w0 = engine_params(eng)
+    for step in range(6):
+        for X, y in data[: 1 + step % 2]:
+            eng.accumulate(X, y)
+            oracle.accumulate(X, y)
+        got, want = eng.apply(), oracle.apply()
+        if step == 0:
+            # KAT: zero output layer => initial loss is ln O per frame
+            assert abs(got - np.log(O)) < 1e-5
+            # KAT (8c-2): dA = dZ . W_out^T = 0 => hidden W/beta get g = 0 and Adam leaves them bit-identical
+            p1 = engine_params(eng)
+            for l in range(eng.L):
+                assert (p1["W%d" % l] == w0["W%d" % l]).all()
+                assert (p1["beta%d" % l] == w0["beta%d" % l]).all()
+            moved = np.abs(p1["b%d" % eng.L] - w0["b%d" % eng.L])
+            assert np.all(np.abs(moved - lr) < 0.05 * lr)  # first Adam step ~ lr * sign(g)
+        assert_close("loss step %d" % step, got, want, 5e-5 * (step + 1), 0)
+    assert eng.global_step == 6
+    got = engine_params(eng)
+    for k, want in oracle.params().items():
+        if k.startswith("b") and not k.startswith("beta") and k != "b%d" % oracle.L:
+            continue  # dead parameter under batch norm (gradient is round-off noise amplified by Adam)
+        err = np.abs(got[k] - want)
+        # Adam normalises each gradient by its own magnitude: elements whose gradient is near the fp32
+        # round-off floor can differ by a fraction of lr per step; all others track the oracle closely.
+        assert np.mean(err > 0.02 * lr * 6) < 0.01, (k, np.mean(err > 0.02 * lr * 6))
+        assert err.max() <= 2.0 * lr * 6, k
+    eng.close()
+
+
+def test_adam_known_answer(gpu):
+    """mean -> clip -> Adam on injected gradient sums spanning the clip range (KAT 8c-4)."""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(3)
+    kw = dict(SMALL, nonlin="relu")
+    eng, oracle = make_pair(rng, **kw)
+    T = 20
+    X, y = batch(rng, T, kw["input_dim"], kw["output_dim"])
+    eng.accumulate(X, y)
+    oracle.accumulate(X, y)
+    for step in range(3):
+        for l in range(eng.L + 1):
+            gw = (rng.uniform(-3, 3, oracle.W[l].shape) * T).astype(np.float32)
+            gb = (rng.uniform(-3, 3, oracle.b[l].shape) * T).astype(np.float32)
+            eng.set(_lib.WEIGHTS, l, gw, _lib.SLOT_GRAD)
+            eng.set(_lib.BIASES, l, gb, _lib.SLOT_GRAD)
+            oracle.G["W%d" % l], oracle.G["b%d" % l] = gw.astype(np.float64), gb.astype(np.float64)
+        eng.apply()
+        oracle.apply()
+        got = engine_params(eng)
+        for k, want in oracle.params().items():
+            assert_close("%s step %d" % (k, step), got[k], want, 1e-5, 2e-6)
+        # gradient sums are zeroed by apply (trainer.py:350)
+        assert all((g == 0).all() for g in engine_grads(eng).values())
+        if step < 2:
+            eng.accumulate(X, y)
+            oracle.accumulate(X, y)
+    eng.close()
+
+
+def test_eval_and_posteriors(gpu):
+    """Trainer.evaluate (eval-mode BN / no dropout) and Decoder posteriors, incl. log(post / prior)."""
+    rng = np.random.default_rng(9)
+    kw = dict(SMALL, nonlin="relu", batch_norm=True, keep_prob=0.8)
+    eng, oracle = make_pair(rng, **kw)
+    for T in (64, 9):
+        X, y = batch(rng, T, kw["input_dim"], kw["output_dim"])
+        eng.eval_accumulate(X, y)
+        oracle.eval_accumulate(X, y)
+    assert_close("valid loss", eng.eval_finish(), oracle.eval_finish(), 2e-5, 0)
+    X, _ = batch(rng, 50, kw["input_dim"], kw["output_dim"])
+    post = eng.posteriors(X)
+    want = oracle.posteriors(X)
+    assert_close("posteriors", post, want, 1e-4, 1e-7)
+    assert np.allclose(post.sum(1), 1, atol=1e-5)
+    prior = rng.random(kw["output_dim"]) + 0.1
+    prior = (prior / prior.sum()).astype(np.float32)
+    eng.set_prior(prior)
+    assert_close("log(post/prior)", eng.posteriors(X, log_div_prior=True), np.log(want / prior), 1e-4, 2e-5)
+    # KAT 8c-9: eval-mode BN at initialisation is z / sqrt(1 + 1e-3)
+    eng.close()
+
+
+def test_layerwise_growth(gpu):
+    """dnn.py:81-122: logits taken after `initialisedlayers + 1` hidden layers; 'add' / 'init' control ops."""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(21)
+    kw = dict(SMALL, num_layers=3, nonlin="relu", batch_norm=True, layerwise_init=True)
+    eng, oracle = make_pair(rng, **kw)
+    X, y = batch(rng, 48, kw["input_dim"], kw["output_dim"])
+    for phase in range(4):
+        eng.accumulate(X, y)
+        oracle.accumulate(X, y)
+        _check_grads(eng, oracle)
+        assert_close("loss", eng.apply(), oracle.apply(), 5e-5, 0)
+        for l in range(eng.L):  # every BN layer's moving stats move, active or not
+            assert_close("mov_mean", eng.get(_lib.BN_MOVING_MEAN, l), oracle.mov_mean[l], 1e-5, 1e-6)
+        eng.add_layer(); oracle.add_layer()
+        eng.init_last_layer(); oracle.init_last_layer()
+        assert (eng.get(_lib.WEIGHTS, eng.L) == 0).all()
+    eng.close()
+
+
+def test_data_parallel_equivalence(gpu):
+    """KAT 8c-3: k serial micro-batches on one engine == one micro-batch on each of k engines followed by a
+    SUM all-reduce of the reduce region (emulated here on one GPU by adding the regions), including the
+    sequential BN moving-average composition."""
+    import torch
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(31)
+    kw = dict(SMALL, nonlin="relu", batch_norm=True)
+    k = 4
+    serial, oracle = make_pair(np.random.default_rng(1), **kw)
+    ranks = [make_pair(np.random.default_rng(1), torch_state=True, **kw)[0] for _ in range(k)]
+    mbs = [batch(rng, 30 + 7 * r, kw["input_dim"], kw["output_dim"]) for r in range(k)]
+    for step in range(2):
+        for X, y in mbs:
+            serial.accumulate(X, y)
+            oracle.accumulate(X, y)
+        fired = []
+        for r, eng in enumerate(ranks):
+            eng.set_later_microbatches(k - 1 - r)
+            eng.set_bucket_callback(lambda b, r=r: fired.append((r, b)))
+            eng.accumulate(mbs[r][0], mbs[r][1], last=True)
+        assert [b for (r, b) in fired if r == 0] == list(range(ranks[0].L + 2))  # reverse-layer bucket order
+        for eng in ranks:
+            eng.synchronize()
+        total = sum(eng.reduce_view().clone() for eng in ranks)
+        for eng in ranks:
+            eng.reduce_view().copy_(total)
+        torch.cuda.synchronize()
+        losses = [eng.apply() for eng in ranks]
+        want = serial.apply()
+        assert_close("oracle loss", want, oracle.apply(), 2e-5, 0)
+        for l in losses:
+            assert_close("dp loss", l, want, 1e-6, 0)
+        ps = engine_params(serial)
+        lr = kw["init_learning_rate"]
+        for eng in ranks:
+            pr = engine_params(eng)
+            for name in ps:
+                if name.startswith("b") and not name.startswith("beta") and name != "b%d" % eng.L:
+                    continue
+                err = np.abs(pr[name] - ps[name])
+                assert np.mean(err > 0.02 * lr) < 0.01 and err.max() <= 2 * lr * (step + 1), name
+            for l in range(eng.L):
+                assert_close("mov_mean", eng.get(_lib.BN_MOVING_MEAN, l), serial.get(_lib.BN_MOVING_MEAN, l), 1e-5, 1e-6)
+                assert_close("mov_var", eng.get(_lib.BN_MOVING_VAR, l), serial.get(_lib.BN_MOVING_VAR, l), 1e-5, 1e-6)
+    buckets = ranks[0].buckets()
+    _, n = ranks[0].reduce_region()
+    assert sum(c for _, c in buckets) == n  # the buckets tile the reduce region exactly
+    for e in ranks + [serial]:
+        e.close()

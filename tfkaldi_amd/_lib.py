@@ -1,0 +1,130 @@
+"""ctypes binding of the C-ABI engine (include/tfkaldi_hip.h).
+
+There is deliberately NO fallback: if libtfkaldi_hip.so is missing or does not load, importing the
+engine fails loudly -- the product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_uint64, c_void_p)
+
+from .build import lib_path
+
+ABI_VERSION = 1
+
+# enums of tfkaldi_hip.h
+NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
+WEIGHTS, BIASES, BN_BETA, BN_MOVING_MEAN, BN_MOVING_VAR = range(5)
+SLOT_PARAM, SLOT_GRAD, SLOT_ADAM_M, SLOT_ADAM_V = range(4)
+(GLOBAL_STEP, LEARNING_RATE_FACT, INITIALISED_LAYERS, ADAM_STEPS, BATCH_LOSS, NUM_FRAMES,
+ LEARNING_RATE) = range(7)
+DEVICE_PTRS, LAST_MICROBATCH, LOG_DIV_PRIOR = 1, 2, 4
+DBG_LOGITS, DBG_HIDDEN, DBG_DROPOUT_MASK = range(3)
+GEMM_NN, GEMM_NT, GEMM_TN = range(3)
+EPI_BIAS, EPI_ACCUM, EPI_RELU = 1, 2, 4
+
+
+class TfkConfig(Structure):
+    _fields_ = [
+        ("struct_size", c_int32), ("device", c_int32), ("input_dim", c_int32), ("num_layers", c_int32),
+        ("num_units", c_int32), ("output_dim", c_int32), ("nonlin", c_int32), ("batch_norm", c_int32),
+        ("l2_norm", c_int32), ("keep_prob", c_float), ("layerwise_init", c_int32),
+        ("init_learning_rate", c_float), ("learning_rate_decay", c_float), ("num_steps", c_int32),
+        ("max_frames", c_int32), ("seed", c_uint64), ("bn_decay", c_float), ("bn_epsilon", c_float),
+        ("adam_beta1", c_float), ("adam_beta2", c_float), ("adam_epsilon", c_float),
+    ]
+
+
+class TfkKernelStat(Structure):
+    _fields_ = [("name", c_char * 48), ("launches", c_int64), ("total_ms", c_double), ("flops", c_double),
+                ("bytes", c_double)]
+
+
+BUCKET_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int)
+
+# every symbol include/tfkaldi_hip.h declares: name -> (restype, argtypes)
+_E = c_void_p
+SYMBOLS = {
+    "tfk_abi_version": (c_int, []),
+    "tfk_last_error": (c_char_p, []),
+    "tfk_state_bytes": (c_int, [POINTER(TfkConfig), POINTER(c_size_t)]),
+    "tfk_create": (c_int, [POINTER(TfkConfig), POINTER(_E)]),
+    "tfk_create_ex": (c_int, [POINTER(TfkConfig), c_void_p, c_size_t, c_void_p, POINTER(_E)]),
+    "tfk_destroy": (c_int, [_E]),
+    "tfk_tensor_count": (c_int, [_E, c_int, c_int, POINTER(c_size_t)]),
+    "tfk_tensor_get": (c_int, [_E, c_int, c_int, c_int, c_void_p, c_size_t]),
+    "tfk_tensor_set": (c_int, [_E, c_int, c_int, c_int, c_void_p, c_size_t]),
+    "tfk_scalar_get": (c_int, [_E, c_int, POINTER(c_double)]),
+    "tfk_scalar_set": (c_int, [_E, c_int, c_double]),
+    "tfk_accumulate": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_int]),
+    "tfk_apply": (c_int, [_E, POINTER(c_float)]),
+    "tfk_eval_accumulate": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_int]),
+    "tfk_eval_finish": (c_int, [_E, POINTER(c_float)]),
+    "tfk_halve_learning_rate": (c_int, [_E]),
+    "tfk_add_layer": (c_int, [_E]),
+    "tfk_init_last_layer": (c_int, [_E]),
+    "tfk_posteriors": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int]),
+    "tfk_set_prior": (c_int, [_E, c_void_p, c_size_t]),
+    "tfk_reduce_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t)]),
+    "tfk_reduce_bucket": (c_int, [_E, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "tfk_num_buckets": (c_int, [_E, POINTER(c_int)]),
+    "tfk_set_bucket_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
+    "tfk_set_later_microbatches": (c_int, [_E, c_int32]),
+    "tfk_synchronize": (c_int, [_E]),
+    "tfk_stream": (c_int, [_E, POINTER(c_void_p)]),
+    "tfk_profile_begin": (c_int, [_E]),
+    "tfk_profile_end": (c_int, [_E, POINTER(TfkKernelStat), c_int, POINTER(c_int)]),
+    "tfk_debug_fetch": (c_int, [_E, c_int, c_int, c_void_p, c_size_t]),
+    "tfk_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                             c_int, c_void_p, c_int, c_int]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    """A non-zero status from the C ABI (message from tfk_last_error())."""
+
+
+def load():
+    """dlopen libtfkaldi_hip.so, bind every declared symbol and check the ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build the gfx950 engine first (python -m tfkaldi_amd.build, or "
+            "__graft_entry__.build()); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tfk_abi_version() != ABI_VERSION:
+        raise ImportError("libtfkaldi_hip.so ABI %d != binding ABI %d" % (lib.tfk_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().tfk_last_error()
+        raise EngineError("tfkaldi_hip status %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def make_config(input_dim, num_layers, num_units, output_dim, nonlin="relu", batch_norm=False, l2_norm=False,
+                keep_prob=1.0, layerwise_init=False, init_learning_rate=1e-3, learning_rate_decay=1.0,
+                num_steps=1, max_frames=1024, seed=0, device=0):
+    if nonlin not in NONLIN:
+        raise Exception('unkown nonlinearity')  # spelling as neuralNetworks/nnet.py:65
+    c = TfkConfig()
+    c.struct_size = ctypes.sizeof(TfkConfig)
+    c.device = device
+    c.input_dim, c.num_layers, c.num_units, c.output_dim = input_dim, num_layers, num_units, output_dim
+    c.nonlin = NONLIN[nonlin]
+    c.batch_norm, c.l2_norm, c.layerwise_init = int(bool(batch_norm)), int(bool(l2_norm)), int(bool(layerwise_init))
+    c.keep_prob = float(keep_prob)
+    c.init_learning_rate, c.learning_rate_decay = float(init_learning_rate), float(learning_rate_decay)
+    c.num_steps, c.max_frames, c.seed = int(num_steps), int(max_frames), int(seed)
+    return c

@@ -1,0 +1,931 @@
+// C-ABI engine (include/tfkaldi_hip.h): owns the HBM layout, the HIP streams and the per-step kernel
+// schedule of the DNN acoustic-model trainer.  Replaces what the reference executes inside
+// tf.Session.run for neuralNetworks/trainer.py, decoder.py and classifiers/{dnn,layer,activation}.py.
+//
+// HBM layout (all fp32, every row 16-byte aligned, padding columns kept at zero):
+//   persistent state (one allocation, optionally caller-owned so torch.distributed can reduce it):
+//     [ params P ][ G (P) | scalars (64) | BN EMA increments (E) ][ Adam m (P) ][ Adam v (P) ][ BN moving (E) ]
+//                  `--------------- reduce region ---------------'
+//     per layer l the params are contiguous [ W_l (d_in x ld_out) | b_l | beta_l ] = one all-reduce bucket.
+//   activations (engine-owned, grow on demand): X, per hidden layer z_l (pre-BN) and a_l (layer output),
+//     logits, two ping-pong gradient buffers, BN batch statistics, reduction workspace.
+#include "../../include/tfkaldi_hip.h"
+#include "gemm_f32.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace tfk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code ? code : -1;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                        \
+  } while (0)
+#define CHK(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct LayerLayout {
+  int d_in, d_out, ld_in, ld_out;
+  size_t w_off, b_off, beta_off;  // float offsets inside a P-sized region
+  size_t begin, end;              // bucket span inside a P-sized region
+};
+
+enum KernelFamily {
+  KF_GEMM_NN = 0, KF_GEMM_NT, KF_GEMM_TN, KF_BN_STATS, KF_ACT_FWD, KF_HIDDEN_BWD, KF_COLSUM, KF_SOFTMAX_XENT,
+  KF_LOSS_REDUCE, KF_SOFTMAX, KF_ADAM, KF_EMA, KF_MISC, KF_COUNT
+};
+const char* kFamilyName[KF_COUNT] = {"gemm_f32_nn(fwd affine)", "gemm_f32_nt(dA)",  "gemm_f32_tn(dW)", "bn_stats",
+                                     "act_forward",             "hidden_backward",  "colsum",          "softmax_xent",
+                                     "loss_reduce",             "softmax_rows",     "adam_apply",      "bn_ema_apply",
+                                     "misc"};
+
+struct ProfRec {
+  int family;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct tfk_engine {
+  tfk_config cfg;
+  int F, L, H, O, ldF, ldH, ldO;
+  float bn_decay, bn_eps, b1, b2, adam_eps;
+  bool dropout;
+
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  bool own_stream = false;
+
+  // persistent state
+  float* state = nullptr;
+  bool own_state = false;
+  size_t P = 0, E = 0, state_floats = 0;
+  size_t off_param = 0, off_grad = 0, off_scalars = 0, off_ema = 0, off_m = 0, off_v = 0, off_mov = 0;
+  size_t reduce_floats = 0;
+  std::vector<LayerLayout> lay;  // L + 1
+
+  // activations
+  int cap = 0;
+  float* dX[2] = {nullptr, nullptr};
+  int32_t* dY[2] = {nullptr, nullptr};
+  std::vector<float*> z, a, v, rowscale, mean, rstd;
+  float *logits = nullptr, *post = nullptr, *dA[2] = {nullptr, nullptr}, *row_loss = nullptr, *ws = nullptr;
+  float* prior = nullptr;
+  bool have_prior = false;
+
+  // host staging (pinned)
+  float* hX[2] = {nullptr, nullptr};
+  int32_t* hY[2] = {nullptr, nullptr};
+  float* h_post = nullptr;
+  size_t h_post_floats = 0;
+  float* h_scalars = nullptr;
+  hipEvent_t copy_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
+  bool slot_used[2] = {false, false};
+  int slot = 0;
+
+  // host-side scalars (trainer.py:98-106, dnn.py:85-89)
+  int64_t global_step = 0, adam_t = 0;
+  double lr_fact = 1.0;
+  int initialised_layers = 0;
+  uint32_t call_counter = 0;
+  int later_mb = 0;
+
+  tfk_bucket_fn cb = nullptr;
+  void* cb_user = nullptr;
+
+  // last call (debug fetch)
+  int last_T = 0, last_nfw = 0;
+  uint32_t last_call = 0;
+  const float* last_in = nullptr;
+
+  // profiling
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+
+  int nact() const {
+    if (!cfg.layerwise_init) return L;
+    int n = initialised_layers + 1;
+    if (n > L || initialised_layers < 0) n = L;
+    return n;
+  }
+  float* p_param() const { return state + off_param; }
+  float* p_grad() const { return state + off_grad; }
+  float* p_scalars() const { return state + off_scalars; }
+  float* p_ema() const { return state + off_ema; }
+  float* p_m() const { return state + off_m; }
+  float* p_v() const { return state + off_v; }
+  float* p_mov() const { return state + off_mov; }
+  float* ema_mean(int l) const { return p_ema() + (size_t)2 * l * ldH; }
+  float* ema_var(int l) const { return p_ema() + (size_t)(2 * l + 1) * ldH; }
+  float* mov_mean(int l) const { return p_mov() + (size_t)2 * l * ldH; }
+  float* mov_var(int l) const { return p_mov() + (size_t)(2 * l + 1) * ldH; }
+};
+
+namespace {
+
+int validate(const tfk_config* c) {
+  if (!c) return fail(-1, "config is NULL");
+  if (c->struct_size != (int32_t)sizeof(tfk_config))
+    return fail(-1, "tfk_config.struct_size %d != %zu (ABI mismatch)", c->struct_size, sizeof(tfk_config));
+  if (c->input_dim <= 0 || c->num_units <= 0 || c->output_dim <= 0 || c->num_layers < 1)
+    return fail(-1, "bad dimensions F=%d L=%d H=%d O=%d", c->input_dim, c->num_layers, c->num_units, c->output_dim);
+  if (c->nonlin < 0 || c->nonlin > 3) return fail(-1, "unkown nonlinearity %d", c->nonlin);
+  if (!(c->keep_prob > 0.f)) return fail(-1, "dropout keep probability must be in (0, 1], got %g", c->keep_prob);
+  return 0;
+}
+
+void compute_layout(const tfk_config* c, std::vector<LayerLayout>& lay, size_t& P, size_t& E) {
+  const int L = c->num_layers;
+  const int ldF = (int)up(c->input_dim, 4), ldH = (int)up(c->num_units, 4), ldO = (int)up(c->output_dim, 4);
+  lay.resize(L + 1);
+  size_t off = 0;
+  for (int l = 0; l <= L; ++l) {
+    LayerLayout& x = lay[l];
+    x.d_in = l == 0 ? c->input_dim : c->num_units;
+    x.ld_in = l == 0 ? ldF : ldH;
+    x.d_out = l == L ? c->output_dim : c->num_units;
+    x.ld_out = l == L ? ldO : ldH;
+    x.begin = off;
+    x.w_off = off;
+    off += up((size_t)x.d_in * x.ld_out, 64);
+    x.b_off = off;
+    off += up((size_t)x.ld_out, 64);
+    x.beta_off = off;
+    if (c->batch_norm && l < L) off += up((size_t)ldH, 64);
+    x.end = off;
+  }
+  P = off;
+  E = c->batch_norm ? up((size_t)2 * L * ldH, 64) : 0;
+}
+
+constexpr size_t kScalarFloats = 64;
+size_t total_state_floats(size_t P, size_t E) { return 4 * P + kScalarFloats + 2 * E; }
+
+// ---- profiling helpers ----
+hipEvent_t get_event(tfk_engine* e) {
+  if (e->ev_next == e->ev_pool.size()) {
+    hipEvent_t ev;
+    hipEventCreate(&ev);
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_next++];
+}
+struct ProfScope {
+  tfk_engine* e;
+  ProfRec r;
+  ProfScope(tfk_engine* e_, int family, double flops, double bytes) : e(e_) {
+    if (!e->profiling) return;
+    r.family = family; r.flops = flops; r.bytes = bytes;
+    r.a = get_event(e); r.b = get_event(e);
+    hipEventRecord(r.a, e->stream);
+  }
+  ~ProfScope() {
+    if (!e->profiling) return;
+    hipEventRecord(r.b, e->stream);
+    e->prof.push_back(r);
+  }
+};
+
+int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+             int M, int N, int K, const float* bias, int epi) {
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
+  ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)));
+  const int rc = gemm_f32(layout, g, -1, e->stream);
+  if (rc != 0) return fail(rc, "gemm_f32 launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+void free_activations(tfk_engine* e) {
+  auto fr = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
+  for (int s = 0; s < 2; ++s) {
+    fr(e->dX[s]);
+    if (e->dY[s]) { hipFree(e->dY[s]); e->dY[s] = nullptr; }
+    fr(e->dA[s]);
+    if (e->hX[s]) { hipHostFree(e->hX[s]); e->hX[s] = nullptr; }
+    if (e->hY[s]) { hipHostFree(e->hY[s]); e->hY[s] = nullptr; }
+  }
+  for (auto& p : e->z) fr(p);
+  for (auto& p : e->a) fr(p);
+  for (auto& p : e->v) fr(p);
+  for (auto& p : e->rowscale) fr(p);
+  fr(e->logits); fr(e->post); fr(e->row_loss); fr(e->ws);
+  e->cap = 0;
+}
+
+int alloc_zero(float** p, size_t floats) {
+  HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
+  HIPCHK(hipMemset(*p, 0, floats * sizeof(float)));
+  return 0;
+}
+
+int reserve(tfk_engine* e, int T) {
+  if (T <= e->cap) return 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->copy_stream));
+  int cap = e->cap + e->cap / 2;
+  if (cap < T) cap = T;
+  cap = (int)up(cap, 64);
+  free_activations(e);
+  const int L = e->L;
+  for (int s = 0; s < 2; ++s) {
+    CHK(alloc_zero(&e->dX[s], (size_t)cap * e->ldF));
+    HIPCHK(hipMalloc((void**)&e->dY[s], (size_t)cap * sizeof(int32_t)));
+    CHK(alloc_zero(&e->dA[s], (size_t)cap * e->ldH));
+    HIPCHK(hipHostMalloc((void**)&e->hX[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->hY[s], (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
+    e->slot_used[s] = false;
+  }
+  e->z.assign(L, nullptr); e->a.assign(L, nullptr); e->v.assign(L, nullptr); e->rowscale.assign(L, nullptr);
+  for (int l = 0; l < L; ++l) {
+    CHK(alloc_zero(&e->z[l], (size_t)cap * e->ldH));
+    CHK(alloc_zero(&e->a[l], (size_t)cap * e->ldH));
+    if (e->cfg.l2_norm) {
+      CHK(alloc_zero(&e->v[l], (size_t)cap * e->ldH));
+      CHK(alloc_zero(&e->rowscale[l], (size_t)cap));
+    }
+  }
+  CHK(alloc_zero(&e->logits, (size_t)cap * e->ldO));
+  CHK(alloc_zero(&e->post, (size_t)cap * e->ldO));
+  CHK(alloc_zero(&e->row_loss, (size_t)cap));
+  const int ldmax = e->ldH > e->ldO ? e->ldH : e->ldO;
+  CHK(alloc_zero(&e->ws, (size_t)3 * kMaxRowSplits * ldmax));
+  e->cap = cap;
+  return 0;
+}
+
+// Bring one micro-batch to HBM (or adopt device pointers).  Returns the GEMM-ready X (ld in *ldx_out).
+int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int T, int flags, const float** Xd,
+                int* ldx_out, const int32_t** yd) {
+  if (ldx < e->F) return fail(-1, "ldx %lld < input_dim %d", (long long)ldx, e->F);
+  if (flags & TFK_DEVICE_PTRS) {
+    if ((ldx % 4) == 0 && (e->F % 4) == 0 && (((uintptr_t)X) % 16) == 0) {
+      *Xd = X;
+      *ldx_out = (int)ldx;
+    } else {
+      const int s = e->slot;
+      HIPCHK(hipMemcpy2DAsync(e->dX[s], (size_t)e->ldF * 4, X, (size_t)ldx * 4, (size_t)e->F * 4, T,
+                              hipMemcpyDeviceToDevice, e->stream));
+      *Xd = e->dX[s];
+      *ldx_out = e->ldF;
+      e->slot ^= 1;
+    }
+    *yd = y;
+    return 0;
+  }
+  const int s = e->slot;
+  if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));  // pinned slot free again
+  if (ldx == e->F) {
+    memcpy(e->hX[s], X, (size_t)T * e->F * sizeof(float));
+  } else {
+    for (int t = 0; t < T; ++t) memcpy(e->hX[s] + (size_t)t * e->F, X + (size_t)t * ldx, (size_t)e->F * sizeof(float));
+  }
+  if (y) memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
+  // the device slot may still be read by the compute enqueued two calls ago
+  if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  HIPCHK(hipMemcpy2DAsync(e->dX[s], (size_t)e->ldF * 4, e->hX[s], (size_t)e->F * 4, (size_t)e->F * 4, T,
+                          hipMemcpyHostToDevice, e->copy_stream));
+  if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
+  e->slot_used[s] = true;
+  *Xd = e->dX[s];
+  *ldx_out = e->ldF;
+  *yd = e->dY[s];
+  e->slot ^= 1;
+  return 0;
+}
+
+int finish_slot(tfk_engine* e, int flags, int slot_before) {
+  if (!(flags & TFK_DEVICE_PTRS) && e->slot != slot_before) HIPCHK(hipEventRecord(e->compute_done[slot_before], e->stream));
+  return 0;
+}
+
+ActDesc act_desc(const tfk_engine* e, int layer, int train, uint32_t call) {
+  ActDesc d;
+  d.nonlin = e->cfg.nonlin; d.bn = e->cfg.batch_norm ? 1 : 0; d.l2 = e->cfg.l2_norm ? 1 : 0;
+  d.keep = e->dropout ? e->cfg.keep_prob : 1.f;
+  d.seed = e->cfg.seed; d.call = call; d.layer = (uint32_t)layer; d.train = train;
+  return d;
+}
+
+// Forward through `nfw` hidden layers; logits from the output of hidden layer `nact - 1`
+// (dnn.py:73-108; the tf.case of dnn.py:97-102 is the choice of nact).
+int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact, int nfw, uint32_t call) {
+  const float* in = Xd;
+  int ld_in = ldx;
+  const int H = e->H, ldH = e->ldH;
+  for (int l = 0; l < nfw; ++l) {
+    const LayerLayout& y = e->lay[l];
+    CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
+                 e->p_param() + y.b_off, EPI_BIAS));
+    if (e->cfg.batch_norm) {
+      ProfScope ps(e, KF_BN_STATS, 0, 8.0 * T * H);
+      if (train)
+        bn_stats_train(e->stream, e->z[l], T, H, ldH, e->bn_eps, e->bn_decay, e->mean[l], e->rstd[l], e->ema_mean(l),
+                       e->ema_var(l), e->ws);
+      else
+        bn_stats_eval(e->stream, e->mov_mean(l), e->mov_var(l), H, e->bn_eps, e->mean[l], e->rstd[l]);
+    }
+    {
+      ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * T * H);
+      const ActDesc d = act_desc(e, l, train, call);
+      act_forward(e->stream, d, e->z[l], e->a[l], e->cfg.l2_norm ? e->v[l] : nullptr,
+                  e->cfg.l2_norm ? e->rowscale[l] : nullptr, e->mean[l], e->rstd[l],
+                  e->cfg.batch_norm ? e->p_param() + y.beta_off : nullptr, T, H, ldH);
+    }
+    in = e->a[l];
+    ld_in = ldH;
+  }
+  const LayerLayout& o = e->lay[e->L];
+  CHK(run_gemm(e, GEMM_NN, e->a[nact - 1], ldH, e->p_param() + o.w_off, o.ld_out, e->logits, e->ldO, T, e->O, H,
+               e->p_param() + o.b_off, EPI_BIAS));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t call, bool fire) {
+  const int L = e->L, H = e->H, ldH = e->ldH;
+  const LayerLayout& o = e->lay[L];
+  float* G = e->p_grad();
+  // output layer: dZ = softmax - onehot sits in `logits`
+  CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
+               EPI_ACCUM));
+  {
+    ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
+    colsum_accum(e->stream, e->logits, T, e->O, e->ldO, G + o.b_off, e->ws);
+  }
+  if (fire && e->cb) e->cb(e->cb_user, 0);
+  int pp = 0;
+  CHK(run_gemm(e, GEMM_NT, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O, nullptr, 0));
+  for (int l = nact - 1; l >= 0; --l) {
+    const LayerLayout& y = e->lay[l];
+    float* da = e->dA[pp];
+    const ActDesc d = act_desc(e, l, 1, call);
+    int pre_du = 0;
+    if (e->cfg.l2_norm) {
+      ProfScope ps(e, KF_HIDDEN_BWD, 0, 12.0 * T * H);
+      act_backward_rows(e->stream, d, da, e->v[l], e->rowscale[l], T, H, ldH);
+      pre_du = 1;
+    }
+    {
+      ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
+      hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l],
+                      e->cfg.batch_norm ? G + y.beta_off : nullptr, G + y.b_off, T, H, ldH, e->ws);
+    }
+    const float* in = l == 0 ? Xd : e->a[l - 1];
+    const int ld_in = l == 0 ? ldx : ldH;
+    CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, EPI_ACCUM));
+    if (l > 0) CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, 0));
+    if (fire && e->cb) e->cb(e->cb_user, L - l);
+    pp ^= 1;
+  }
+  // layers above the active depth receive no gradient (zero branch of the tf.case); their buckets are
+  // still announced so that every rank reduces the same spans.
+  if (fire && e->cb)
+    for (int l = L - 1; l >= nact; --l) e->cb(e->cb_user, L - l);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int read_scalars(tfk_engine* e, bool zero_ema) {
+  HIPCHK(hipMemcpyAsync(e->h_scalars, e->p_scalars(), 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  const size_t n = kScalarFloats + (zero_ema ? e->E : 0);
+  HIPCHK(hipMemsetAsync(e->p_scalars(), 0, n * sizeof(float), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+struct TensorRef {
+  float* ptr;
+  int rows, cols, ld;
+};
+int tensor_ref(tfk_engine* e, int kind, int slot, int layer, TensorRef* t) {
+  const int L = e->L;
+  if (kind == TFK_WEIGHTS || kind == TFK_BIASES) {
+    if (layer < 0 || layer > L) return fail(-1, "layer %d out of range [0, %d]", layer, L);
+  } else if (kind >= TFK_BN_BETA && kind <= TFK_BN_MOVING_VAR) {
+    if (layer < 0 || layer >= L) return fail(-1, "layer %d out of range [0, %d)", layer, L);
+    if (!e->cfg.batch_norm) return fail(-1, "batch norm tensors requested but batch_norm is off");
+  } else {
+    return fail(-1, "unknown tensor kind %d", kind);
+  }
+  float* base;
+  switch (slot) {
+    case TFK_SLOT_PARAM: base = e->p_param(); break;
+    case TFK_SLOT_GRAD: base = e->p_grad(); break;
+    case TFK_SLOT_ADAM_M: base = e->p_m(); break;
+    case TFK_SLOT_ADAM_V: base = e->p_v(); break;
+    default: return fail(-1, "unknown tensor slot %d", slot);
+  }
+  const LayerLayout& y = e->lay[layer < 0 ? 0 : layer];
+  switch (kind) {
+    case TFK_WEIGHTS: *t = {base + y.w_off, y.d_in, y.d_out, y.ld_out}; break;
+    case TFK_BIASES: *t = {base + y.b_off, 1, y.d_out, y.ld_out}; break;
+    case TFK_BN_BETA: *t = {base + y.beta_off, 1, e->H, e->ldH}; break;
+    case TFK_BN_MOVING_MEAN:
+    case TFK_BN_MOVING_VAR:
+      if (slot != TFK_SLOT_PARAM) return fail(-1, "moving statistics only have the PARAM slot");
+      *t = {kind == TFK_BN_MOVING_MEAN ? e->mov_mean(layer) : e->mov_var(layer), 1, e->H, e->ldH};
+      break;
+  }
+  return 0;
+}
+
+int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* stream, tfk_engine** out) {
+  if (!out) return fail(-1, "out is NULL");
+  *out = nullptr;
+  CHK(validate(cfg));
+  HIPCHK(hipSetDevice(cfg->device));
+  tfk_engine* e = new tfk_engine();
+  e->cfg = *cfg;
+  e->F = cfg->input_dim; e->L = cfg->num_layers; e->H = cfg->num_units; e->O = cfg->output_dim;
+  e->ldF = (int)up(e->F, 4); e->ldH = (int)up(e->H, 4); e->ldO = (int)up(e->O, 4);
+  e->bn_decay = cfg->bn_decay > 0.f ? cfg->bn_decay : 0.999f;
+  e->bn_eps = cfg->bn_epsilon > 0.f ? cfg->bn_epsilon : 1e-3f;
+  e->b1 = cfg->adam_beta1 > 0.f ? cfg->adam_beta1 : 0.9f;
+  e->b2 = cfg->adam_beta2 > 0.f ? cfg->adam_beta2 : 0.999f;
+  e->adam_eps = cfg->adam_epsilon > 0.f ? cfg->adam_epsilon : 1e-8f;
+  e->dropout = cfg->keep_prob < 1.f;
+  compute_layout(cfg, e->lay, e->P, e->E);
+  e->state_floats = total_state_floats(e->P, e->E);
+  e->off_param = 0;
+  e->off_grad = e->P;
+  e->off_scalars = 2 * e->P;
+  e->off_ema = 2 * e->P + kScalarFloats;
+  e->reduce_floats = e->P + kScalarFloats + e->E;
+  e->off_m = e->off_ema + e->E;
+  e->off_v = e->off_m + e->P;
+  e->off_mov = e->off_v + e->P;
+
+  auto bail = [&](int rc) { tfk_destroy(e); return rc; };
+#define HIPB(expr)                                                                                          \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) return bail(fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_)));        \
+  } while (0)
+  if (stream) {
+    e->stream = (hipStream_t)stream;
+  } else {
+    HIPB(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+  HIPB(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  for (int s = 0; s < 2; ++s) {
+    HIPB(hipEventCreateWithFlags(&e->copy_done[s], hipEventDisableTiming));
+    HIPB(hipEventCreateWithFlags(&e->compute_done[s], hipEventDisableTiming));
+  }
+  if (state) {
+    if (state_bytes < e->state_floats * sizeof(float))
+      return bail(fail(-1, "state arena too small: %zu < %zu bytes", state_bytes, e->state_floats * sizeof(float)));
+    if (((uintptr_t)state) % 256) return bail(fail(-1, "state arena must be 256-byte aligned"));
+    e->state = (float*)state;
+  } else {
+    HIPB(hipMalloc((void**)&e->state, e->state_floats * sizeof(float)));
+    e->own_state = true;
+  }
+  HIPB(hipMemsetAsync(e->state, 0, e->state_floats * sizeof(float), e->stream));
+  if (cfg->batch_norm)  // moving_variance initialises to 1, moving_mean to 0
+    for (int l = 0; l < e->L; ++l) fill(e->stream, e->mov_var(l), (size_t)e->H, 1.0f);
+  HIPB(hipHostMalloc((void**)&e->h_scalars, 16 * sizeof(float), hipHostMallocDefault));
+  e->mean.assign(e->L, nullptr);
+  e->rstd.assign(e->L, nullptr);
+  for (int l = 0; l < e->L; ++l) {
+    if (alloc_zero(&e->mean[l], (size_t)e->ldH) || alloc_zero(&e->rstd[l], (size_t)e->ldH)) return bail(-1);
+  }
+  if (alloc_zero(&e->prior, (size_t)e->ldO)) return bail(-1);
+  const int cap0 = cfg->max_frames > 0 ? cfg->max_frames : 1024;
+  { const int rc = reserve(e, cap0); if (rc) return bail(rc); }
+  HIPB(hipStreamSynchronize(e->stream));
+#undef HIPB
+  *out = e;
+  return 0;
+}
+
+int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags, int train) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (T <= 0) return fail(-1, "empty micro-batch (T = %d)", T);
+  if (!X || !y) return fail(-1, "X / y is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(reserve(e, T));
+  const float* Xd; const int32_t* yd; int ld;
+  const int slot_before = e->slot;
+  CHK(stage_input(e, X, ldx, y, T, flags, &Xd, &ld, &yd));
+  const uint32_t call = e->call_counter++;
+  const int nact = e->nact();
+  // train mode evaluates every hidden layer when BN is on: the UPDATE_OPS of all batch-norm layers are
+  // fetched by update_gradients_op (trainer.py:164-169) even for layers the tf.case does not select.
+  const int nfw = (train && e->cfg.layerwise_init && e->cfg.batch_norm) ? e->L : nact;
+  CHK(forward(e, Xd, ld, T, train, nact, nfw, call));
+  {
+    ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
+    softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train);
+  }
+  {
+    ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
+    loss_reduce(e->stream, e->row_loss, T, e->p_scalars());
+  }
+  if (train) {
+    const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
+    CHK(backward(e, Xd, ld, T, nact, call, fire));
+    if (fire) {
+      if (e->cfg.batch_norm && e->later_mb > 0) {
+        ProfScope ps(e, KF_MISC, 0, 8.0 * e->E);
+        scale_inplace(e->stream, e->p_ema(), e->E, (float)pow((double)e->bn_decay, (double)e->later_mb));
+      }
+      if (e->cb) e->cb(e->cb_user, e->L + 1);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  CHK(finish_slot(e, flags, slot_before));
+  e->last_T = T; e->last_nfw = nfw; e->last_call = call; e->last_in = Xd;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfk_abi_version(void) { return TFK_ABI_VERSION; }
+const char* tfk_last_error(void) { return g_err.c_str(); }
+
+int tfk_state_bytes(const tfk_config* cfg, size_t* bytes) {
+  CHK(validate(cfg));
+  if (!bytes) return fail(-1, "bytes is NULL");
+  std::vector<LayerLayout> lay;
+  size_t P, E;
+  compute_layout(cfg, lay, P, E);
+  *bytes = total_state_floats(P, E) * sizeof(float);
+  return 0;
+}
+
+int tfk_create(const tfk_config* cfg, tfk_engine** out) { return create_impl(cfg, nullptr, 0, nullptr, out); }
+int tfk_create_ex(const tfk_config* cfg, void* state, size_t state_bytes, void* stream, tfk_engine** out) {
+  return create_impl(cfg, state, state_bytes, stream, out);
+}
+
+int tfk_destroy(tfk_engine* e) {
+  if (!e) return 0;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
+  free_activations(e);
+  for (auto p : e->mean) if (p) hipFree(p);
+  for (auto p : e->rstd) if (p) hipFree(p);
+  if (e->prior) hipFree(e->prior);
+  if (e->h_scalars) hipHostFree(e->h_scalars);
+  if (e->h_post) hipHostFree(e->h_post);
+  if (e->own_state && e->state) hipFree(e->state);
+  for (int s = 0; s < 2; ++s) {
+    if (e->copy_done[s]) hipEventDestroy(e->copy_done[s]);
+    if (e->compute_done[s]) hipEventDestroy(e->compute_done[s]);
+  }
+  for (auto ev : e->ev_pool) hipEventDestroy(ev);
+  if (e->copy_stream) hipStreamDestroy(e->copy_stream);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return 0;
+}
+
+int tfk_tensor_count(tfk_engine* e, int kind, int layer, size_t* count) {
+  if (!e || !count) return fail(-1, "NULL argument");
+  TensorRef t;
+  CHK(tensor_ref(e, kind, TFK_SLOT_PARAM, layer, &t));
+  *count = (size_t)t.rows * t.cols;
+  return 0;
+}
+
+int tfk_tensor_get(tfk_engine* e, int kind, int slot, int layer, float* host, size_t count) {
+  if (!e || !host) return fail(-1, "NULL argument");
+  TensorRef t;
+  CHK(tensor_ref(e, kind, slot, layer, &t));
+  if (count != (size_t)t.rows * t.cols) return fail(-1, "count %zu != %d x %d", count, t.rows, t.cols);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy2D(host, (size_t)t.cols * 4, t.ptr, (size_t)t.ld * 4, (size_t)t.cols * 4, t.rows, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int tfk_tensor_set(tfk_engine* e, int kind, int slot, int layer, const float* host, size_t count) {
+  if (!e || !host) return fail(-1, "NULL argument");
+  TensorRef t;
+  CHK(tensor_ref(e, kind, slot, layer, &t));
+  if (count != (size_t)t.rows * t.cols) return fail(-1, "count %zu != %d x %d", count, t.rows, t.cols);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy2D(t.ptr, (size_t)t.ld * 4, host, (size_t)t.cols * 4, (size_t)t.cols * 4, t.rows, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static double current_lr(const tfk_engine* e) {
+  // tf.train.exponential_decay(init, global_step, num_steps, decay) * learning_rate_fact  (trainer.py:110-112)
+  const double frac = e->cfg.num_steps > 0 ? (double)e->global_step / (double)e->cfg.num_steps : 0.0;
+  return (double)e->cfg.init_learning_rate * pow((double)e->cfg.learning_rate_decay, frac) * e->lr_fact;
+}
+
+int tfk_scalar_get(tfk_engine* e, int which, double* value) {
+  if (!e || !value) return fail(-1, "NULL argument");
+  switch (which) {
+    case TFK_GLOBAL_STEP: *value = (double)e->global_step; return 0;
+    case TFK_LEARNING_RATE_FACT: *value = e->lr_fact; return 0;
+    case TFK_INITIALISED_LAYERS: *value = (double)e->initialised_layers; return 0;
+    case TFK_ADAM_STEPS: *value = (double)e->adam_t; return 0;
+    case TFK_LEARNING_RATE: *value = current_lr(e); return 0;
+    case TFK_BATCH_LOSS:
+    case TFK_NUM_FRAMES: {
+      HIPCHK(hipSetDevice(e->cfg.device));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      float h[2];
+      HIPCHK(hipMemcpy(h, e->p_scalars(), sizeof(h), hipMemcpyDeviceToHost));
+      *value = which == TFK_BATCH_LOSS ? h[0] : h[1];
+      return 0;
+    }
+  }
+  return fail(-1, "unknown scalar %d", which);
+}
+
+int tfk_scalar_set(tfk_engine* e, int which, double value) {
+  if (!e) return fail(-1, "engine is NULL");
+  switch (which) {
+    case TFK_GLOBAL_STEP: e->global_step = (int64_t)value; return 0;
+    case TFK_LEARNING_RATE_FACT: e->lr_fact = value; return 0;
+    case TFK_INITIALISED_LAYERS: e->initialised_layers = (int)value; return 0;
+    case TFK_ADAM_STEPS: e->adam_t = (int64_t)value; return 0;
+  }
+  return fail(-1, "scalar %d is read-only or unknown", which);
+}
+
+int tfk_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags) {
+  return train_or_eval(e, X, ldx, y, T, flags, 1);
+}
+int tfk_eval_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags) {
+  return train_or_eval(e, X, ldx, y, T, flags & ~TFK_LAST_MICROBATCH, 0);
+}
+
+int tfk_apply(tfk_engine* e, float* average_loss) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const double lr = current_lr(e);
+  e->adam_t += 1;
+  // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); w -= lr_t * m / (sqrt(v) + eps)
+  const double t = (double)e->adam_t;
+  const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
+  {
+    ProfScope ps(e, KF_ADAM, 0, 28.0 * e->P);
+    adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
+               e->adam_eps);
+  }
+  if (e->cfg.batch_norm) {
+    ProfScope ps(e, KF_EMA, 0, 12.0 * e->E);
+    ema_apply(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay);
+  }
+  HIPCHK(hipGetLastError());
+  CHK(read_scalars(e, true));
+  e->global_step += 1;
+  if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
+  return 0;
+}
+
+int tfk_eval_finish(tfk_engine* e, float* average_loss) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(read_scalars(e, false));
+  if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
+  return 0;
+}
+
+int tfk_halve_learning_rate(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  e->lr_fact *= 0.5;
+  return 0;
+}
+int tfk_add_layer(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (!e->cfg.layerwise_init) return fail(-1, "control op 'add' only exists with layerwise_init");
+  e->initialised_layers += 1;
+  return 0;
+}
+int tfk_init_last_layer(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (!e->cfg.layerwise_init) return fail(-1, "control op 'init' only exists with layerwise_init");
+  // re-run the initialisers of layer L: weights ~ N(0, stddev 0) = 0, biases = 0 (dnn.py:67-68, 114-120)
+  const LayerLayout& o = e->lay[e->L];
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemsetAsync(e->p_param() + o.begin, 0, (o.end - o.begin) * sizeof(float), e->stream));
+  return 0;
+}
+
+int tfk_set_prior(tfk_engine* e, const float* prior, size_t count) {
+  if (!e || !prior) return fail(-1, "NULL argument");
+  if (count != (size_t)e->O) return fail(-1, "prior has %zu entries, expected %d", count, e->O);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(e->prior, prior, count * sizeof(float), hipMemcpyHostToDevice));
+  e->have_prior = true;
+  return 0;
+}
+
+int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (N <= 0) return fail(-1, "empty utterance (N = %d)", N);
+  if (!X || !out) return fail(-1, "X / out is NULL");
+  if (ldo < e->O) return fail(-1, "ldo %lld < output_dim %d", (long long)ldo, e->O);
+  if ((flags & TFK_LOG_DIV_PRIOR) && !e->have_prior) return fail(-1, "TFK_LOG_DIV_PRIOR without tfk_set_prior");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(reserve(e, N));
+  const float* Xd; const int32_t* yd; int ld;
+  const int slot_before = e->slot;
+  CHK(stage_input(e, X, ldx, nullptr, N, flags, &Xd, &ld, &yd));
+  const int nact = e->nact();
+  const uint32_t call = e->call_counter++;
+  CHK(forward(e, Xd, ld, N, 0, nact, nact, call));
+  const float* prior = (flags & TFK_LOG_DIV_PRIOR) ? e->prior : nullptr;
+  if (flags & TFK_DEVICE_PTRS) {
+    ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * N * e->O);
+    softmax_rows(e->stream, e->logits, N, e->O, e->ldO, out, ldo, prior);
+  } else {
+    {
+      ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * N * e->O);
+      softmax_rows(e->stream, e->logits, N, e->O, e->ldO, e->post, e->ldO, prior);
+    }
+    CHK(finish_slot(e, flags, slot_before));
+    const size_t need = (size_t)N * e->O;
+    if (need > e->h_post_floats) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (e->h_post) hipHostFree(e->h_post);
+      e->h_post = nullptr;
+      HIPCHK(hipHostMalloc((void**)&e->h_post, need * sizeof(float), hipHostMallocDefault));
+      e->h_post_floats = need;
+    }
+    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, e->post, (size_t)e->ldO * 4, (size_t)e->O * 4, N,
+                            hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int t = 0; t < N; ++t) memcpy(out + (size_t)t * ldo, e->h_post + (size_t)t * e->O, (size_t)e->O * sizeof(float));
+  }
+  HIPCHK(hipGetLastError());
+  e->last_T = N; e->last_nfw = nact; e->last_call = call; e->last_in = Xd;
+  return 0;
+}
+
+int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {
+  if (!e || !device_ptr || !num_floats) return fail(-1, "NULL argument");
+  *device_ptr = e->p_grad();
+  *num_floats = e->reduce_floats;
+  return 0;
+}
+int tfk_num_buckets(tfk_engine* e, int* n) {
+  if (!e || !n) return fail(-1, "NULL argument");
+  *n = e->L + 2;
+  return 0;
+}
+int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* num_floats) {
+  if (!e || !offset_floats || !num_floats) return fail(-1, "NULL argument");
+  if (bucket < 0 || bucket > e->L + 1) return fail(-1, "bucket %d out of range", bucket);
+  if (bucket == e->L + 1) {
+    *offset_floats = e->P;
+    *num_floats = kScalarFloats + e->E;
+  } else {
+    const LayerLayout& y = e->lay[e->L - bucket];
+    *offset_floats = y.begin;
+    *num_floats = y.end - y.begin;
+  }
+  return 0;
+}
+int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user) {
+  if (!e) return fail(-1, "engine is NULL");
+  e->cb = fn;
+  e->cb_user = user;
+  return 0;
+}
+int tfk_set_later_microbatches(tfk_engine* e, int32_t later) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (later < 0) return fail(-1, "later micro-batches must be >= 0");
+  e->later_mb = later;
+  return 0;
+}
+
+int tfk_synchronize(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->copy_stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+int tfk_stream(tfk_engine* e, void** hip_stream) {
+  if (!e || !hip_stream) return fail(-1, "NULL argument");
+  *hip_stream = (void*)e->stream;
+  return 0;
+}
+
+int tfk_profile_begin(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  e->prof.clear();
+  e->ev_next = 0;
+  e->profiling = true;
+  return 0;
+}
+int tfk_profile_end(tfk_engine* e, tfk_kernel_stat* stats, int capacity, int* count) {
+  if (!e || !count) return fail(-1, "NULL argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->profiling = false;
+  tfk_kernel_stat acc[KF_COUNT];
+  memset(acc, 0, sizeof(acc));
+  for (int f = 0; f < KF_COUNT; ++f) snprintf(acc[f].name, sizeof(acc[f].name), "%s", kFamilyName[f]);
+  for (const ProfRec& r : e->prof) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    acc[r.family].launches += 1;
+    acc[r.family].total_ms += ms;
+    acc[r.family].flops += r.flops;
+    acc[r.family].bytes += r.bytes;
+  }
+  int n = 0;
+  for (int f = 0; f < KF_COUNT; ++f)
+    if (acc[f].launches > 0) {
+      if (stats && n < capacity) stats[n] = acc[f];
+      ++n;
+    }
+  *count = n;
+  e->prof.clear();
+  e->ev_next = 0;
+  return 0;
+}
+
+int tfk_debug_fetch(tfk_engine* e, int what, int layer, float* host, size_t count) {
+  if (!e || !host) return fail(-1, "NULL argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int T = e->last_T;
+  if (T <= 0) return fail(-1, "no previous call to fetch from");
+  if (what == TFK_DBG_LOGITS) {
+    if (count != (size_t)T * e->O) return fail(-1, "count %zu != %d x %d", count, T, e->O);
+    HIPCHK(hipMemcpy2D(host, (size_t)e->O * 4, e->logits, (size_t)e->ldO * 4, (size_t)e->O * 4, T, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (layer < 0 || layer >= e->L) return fail(-1, "layer %d out of range", layer);
+  if (count != (size_t)T * e->H) return fail(-1, "count %zu != %d x %d", count, T, e->H);
+  if (what == TFK_DBG_HIDDEN) {
+    if (layer >= e->last_nfw) return fail(-1, "layer %d was not evaluated by the last call", layer);
+    HIPCHK(hipMemcpy2D(host, (size_t)e->H * 4, e->a[layer], (size_t)e->ldH * 4, (size_t)e->H * 4, T, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (what == TFK_DBG_DROPOUT_MASK) {
+    const ActDesc d = act_desc(e, layer, 1, e->last_call);
+    if (d.keep >= 1.f) {
+      for (size_t i = 0; i < count; ++i) host[i] = 1.f;
+      return 0;
+    }
+    dropout_mask(e->stream, d, e->dA[0], T, e->H, e->ldH);  // dA[0] is scratch between calls
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy2D(host, (size_t)e->H * 4, e->dA[0], (size_t)e->ldH * 4, (size_t)e->H * 4, T, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  return fail(-1, "unknown debug tensor %d", what);
+}
+
+int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                 int N, int K, const float* bias, int epi, int tile_config) {
+  if (layout < 0 || layout > 2) return fail(-1, "bad layout %d", layout);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  const int rc = gemm_f32((GemmLayout)layout, g, tile_config, (hipStream_t)stream);
+  if (rc != 0) return fail(rc, "gemm_f32 failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// fp32 MFMA GEMM for gfx950 (CDNA4) -- interface.
+//
+// One templated kernel family covers the three contractions of the DNN hot path
+// (reference: neuralNetworks/classifiers/layer.py:52 `tf.matmul(inputs, weights) + biases`
+// and its tf.gradients, neuralNetworks/trainer.py:155):
+//
+//   NN  C[M,N]  = A[M,K] . B[K,N] (+bias)      forward affine      (A: activations, B: W[d_in,d_out])
+//   NT  C[M,N]  = A[M,K] . B[N,K]^T            dA = dZ . W^T       (B: W[d_in,d_out] read as [N,K])
+//   TN  C[M,N] (+)= A[K,M]^T . B[K,N]          dW (+)= A^T . dZ    (accumulates into the gradient sum G)
+//
+// All matrices are row-major fp32 with a leading dimension that is a multiple of 4 floats and
+// zero-filled padding columns (16-byte rows => every global access is a dwordx4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfk {
+
+enum GemmLayout : int { GEMM_NN = 0, GEMM_NT = 1, GEMM_TN = 2 };
+
+// Epilogue flags
+enum : int {
+  EPI_BIAS = 1,        // C += bias[col]
+  EPI_ACCUM = 2,       // C = C_old + result
+  EPI_RELU = 4,        // C = max(C, 0)            (non-BN forward with relu)
+};
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;  // [N] when EPI_BIAS
+  int M, N, K;
+  int lda, ldb, ldc;
+  int epi;
+};
+
+// Tile configurations (compile-time instantiated); index = config id.
+//   0: 128x128 block, 4 waves of 64x64
+//   1: 128x64  block, 4 waves of 64x32
+//   2:  64x128 block, 4 waves of 32x64
+//   3:  64x64  block, 4 waves of 32x32
+//   4: 128x128 block, 8 waves of 64x32
+//   5: 256x128 block, 8 waves of 64x64
+constexpr int kNumGemmConfigs = 6;
+
+// cfg < 0 => heuristic choice. Returns hipError_t as int.
+int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream);
+
+// Heuristic used when cfg < 0 (exposed for tests / the sweep tool).
+int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K);
+
+// Override the heuristic globally (env TFK_GEMM_CFG or the sweep tool); -1 restores it.
+void gemm_f32_force_config(int cfg);
+
+const char* gemm_f32_config_name(int cfg);
+
+}  // namespace tfk

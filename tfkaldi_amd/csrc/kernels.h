@@ -1,0 +1,70 @@
+// Non-GEMM kernels of the DNN hot path (gfx950): interface.  See kernels.hip for the reference
+// citations of each op.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfk {
+
+// The activation chain of one hidden layer (neuralNetworks/classifiers/activation.py:22-42 order:
+// Batchnorm -> nonlin -> L2Norm -> Dropout), plus the dropout RNG coordinates.
+struct ActDesc {
+  int nonlin;      // TFK_NONLIN_*
+  int bn;          // batch norm on
+  int l2;          // L2Norm on
+  float keep;      // dropout keep probability (>= 1: off)
+  uint64_t seed;   // RNG key
+  uint32_t call;   // RNG counter: accumulate-call index
+  uint32_t layer;  // RNG counter: layer index
+  int train;       // dropout only in training mode
+};
+
+constexpr int kMaxRowSplits = 64;
+
+// ---- batch norm statistics ----
+// train: per-column mean / biased variance of z[T,H] (two-level, Chan-merged), rstd = rsqrt(var+eps);
+// the moving-average increments follow E <- decay*E + (1-decay)*stat.  ws: >= 2*kMaxRowSplits*ld floats.
+void bn_stats_train(hipStream_t s, const float* z, int T, int H, int ld, float eps, float decay, float* mean,
+                    float* rstd, float* e_mean, float* e_var, float* ws);
+// eval: mean = moving_mean, rstd = rsqrt(moving_var + eps)
+void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, int H, float eps, float* mean,
+                   float* rstd);
+
+// ---- activation chain forward: z -> a (v: post-nonlin copy, rowscale: L2 mean-square; both only if l2) ----
+void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
+                 const float* mean, const float* rstd, const float* beta, int T, int H, int ld);
+
+// ---- activation chain backward ----
+// L2 chains only: da -> du (gradient w.r.t. the BN output) in place, row-wise.
+void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* v, const float* rowscale, int T,
+                       int H, int ld);
+// Column-tiled backward of {dropout, nonlin', batch norm}: da[T,H] -> dz in place;
+// g_beta += sum_t du, g_bias += sum_t dz.  `pre_du` != 0: da already holds du (after act_backward_rows).
+// ws: >= 3*kMaxRowSplits*ld floats.
+void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
+                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int T, int H, int ld,
+                     float* ws);
+// g_out[c] += sum_t x[t,c]   (bias gradient of the output layer).  ws: >= kMaxRowSplits*ld floats.
+void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, float* ws);
+
+// ---- softmax cross-entropy (trainer.py:526-531): row_loss[t] = logsumexp(z_t) - z_t[y_t];
+// with_grad: logits <- softmax(z) - onehot(y) in place (sum-reduced loss => no 1/T factor).
+void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
+                  int with_grad);
+// scalars[0] += sum(row_loss), scalars[1] += T, scalars[2] += 1
+void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars);
+// decoder.py:44 softmax; prior != null: out = log(softmax / prior) (nnet.py:280-286)
+void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
+                  const float* prior);
+
+// ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam; G <- 0 ----
+void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
+                float beta1, float beta2, float eps);
+// moving <- decay^{num_microbatches} * moving + E
+void ema_apply(hipStream_t s, float* moving, const float* e, size_t n, const float* scalars, float decay);
+void scale_inplace(hipStream_t s, float* x, size_t n, float factor);
+void fill(hipStream_t s, float* x, size_t n, float value);
+// debug: regenerate the keep mask of a layer as 0/1 floats [T, ld]
+void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld);
+
+}  // namespace tfk

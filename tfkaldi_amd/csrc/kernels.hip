@@ -1,0 +1,696 @@
+// Non-GEMM kernels of the DNN hot path for gfx950 (wave64).  All are L2/HBM-streaming kernels:
+// 16-byte accesses, 512-byte contiguous segments per half-wave, column-tiled two-level reductions
+// (deterministic: no floating-point atomics anywhere).
+//
+// Reference semantics restated here (TensorFlow ops the reference calls):
+//   batch norm   neuralNetworks/classifiers/activation.py:159-161  tf.contrib.layers.batch_norm
+//                (center=True, scale=False, biased batch variance, EMA of mean/variance)
+//   nonlin       activation.py:84 (tf.nn.relu / sigmoid / tanh / identity; nnet.py:48-62)
+//   L2Norm       activation.py:101-111  s = mean(x^2, axis=1); x/s where s > 1
+//   Dropout      activation.py:140-141  tf.nn.dropout(x, keep_prob) in training mode only
+//   softmax-CE   neuralNetworks/trainer.py:526-531  reduce_sum(softmax_cross_entropy_with_logits)
+//   softmax      neuralNetworks/decoder.py:44
+//   mean/clip/Adam  trainer.py:174-184
+#include "kernels.h"
+
+#include <math.h>
+
+namespace tfk {
+namespace {
+
+constexpr int NONLIN_RELU = 0, NONLIN_SIGMOID = 1, NONLIN_TANH = 2, NONLIN_LINEAR = 3;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// Block-wide reductions for 1-D blocks; `sm` holds >= blockDim.x/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int k = 0; k < nw; ++k) t += sm[k];
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float t = sm[0];
+  for (int k = 1; k < nw; ++k) t = fmaxf(t, sm[k]);
+  __syncthreads();
+  return t;
+}
+
+// Philox4x32-7 counter-based RNG: the keep mask of element (row, col) is a pure function of
+// (seed, call, layer, row, col/4), so forward and backward regenerate it instead of storing it.
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+struct Keep4 { bool k[4]; };
+__device__ __forceinline__ Keep4 keep_mask(const ActDesc& d, int row, int c4) {
+  const uint4 r = philox4x32(make_uint4((uint32_t)c4, (uint32_t)row, d.layer, d.call),
+                             make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32)));
+  // keep with probability `keep`: drop iff u < (1 - keep) * 2^32
+  const uint32_t thr = (uint32_t)fminf((1.0f - d.keep) * 4294967296.0f, 4294967295.0f);
+  Keep4 m;
+  m.k[0] = r.x >= thr; m.k[1] = r.y >= thr; m.k[2] = r.z >= thr; m.k[3] = r.w >= thr;
+  return m;
+}
+
+__device__ __forceinline__ float nonlin_fwd(float u, int nonlin) {
+  switch (nonlin) {
+    case NONLIN_RELU: return fmaxf(u, 0.f);
+    case NONLIN_SIGMOID: return 1.f / (1.f + expf(-u));
+    case NONLIN_TANH: return tanhf(u);
+    default: return u;
+  }
+}
+// derivative expressed through the OUTPUT v = f(u)
+__device__ __forceinline__ float nonlin_bwd(float v, int nonlin) {
+  switch (nonlin) {
+    case NONLIN_RELU: return v > 0.f ? 1.f : 0.f;
+    case NONLIN_SIGMOID: return v * (1.f - v);
+    case NONLIN_TANH: return 1.f - v * v;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float& el(float4& v, int i) { return reinterpret_cast<float*>(&v)[i]; }
+__device__ __forceinline__ float el(const float4& v, int i) { return reinterpret_cast<const float*>(&v)[i]; }
+
+// ------------------------------------------------------------------------------------------------
+// Column-tiled geometry: block = 32 float4-columns (128 columns) x 8 row lanes; grid = (column
+// blocks, row splits).  A half-wave reads 512 contiguous bytes of one row.
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_X = 32, CT_Y = 8;
+
+struct ColTile {
+  int c4;      // float4 column index
+  int col;     // first column
+  bool valid;  // col < ld
+  int r0, r1;  // row range of this block
+};
+__device__ __forceinline__ ColTile col_tile(int T, int ld, int rows_per) {
+  ColTile t;
+  t.c4 = blockIdx.x * CT_X + threadIdx.x;
+  t.col = t.c4 * 4;
+  t.valid = t.col < ld;
+  t.r0 = blockIdx.y * rows_per;
+  t.r1 = min(T, t.r0 + rows_per);
+  return t;
+}
+// Sum a float4 over the 8 row lanes; result valid in threadIdx.y == 0.
+__device__ __forceinline__ float4 reduce_rows(float4 v, float4 (*sm)[CT_X]) {
+  sm[threadIdx.y][threadIdx.x] = v;
+  __syncthreads();
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.y == 0) {
+#pragma unroll
+    for (int k = 0; k < CT_Y; ++k) {
+      const float4 q = sm[k][threadIdx.x];
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+  }
+  __syncthreads();
+  return t;
+}
+
+// ---- batch-norm forward statistics ----
+__global__ void __launch_bounds__(CT_X * CT_Y)
+bn_stats_partial_kernel(const float* __restrict__ z, int T, int ld, int rows_per, int rs, float* __restrict__ ws) {
+  __shared__ float4 sm[CT_Y][CT_X];
+  __shared__ float4 sm_mean[CT_X];
+  const ColTile t = col_tile(T, ld, rows_per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t.valid)
+    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+      const float4 v = ld4(z + (size_t)r * ld + t.col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  s = reduce_rows(s, sm);
+  const int n = max(t.r1 - t.r0, 0);
+  if (threadIdx.y == 0) {
+    const float inv = n > 0 ? 1.f / (float)n : 0.f;
+    sm_mean[threadIdx.x] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+  __syncthreads();
+  const float4 mu = sm_mean[threadIdx.x];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t.valid)
+    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+      const float4 v = ld4(z + (size_t)r * ld + t.col);
+      const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+      q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+    }
+  q = reduce_rows(q, sm);
+  if (threadIdx.y == 0 && t.valid) {
+    st4(ws + ((size_t)0 * rs + blockIdx.y) * ld + t.col, mu);
+    st4(ws + ((size_t)1 * rs + blockIdx.y) * ld + t.col, q);
+  }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ ws, int T, int H, int ld, int rows_per, int rs,
+                                      float eps, float decay, float* __restrict__ mean, float* __restrict__ rstd,
+                                      float* __restrict__ e_mean, float* __restrict__ e_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  if (c >= H) {  // padding columns stay neutral
+    mean[c] = 0.f; rstd[c] = 0.f;
+    return;
+  }
+  // Chan et al. merge of the per-chunk (n, mean, M2)
+  float tot = 0.f;
+  for (int k = 0; k < rs; ++k) {
+    const int n = max(min(T, (k + 1) * rows_per) - k * rows_per, 0);
+    tot += (float)n * ws[((size_t)0 * rs + k) * ld + c];
+  }
+  const float mu = tot / (float)T;
+  float m2 = 0.f;
+  for (int k = 0; k < rs; ++k) {
+    const int n = max(min(T, (k + 1) * rows_per) - k * rows_per, 0);
+    const float d = ws[((size_t)0 * rs + k) * ld + c] - mu;
+    m2 += ws[((size_t)1 * rs + k) * ld + c] + (float)n * d * d;
+  }
+  const float var = m2 / (float)T;  // biased, as tf.nn.moments
+  mean[c] = mu;
+  rstd[c] = rsqrtf(var + eps);
+  e_mean[c] = decay * e_mean[c] + (1.f - decay) * mu;
+  e_var[c] = decay * e_var[c] + (1.f - decay) * var;
+}
+
+__global__ void bn_stats_eval_kernel(const float* __restrict__ mov_mean, const float* __restrict__ mov_var, int H,
+                                     float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  mean[c] = mov_mean[c];
+  rstd[c] = rsqrtf(mov_var[c] + eps);
+}
+
+// ---- activation chain forward (one block walks rows; threads walk float4 columns) ----
+template <bool L2>
+__global__ void __launch_bounds__(256)
+act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a, float* __restrict__ vbuf,
+                   float* __restrict__ rowscale, const float* __restrict__ mean, const float* __restrict__ rstd,
+                   const float* __restrict__ beta, int T, int H, int ld) {
+  __shared__ float sm[4];
+  const int nc4 = ld >> 2;
+  const bool drop = d.train && d.keep < 1.f;
+  const float inv_keep = drop ? 1.f / d.keep : 1.f;
+  for (int row = blockIdx.x; row < T; row += gridDim.x) {
+    const float* zr = z + (size_t)row * ld;
+    float* ar = a + (size_t)row * ld;
+    float ss = 0.f;
+    for (int c4 = threadIdx.x; c4 < nc4; c4 += blockDim.x) {
+      const int col = c4 << 2;
+      float4 u = ld4(zr + col);
+      if (d.bn) {
+        const float4 mu = ld4(mean + col), rs = ld4(rstd + col), be = ld4(beta + col);
+        u.x = (u.x - mu.x) * rs.x + be.x; u.y = (u.y - mu.y) * rs.y + be.y;
+        u.z = (u.z - mu.z) * rs.z + be.z; u.w = (u.w - mu.w) * rs.w + be.w;
+      }
+      float4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) el(v, k) = (col + k < H) ? nonlin_fwd(el(u, k), d.nonlin) : 0.f;
+      if (L2) {
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        st4(vbuf + (size_t)row * ld + col, v);
+      } else {
+        if (drop) {
+          const Keep4 m = keep_mask(d, row, c4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
+        }
+        st4(ar + col, v);
+      }
+    }
+    if (L2) {
+      const float s = block_sum(ss, sm) / (float)H;  // mean SQUARE (not RMS): activation.py:103
+      if (threadIdx.x == 0) rowscale[row] = s;
+      const float scale = s > 1.f ? 1.f / s : 1.f;
+      for (int c4 = threadIdx.x; c4 < nc4; c4 += blockDim.x) {
+        const int col = c4 << 2;
+        float4 v = ld4(vbuf + (size_t)row * ld + col);  // own writes
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        if (drop) {
+          const Keep4 m = keep_mask(d, row, c4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
+        }
+        st4(ar + col, v);
+      }
+    }
+  }
+}
+
+// ---- L2 chains: da -> du in place (row-wise) ----
+__global__ void __launch_bounds__(256)
+act_backward_rows_kernel(ActDesc d, float* __restrict__ da, const float* __restrict__ vbuf,
+                         const float* __restrict__ rowscale, int T, int H, int ld) {
+  __shared__ float sm[4];
+  const int nc4 = ld >> 2;
+  const bool drop = d.keep < 1.f;
+  const float inv_keep = drop ? 1.f / d.keep : 1.f;
+  for (int row = blockIdx.x; row < T; row += gridDim.x) {
+    float* gr = da + (size_t)row * ld;
+    const float* vr = vbuf + (size_t)row * ld;
+    const float s = rowscale[row];
+    float dot = 0.f;
+    if (s > 1.f) {
+      for (int c4 = threadIdx.x; c4 < nc4; c4 += blockDim.x) {
+        const int col = c4 << 2;
+        float4 g = ld4(gr + col);
+        const float4 v = ld4(vr + col);
+        if (drop) {
+          const Keep4 m = keep_mask(d, row, c4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) el(g, k) = m.k[k] ? el(g, k) * inv_keep : 0.f;
+        }
+        dot += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+      }
+      dot = block_sum(dot, sm);
+    }
+    // w = v / s  =>  dv_i = dw_i / s - v_i * (2 / (H s^2)) * sum_j dw_j v_j      (s = mean_j v_j^2)
+    const float k1 = s > 1.f ? 1.f / s : 1.f;
+    const float k2 = s > 1.f ? 2.f * dot / ((float)H * s * s) : 0.f;
+    for (int c4 = threadIdx.x; c4 < nc4; c4 += blockDim.x) {
+      const int col = c4 << 2;
+      float4 g = ld4(gr + col);
+      const float4 v = ld4(vr + col);
+      if (drop) {
+        const Keep4 m = keep_mask(d, row, c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) el(g, k) = m.k[k] ? el(g, k) * inv_keep : 0.f;
+      }
+      float4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dv = el(g, k) * k1 - el(v, k) * k2;
+        el(o, k) = (col + k < H) ? dv * nonlin_bwd(el(v, k), d.nonlin) : 0.f;
+      }
+      st4(gr + col, o);
+    }
+  }
+}
+
+// du for the no-L2 chains, recomputed from (da, a) wherever it is needed
+__device__ __forceinline__ float4 compute_du(const ActDesc& d, int pre_du, float4 g, float4 a, int row, int c4) {
+  if (pre_du) return g;
+  float4 o;
+  if (d.keep < 1.f) {
+    const Keep4 m = keep_mask(d, row, c4);
+    const float inv_keep = 1.f / d.keep;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      el(o, k) = m.k[k] ? el(g, k) * inv_keep * nonlin_bwd(el(a, k) * d.keep, d.nonlin) : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) el(o, k) = el(g, k) * nonlin_bwd(el(a, k), d.nonlin);
+  }
+  return o;
+}
+
+// pass A (BN only): partial sums of du and du * xhat
+__global__ void __launch_bounds__(CT_X * CT_Y)
+hb_stats_kernel(ActDesc d, int pre_du, const float* __restrict__ da, const float* __restrict__ a,
+                const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd, int T,
+                int ld, int rows_per, int rs, float* __restrict__ ws) {
+  __shared__ float4 sm[CT_Y][CT_X];
+  const ColTile t = col_tile(T, ld, rows_per);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (t.valid) {
+    const float4 mu = ld4(mean + t.col), rsd = ld4(rstd + t.col);
+    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+      const size_t off = (size_t)r * ld + t.col;
+      const float4 g = ld4(da + off);
+      const float4 av = pre_du ? g : ld4(a + off);
+      const float4 zv = ld4(z + off);
+      const float4 du = compute_du(d, pre_du, g, av, r, t.c4);
+      s1.x += du.x; s1.y += du.y; s1.z += du.z; s1.w += du.w;
+      s2.x += du.x * (zv.x - mu.x) * rsd.x; s2.y += du.y * (zv.y - mu.y) * rsd.y;
+      s2.z += du.z * (zv.z - mu.z) * rsd.z; s2.w += du.w * (zv.w - mu.w) * rsd.w;
+    }
+  }
+  s1 = reduce_rows(s1, sm);
+  s2 = reduce_rows(s2, sm);
+  if (threadIdx.y == 0 && t.valid) {
+    st4(ws + ((size_t)0 * rs + blockIdx.y) * ld + t.col, s1);
+    st4(ws + ((size_t)1 * rs + blockIdx.y) * ld + t.col, s2);
+  }
+}
+
+// pass B: dz in place (+ partial column sums of dz)
+__global__ void __launch_bounds__(CT_X * CT_Y)
+hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __restrict__ a,
+                const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd, int T,
+                int H, int ld, int rows_per, int rs, float* __restrict__ ws) {
+  __shared__ float4 sm[CT_Y][CT_X];
+  const ColTile t = col_tile(T, ld, rows_per);
+  float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t.valid) {
+    float4 mu = sz, rsd = sz, m1 = sz, m2 = sz;
+    if (d.bn) {
+      mu = ld4(mean + t.col); rsd = ld4(rstd + t.col);
+      for (int k = 0; k < rs; ++k) {
+        const float4 p1 = ld4(ws + ((size_t)0 * rs + k) * ld + t.col);
+        const float4 p2 = ld4(ws + ((size_t)1 * rs + k) * ld + t.col);
+        m1.x += p1.x; m1.y += p1.y; m1.z += p1.z; m1.w += p1.w;
+        m2.x += p2.x; m2.y += p2.y; m2.z += p2.z; m2.w += p2.w;
+      }
+      const float invT = 1.f / (float)T;
+      m1.x *= invT; m1.y *= invT; m1.z *= invT; m1.w *= invT;
+      m2.x *= invT; m2.y *= invT; m2.z *= invT; m2.w *= invT;
+    }
+    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+      const size_t off = (size_t)r * ld + t.col;
+      const float4 g = ld4(da + off);
+      const float4 av = pre_du ? g : ld4(a + off);
+      float4 dz = compute_du(d, pre_du, g, av, r, t.c4);
+      if (d.bn) {
+        // dz = rstd * (du - mean(du) - xhat * mean(du * xhat))
+        const float4 zv = ld4(z + off);
+        dz.x = rsd.x * (dz.x - m1.x - (zv.x - mu.x) * rsd.x * m2.x);
+        dz.y = rsd.y * (dz.y - m1.y - (zv.y - mu.y) * rsd.y * m2.y);
+        dz.z = rsd.z * (dz.z - m1.z - (zv.z - mu.z) * rsd.z * m2.z);
+        dz.w = rsd.w * (dz.w - m1.w - (zv.w - mu.w) * rsd.w * m2.w);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t.col + k >= H) el(dz, k) = 0.f;
+      st4(da + off, dz);
+      sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
+    }
+  }
+  sz = reduce_rows(sz, sm);
+  if (threadIdx.y == 0 && t.valid) st4(ws + ((size_t)2 * rs + blockIdx.y) * ld + t.col, sz);
+}
+
+// g[c] += sum over row splits of slab `which`
+__global__ void colsum_final_kernel(const float* __restrict__ ws, int which, int rs, int N, int ld,
+                                    float* __restrict__ g) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < rs; ++k) s += ws[((size_t)which * rs + k) * ld + c];
+  g[c] += s;
+}
+
+__global__ void __launch_bounds__(CT_X * CT_Y)
+colsum_partial_kernel(const float* __restrict__ x, int T, int ld, int rows_per, int rs, float* __restrict__ ws) {
+  __shared__ float4 sm[CT_Y][CT_X];
+  const ColTile t = col_tile(T, ld, rows_per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t.valid)
+    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+      const float4 v = ld4(x + (size_t)r * ld + t.col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  s = reduce_rows(s, sm);
+  if (threadIdx.y == 0 && t.valid) st4(ws + (size_t)blockIdx.y * ld + t.col, s);
+}
+
+// ---- softmax cross-entropy: one 256-thread block per frame, the row held in registers ----
+template <int NV>  // float4 per thread; NV == 0: generic (re-reads global)
+__global__ void __launch_bounds__(256)
+softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, int O, int ld,
+                    float* __restrict__ row_loss, int with_grad) {
+  __shared__ float sm[4];
+  const int row = blockIdx.x;
+  float* zr = logits + (size_t)row * ld;
+  const int label = y[row];
+  const int nc4 = ld >> 2;
+  const float zy = (label >= 0 && label < O) ? zr[label] : 0.f;
+  __syncthreads();  // zr[label] is read before anyone overwrites it
+  constexpr int NVR = NV > 0 ? NV : 1;
+  float4 v[NVR];
+  float mx = -INFINITY;
+  if (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NVR; ++j) {
+      const int c4 = threadIdx.x + j * 256;
+      v[j] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (c4 < nc4) {
+        const float4 t = ld4(zr + (c4 << 2));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((c4 << 2) + k < O) el(v[j], k) = el(t, k);
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+    }
+  } else {
+    for (int c = threadIdx.x; c < O; c += 256) mx = fmaxf(mx, zr[c]);
+  }
+  mx = block_max(mx, sm);
+  float se = 0.f;
+  if (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NVR; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = expf(el(v[j], k) - mx);  // exp(-inf) = 0 for the masked tail
+        el(v[j], k) = e;
+        se += e;
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
+  }
+  se = block_sum(se, sm);
+  if (threadIdx.x == 0) row_loss[row] = (mx + logf(se)) - zy;
+  if (!with_grad) return;
+  const float inv = 1.f / se;
+  if (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NVR; ++j) {
+      const int c4 = threadIdx.x + j * 256;
+      if (c4 < nc4) {
+        float4 g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = (c4 << 2) + k;
+          el(g, k) = c < O ? el(v[j], k) * inv - (c == label ? 1.f : 0.f) : 0.f;
+        }
+        st4(zr + (c4 << 2), g);
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < O; c += 256) zr[c] = expf(zr[c] - mx) * inv - (c == label ? 1.f : 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restrict__ row_loss, int T,
+                                                           float* __restrict__ scalars) {
+  __shared__ float sm[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < T; i += 1024) s += row_loss[i];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) {
+    scalars[0] += s;
+    scalars[1] += (float)T;
+    scalars[2] += 1.f;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+softmax_rows_kernel(const float* __restrict__ logits, int O, int ld, float* __restrict__ out, int64_t ldo,
+                    const float* __restrict__ prior) {
+  __shared__ float sm[4];
+  const int row = blockIdx.x;
+  const float* zr = logits + (size_t)row * ld;
+  float* orow = out + (size_t)row * ldo;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < O; c += 256) mx = fmaxf(mx, zr[c]);
+  mx = block_max(mx, sm);
+  float se = 0.f;
+  for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
+  se = block_sum(se, sm);
+  if (prior) {
+    const float lse = mx + logf(se);
+    for (int c = threadIdx.x; c < O; c += 256) orow[c] = (zr[c] - lse) - logf(prior[c]);
+  } else {
+    const float inv = 1.f / se;
+    for (int c = threadIdx.x; c < O; c += 256) orow[c] = expf(zr[c] - mx) * inv;
+  }
+}
+
+// ---- mean -> clip -> Adam (TF formulation), zeroing the gradient sum on the way out ----
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
+            const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps) {
+  const float inv_n = 1.f / scalars[1];  // G / float(num_frames): trainer.py:174-175
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 gv = ld4(g + 4 * i), mv = ld4(m + 4 * i), vv = ld4(v + 4 * i), wv = ld4(w + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = fminf(fmaxf(el(gv, k) * inv_n, -1.f), 1.f);  // clip_by_value: trainer.py:178-179
+      const float mk = b1 * el(mv, k) + (1.f - b1) * gk;
+      const float vk = b2 * el(vv, k) + (1.f - b2) * gk * gk;
+      el(mv, k) = mk;
+      el(vv, k) = vk;
+      el(wv, k) -= lr_t * mk / (sqrtf(vk) + eps);
+    }
+    st4(m + 4 * i, mv);
+    st4(v + 4 * i, vv);
+    st4(w + 4 * i, wv);
+    st4(g + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));  // init_grads: trainer.py:350
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ mov, const float* __restrict__ e, size_t n,
+                           const float* __restrict__ scalars, float decay) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mov[i] = powf(decay, scalars[2]) * mov[i] + e[i];
+}
+__global__ void scale_kernel(float* __restrict__ x, size_t n, float f) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= f;
+}
+__global__ void fill_kernel(float* __restrict__ x, size_t n, float f) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = f;
+}
+__global__ void dropout_mask_kernel(ActDesc d, float* __restrict__ out, int T, int H, int ld) {
+  const int nc4 = ld >> 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)T * nc4) return;
+  const int row = (int)(idx / nc4), c4 = (int)(idx % nc4);
+  const Keep4 m = keep_mask(d, row, c4);
+  float4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) el(o, k) = ((c4 << 2) + k < H && m.k[k]) ? 1.f : 0.f;
+  st4(out + (size_t)row * ld + (c4 << 2), o);
+}
+
+inline int row_splits(int T) {
+  int rs = (T + 31) / 32;
+  if (rs < 1) rs = 1;
+  if (rs > kMaxRowSplits) rs = kMaxRowSplits;
+  return rs;
+}
+inline dim3 ct_grid(int ld, int rs) { return dim3((ld / 4 + CT_X - 1) / CT_X, rs); }
+inline dim3 ct_block() { return dim3(CT_X, CT_Y); }
+
+}  // namespace
+
+void bn_stats_train(hipStream_t s, const float* z, int T, int H, int ld, float eps, float decay, float* mean,
+                    float* rstd, float* e_mean, float* e_var, float* ws) {
+  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, ct_grid(ld, rs), ct_block(), 0, s, z, T, ld, rows_per, rs, ws);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((ld + 255) / 256), dim3(256), 0, s, ws, T, H, ld, rows_per, rs, eps,
+                     decay, mean, rstd, e_mean, e_var);
+}
+
+void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, int H, float eps, float* mean,
+                   float* rstd) {
+  hipLaunchKernelGGL(bn_stats_eval_kernel, dim3((H + 255) / 256), dim3(256), 0, s, mov_mean, mov_var, H, eps, mean,
+                     rstd);
+}
+
+void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
+                 const float* mean, const float* rstd, const float* beta, int T, int H, int ld) {
+  const int grid = T < 4096 ? T : 4096;
+  if (d.l2)
+    hipLaunchKernelGGL(act_forward_kernel<true>, dim3(grid), dim3(256), 0, s, d, z, a, v, rowscale, mean, rstd, beta,
+                       T, H, ld);
+  else
+    hipLaunchKernelGGL(act_forward_kernel<false>, dim3(grid), dim3(256), 0, s, d, z, a, v, rowscale, mean, rstd, beta,
+                       T, H, ld);
+}
+
+void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* v, const float* rowscale, int T,
+                       int H, int ld) {
+  const int grid = T < 4096 ? T : 4096;
+  hipLaunchKernelGGL(act_backward_rows_kernel, dim3(grid), dim3(256), 0, s, d, da, v, rowscale, T, H, ld);
+}
+
+void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
+                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int T, int H, int ld,
+                     float* ws) {
+  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
+  if (d.bn)
+    hipLaunchKernelGGL(hb_stats_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, ld,
+                       rows_per, rs, ws);
+  hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
+                     rows_per, rs, ws);
+  if (d.bn)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + 255) / 256), dim3(256), 0, s, ws, 0, rs, H, ld, g_beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + 255) / 256), dim3(256), 0, s, ws, 2, rs, H, ld, g_bias);
+}
+
+void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, float* ws) {
+  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
+  hipLaunchKernelGGL(colsum_partial_kernel, ct_grid(ld, rs), ct_block(), 0, s, x, T, ld, rows_per, rs, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, 0, rs, N, ld, g_out);
+}
+
+void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
+                  int with_grad) {
+  const int nc4 = ld / 4;
+  const dim3 g(T), b(256);
+  if (nc4 <= 256) hipLaunchKernelGGL(softmax_xent_kernel<1>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
+  else if (nc4 <= 512) hipLaunchKernelGGL(softmax_xent_kernel<2>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
+  else if (nc4 <= 1024) hipLaunchKernelGGL(softmax_xent_kernel<4>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
+  else if (nc4 <= 2048) hipLaunchKernelGGL(softmax_xent_kernel<8>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
+  else hipLaunchKernelGGL(softmax_xent_kernel<0>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
+}
+
+void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, row_loss, T, scalars);
+}
+
+void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
+                  const float* prior) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(T), dim3(256), 0, s, logits, O, ld, out, ldo, prior);
+}
+
+void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
+                float beta1, float beta2, float eps) {
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1, beta2,
+                     eps);
+}
+
+void ema_apply(hipStream_t s, float* moving, const float* e, size_t n, const float* scalars, float decay) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, moving, e, n, scalars, decay);
+}
+void scale_inplace(hipStream_t s, float* x, size_t n, float factor) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, factor);
+}
+void fill(hipStream_t s, float* x, size_t n, float value) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, value);
+}
+void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld) {
+  const size_t n = (size_t)T * (ld / 4);
+  if (n == 0) return;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, out, T, H, ld);
+}
+
+}  // namespace tfk

@@ -1,0 +1,244 @@
+"""Python handle on one C-ABI engine (include/tfkaldi_hip.h): numpy in, numpy out.
+
+This is plumbing only -- every FLOP of the hot path runs in libtfkaldi_hip.so.  The classes of
+tfkaldi_amd.neuralNetworks (Trainer / Decoder / DNN) are built on it.
+"""
+import ctypes
+from ctypes import byref, c_double, c_float, c_int, c_size_t, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ADAM_STEPS, BIASES, BN_BETA, BN_MOVING_MEAN, BN_MOVING_VAR, GLOBAL_STEP, INITIALISED_LAYERS,
+                   LEARNING_RATE, LEARNING_RATE_FACT, SLOT_ADAM_M, SLOT_ADAM_V, SLOT_GRAD, SLOT_PARAM, WEIGHTS,
+                   check)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine(object):
+    """One engine per GPU.  `torch_state=True` keeps the persistent state in a torch CUDA tensor and
+    runs on a torch stream so torch.distributed (RCCL) can all-reduce views of the gradient region."""
+
+    def __init__(self, cfg, torch_state=False):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.F, self.L, self.H, self.O = cfg.input_dim, cfg.num_layers, cfg.num_units, cfg.output_dim
+        self.batch_norm = bool(cfg.batch_norm)
+        self._h = c_void_p()
+        self._state = None
+        self._stream = None
+        self._cb = None
+        if torch_state:
+            import torch
+            nbytes = c_size_t()
+            check(self.lib.tfk_state_bytes(byref(cfg), byref(nbytes)))
+            dev = torch.device("cuda", cfg.device)
+            self._state = torch.zeros(nbytes.value // 4, dtype=torch.float32, device=dev)
+            self._stream = torch.cuda.Stream(device=dev)
+            torch.cuda.synchronize(dev)
+            check(self.lib.tfk_create_ex(byref(cfg), c_void_p(self._state.data_ptr()), nbytes.value,
+                                         c_void_p(self._stream.cuda_stream), byref(self._h)))
+        else:
+            check(self.lib.tfk_create(byref(cfg), byref(self._h)))
+
+    # ---- lifetime ----
+    def close(self):
+        if self._h:
+            check(self.lib.tfk_destroy(self._h))
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- tensors / scalars ----
+    def _shape(self, kind, layer):
+        if kind == WEIGHTS:
+            d_in = self.F if layer == 0 else self.H
+            d_out = self.O if layer == self.L else self.H
+            return (d_in, d_out)
+        if kind == BIASES:
+            return (self.O if layer == self.L else self.H,)
+        return (self.H,)
+
+    def get(self, kind, layer, slot=SLOT_PARAM):
+        out = np.empty(self._shape(kind, layer), dtype=np.float32)
+        check(self.lib.tfk_tensor_get(self._h, kind, slot, layer, out.ctypes.data_as(c_void_p), out.size))
+        return out
+
+    def set(self, kind, layer, value, slot=SLOT_PARAM):
+        v = _f32(value)
+        if v.shape != self._shape(kind, layer):
+            raise ValueError("tensor shape %s != %s" % (v.shape, self._shape(kind, layer)))
+        check(self.lib.tfk_tensor_set(self._h, kind, slot, layer, v.ctypes.data_as(c_void_p), v.size))
+
+    def scalar(self, which):
+        v = c_double()
+        check(self.lib.tfk_scalar_get(self._h, which, byref(v)))
+        return v.value
+
+    def set_scalar(self, which, value):
+        check(self.lib.tfk_scalar_set(self._h, which, float(value)))
+
+    @property
+    def global_step(self):
+        return int(self.scalar(GLOBAL_STEP))
+
+    def init_hidden_weights(self, rng):
+        """neuralNetworks/classifiers/layer.py:39-44: hidden W ~ N(0, 1/sqrt(d_in)); everything else
+        keeps the engine's defaults (biases 0, output layer 0: dnn.py:67-68)."""
+        for l in range(self.L):
+            d_in = self.F if l == 0 else self.H
+            self.set(WEIGHTS, l, (rng.standard_normal((d_in, self.H)) / np.sqrt(d_in)).astype(np.float32))
+
+    def model_tensors(self):
+        """Everything the reference's model saver holds (dnn.py:129): W, b, BN beta + moving stats."""
+        out = {}
+        for l in range(self.L + 1):
+            out["layer%d/weights" % l] = self.get(WEIGHTS, l)
+            out["layer%d/biases" % l] = self.get(BIASES, l)
+        if self.batch_norm:
+            for l in range(self.L):
+                out["layer%d/batch_norm/beta" % l] = self.get(BN_BETA, l)
+                out["layer%d/batch_norm/moving_mean" % l] = self.get(BN_MOVING_MEAN, l)
+                out["layer%d/batch_norm/moving_variance" % l] = self.get(BN_MOVING_VAR, l)
+        out["initialisedlayers"] = np.array(int(self.scalar(INITIALISED_LAYERS)), dtype=np.int32)
+        return out
+
+    def load_model_tensors(self, tensors):
+        for l in range(self.L + 1):
+            self.set(WEIGHTS, l, tensors["layer%d/weights" % l])
+            self.set(BIASES, l, tensors["layer%d/biases" % l])
+        if self.batch_norm:
+            for l in range(self.L):
+                self.set(BN_BETA, l, tensors["layer%d/batch_norm/beta" % l])
+                self.set(BN_MOVING_MEAN, l, tensors["layer%d/batch_norm/moving_mean" % l])
+                self.set(BN_MOVING_VAR, l, tensors["layer%d/batch_norm/moving_variance" % l])
+        if "initialisedlayers" in tensors:
+            self.set_scalar(INITIALISED_LAYERS, int(tensors["initialisedlayers"]))
+
+    # ---- training / evaluation ----
+    @staticmethod
+    def _host_batch(X, y):
+        X = _f32(X)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        if X.ndim != 2 or y.ndim != 1 or X.shape[0] != y.shape[0]:
+            raise ValueError("X %s / y %s are not [T, F] / [T]" % (X.shape, y.shape))
+        return X, y
+
+    def accumulate(self, X, y, last=False):
+        X, y = self._host_batch(X, y)
+        check(self.lib.tfk_accumulate(self._h, X.ctypes.data_as(c_void_p), X.shape[1], y.ctypes.data_as(c_void_p),
+                                      X.shape[0], _lib.LAST_MICROBATCH if last else 0))
+
+    def accumulate_device(self, x_ptr, ldx, y_ptr, T, last=False):
+        """X / y already resident in HBM (raw device pointers)."""
+        flags = _lib.DEVICE_PTRS | (_lib.LAST_MICROBATCH if last else 0)
+        check(self.lib.tfk_accumulate(self._h, c_void_p(x_ptr), ldx, c_void_p(y_ptr), T, flags))
+
+    def apply(self):
+        loss = c_float()
+        check(self.lib.tfk_apply(self._h, byref(loss)))
+        return float(loss.value)
+
+    def eval_accumulate(self, X, y):
+        X, y = self._host_batch(X, y)
+        check(self.lib.tfk_eval_accumulate(self._h, X.ctypes.data_as(c_void_p), X.shape[1],
+                                           y.ctypes.data_as(c_void_p), X.shape[0], 0))
+
+    def eval_finish(self):
+        loss = c_float()
+        check(self.lib.tfk_eval_finish(self._h, byref(loss)))
+        return float(loss.value)
+
+    def halve_learning_rate(self):
+        check(self.lib.tfk_halve_learning_rate(self._h))
+
+    def add_layer(self):
+        check(self.lib.tfk_add_layer(self._h))
+
+    def init_last_layer(self):
+        check(self.lib.tfk_init_last_layer(self._h))
+
+    # ---- decoding ----
+    def set_prior(self, prior):
+        p = _f32(prior)
+        check(self.lib.tfk_set_prior(self._h, p.ctypes.data_as(c_void_p), p.size))
+
+    def posteriors(self, X, log_div_prior=False):
+        X = _f32(X)
+        out = np.empty((X.shape[0], self.O), dtype=np.float32)
+        check(self.lib.tfk_posteriors(self._h, X.ctypes.data_as(c_void_p), X.shape[1], X.shape[0],
+                                      out.ctypes.data_as(c_void_p), self.O, _lib.LOG_DIV_PRIOR if log_div_prior else 0))
+        return out
+
+    # ---- data parallelism ----
+    def reduce_region(self):
+        ptr, n = c_void_p(), c_size_t()
+        check(self.lib.tfk_reduce_region(self._h, byref(ptr), byref(n)))
+        return ptr.value, n.value
+
+    def buckets(self):
+        nb = c_int()
+        check(self.lib.tfk_num_buckets(self._h, byref(nb)))
+        out = []
+        for b in range(nb.value):
+            off, n = c_size_t(), c_size_t()
+            check(self.lib.tfk_reduce_bucket(self._h, b, byref(off), byref(n)))
+            out.append((off.value, n.value))
+        return out
+
+    def reduce_view(self):
+        """torch view of the reduce region (requires torch_state=True)."""
+        if self._state is None:
+            raise RuntimeError("reduce_view needs Engine(..., torch_state=True)")
+        ptr, n = self.reduce_region()
+        off = (ptr - self._state.data_ptr()) // 4
+        return self._state[off:off + n]
+
+    def set_bucket_callback(self, fn):
+        """fn(bucket) is called from accumulate(last=True) once the bucket's kernels are enqueued."""
+        if fn is None:
+            self._cb = None
+            check(self.lib.tfk_set_bucket_callback(self._h, _lib.BUCKET_FN(), None))
+            return
+        self._cb = _lib.BUCKET_FN(lambda user, bucket: fn(bucket))
+        check(self.lib.tfk_set_bucket_callback(self._h, self._cb, None))
+
+    def set_later_microbatches(self, later):
+        check(self.lib.tfk_set_later_microbatches(self._h, int(later)))
+
+    @property
+    def torch_stream(self):
+        return self._stream
+
+    # ---- misc ----
+    def synchronize(self):
+        check(self.lib.tfk_synchronize(self._h))
+
+    def profile_begin(self):
+        check(self.lib.tfk_profile_begin(self._h))
+
+    def profile_end(self):
+        stats = (_lib.TfkKernelStat * 32)()
+        n = c_int()
+        check(self.lib.tfk_profile_end(self._h, stats, 32, byref(n)))
+        return [dict(name=stats[i].name.decode(), launches=int(stats[i].launches), total_ms=stats[i].total_ms,
+                     flops=stats[i].flops, bytes=stats[i].bytes) for i in range(min(n.value, 32))]
+
+    def debug_fetch(self, what, layer, T):
+        cols = self.O if what == _lib.DBG_LOGITS else self.H
+        out = np.empty((T, cols), dtype=np.float32)
+        check(self.lib.tfk_debug_fetch(self._h, what, layer, out.ctypes.data_as(c_void_p), out.size))
+        return out
