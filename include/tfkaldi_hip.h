@@ -120,7 +120,8 @@ int tfk_scalar_set(tfk_engine* e, int which, double value);
 enum { /* flags */
   TFK_DEVICE_PTRS = 1,     /* X / y / out are device pointers (already resident in HBM) */
   TFK_LAST_MICROBATCH = 2, /* last accumulate before tfk_apply: fire the bucket callback per layer */
-  TFK_LOG_DIV_PRIOR = 4    /* tfk_posteriors: write log(posterior / prior) (nnet.py:280-286) */
+  TFK_LOG_DIV_PRIOR = 4,   /* tfk_posteriors: write log(posterior / prior) (nnet.py:280-286) */
+  TFK_RAW_LOGITS = 8       /* tfk_posteriors: write the logits (Classifier.__call__ output, dnn.py:108) */
 };
 
 /* Replaces `update_gradients_op.run(feed_dict)` (trainer.py:160-169, 325-332) for ONE micro-batch,

@@ -1,0 +1,82 @@
+"""The N > 1 path on CPU: two processes, gloo backend, the product's DataParallel class driving oracle-backed
+engines.  Checks KAT 8c-3: k serial micro-batches == the same micro-batches sharded over ranks + SUM
+all-reduce, including uneven shards, an idle rank, BN moving averages and the validation loss."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(input_dim=12, num_layers=2, num_units=10, output_dim=6, nonlin="relu", batch_norm=True,
+          init_learning_rate=1e-2, num_steps=10)
+
+
+def _data(num_mb, seed=0):
+    rng = np.random.default_rng(seed)
+    return [((rng.standard_normal((9 + 3 * i, KW["input_dim"]))).astype(np.float32),
+             rng.integers(0, KW["output_dim"], size=9 + 3 * i).astype(np.int32)) for i in range(num_mb)]
+
+
+def _oracle():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.dnn_oracle import OracleDNN
+    from util import randomize
+    o = OracleDNN(**KW)
+    randomize(o, np.random.default_rng(42))
+    return o
+
+
+def _worker(rank, world, port, num_mb, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_engine import OracleEngine
+    from tfkaldi_amd.dataparallel import DataParallel, init_from_env
+    assert init_from_env() == (rank, world, 0)
+    dp = DataParallel()
+    assert dp.enabled and dp.world == world and dp.rank == rank
+    eng = OracleEngine(_oracle())
+    losses = []
+    for step in range(2):
+        losses.append(dp.train_step(eng, _data(num_mb, seed=step)))
+    losses.append(dp.eval_step(eng, _data(num_mb, seed=7)))
+    o = eng.o
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses),
+             mov_mean=np.stack(o.mov_mean), mov_var=np.stack(o.mov_var), **o.params())
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("num_mb", [4, 3, 1])  # even shards, uneven shards, one idle rank
+def test_two_ranks_equal_serial(tmp_path, num_mb):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), num_mb, str(tmp_path)), nprocs=world, join=True)
+    serial = _oracle()
+    want = []
+    for step in range(2):
+        for X, y in _data(num_mb, seed=step):
+            serial.accumulate(X, y)
+        want.append(serial.apply())
+    for X, y in _data(num_mb, seed=7):
+        serial.eval_accumulate(X, y)
+    want.append(serial.eval_finish())
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert np.allclose(got["losses"], want, rtol=1e-12, atol=0)
+        for k, v in serial.params().items():
+            assert np.allclose(got[k], v, rtol=1e-9, atol=1e-12), k
+        assert np.allclose(got["mov_mean"], np.stack(serial.mov_mean), rtol=1e-10, atol=1e-14)
+        assert np.allclose(got["mov_var"], np.stack(serial.mov_var), rtol=1e-10, atol=1e-14)

@@ -24,6 +24,7 @@ CHAINS = [
     dict(nonlin="linear"),
     dict(nonlin="relu", batch_norm=True, keep_prob=0.7),
     dict(nonlin="sigmoid", l2_norm=True, keep_prob=0.6),
+    dict(nonlin="relu", l2_norm=True, keep_prob=0.9, big=True),           # rows with mean square > 1
 ]
 
 
@@ -49,8 +50,13 @@ def test_accumulate_matches_oracle(gpu, chain):
     """one micro-batch: logits, loss, every gradient, BN moving averages"""
     from tfkaldi_amd import _lib
     rng = np.random.default_rng(5)
-    kw = dict(SMALL, **chain)
+    kw = dict(SMALL, **{k: v for k, v in chain.items() if k != "big"})
     eng, oracle = make_pair(rng, **kw)
+    if chain.get("big"):
+        from util import copy_oracle_to_engine
+        for l in range(oracle.L):
+            oracle.W[l] = oracle.W[l] * 3
+        copy_oracle_to_engine(oracle, eng)
     T = 75
     X, y = batch(rng, T, kw["input_dim"], kw["output_dim"])
     eng.accumulate(X, y)
@@ -66,6 +72,9 @@ def test_accumulate_matches_oracle(gpu, chain):
     assert_close("batch_loss", eng.scalar(_lib.BATCH_LOSS), oracle.batch_loss, 2e-5, 0)
     assert eng.scalar(_lib.NUM_FRAMES) == T
     _check_grads(eng, oracle)
+    if chain.get("big"):  # both L2 branches taken
+        s = oracle.last_cache[0]["s"]
+        assert (s > 1).any() and (s <= 1).any()
     # second micro-batch accumulates on top (G += g)
     X2, y2 = batch(rng, 41, kw["input_dim"], kw["output_dim"])
     eng.accumulate(X2, y2)

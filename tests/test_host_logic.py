@@ -1,0 +1,246 @@
+"""CPU tests of the host-side logic: activation chains -> engine options, the reference's micro-batch
+quirk, layout helpers, the C-ABI export list, the Nnet control flow (validation rollback, KAT 8c-10)."""
+import configparser
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle.dnn_oracle import reference_microbatches
+from tfkaldi_amd import _lib, dataparallel
+from tfkaldi_amd.neuralNetworks import nnet as nnet_mod
+from tfkaldi_amd.neuralNetworks.classifiers import activation as act
+from tfkaldi_amd.neuralNetworks.classifiers import seq_convertors
+from tfkaldi_amd.neuralNetworks.classifiers.dnn import DNN
+from tfkaldi_amd.neuralNetworks.trainer import Trainer, microbatch_indices
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """the C-ABI library loads (no GPU needed) and exports exactly the functions include/tfkaldi_hip.h declares"""
+    header = open(os.path.join(ROOT, "include", "tfkaldi_hip.h")).read()
+    declared = set(re.findall(r"\b(tfk_[a-z0-9_]+)\s*\(", header)) - {"tfk_bucket_fn"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tfk_abi_version() == _lib.ABI_VERSION
+    assert ctypes.sizeof(_lib.TfkConfig) == 96  # layout of struct tfk_config (the C side re-checks struct_size)
+    nbytes = ctypes.c_size_t()
+    cfg = _lib.make_config(440, 6, 2048, 2000, batch_norm=True)
+    assert lib.tfk_state_bytes(ctypes.byref(cfg), ctypes.byref(nbytes)) == 0
+    # P = 25,995,216 parameters for cfg2; 4 copies (w, G, m, v) + small tails
+    assert 4 * 25995216 * 4 <= nbytes.value < 4 * 25995216 * 4 * 1.01
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tfkaldi_amd.engine import Engine
+    with pytest.raises(_lib.EngineError):
+        Engine(_lib.make_config(8, 1, 8, 4))
+
+
+def test_bad_config_is_rejected():
+    lib = _lib.load()
+    cfg = _lib.make_config(8, 1, 8, 4)
+    cfg.struct_size = 12
+    n = ctypes.c_size_t()
+    assert lib.tfk_state_bytes(ctypes.byref(cfg), ctypes.byref(n)) != 0
+    assert b"ABI mismatch" in lib.tfk_last_error()
+    with pytest.raises(Exception, match="unkown nonlinearity"):
+        _lib.make_config(8, 1, 8, 4, nonlin="softplus")
+
+
+def test_activation_chain_to_engine_options():
+    chain = act.Dropout(act.L2Norm(act.TfActivation(act.Batchnorm(None), "relu")), 0.5)
+    assert chain.chain_spec() == [("batch_norm", None), ("nonlin", "relu"), ("l2_norm", None), ("dropout", 0.5)]
+    assert act.engine_options(chain) == dict(batch_norm=True, nonlin="relu", l2_norm=True, keep_prob=0.5)
+    assert act.engine_options(act.TfActivation(None, np.tanh))["nonlin"] == "tanh"
+    assert act.engine_options(act.TfActivation(None, lambda x: x))["nonlin"] == "linear"
+    assert act.engine_options(act.TfActivation(None, lambda x: np.maximum(x, 0)))["nonlin"] == "relu"
+    with pytest.raises(Exception, match="unkown nonlinearity"):
+        act.TfActivation(None, np.square)
+    with pytest.raises(NotImplementedError):
+        act.engine_options(act.Batchnorm(act.TfActivation(None, "relu")))  # BN after the nonlinearity
+    with pytest.raises(AssertionError):
+        act.Dropout(None, 0.0)
+    with pytest.raises(TypeError):
+        chain(np.zeros((2, 2)))
+
+
+def test_dnn_engine_config():
+    dnn = DNN(2000, 6, 2048, act.TfActivation(act.Batchnorm(None), "relu"), False)
+    cfg = dnn.engine_config(440, init_learning_rate=1e-3, num_steps=100, max_frames=1024)
+    assert (cfg.input_dim, cfg.num_layers, cfg.num_units, cfg.output_dim) == (440, 6, 2048, 2000)
+    assert (cfg.batch_norm, cfg.nonlin, cfg.l2_norm, cfg.layerwise_init) == (1, 0, 0, 0)
+    hidden, out = dnn.layers()
+    rng = np.random.default_rng(0)
+    w = hidden.initial_weights(440, rng)
+    assert w.shape == (440, 2048) and abs(w.std() - 1 / np.sqrt(440)) < 1e-3
+    assert (out.initial_weights(2048, rng) == 0).all()  # weights_std = 0 (reference dnn.py:67-68)
+
+
+def test_microbatch_quirk_matches_reference_restatement():
+    # B % U == 0: the AURORA4 recipe, 128 / 16 -> 8 micro-batches
+    assert [len(m) for m in microbatch_indices(128, 16)] == [16] * 8
+    # B % U != 0: the reference pads with B % U dummies and floors: 5 utts, U = 4 -> only the first 4 are used
+    assert microbatch_indices(5, 4) == [[0, 1, 2, 3]]
+    assert microbatch_indices(7, 4) == [[0, 1, 2, 3], [4, 5, 6]]
+    assert microbatch_indices(1, 4) == []
+    for b in range(1, 40):
+        for u in range(1, 9):
+            assert microbatch_indices(b, u) == reference_microbatches(b, u)
+
+
+def test_seq_convertors_round_trip():
+    rng = np.random.default_rng(0)
+    lens = [5, 2, 7]
+    tmax, dim = 8, 3
+    seq = np.zeros((tmax, len(lens), dim), dtype=np.float32)
+    for s, n in enumerate(lens):
+        seq[:n, s] = rng.standard_normal((n, dim))
+    flat = seq_convertors.seq2nonseq(list(seq), lens)
+    assert flat.shape == (14, dim)
+    assert (flat[:5] == seq[:5, 0]).all() and (flat[5:7] == seq[:2, 1]).all()  # utterance-major, order kept
+    back = seq_convertors.nonseq2seq(flat, lens, tmax)
+    assert len(back) == tmax and (np.stack(back) == seq).all()
+
+
+def test_partition():
+    assert dataparallel.partition(8, 8) == [(i, i + 1) for i in range(8)]
+    assert dataparallel.partition(8, 2) == [(0, 4), (4, 8)]
+    assert dataparallel.partition(5, 3) == [(0, 2), (2, 4), (4, 5)]
+    assert dataparallel.partition(1, 2) == [(0, 1), (1, 1)]
+
+
+def test_trainer_is_abstract():
+    with pytest.raises(TypeError):
+        Trainer(None, 1, 1, 1, 1e-3, 1.0, 1, 1)
+
+
+# ---- Nnet.train control flow against a scripted trainer (KAT 8c-10) --------------------------------
+
+class ScriptedTrainer(object):
+    """records every call; validation losses come from a script"""
+    log = None
+    valid_losses = None
+
+    def __init__(self, classifier, input_dim, max_input_length, max_target_length, lr, decay, num_steps, U):
+        ScriptedTrainer.log.append(("init", input_dim, max_input_length, max_target_length, lr, decay, num_steps, U))
+        self.control_ops = {"add": self._op("add"), "init": self._op("init")}
+
+    def _op(self, name):
+        class Op(object):
+            def run(_self):
+                ScriptedTrainer.log.append((name,))
+        return Op()
+
+    def initialize(self): self.log.append(("initialize",))
+    def start_visualization(self, d): self.log.append(("visualise",))
+    def restore_trainer(self, f): self.log.append(("restore", os.path.basename(f)))
+    def save_trainer(self, f): self.log.append(("save", os.path.basename(f)))
+    def save_model(self, f): self.log.append(("save_model", os.path.basename(f)))
+    def halve_learning_rate(self): self.log.append(("halve",))
+    def close(self): self.log.append(("close",))
+
+    def evaluate(self, x, y):
+        self.log.append(("evaluate", len(x)))
+        return ScriptedTrainer.valid_losses.pop(0)
+
+    def update(self, x, y):
+        self.log.append(("update", len(x)))
+        return 1.0
+
+
+class ScriptedDispenser(object):
+    def __init__(self, size, num_batches):
+        self.size, self.num_batches = size, num_batches
+        self.max_input_length, self.max_target_length = 50, 50
+        self.pos = 0
+        self.events = []
+
+    def get_batch(self):
+        self.pos += 1
+        return [np.zeros((3, 4))] * self.size, [np.zeros(3, dtype=np.uint32)] * self.size
+
+    def split(self): self.events.append("split")
+    def skip_batch(self): self.pos += 1; self.events.append("skip")
+    def return_batch(self): self.pos -= 1; self.events.append("return")
+    def compute_target_count(self): return np.array([1, 3, 0, 4])
+
+
+def _conf(tmp_path, **over):
+    c = configparser.ConfigParser()
+    c.add_section("directories"); c.set("directories", "expdir", str(tmp_path))
+    c.add_section("nnet")
+    values = dict(name="net", context_width="5", num_hidden_units="16", num_hidden_layers="3", add_layer_period="0",
+                  starting_step="0", nonlin="relu", l2_norm="False", dropout="1", batch_norm="True", num_epochs="2",
+                  initial_learning_rate="0.001", learning_rate_decay="1", batch_size="4",
+                  numutterances_per_minibatch="2", valid_batches="2", valid_frequency="2", valid_adapt="True",
+                  valid_retries="1", check_freq="4", visualise="False")
+    values.update(over)
+    for k, v in values.items():
+        c.set("nnet", k, v)
+    return c
+
+
+def test_nnet_train_rollback_trace(tmp_path, monkeypatch, capsys):
+    monkeypatch.setattr(nnet_mod, "CrossEnthropyTrainer", ScriptedTrainer)
+    ScriptedTrainer.log = []
+    # initial 5.0; step 2: 4.0 (better); step 4: 4.5 (worse -> rollback, halve); step 4 again: 4.6 (worse, retries
+    # exhausted -> terminate)
+    ScriptedTrainer.valid_losses = [5.0, 4.0, 4.5, 4.6]
+    net = nnet_mod.Nnet(_conf(tmp_path), 40, 100)
+    assert net.input_dim == 440
+    disp = ScriptedDispenser(4, 4)
+    net.train(disp)
+    log = ScriptedTrainer.log
+    assert log[0] == ("init", 440, 50, 50, 0.001, 1.0, 8, 2)  # num_steps = num_batches * num_epochs
+    ops = [e[0] if e[0] not in ("save", "restore", "evaluate") else e for e in log[1:]]
+    assert ops == ["initialize", ("evaluate", 8), ("save", "validated"),
+                   "update", "update", ("evaluate", 8), ("save", "validated"),
+                   "update", "update", ("evaluate", 8), ("restore", "validated"), "halve",
+                   "update", "update", ("evaluate", 8), ("restore", "validated"), "halve",
+                   "save_model", "close"]
+    assert disp.events == ["split", "return", "return", "return", "return"]
+    out = capsys.readouterr().out
+    assert "validation loss at step 0: 5.000000" in out and "step 0/8 loss: 1.000000" in out
+    assert "returning to the previously validated model with halved learning rate" in out
+    assert "terminating training" in out
+    prior = np.load(os.path.join(str(tmp_path), "net", "prior.npy"))
+    assert prior.dtype == np.float32 and np.allclose(prior, [0.125, 0.375, 0, 0.5])
+
+
+def test_nnet_train_resume_layerwise_checkpoints(tmp_path, monkeypatch):
+    monkeypatch.setattr(nnet_mod, "CrossEnthropyTrainer", ScriptedTrainer)
+    ScriptedTrainer.log = []
+    ScriptedTrainer.valid_losses = [5.0] + [4.0 - 0.1 * i for i in range(20)]
+    conf = _conf(tmp_path, starting_step="5", add_layer_period="3", valid_adapt="False", num_epochs="3",
+                 numutterances_per_minibatch="-1")
+    net = nnet_mod.Nnet(conf, 40, 100)
+    assert net.dnn.layerwise_init
+    disp = ScriptedDispenser(4, 4)
+    net.train(disp)
+    log = ScriptedTrainer.log
+    assert log[0][-1] == 4 and log[0][-2] == 12      # -1 -> whole batch; 12 steps
+    assert disp.events[:5] == ["split", "skip", "skip", "skip", "skip"]  # resume at step 4 = 5 - 5 % 4
+    assert ("restore", "step4") in log
+    names = [e for e in log if e[0] in ("add", "init", "save")]
+    # layers are added at steps 6 (-> 3/3) ... only while step / period < num_hidden_layers; checkpoints at 8, 12
+    assert names == [("add",), ("init",), ("save", "validated"), ("save", "step8"),
+                     ("add",), ("init",), ("save", "validated"), ("save", "step12")] or \
+        [n for n in names if n[0] == "save" and n[1].startswith("step")] == [("save", "step8"), ("save", "step12")]
+
+
+def test_nnet_rejects_unknown_nonlinearity(tmp_path):
+    with pytest.raises(Exception, match="unkown nonlinearity"):
+        nnet_mod.Nnet(_conf(tmp_path, nonlin="maxout"), 40, 100)
+    with pytest.raises(KeyError):
+        c = _conf(tmp_path)
+        c.remove_option("nnet", "batch_norm")  # config_CGN.cfg lacks it: KeyError as in the reference
+        nnet_mod.Nnet(c, 40, 100)

@@ -773,11 +773,17 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
   const uint32_t call = e->call_counter++;
   CHK(forward(e, Xd, ld, N, 0, nact, nact, call));
   const float* prior = (flags & TFK_LOG_DIV_PRIOR) ? e->prior : nullptr;
+  const bool raw = (flags & TFK_RAW_LOGITS) != 0;
   if (flags & TFK_DEVICE_PTRS) {
-    ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * N * e->O);
-    softmax_rows(e->stream, e->logits, N, e->O, e->ldO, out, ldo, prior);
+    if (raw) {
+      HIPCHK(hipMemcpy2DAsync(out, (size_t)ldo * 4, e->logits, (size_t)e->ldO * 4, (size_t)e->O * 4, N,
+                              hipMemcpyDeviceToDevice, e->stream));
+    } else {
+      ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * N * e->O);
+      softmax_rows(e->stream, e->logits, N, e->O, e->ldO, out, ldo, prior);
+    }
   } else {
-    {
+    if (!raw) {
       ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * N * e->O);
       softmax_rows(e->stream, e->logits, N, e->O, e->ldO, e->post, e->ldO, prior);
     }
@@ -790,8 +796,8 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
       HIPCHK(hipHostMalloc((void**)&e->h_post, need * sizeof(float), hipHostMallocDefault));
       e->h_post_floats = need;
     }
-    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, e->post, (size_t)e->ldO * 4, (size_t)e->O * 4, N,
-                            hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, raw ? e->logits : e->post, (size_t)e->ldO * 4,
+                            (size_t)e->O * 4, N, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int t = 0; t < N; ++t) memcpy(out + (size_t)t * ldo, e->h_post + (size_t)t * e->O, (size_t)e->O * sizeof(float));
   }

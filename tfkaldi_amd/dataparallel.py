@@ -1,0 +1,127 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI) for the single exchange step of the path.
+
+The reference splits every optimiser step into B/U independent micro-batches whose only coupling is
+`G += g`, `batch_loss += loss`, `num_frames += n` (reference neuralNetworks/trainer.py:165-169) followed by
+one mean -> clip -> Adam (:174-184).  Running the micro-batches on different GPUs and SUM-all-reducing the
+engine's reduce region ([G | loss, frames, #micro-batches | BN moving-average increments]) before
+`apply` is therefore the same computation.  Micro-batches are assigned to ranks in contiguous blocks (rank
+order = the reference's serial order) so the BN moving averages compose exactly as its sequential updates
+do (tfk_set_later_microbatches).  The all-reduce is bucketed per layer and launched from the engine's
+bucket callback while the rest of backward is still being enqueued, i.e. overlapped with backward.
+
+Works with any object that has the Engine methods used below; tests drive it with world_size-2 gloo
+process groups on CPU.
+"""
+import contextlib
+import os
+
+
+def init_from_env():
+    """Join the process group described by torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); a no-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            use_gpu = torch.cuda.is_available()
+            if use_gpu:
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def partition(num_items, world):
+    """contiguous [start, end) blocks per rank, sizes differing by at most one (larger blocks first)"""
+    base, extra = divmod(num_items, world)
+    out, start = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+class DataParallel(object):
+    """Shards the micro-batches of one optimiser step over the ranks of a process group."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        except ImportError:
+            pass
+
+    @property
+    def enabled(self):
+        return self.world > 1
+
+    @staticmethod
+    def _stream_ctx(engine):
+        stream = getattr(engine, "torch_stream", None)
+        if stream is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(stream)
+
+    def train_step(self, engine, microbatches):
+        """`microbatches`: the (X[T, F], y[T]) micro-batches of the WHOLE step, identical on every rank.
+        Returns the average loss over all of them (reference Trainer.update's return value)."""
+        if not self.enabled:
+            for i, (X, y) in enumerate(microbatches):
+                engine.accumulate(X, y, last=(i == len(microbatches) - 1))
+            return engine.apply()
+        import torch.distributed as dist
+        start, end = partition(len(microbatches), self.world)[self.rank]
+        mine = microbatches[start:end]
+        engine.set_later_microbatches(len(microbatches) - end)
+        view, buckets = engine.reduce_view(), engine.buckets()
+        handles, errors = [], []
+
+        def on_bucket(b):
+            try:  # exceptions cannot propagate through the C callback
+                off, n = buckets[b]
+                with self._stream_ctx(engine):
+                    handles.append(dist.all_reduce(view[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True))
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        engine.set_bucket_callback(on_bucket)
+        try:
+            for i, (X, y) in enumerate(mine):
+                engine.accumulate(X, y, last=(i == len(mine) - 1))
+            if not mine:  # more ranks than micro-batches: contribute zeros
+                for b in range(len(buckets)):
+                    on_bucket(b)
+        finally:
+            engine.set_bucket_callback(None)
+        if errors:
+            raise errors[0]
+        with self._stream_ctx(engine):
+            for h in handles:
+                h.wait()
+        return engine.apply()
+
+    def eval_step(self, engine, microbatches):
+        """average validation loss (reference Trainer.evaluate); only the scalar tail is reduced"""
+        if not self.enabled:
+            for X, y in microbatches:
+                engine.eval_accumulate(X, y)
+            return engine.eval_finish()
+        import torch.distributed as dist
+        start, end = partition(len(microbatches), self.world)[self.rank]
+        for X, y in microbatches[start:end]:
+            engine.eval_accumulate(X, y)
+        off, n = engine.buckets()[-1]
+        with self._stream_ctx(engine):
+            dist.all_reduce(engine.reduce_view()[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
+        return engine.eval_finish()

@@ -176,11 +176,12 @@ class Engine(object):
         p = _f32(prior)
         check(self.lib.tfk_set_prior(self._h, p.ctypes.data_as(c_void_p), p.size))
 
-    def posteriors(self, X, log_div_prior=False):
+    def posteriors(self, X, log_div_prior=False, raw_logits=False):
         X = _f32(X)
         out = np.empty((X.shape[0], self.O), dtype=np.float32)
+        flags = (_lib.LOG_DIV_PRIOR if log_div_prior else 0) | (_lib.RAW_LOGITS if raw_logits else 0)
         check(self.lib.tfk_posteriors(self._h, X.ctypes.data_as(c_void_p), X.shape[1], X.shape[0],
-                                      out.ctypes.data_as(c_void_p), self.O, _lib.LOG_DIV_PRIOR if log_div_prior else 0))
+                                      out.ctypes.data_as(c_void_p), self.O, flags))
         return out
 
     # ---- data parallelism ----

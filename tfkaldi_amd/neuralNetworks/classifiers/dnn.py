@@ -1,0 +1,116 @@
+"""The DNN classifier (reference neuralNetworks/classifiers/dnn.py): `num_layers` hidden FFLayers sharing
+one activation chain plus a linear output layer, executed by the HIP engine."""
+import numpy as np
+
+from ... import _lib
+from ...engine import Engine
+from . import seq_convertors
+from .activation import TfActivation, engine_options
+from .classifier import Classifier
+from .layer import FFLayer
+
+
+class ModelSaver(object):
+    """Stands in for the `tf.train.Saver` the reference creates inside the classifier scope (dnn.py:129):
+    it holds every Classifier variable -- weights, biases, batch-norm beta and moving statistics,
+    `initialisedlayers` -- and nothing of the optimiser.  One file per checkpoint, written at exactly the
+    path prefix the caller gives (numpy .npz container)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def save(self, sess, filename):
+        with open(filename, "wb") as fid:
+            np.savez(fid, **self.engine.model_tensors())
+
+    def restore(self, sess, filename):
+        with np.load(filename) as data:
+            self.engine.load_model_tensors({k: data[k] for k in data.files})
+
+
+class ControlOp(object):
+    """a graph operation with a .run() (the reference's control_ops values are tf Operations)"""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def run(self, feed_dict=None, session=None):
+        self._fn()
+
+
+class DNN(Classifier):
+    """feed-forward fully connected network"""
+
+    def __init__(self, output_dim, num_layers, num_units, activation, layerwise_init=True):
+        super(DNN, self).__init__(output_dim)
+        self.num_layers = num_layers
+        self.num_units = num_units
+        self.activation = activation
+        self.layerwise_init = layerwise_init
+        self._scopes = {}
+
+    # ---- structure ----
+    def layers(self):
+        """the FFLayer objects of dnn.py:64-68: one shared hidden layer description and the output layer,
+        whose weights start at zero (weights_std = 0)"""
+        hidden = FFLayer(self.num_units, self.activation)
+        out = FFLayer(self.output_dim, TfActivation(None, "linear"), 0)
+        return hidden, out
+
+    def engine_config(self, input_dim, init_learning_rate=1e-3, learning_rate_decay=1.0, num_steps=1,
+                      max_frames=1024, seed=0, device=0):
+        opts = engine_options(self.activation)
+        return _lib.make_config(input_dim, self.num_layers, self.num_units, self.output_dim,
+                                layerwise_init=self.layerwise_init, init_learning_rate=init_learning_rate,
+                                learning_rate_decay=learning_rate_decay, num_steps=num_steps, max_frames=max_frames,
+                                seed=seed, device=device, **opts)
+
+    def create_engine(self, input_dim, torch_state=False, **options):
+        return Engine(self.engine_config(input_dim, **options), torch_state=torch_state)
+
+    def initialize(self, engine, rng):
+        """run the variable initialisers: hidden weights N(0, 1/sqrt(d_in)), output weights N(0, 0) = 0,
+        biases 0, beta 0, moving mean 0 / variance 1 (layer.py:39-48, dnn.py:67-68)"""
+        hidden, out = self.layers()
+        for l in range(self.num_layers):
+            d_in = engine.F if l == 0 else self.num_units
+            engine.set(_lib.WEIGHTS, l, hidden.initial_weights(d_in, rng))
+            engine.set(_lib.BIASES, l, np.zeros(self.num_units, dtype=np.float32))
+            if engine.batch_norm:
+                engine.set(_lib.BN_BETA, l, np.zeros(self.num_units, dtype=np.float32))
+                engine.set(_lib.BN_MOVING_MEAN, l, np.zeros(self.num_units, dtype=np.float32))
+                engine.set(_lib.BN_MOVING_VAR, l, np.ones(self.num_units, dtype=np.float32))
+        engine.set(_lib.WEIGHTS, self.num_layers, out.initial_weights(self.num_units, rng))
+        engine.set(_lib.BIASES, self.num_layers, np.zeros(self.output_dim, dtype=np.float32))
+        engine.set_scalar(_lib.INITIALISED_LAYERS, 0)
+
+    def control_ops(self, engine):
+        """{'add': ..., 'init': ...} with layer-wise initialisation, else None (dnn.py:114-122)"""
+        if not self.layerwise_init:
+            return None
+        return {"add": ControlOp(engine.add_layer), "init": ControlOp(engine.init_last_layer)}
+
+    # ---- the reference's call signature, evaluated eagerly ----
+    def __call__(self, inputs, seq_length, is_training=False, reuse=False, scope=None):
+        """Forward computation on sequential data: `inputs` is a list with a [batch, input_dim] array per
+        time step, `seq_length` the utterance lengths.  Returns (sequential logits, seq_length, saver,
+        control_ops) like reference dnn.py:37-131.  Variables live in `scope`; reuse=False creates them
+        (freshly initialised), reuse=True shares the ones created earlier.  Only inference mode is
+        available through this entry point -- training runs through a Trainer."""
+        if is_training:
+            raise NotImplementedError("training-mode evaluation runs through neuralNetworks.trainer.Trainer")
+        scope = scope or type(self).__name__
+        if reuse:
+            if scope not in self._scopes:
+                raise ValueError("Variable scope %s does not exist, reuse=True" % scope)
+            engine = self._scopes[scope]
+        else:
+            if scope in self._scopes:
+                raise ValueError("Variable scope %s already exists, did you mean to set reuse=True?" % scope)
+            engine = self.create_engine(int(np.asarray(inputs[0]).shape[1]))
+            self.initialize(engine, np.random.default_rng())
+            self._scopes[scope] = engine
+        flat = seq_convertors.seq2nonseq([np.asarray(x, dtype=np.float32) for x in inputs], seq_length)
+        logits = engine.posteriors(flat, raw_logits=True)
+        seq_logits = seq_convertors.nonseq2seq(logits, seq_length, len(inputs))
+        return seq_logits, seq_length, ModelSaver(engine), self.control_ops(engine)

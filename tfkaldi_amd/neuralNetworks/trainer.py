@@ -1,0 +1,212 @@
+"""Training environment with the reference's interface (neuralNetworks/trainer.py): Trainer,
+CrossEnthropyTrainer, CTCTrainer.
+
+The reference builds a TensorFlow graph (trainer.py:37-215) and drives it with session runs; here the
+"graph + session" is one HIP engine (include/tfkaldi_hip.h).  What each reference fetch became:
+
+    update_gradients_op.run(feed_dict)          -> engine.accumulate(X, y)      per micro-batch
+    [average_loss, apply_gradients_op] + re-init -> engine.apply()
+    update_valid_loss.run / average_loss.eval()  -> engine.eval_accumulate / eval_finish
+    modelsaver / saver                           -> ModelSaver (.npz) / <prefix>_trainvars (.npz)
+
+The host never pads: the reference zero-pads every utterance to max_input_length in float64 and the graph
+immediately strips the padding again (trainer.py:298-307, seq_convertors.py:12-39); the engine takes the
+flat utterance-major [T, F] matrix that seq2nonseq would have produced.
+"""
+import json
+import os
+from abc import ABCMeta, abstractmethod
+
+import numpy as np
+
+from .. import _lib
+from ..dataparallel import DataParallel
+from .classifiers.dnn import ModelSaver
+
+
+class _Graph(object):
+    """placeholder for the `.graph` attribute (reference callers pass it to tf.Session, nnet.py:134)"""
+
+    def finalize(self):
+        pass
+
+
+class _StepVariable(object):
+    """`.global_step` with the .eval() of a tf Variable (trainer.py:98-100, 342)"""
+
+    def __init__(self, engine):
+        self._engine = engine
+
+    def eval(self, session=None):
+        return self._engine.global_step
+
+
+def microbatch_indices(num_utt, per_minibatch):
+    """Utterance indices of the micro-batches the reference feeds (trainer.py:280-332).  It appends
+    `num_utt % U` zero-length dummy utterances (sic -- not U - num_utt % U) and runs floor(len / U)
+    micro-batches, so with num_utt % U != 0 the tail can be truncated; the dummies contribute nothing."""
+    U = per_minibatch
+    total = num_utt + (num_utt % U)
+    return [[i for i in range(k * U, (k + 1) * U) if i < num_utt] for k in range(total // U)]
+
+
+class Trainer(object, metaclass=ABCMeta):
+    """General class for the training environment of a neural-net classifier"""
+
+    def __init__(self, classifier, input_dim, max_input_length, max_target_length, init_learning_rate,
+                 learning_rate_decay, num_steps, numutterances_per_minibatch, seed=None, device=None):
+        """
+        Args (as reference trainer.py:13-31):
+            classifier: the neural net classifier that will be trained
+            input_dim: the input dimension to the nnnetgraph
+            max_input_length: the maximal length of the input sequences
+            max_target_length: the maximal length of the target sequences
+            init_learning_rate: the initial learning rate
+            learning_rate_decay: the parameter for exponential learning rate decay
+            num_steps: the total number of steps that will be taken
+            numutterances_per_minibatch: how many utterances are processed at a time
+        Extra (optional): seed for weight initialisation / dropout, HIP device ordinal
+        """
+        self.numutterances_per_minibatch = numutterances_per_minibatch
+        self.max_input_length = max_input_length
+        self.max_target_length = max_target_length
+        self.classifier = classifier
+        self.input_dim = input_dim
+        self._seed = seed if seed is not None else int.from_bytes(os.urandom(4), "little")
+        self.dp = DataParallel()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if self.dp.enabled else 0
+        self.graph = _Graph()
+        # the loss is part of the graph: abstract in the base class (trainer.py:219-242)
+        self.loss_kind = self.compute_loss(None, None, None, None)
+        if self.loss_kind != "cross_enthropy":
+            raise NotImplementedError("the HIP engine implements the cross-enthropy loss only")
+        max_frames = max(1, int(numutterances_per_minibatch)) * max(1, int(max_input_length))
+        self.engine = classifier.create_engine(
+            input_dim, torch_state=self.dp.enabled, init_learning_rate=init_learning_rate,
+            learning_rate_decay=learning_rate_decay, num_steps=num_steps, max_frames=min(max_frames, 1 << 16),
+            seed=self._seed, device=device)
+        self.modelsaver = ModelSaver(self.engine)
+        self.control_ops = classifier.control_ops(self.engine)
+        self.global_step = _StepVariable(self.engine)
+        self.summarywriter = None
+        self.graph.finalize()
+
+    @abstractmethod
+    def compute_loss(self, targets, logits, logit_seq_length, target_seq_length):
+        """the loss of the training graph; subclasses name the loss the engine runs"""
+        raise NotImplementedError("Abstract method")
+
+    def initialize(self):
+        """Initialize all the variables (reference trainer.py:244-247): random hidden weights, zero output
+        layer, step counters, Adam state.  Every data-parallel rank draws the same weights."""
+        if self.dp.enabled:
+            import torch
+            import torch.distributed as dist
+            seed = torch.tensor([self._seed], dtype=torch.int64)
+            if dist.get_backend(self.dp.group) == "nccl":
+                seed = seed.cuda(self.engine.cfg.device)
+            dist.broadcast(seed, src=0, group=self.dp.group)
+            self._seed = int(seed.item())
+        self.classifier.initialize(self.engine, np.random.default_rng(self._seed))
+        for l in range(self.engine.L + 1):
+            for kind in (_lib.WEIGHTS, _lib.BIASES) + ((_lib.BN_BETA,) if self.engine.batch_norm and l < self.engine.L else ()):
+                zeros = np.zeros(self.engine._shape(kind, l), dtype=np.float32)
+                for slot in (_lib.SLOT_GRAD, _lib.SLOT_ADAM_M, _lib.SLOT_ADAM_V):
+                    self.engine.set(kind, l, zeros, slot)
+        self.engine.set_scalar(_lib.GLOBAL_STEP, 0)
+        self.engine.set_scalar(_lib.LEARNING_RATE_FACT, 1.0)
+        self.engine.set_scalar(_lib.ADAM_STEPS, 0)
+
+    def start_visualization(self, logdir):
+        """open a summary log (the reference writes TensorBoard events: trainer.py:249-258); one JSON line
+        per update with step, loss and learning rate is appended to <logdir>/summaries.jsonl"""
+        os.makedirs(logdir, exist_ok=True)
+        self.summarywriter = open(os.path.join(logdir, "summaries.jsonl"), "a")
+
+    # ---- batching ----
+    def _microbatches(self, inputs, targets):
+        out = []
+        for idx in microbatch_indices(len(inputs), self.numutterances_per_minibatch):
+            if not idx:
+                continue
+            for i in idx:
+                if inputs[i].shape[0] != targets[i].shape[0]:
+                    raise ValueError("utterance %d: %d input frames but %d targets (the cross-enthropy trainer "
+                                     "needs equal lengths)" % (i, inputs[i].shape[0], targets[i].shape[0]))
+            X = np.concatenate([np.asarray(inputs[i], dtype=np.float32) for i in idx], axis=0)
+            y = np.concatenate([np.asarray(targets[i]).astype(np.int32) for i in idx], axis=0)
+            if X.shape[0] > 0:
+                out.append((X, y))
+        return out
+
+    def update(self, inputs, targets):
+        """
+        update the neural model with a batch of training data
+
+        Args:
+            inputs: a list containing an NxF matrix for each utterance in the batch
+            targets: a list containing an N-dimensional vector for each utterance
+        Returns:
+            the loss at this step (batch_loss / num_frames, evaluated before the parameter update)
+        """
+        loss = self.dp.train_step(self.engine, self._microbatches(inputs, targets))
+        if self.summarywriter is not None:
+            self.summarywriter.write(json.dumps({"step": self.engine.global_step, "loss": loss,
+                                                 "learning_rate": self.engine.scalar(_lib.LEARNING_RATE)}) + "\n")
+            self.summarywriter.flush()
+        return loss
+
+    def evaluate(self, inputs, targets):
+        """the loss of the batch in evaluation mode; None when there is no data (trainer.py:372-373)"""
+        if inputs is None or targets is None:
+            return None
+        return self.dp.eval_step(self.engine, self._microbatches(inputs, targets))
+
+    def halve_learning_rate(self):
+        self.engine.halve_learning_rate()
+
+    # ---- persistence (path prefixes chosen by the caller: nnet.py:140, 148, 206, 233, 238) ----
+    def save_model(self, filename):
+        self.modelsaver.save(None, filename)
+
+    def restore_model(self, filename):
+        self.modelsaver.restore(None, filename)
+
+    def save_trainer(self, filename):
+        """model + the `train_variables` scope: global_step and learning_rate_fact.  As in the reference
+        (trainer.py:204-205) the Adam moments and beta powers are NOT part of a checkpoint."""
+        self.modelsaver.save(None, filename)
+        with open(filename + "_trainvars", "wb") as fid:
+            np.savez(fid, global_step=np.array(self.engine.global_step, dtype=np.int64),
+                     learning_rate_fact=np.array(self.engine.scalar(_lib.LEARNING_RATE_FACT), dtype=np.float64))
+
+    def restore_trainer(self, filename):
+        self.modelsaver.restore(None, filename)
+        with np.load(filename + "_trainvars") as data:
+            self.engine.set_scalar(_lib.GLOBAL_STEP, int(data["global_step"]))
+            self.engine.set_scalar(_lib.LEARNING_RATE_FACT, float(data["learning_rate_fact"]))
+
+    def close(self):
+        if self.summarywriter is not None:
+            self.summarywriter.close()
+            self.summarywriter = None
+        self.engine.close()
+
+
+class CrossEnthropyTrainer(Trainer):
+    """A trainer that minimises the cross-enthropy loss; the output sequences must be of the same length as
+    the input sequences (reference trainer.py:488-531).  The loss is the SUM over frames of
+    softmax_cross_entropy_with_logits against the one-hot pdf-ids."""
+
+    def compute_loss(self, targets, logits, logit_seq_length, target_seq_length):
+        return "cross_enthropy"
+
+
+class CTCTrainer(Trainer):
+    """The reference's CTCTrainer.compute_loss (trainer.py:533-570) cannot run: it iterates over
+    range(len(batch_size)) of an int, fills the sparse targets from the logits and returns nothing, and
+    the repository has no recurrent classifier to train with it.  There is no behaviour to reproduce."""
+
+    def compute_loss(self, targets, logits, logit_seq_length, target_seq_length):
+        raise NotImplementedError("CTC training is not functional in the reference (trainer.py:558-570)")
