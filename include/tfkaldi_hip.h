@@ -161,6 +161,10 @@ int tfk_set_prior(tfk_engine* e, const float* prior, size_t count); /* prior.npy
  * one micro-batch on each of B/U GPUs the same computation.  Buckets: b in [0, L] is the
  * gradient span of layer L - b (the order backward produces them), bucket L + 1 the scalars + BN tail. */
 int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
+/* `init_grads` / `init_loss` / `init_num_frames` (trainer.py:350-352) done eagerly: writes zeros over the whole
+ * reduce region.  tfk_apply re-initialises lazily (the next step's first micro-batch overwrites G), so a rank
+ * that contributes NO micro-batch to a step must call this before the all-reduce. */
+int tfk_zero_accumulators(tfk_engine* e);
 int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* num_floats);
 int tfk_num_buckets(tfk_engine* e, int* n);
 

@@ -54,7 +54,7 @@ class TorchCpuTrainer(object):
         with torch.no_grad():
             for G, g in zip(self.G, grads):
                 G.add_(g)
-        self.loss += float(loss)
+        self.loss += float(loss.detach())
         self.frames += int(a.shape[0])
 
     def apply(self):

@@ -34,6 +34,9 @@ class OracleEngine(object):
     def reduce_view(self):
         return self.region
 
+    def zero_accumulators(self):
+        self.region.zero_()
+
     def set_later_microbatches(self, later):
         self.later = later
 

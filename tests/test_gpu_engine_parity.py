@@ -59,6 +59,8 @@ def test_accumulate_matches_oracle(gpu, chain):
         copy_oracle_to_engine(oracle, eng)
     T = 75
     X, y = batch(rng, T, kw["input_dim"], kw["output_dim"])
+    if chain.get("big"):
+        X[: T // 2] *= 0.02  # quiet frames stay below the L2Norm threshold, loud ones exceed it
     eng.accumulate(X, y)
     oracle.accumulate(X, y, _masks(eng, T))
     # the buffer holds dLogits = softmax - onehot after the backward pass

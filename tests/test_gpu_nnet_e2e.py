@@ -96,7 +96,7 @@ def test_nnet_train_and_decode(gpu, tmp_path, capsys):
                      add_layer_period="3", starting_step="0", nonlin="relu", l2_norm="False", dropout="1",
                      batch_norm="True", num_epochs="2", initial_learning_rate="0.01", learning_rate_decay="1",
                      batch_size="4", numutterances_per_minibatch="2", valid_batches="1", valid_frequency="2",
-                     valid_adapt="True", valid_retries="3", check_freq="4", visualise="True").items():
+                     valid_adapt="False", valid_retries="3", check_freq="4", visualise="True").items():
         conf.set("nnet", k, v)
     net = nnet.Nnet(conf, F_RAW, O)
     disp = _dispenser(paths, 4)

@@ -66,6 +66,7 @@ SYMBOLS = {
     "tfk_posteriors": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int]),
     "tfk_set_prior": (c_int, [_E, c_void_p, c_size_t]),
     "tfk_reduce_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t)]),
+    "tfk_zero_accumulators": (c_int, [_E]),
     "tfk_reduce_bucket": (c_int, [_E, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "tfk_num_buckets": (c_int, [_E, POINTER(c_int)]),
     "tfk_set_bucket_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
@@ -91,6 +92,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # The engine shares device memory and streams with torch in one process, so both must bind the SAME
+        # HIP runtime: torch's bundled libamdhip64 has to be loaded before this library is dlopen'ed.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(

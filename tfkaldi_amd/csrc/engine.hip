@@ -118,6 +118,9 @@ struct tfk_engine {
   int initialised_layers = 0;
   uint32_t call_counter = 0;
   int later_mb = 0;
+  // G is logically zero after apply (init_grads, trainer.py:350) but is not rewritten: the first
+  // micro-batch of the next step overwrites it instead of accumulating (saves 3 x 4P bytes per step).
+  bool grads_fresh = true;
 
   tfk_bucket_fn cb = nullptr;
   void* cb_user = nullptr;
@@ -381,12 +384,17 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   const int L = e->L, H = e->H, ldH = e->ldH;
   const LayerLayout& o = e->lay[L];
   float* G = e->p_grad();
+  const int acc = e->grads_fresh ? 0 : 1;
+  const int epi_w = acc ? EPI_ACCUM : 0;
+  if (!acc)  // layers above the active depth are not visited below: their (logically zero) G must be zero
+    for (int l = nact; l < L; ++l)
+      HIPCHK(hipMemsetAsync(G + e->lay[l].begin, 0, (e->lay[l].end - e->lay[l].begin) * sizeof(float), e->stream));
   // output layer: dZ = softmax - onehot sits in `logits`
   CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
-               EPI_ACCUM));
+               epi_w));
   {
     ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
-    colsum_accum(e->stream, e->logits, T, e->O, e->ldO, G + o.b_off, e->ws);
+    colsum_accum(e->stream, e->logits, T, e->O, e->ldO, G + o.b_off, acc, e->ws);
   }
   if (fire && e->cb) e->cb(e->cb_user, 0);
   int pp = 0;
@@ -404,11 +412,11 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
       hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l],
-                      e->cfg.batch_norm ? G + y.beta_off : nullptr, G + y.b_off, T, H, ldH, e->ws);
+                      e->cfg.batch_norm ? G + y.beta_off : nullptr, G + y.b_off, acc, T, H, ldH, e->ws);
     }
     const float* in = l == 0 ? Xd : e->a[l - 1];
     const int ld_in = l == 0 ? ldx : ldH;
-    CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, EPI_ACCUM));
+    CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w));
     if (l > 0) CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, 0));
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
@@ -568,6 +576,7 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
       }
       if (e->cb) e->cb(e->cb_user, e->L + 1);
     }
+    e->grads_fresh = false;
   }
   HIPCHK(hipGetLastError());
   CHK(finish_slot(e, flags, slot_before));
@@ -634,6 +643,10 @@ int tfk_tensor_get(tfk_engine* e, int kind, int slot, int layer, float* host, si
   CHK(tensor_ref(e, kind, slot, layer, &t));
   if (count != (size_t)t.rows * t.cols) return fail(-1, "count %zu != %d x %d", count, t.rows, t.cols);
   HIPCHK(hipSetDevice(e->cfg.device));
+  if (slot == TFK_SLOT_GRAD && e->grads_fresh) {  // logically zero (not yet rewritten in memory)
+    memset(host, 0, count * sizeof(float));
+    return 0;
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy2D(host, (size_t)t.cols * 4, t.ptr, (size_t)t.ld * 4, (size_t)t.cols * 4, t.rows, hipMemcpyDeviceToHost));
   return 0;
@@ -645,6 +658,10 @@ int tfk_tensor_set(tfk_engine* e, int kind, int slot, int layer, const float* ho
   CHK(tensor_ref(e, kind, slot, layer, &t));
   if (count != (size_t)t.rows * t.cols) return fail(-1, "count %zu != %d x %d", count, t.rows, t.cols);
   HIPCHK(hipSetDevice(e->cfg.device));
+  if (slot == TFK_SLOT_GRAD && e->grads_fresh) {
+    HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
+    e->grads_fresh = false;
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy2D(t.ptr, (size_t)t.ld * 4, host, (size_t)t.cols * 4, (size_t)t.cols * 4, t.rows, hipMemcpyHostToDevice));
   return 0;
@@ -703,6 +720,8 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); w -= lr_t * m / (sqrt(v) + eps)
   const double t = (double)e->adam_t;
   const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
+  if (e->grads_fresh)  // no micro-batch since the last apply: materialise the zeros Adam is about to read
+    HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
   {
     ProfScope ps(e, KF_ADAM, 0, 28.0 * e->P);
     adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
@@ -714,6 +733,7 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   }
   HIPCHK(hipGetLastError());
   CHK(read_scalars(e, true));
+  e->grads_fresh = true;
   e->global_step += 1;
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
   return 0;
@@ -828,6 +848,13 @@ int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* 
     *offset_floats = y.begin;
     *num_floats = y.end - y.begin;
   }
+  return 0;
+}
+int tfk_zero_accumulators(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->reduce_floats * sizeof(float), e->stream));
+  e->grads_fresh = false;  // physically zero now
   return 0;
 }
 int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user) {

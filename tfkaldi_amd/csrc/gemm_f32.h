@@ -36,13 +36,15 @@ struct GemmArgs {
 };
 
 // Tile configurations (compile-time instantiated); index = config id.
-//   0: 128x128 block, 4 waves of 64x64
-//   1: 128x64  block, 4 waves of 64x32
-//   2:  64x128 block, 4 waves of 32x64
-//   3:  64x64  block, 4 waves of 32x32
-//   4: 128x128 block, 8 waves of 64x32
-//   5: 256x128 block, 8 waves of 64x64
-constexpr int kNumGemmConfigs = 6;
+// (sN = LDS ring slots, pN = global-load prefetch distance in tiles)
+//   0: 128x128 block, 4 waves of 64x64, s2 p1     5: 256x128 block, 8 waves of 64x64, s2 p1
+//   1: 128x64  block, 4 waves of 64x32, s3 p2     6:  64x128 block, 8 waves of 32x32, s3 p2
+//   2:  64x128 block, 4 waves of 32x64, s3 p2     7: 128x64  block, 8 waves of 32x32, s3 p2
+//   3:  64x64  block, 4 waves of 32x32, s3 p2     8:  64x64  block, 4 waves of 32x32, s3 p1
+//   4: 128x128 block, 8 waves of 64x32, s3 p1
+// The heuristic uses 0 (>= 512 tiles of 128x128) and 3 (everything smaller); the rest are kept for the sweep
+// tool (tools/gemm_sweep.py) that produced profiles/r01_gemm_sweep_*.txt.
+constexpr int kNumGemmConfigs = 9;
 
 // cfg < 0 => heuristic choice. Returns hipError_t as int.
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream);

@@ -1,4 +1,4 @@
-// fp32 MFMA GEMM for gfx950 (CDNA4): LDS-tiled, register-staged, double-buffered.
+// fp32 MFMA GEMM for gfx950 (CDNA4): LDS-tiled, register-staged, software-pipelined.
 //
 // Replaces the TensorFlow matmul kernels behind neuralNetworks/classifiers/layer.py:52 and the
 // tf.gradients of it (neuralNetworks/trainer.py:155) -- see gemm_f32.h for the three layouts.
@@ -13,11 +13,16 @@
 //     an operand contiguous along m/n ("MC") uses one conflict-free ds_read_b32 per step.
 //   * LDS rows of KC tiles are padded by 4 floats (row stride 36 floats = 9 x 16 B, odd in 16-B slots)
 //     so the 16-lane service groups of ds_read_b128 hit 16 distinct slots.
-//   * One barrier per K-tile (two LDS buffers); the next tile's global loads are issued before the
-//     MFMA block of the current tile so L2/HBM latency hides under ~1-4k cycles of matrix work.
+//   * Pipeline (NSTAGE = 3): iteration t writes the register-staged tile t+2 into ring slot (t+2)%3,
+//     issues the global loads of tile t+3, and computes tile t.  Tile t+1 has been visible in LDS since
+//     the previous barrier, so the fragments of its first k-group are fetched BEFORE this iteration's
+//     barrier, under the last MFMAs of tile t: the matrix pipe never waits for an LDS round trip after a
+//     barrier.  Fragment registers are double-buffered inside a tile as well.  (NSTAGE = 2 is the plain
+//     double buffer for the tiles whose 3-slot ring would not fit two blocks per CU.)
 //   * Tiles are walked in a grouped order (8 tile-rows, column-major inside) and the sequence is cut
 //     into 8 contiguous chunks, one per XCD (block b runs on XCD b % 8), so each XCD's L2 sees a
 //     compact ~8x8 patch of tiles that share A row-panels and B column-panels.
+//   * Epilogues are compile-time: the accumulate form loads its 16 C values per fragment as one batch.
 #include "gemm_f32.h"
 
 #include <stdio.h>
@@ -30,13 +35,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
+constexpr int NG = BK / 8;  // k-groups per tile (even: fragment double-buffer parity is tile-invariant)
 constexpr int KC_PAD = 4;
 constexpr int GROUP_ROWS = 8;
 constexpr int NUM_XCD = 8;
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KC_, bool B_KC_>
+// NSTAGE_: LDS ring slots (2 or 3); PF_: global-load prefetch distance in tiles beyond the ring (1 or 2
+// register sets in flight; 2 only with the 3-slot ring).
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int PF_, bool A_KC_, bool B_KC_>
 struct Tile {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, PF = PF_;
+  static_assert(PF_ == 1 || (PF_ == 2 && NSTAGE_ == 3), "prefetch distance");
   static constexpr bool A_KC = A_KC_, B_KC = B_KC_;
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
   static constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -48,37 +57,62 @@ struct Tile {
   static constexpr int B_LD = B_KC ? (BK + KC_PAD) : BN;
   static constexpr int B_SZ = (B_KC ? BN : BK) * B_LD;
   static constexpr int STAGE = A_SZ + B_SZ;
-  static constexpr int LDS_BYTES = 2 * STAGE * 4;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE * 4;
   // global staging: float4 per thread per tile
   static constexpr int A_F4 = BM * BK / 4 / NT;
   static constexpr int B_F4 = BN * BK / 4 / NT;
   static_assert(BM % WM == 0 && BN % WN == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "staging divisibility");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-// Operand tile loader: ROWS_KC = tile extent along m (or n); `kc` selects the memory order.
+// Operand tile loader: EXT = tile extent along m (or n); KC selects the memory order.
+// Loads go through a buffer resource (hardware bounds check): an out-of-range element is requested at an
+// offset beyond num_records and comes back as 0 WITHOUT a branch, so the K-loop stays one basic block and
+// the loads / LDS writes can be scheduled into the gaps between MFMAs.
+constexpr int kOOB = (int)0x80000000;
+
 template <int EXT, int NT, int NF4, bool KC>
-__device__ __forceinline__ void load_tile(float4 (&r)[NF4], const float* __restrict__ base, int ld,
-                                          int ext0, int ext_lim, int k0, int k_lim, int tid) {
+struct TileLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[NF4];   // byte offset of this thread's float4 inside the matrix, k-tile term excluded;
+                   // kOOB when its m/n coordinate is outside the matrix
+  int kidx[NF4];   // its k coordinate inside a tile
+  int kstride;     // bytes per unit of k (4 for KC, 4*ld for MC)
+  int k_lim;
+
+  __device__ __forceinline__ void init(const float* base, int ld, int rows, int ext0, int ext_lim, int k_lim_,
+                                       int tid) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ld * 4, 0x00020000);
+    k_lim = k_lim_;
+    kstride = KC ? 4 : ld * 4;
 #pragma unroll
-  for (int i = 0; i < NF4; ++i) {
-    const int idx = tid + i * NT;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
-      // memory [ext][k]: 8 float4 per 32-k row
-      const int e = ext0 + (idx >> 3);
-      const int k = k0 + ((idx & 7) << 2);
-      if (e < ext_lim && k < k_lim) v = *reinterpret_cast<const float4*>(base + (size_t)e * ld + k);
-    } else {
-      // memory [k][ext]: EXT/4 float4 per k row
-      constexpr int C4 = EXT / 4;
-      const int k = k0 + idx / C4;
-      const int e = ext0 + ((idx % C4) << 2);
-      if (k < k_lim && e < ext_lim) v = *reinterpret_cast<const float4*>(base + (size_t)k * ld + e);
+    for (int i = 0; i < NF4; ++i) {
+      const int idx = tid + i * NT;
+      int e, k;
+      if (KC) {  // memory [ext][k]: 8 float4 per 32-k row
+        e = ext0 + (idx >> 3);
+        k = (idx & 7) << 2;
+        voff[i] = e < ext_lim ? (e * ld + k) * 4 : kOOB;
+      } else {   // memory [k][ext]: EXT/4 float4 per k row
+        constexpr int C4 = EXT / 4;
+        k = idx / C4;
+        e = ext0 + ((idx % C4) << 2);
+        voff[i] = e < ext_lim ? (k * ld + e) * 4 : kOOB;
+      }
+      kidx[i] = k;
     }
-    r[i] = v;
   }
-}
+  __device__ __forceinline__ void load(float4 (&r)[NF4], int k0) const {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int off = (k0 + kidx[i] < k_lim) ? voff[i] : kOOB;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, k0 * kstride, 0);
+      r[i] = *reinterpret_cast<const float4*>(&v);
+    }
+  }
+};
 
 template <int EXT, int NT, int NF4, bool KC, int LD>
 __device__ __forceinline__ void store_tile(const float4 (&r)[NF4], float* __restrict__ s, int tid) {
@@ -112,7 +146,7 @@ __device__ __forceinline__ void read_frags(float (&f)[NF][4], const float* __res
   }
 }
 
-template <class T>
+template <class T, int EPI>
 __global__ void __launch_bounds__(T::NT)
 gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -158,104 +192,267 @@ gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 ra[T::A_F4], rb[T::B_F4];
+  float4 ra[T::PF][T::A_F4], rb[T::PF][T::B_F4];
+  float fa[2][T::FM][4], fb[2][T::FN][4];
   const int nk = (p.K + BK - 1) / BK;
 
-  load_tile<T::BM, T::NT, T::A_F4, T::A_KC>(ra, p.A, p.lda, m0, a_ext_lim, 0, a_k_lim, tid);
-  load_tile<T::BN, T::NT, T::B_F4, T::B_KC>(rb, p.B, p.ldb, n0, b_ext_lim, 0, b_k_lim, tid);
-  store_tile<T::BM, T::NT, T::A_F4, T::A_KC, T::A_LD>(ra, smem, tid);
-  store_tile<T::BN, T::NT, T::B_F4, T::B_KC, T::B_LD>(rb, smem + T::A_SZ, tid);
-  __syncthreads();
+  TileLoader<T::BM, T::NT, T::A_F4, T::A_KC> lda_;
+  TileLoader<T::BN, T::NT, T::B_F4, T::B_KC> ldb_;
+  lda_.init(p.A, p.lda, T::A_KC ? p.M : p.K, m0, a_ext_lim, a_k_lim, tid);
+  ldb_.init(p.B, p.ldb, T::B_KC ? p.N : p.K, n0, b_ext_lim, b_k_lim, tid);
+#define TFK_LOAD(set, kt)            \
+  do {                               \
+    lda_.load(ra[set], (kt) * BK);   \
+    ldb_.load(rb[set], (kt) * BK);   \
+  } while (0)
+#define TFK_STORE(set, slot)                                                                    \
+  do {                                                                                          \
+    store_tile<T::BM, T::NT, T::A_F4, T::A_KC, T::A_LD>(ra[set], (slot), tid);                  \
+    store_tile<T::BN, T::NT, T::B_F4, T::B_KC, T::B_LD>(rb[set], (slot) + T::A_SZ, tid);        \
+  } while (0)
+#define TFK_FRAGS(buf, slot, g)                                                            \
+  do {                                                                                     \
+    read_frags<T::FM, T::A_KC, T::A_LD>(fa[buf], (slot), wm * T::WM, (g), i, h);           \
+    read_frags<T::FN, T::B_KC, T::B_LD>(fb[buf], (slot) + T::A_SZ, wn * T::WN, (g), i, h); \
+  } while (0)
+#define TFK_MFMA(buf)                                                                                       \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                             \
+  _Pragma("unroll") for (int a = 0; a < T::FM; ++a)                                                         \
+  _Pragma("unroll") for (int b = 0; b < T::FN; ++b)                                                         \
+    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][a][t], fb[buf][b][t], acc[a][b], 0, 0, 0)
 
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      const int k0 = (kt + 1) * BK;
-      load_tile<T::BM, T::NT, T::A_F4, T::A_KC>(ra, p.A, p.lda, m0, a_ext_lim, k0, a_k_lim, tid);
-      load_tile<T::BN, T::NT, T::B_F4, T::B_KC>(rb, p.B, p.ldb, n0, b_ext_lim, k0, b_k_lim, tid);
-    }
-    const float* As = smem + cur * T::STAGE;
-    const float* Bs = As + T::A_SZ;
-#pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      float fa[T::FM][4], fb[T::FN][4];
-      read_frags<T::FM, T::A_KC, T::A_LD>(fa, As, wm * T::WM, g, i, h);
-      read_frags<T::FN, T::B_KC, T::B_LD>(fb, Bs, wn * T::WN, g, i, h);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int a = 0; a < T::FM; ++a)
-#pragma unroll
-          for (int b = 0; b < T::FN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][t], fb[b][t], acc[a][b], 0, 0, 0);
-    }
-    if (more) {
-      float* Ad = smem + (cur ^ 1) * T::STAGE;
-      store_tile<T::BM, T::NT, T::A_F4, T::A_KC, T::A_LD>(ra, Ad, tid);
-      store_tile<T::BN, T::NT, T::B_F4, T::B_KC, T::B_LD>(rb, Ad + T::A_SZ, tid);
-    }
+  if (T::NSTAGE == 3) {
+    // ring slots as rotating pointers: s0 = tile t, s1 = tile t+1, s2 = tile t+2
+    float* s0 = smem;
+    float* s1 = smem + T::STAGE;
+    float* s2 = smem + 2 * T::STAGE;
+    // Prologue (unconditional: tiles past the end of K load as zeros): tiles 0 and 1 go to the ring, tiles
+    // 2 .. 1+PF stay in the register sets until their iteration stores them.
+    TFK_LOAD(0, 0);
+    TFK_STORE(0, s0);
+    TFK_LOAD(0, 1);
+    TFK_STORE(0, s1);
+    TFK_LOAD(0, 2);
+    if (T::PF == 2) TFK_LOAD(1, 3);
     __syncthreads();
-    cur ^= 1;
+    TFK_FRAGS(0, s0, 0);
+    // One iteration = ONE basic block.  Schedule pins (sched_barrier): every k-group first issues the NEXT
+    // group's fragment reads, then its four MFMAs; the ring-slot write of tile kt+2 rides in the gaps of
+    // group 0 and the global loads of tile kt+2+PF follow at once into the register set just freed, so their
+    // data has PF full MFMA blocks (PF x ~1000 cycles for a 32x32 wave tile) to arrive.  Past the end of K
+    // the loads return zeros (kOOB) and the MFMAs of a rounded-up trip count add zeros.
+// TFK_ABL (tools/gemm_ablate.sh only): timing-only variants with pieces of the loop removed --
+// 1 global loads, 2 ring-slot writes, 4 fragment reads, 8 barrier.  Results are then meaningless.
+#ifndef TFK_ABL
+#define TFK_ABL 0
+#endif
+// Instruction placement inside one iteration (sched_group_barrier = "emit N instructions of this class
+// here"): an MFMA occupies the SIMD's matrix pipe for 64 cycles, and whatever the wave issues before its
+// next MFMA must fit in that gap or the pipe idles.  Measured (tools/gemm_ablate.sh): four back-to-back
+// ds_write_b128 (13+ issue cycles each plus LDS data-FIFO back-pressure) in one gap cost 20 % of the kernel;
+// so group 0 interleaves ONE ring-slot write per MFMA, group 1 ONE global load per MFMA, and every group
+// starts with the fragment reads of the group after it.
+#define TFK_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#define TFK_ITER(SET, KT)                                                   \
+  do {                                                                      \
+    constexpr int MFG = 4 * T::FM * T::FN;          /* MFMAs per k-group */  \
+    constexpr int NST = T::A_F4 + T::B_F4;          /* staging float4 per thread */ \
+    constexpr int NIL = NST < MFG ? NST : MFG;                              \
+    if (!(TFK_ABL & 4)) TFK_FRAGS(1, s0, 1);                                \
+    TFK_MFMA(0);                                                            \
+    if (!(TFK_ABL & 2)) TFK_STORE(SET, s2);                                 \
+    TFK_SGB(0x100, 16);                             /* DS_READ */            \
+    _Pragma("unroll") for (int j = 0; j < NIL; ++j) {                       \
+      TFK_SGB(0x008, 1);                            /* MFMA */               \
+      TFK_SGB(0x200, 1);                            /* DS_WRITE */           \
+    }                                                                       \
+    TFK_SGB(0x200, 8);                                                      \
+    TFK_SGB(0x008, MFG);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    if (!(TFK_ABL & 4)) TFK_FRAGS(0, s0, 2);                                \
+    if (!(TFK_ABL & 1)) TFK_LOAD(SET, (KT) + 2 + T::PF);                    \
+    TFK_MFMA(1);                                                            \
+    TFK_SGB(0x100, 16);                                                     \
+    _Pragma("unroll") for (int j = 0; j < NIL; ++j) {                       \
+      TFK_SGB(0x008, 1);                                                    \
+      TFK_SGB(0x020, 1);                            /* VMEM_READ */          \
+    }                                                                       \
+    TFK_SGB(0x020, 8);                                                      \
+    TFK_SGB(0x008, MFG);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    _Pragma("unroll") for (int g = 2; g < NG; ++g) {                        \
+      if (!(TFK_ABL & 4)) {                                                 \
+        if (g + 1 < NG) {                                                   \
+          TFK_FRAGS((g + 1) & 1, s0, g + 1);                                \
+        } else {                                                            \
+          TFK_FRAGS(0, s1, 0); /* next tile: visible since the last barrier */ \
+        }                                                                   \
+      }                                                                     \
+      TFK_MFMA(g & 1);                                                      \
+      TFK_SGB(0x100, 16);                                                   \
+      TFK_SGB(0x008, MFG);                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                    \
+    }                                                                       \
+    if (!(TFK_ABL & 8)) __syncthreads();                                    \
+    float* tmp = s0; s0 = s1; s1 = s2; s2 = tmp;                            \
+  } while (0)
+    if (T::PF == 2) {
+      for (int kt = 0; kt < nk; kt += 2) {
+        TFK_ITER(0, kt);
+        TFK_ITER(1, kt + 1);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) TFK_ITER(0, kt);
+    }
+#undef TFK_ITER
+  } else {
+    float* s0 = smem;
+    float* s1 = smem + T::STAGE;
+    TFK_LOAD(0, 0);
+    TFK_STORE(0, s0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      TFK_LOAD(0, kt + 1);  // pinned first: its latency hides under the whole MFMA block
+      __builtin_amdgcn_sched_barrier(0);
+      TFK_FRAGS(0, s0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) TFK_FRAGS((g + 1) & 1, s0, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        TFK_MFMA(g & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      TFK_STORE(0, s1);
+      __syncthreads();
+      float* tmp = s0; s0 = s1; s1 = tmp;
+    }
   }
+#undef TFK_LOAD
+#undef TFK_STORE
+#undef TFK_FRAGS
+#undef TFK_MFMA
 
   // ---- epilogue: D reg r of lane (i,h) is row (r&3) + 8*(r>>2) + 4*h, col i of its 32x32 fragment ----
-  const bool do_bias = (p.epi & EPI_BIAS) != 0;
-  const bool do_acc = (p.epi & EPI_ACCUM) != 0;
-  const bool do_relu = (p.epi & EPI_RELU) != 0;
+  const bool full_tile = (m0 + T::BM <= p.M) && (n0 + T::BN <= p.N);
 #pragma unroll
   for (int b = 0; b < T::FN; ++b) {
     const int col = n0 + wn * T::WN + b * 32 + i;
-    if (col >= p.N) continue;
-    const float bv = do_bias ? p.bias[col] : 0.f;
+    const bool col_ok = col < p.N;
+    const int colc = col_ok ? col : p.N - 1;
+    float bv = 0.f;
+    if (EPI & EPI_BIAS) bv = p.bias[colc];
 #pragma unroll
     for (int a = 0; a < T::FM; ++a) {
       const int rbase = m0 + wm * T::WM + a * 32 + 4 * h;
+      float old[16];
+      if (EPI & EPI_ACCUM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = rbase + (r & 3) + 8 * (r >> 2);
+          row = row < p.M ? row : p.M - 1;  // clamped address: one batch of 16 loads, no branches
+          old[r] = p.C[(size_t)row * p.ldc + colc];
+        }
+      }
+      float outv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row < p.M) {
-          float* dst = p.C + (size_t)row * p.ldc + col;
-          float v = acc[a][b][r] + bv;
-          if (do_acc) v += *dst;
-          if (do_relu) v = fmaxf(v, 0.f);
-          *dst = v;
+        float v = acc[a][b][r] + bv;
+        if (EPI & EPI_ACCUM) v += old[r];
+        if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+        outv[r] = v;
+      }
+      if (full_tile) {  // block-uniform: straight-line stores, no per-element exec masking
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          p.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.ldc + col] = outv[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = outv[r];
         }
       }
     }
   }
 }
 
-template <class T>
+int g_min_lds = 0;        // env TFK_GEMM_MIN_LDS (experiments): lower bound of the LDS request
+int g_even_spread = 1;    // env TFK_GEMM_EVEN_SPREAD=0 disables the residency cap below
+
+template <class T, int EPI>
 int launch(const GemmArgs& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (T::LDS_BYTES > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-      if (e != hipSuccess) return (int)e;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<T, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   const int tiles_m = (p.M + T::BM - 1) / T::BM;
   const int tiles_n = (p.N + T::BN - 1) / T::BN;
   if (tiles_m <= 0 || tiles_n <= 0) return 0;
-  hipLaunchKernelGGL(gemm_f32_kernel<T>, dim3(tiles_m * tiles_n), dim3(T::NT), T::LDS_BYTES, stream, p,
-                     tiles_m, tiles_n);
+  // The LDS request doubles as the residency limit (blocks per CU = floor(160 KiB / request)): when the grid
+  // is a small multiple of the 256 CUs the blocks must spread evenly, or the CU that received an extra
+  // block sets the kernel time.
+  int lds = T::LDS_BYTES;
+  const int tiles = tiles_m * tiles_n;
+  const int per_cu = (tiles + 255) / 256;  // blocks per CU of an even spread
+  if (g_even_spread && per_cu <= 4) {
+    const int cap = (160 * 1024 / per_cu) & ~1023;
+    const int floor_next = (160 * 1024 / (per_cu + 1) / 1024 + 1) * 1024;  // just too big for per_cu + 1 blocks
+    if (lds < floor_next && floor_next <= cap) lds = floor_next;
+  }
+  if (g_min_lds > lds) lds = g_min_lds;
+  if (lds > 160 * 1024) lds = 160 * 1024;
+  hipLaunchKernelGGL((gemm_f32_kernel<T, EPI>), dim3(tiles), dim3(T::NT), lds, stream, p, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 
-template <bool A_KC, bool B_KC>
+struct CfgDesc {
+  int bm, bn;
+  const char* name;
+};
+const CfgDesc kCfg[kNumGemmConfigs] = {
+    {128, 128, "128x128/4w64x64/s2"},   {128, 64, "128x64/4w64x32/s3p2"},   {64, 128, "64x128/4w32x64/s3p2"},
+    {64, 64, "64x64/4w32x32/s3p2"},     {128, 128, "128x128/8w64x32/s3p1"}, {256, 128, "256x128/8w64x64/s2"},
+    {64, 128, "64x128/8w32x32/s3p2"},   {128, 64, "128x64/8w32x32/s3p2"},   {64, 64, "64x64/4w32x32/s3p1"},
+};
+
+template <bool A_KC, bool B_KC, int EPI>
 int dispatch_cfg(const GemmArgs& p, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 0: return launch<Tile<128, 128, 64, 64, A_KC, B_KC>>(p, s);
-    case 1: return launch<Tile<128, 64, 64, 32, A_KC, B_KC>>(p, s);
-    case 2: return launch<Tile<64, 128, 32, 64, A_KC, B_KC>>(p, s);
-    case 3: return launch<Tile<64, 64, 32, 32, A_KC, B_KC>>(p, s);
-    case 4: return launch<Tile<128, 128, 64, 32, A_KC, B_KC>>(p, s);
-    case 5: return launch<Tile<256, 128, 64, 64, A_KC, B_KC>>(p, s);
+    case 0: return launch<Tile<128, 128, 64, 64, 2, 1, A_KC, B_KC>, EPI>(p, s);
+    case 1: return launch<Tile<128, 64, 64, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
+    case 2: return launch<Tile<64, 128, 32, 64, 3, 2, A_KC, B_KC>, EPI>(p, s);
+    case 3: return launch<Tile<64, 64, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
+    case 4: return launch<Tile<128, 128, 64, 32, 3, 1, A_KC, B_KC>, EPI>(p, s);
+    case 5: return launch<Tile<256, 128, 64, 64, 2, 1, A_KC, B_KC>, EPI>(p, s);
+    case 6: return launch<Tile<64, 128, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
+    case 7: return launch<Tile<128, 64, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
+    case 8: return launch<Tile<64, 64, 32, 32, 3, 1, A_KC, B_KC>, EPI>(p, s);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+// The epilogues each layout is used with (anything else is rejected): keeps the kernel count at 6 x configs.
+int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
+  switch (layout) {
+    case GEMM_NN:
+      switch (p.epi) {
+        case 0: return dispatch_cfg<true, false, 0>(p, cfg, s);
+        case EPI_BIAS: return dispatch_cfg<true, false, EPI_BIAS>(p, cfg, s);
+        case EPI_BIAS | EPI_RELU: return dispatch_cfg<true, false, EPI_BIAS | EPI_RELU>(p, cfg, s);
+      }
+      break;
+    case GEMM_NT:
+      if (p.epi == 0) return dispatch_cfg<true, true, 0>(p, cfg, s);
+      break;
+    case GEMM_TN:
+      if (p.epi == 0) return dispatch_cfg<false, false, 0>(p, cfg, s);
+      if (p.epi == EPI_ACCUM) return dispatch_cfg<false, false, EPI_ACCUM>(p, cfg, s);
+      break;
+  }
+  return (int)hipErrorInvalidValue;
 }
 
 int g_forced_cfg = -2;  // -2: env not read yet; -1: heuristic
@@ -263,40 +460,37 @@ int g_forced_cfg = -2;  // -2: env not read yet; -1: heuristic
 }  // namespace
 
 const char* gemm_f32_config_name(int cfg) {
-  static const char* names[kNumGemmConfigs] = {"128x128/4w64x64", "128x64/4w64x32", "64x128/4w32x64",
-                                               "64x64/4w32x32",   "128x128/8w64x32", "256x128/8w64x64"};
-  return (cfg >= 0 && cfg < kNumGemmConfigs) ? names[cfg] : "?";
+  return (cfg >= 0 && cfg < kNumGemmConfigs) ? kCfg[cfg].name : "?";
 }
 
 void gemm_f32_force_config(int cfg) { g_forced_cfg = cfg; }
 
 int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
-  (void)layout;
   (void)K;
-  // Fill the 256 CUs first, then prefer the larger tile (fewer L2 reads per flop).
-  static const int bm[kNumGemmConfigs] = {128, 128, 64, 64, 128, 256};
-  static const int bn[kNumGemmConfigs] = {128, 64, 128, 64, 128, 128};
-  static const int order[] = {0, 2, 1, 3};
-  for (int c : order) {
-    const long tiles = (long)((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
-    if (tiles >= 256) return c;
-  }
-  return 3;
+  (void)layout;
+  // Measured on MI355X (profiles/r01_gemm_sweep_v3.txt): the 128x128 tile (4 waves of 64x64: half the LDS
+  // staging per MFMA of a 64x64 tile) wins once it yields two blocks per CU; below that the 64x64 tile with
+  // its 3-slot ring and 2-tile prefetch (two or more independent blocks per CU) is fastest for all layouts.
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return tiles128 >= 512 ? 0 : 3;
 }
 
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream) {
   if (g_forced_cfg == -2) {
     const char* e = getenv("TFK_GEMM_CFG");
     g_forced_cfg = e ? atoi(e) : -1;
+    if ((e = getenv("TFK_GEMM_MIN_LDS"))) g_min_lds = atoi(e);
+    if ((e = getenv("TFK_GEMM_EVEN_SPREAD"))) g_even_spread = atoi(e);
   }
   if (cfg < 0) cfg = (g_forced_cfg >= 0) ? g_forced_cfg : gemm_f32_pick_config(layout, args.M, args.N, args.K);
-  if ((args.lda & 3) || (args.ldb & 3) || (args.ldc & 0)) return (int)hipErrorInvalidValue;
-  switch (layout) {
-    case GEMM_NN: return dispatch_cfg<true, false>(args, cfg, stream);
-    case GEMM_NT: return dispatch_cfg<true, true>(args, cfg, stream);
-    case GEMM_TN: return dispatch_cfg<false, false>(args, cfg, stream);
+  if ((args.lda & 3) || (args.ldb & 3)) return (int)hipErrorInvalidValue;
+  if (args.M <= 0 || args.N <= 0 || args.K <= 0) return (int)hipErrorInvalidValue;
+  {  // operands are addressed with 32-bit byte offsets through buffer resources
+    const long a_rows = layout == GEMM_TN ? args.K : args.M;
+    const long b_rows = layout == GEMM_NT ? args.N : args.K;
+    if (a_rows * args.lda * 4 >= (1L << 31) || b_rows * args.ldb * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;
   }
-  return (int)hipErrorInvalidValue;
+  return dispatch_epi(layout, args, cfg, stream);
 }
 
 }  // namespace tfk

@@ -39,13 +39,13 @@ void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, floa
 void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* v, const float* rowscale, int T,
                        int H, int ld);
 // Column-tiled backward of {dropout, nonlin', batch norm}: da[T,H] -> dz in place;
-// g_beta += sum_t du, g_bias += sum_t dz.  `pre_du` != 0: da already holds du (after act_backward_rows).
-// ws: >= 3*kMaxRowSplits*ld floats.
+// g_beta (+)= sum_t du, g_bias (+)= sum_t dz (accumulate = 0 overwrites: first micro-batch of a step).
+// `pre_du` != 0: da already holds du (after act_backward_rows).  ws: >= 3*kMaxRowSplits*ld floats.
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int T, int H, int ld,
-                     float* ws);
-// g_out[c] += sum_t x[t,c]   (bias gradient of the output layer).  ws: >= kMaxRowSplits*ld floats.
-void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, float* ws);
+                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int accumulate, int T, int H,
+                     int ld, float* ws);
+// g_out[c] (+)= sum_t x[t,c]   (bias gradient of the output layer).  ws: >= kMaxRowSplits*ld floats.
+void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, int accumulate, float* ws);
 
 // ---- softmax cross-entropy (trainer.py:526-531): row_loss[t] = logsumexp(z_t) - z_t[y_t];
 // with_grad: logits <- softmax(z) - onehot(y) in place (sum-reduced loss => no 1/T factor).
@@ -57,7 +57,7 @@ void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars);
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
                   const float* prior);
 
-// ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam; G <- 0 ----
+// ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam (G is left as is) ----
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
                 float beta1, float beta2, float eps);
 // moving <- decay^{num_microbatches} * moving + E

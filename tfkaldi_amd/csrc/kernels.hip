@@ -170,30 +170,51 @@ bn_stats_partial_kernel(const float* __restrict__ z, int T, int ld, int rows_per
   }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ ws, int T, int H, int ld, int rows_per, int rs,
+// geometry of the "final" kernels that combine the per-chunk partials of a column
+constexpr int FIN_COLS = 64, FIN_KL = 4, FIN_PER = kMaxRowSplits / FIN_KL;
+
+__global__ void __launch_bounds__(FIN_COLS * FIN_KL)
+bn_stats_final_kernel(const float* __restrict__ ws, int T, int H, int ld, int rows_per, int rs,
                                       float eps, float decay, float* __restrict__ mean, float* __restrict__ rstd,
                                       float* __restrict__ e_mean, float* __restrict__ e_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ld) return;
-  if (c >= H) {  // padding columns stay neutral
-    mean[c] = 0.f; rstd[c] = 0.f;
-    return;
+  // block = 64 columns x 4 chunk lanes: every thread issues its <= 16 chunk loads back to back (one
+  // memory round trip), then the four lanes of a column combine through LDS in a fixed order.
+  __shared__ float sm[FIN_KL][FIN_COLS];
+  const int c = blockIdx.x * FIN_COLS + threadIdx.x;
+  const int ky = threadIdx.y;
+  const bool live = c < H;
+  float mk[FIN_PER], qk[FIN_PER], nk[FIN_PER];
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) {
+    const int k = ky + j * FIN_KL;
+    const bool ok = live && k < rs;
+    nk[j] = ok ? (float)max(min(T, (k + 1) * rows_per) - k * rows_per, 0) : 0.f;
+    mk[j] = ok ? ws[((size_t)0 * rs + k) * ld + c] : 0.f;
+    qk[j] = ok ? ws[((size_t)1 * rs + k) * ld + c] : 0.f;
   }
   // Chan et al. merge of the per-chunk (n, mean, M2)
   float tot = 0.f;
-  for (int k = 0; k < rs; ++k) {
-    const int n = max(min(T, (k + 1) * rows_per) - k * rows_per, 0);
-    tot += (float)n * ws[((size_t)0 * rs + k) * ld + c];
-  }
-  const float mu = tot / (float)T;
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) tot += nk[j] * mk[j];
+  sm[ky][threadIdx.x] = tot;
+  __syncthreads();
+  const float mu = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)T;
+  __syncthreads();
   float m2 = 0.f;
-  for (int k = 0; k < rs; ++k) {
-    const int n = max(min(T, (k + 1) * rows_per) - k * rows_per, 0);
-    const float d = ws[((size_t)0 * rs + k) * ld + c] - mu;
-    m2 += ws[((size_t)1 * rs + k) * ld + c] + (float)n * d * d;
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) {
+    const float d = mk[j] - mu;
+    m2 += qk[j] + nk[j] * d * d;
   }
-  const float var = m2 / (float)T;  // biased, as tf.nn.moments
-  mean[c] = mu;
+  sm[ky][threadIdx.x] = m2;
+  __syncthreads();
+  if (ky != 0 || c >= ld) return;
+  if (!live) {  // padding columns stay neutral
+    mean[c] = 0.f; rstd[c] = 0.f;
+    return;
+  }
+  const float var = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)T;
+  mean[c] = mu;              // var is biased, as tf.nn.moments
   rstd[c] = rsqrtf(var + eps);
   e_mean[c] = decay * e_mean[c] + (1.f - decay) * mu;
   e_var[c] = decay * e_var[c] + (1.f - decay) * var;
@@ -405,14 +426,26 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
   if (threadIdx.y == 0 && t.valid) st4(ws + ((size_t)2 * rs + blockIdx.y) * ld + t.col, sz);
 }
 
-// g[c] += sum over row splits of slab `which`
-__global__ void colsum_final_kernel(const float* __restrict__ ws, int which, int rs, int N, int ld,
-                                    float* __restrict__ g) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+// g[c] (+)= sum over row splits of slab `which`   (accumulate = 0: first micro-batch of a step overwrites)
+__global__ void __launch_bounds__(FIN_COLS * FIN_KL) colsum_final_kernel(const float* __restrict__ ws, int which, int rs, int N, int ld,
+                                    float* __restrict__ g, int accumulate) {
+  __shared__ float sm[FIN_KL][FIN_COLS];
+  const int c = blockIdx.x * FIN_COLS + threadIdx.x;
+  const int ky = threadIdx.y;
+  float v[FIN_PER];
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) {
+    const int k = ky + j * FIN_KL;
+    v[j] = (c < N && k < rs) ? ws[((size_t)which * rs + k) * ld + c] : 0.f;
+  }
   float s = 0.f;
-  for (int k = 0; k < rs; ++k) s += ws[((size_t)which * rs + k) * ld + c];
-  g[c] += s;
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) s += v[j];
+  sm[ky][threadIdx.x] = s;
+  __syncthreads();
+  if (ky != 0 || c >= N) return;
+  s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+  g[c] = accumulate ? g[c] + s : s;
 }
 
 __global__ void __launch_bounds__(CT_X * CT_Y)
@@ -553,7 +586,7 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
     st4(m + 4 * i, mv);
     st4(v + 4 * i, vv);
     st4(w + 4 * i, wv);
-    st4(g + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));  // init_grads: trainer.py:350
+    // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
   }
 }
 
@@ -598,7 +631,7 @@ void bn_stats_train(hipStream_t s, const float* z, int T, int H, int ld, float e
                     float* rstd, float* e_mean, float* e_var, float* ws) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   hipLaunchKernelGGL(bn_stats_partial_kernel, ct_grid(ld, rs), ct_block(), 0, s, z, T, ld, rows_per, rs, ws);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((ld + 255) / 256), dim3(256), 0, s, ws, T, H, ld, rows_per, rs, eps,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((ld + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, T, H, ld, rows_per, rs, eps,
                      decay, mean, rstd, e_mean, e_var);
 }
 
@@ -626,8 +659,8 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 }
 
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int T, int H, int ld,
-                     float* ws) {
+                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int accumulate, int T, int H,
+                     int ld, float* ws) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   if (d.bn)
     hipLaunchKernelGGL(hb_stats_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, ld,
@@ -635,14 +668,17 @@ void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, con
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
                      rows_per, rs, ws);
   if (d.bn)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + 255) / 256), dim3(256), 0, s, ws, 0, rs, H, ld, g_beta);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + 255) / 256), dim3(256), 0, s, ws, 2, rs, H, ld, g_bias);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, 0, rs, H, ld, g_beta,
+                       accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, 2, rs, H, ld, g_bias,
+                     accumulate);
 }
 
-void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, float* ws) {
+void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, int accumulate, float* ws) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   hipLaunchKernelGGL(colsum_partial_kernel, ct_grid(ld, rs), ct_block(), 0, s, x, T, ld, rows_per, rs, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ws, 0, rs, N, ld, g_out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, 0, rs, N, ld, g_out,
+                     accumulate);
 }
 
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,

@@ -100,6 +100,7 @@ class DataParallel(object):
             for i, (X, y) in enumerate(mine):
                 engine.accumulate(X, y, last=(i == len(mine) - 1))
             if not mine:  # more ranks than micro-batches: contribute zeros
+                engine.zero_accumulators()
                 for b in range(len(buckets)):
                     on_bucket(b)
         finally:

@@ -217,6 +217,9 @@ class Engine(object):
         self._cb = _lib.BUCKET_FN(lambda user, bucket: fn(bucket))
         check(self.lib.tfk_set_bucket_callback(self._h, self._cb, None))
 
+    def zero_accumulators(self):
+        check(self.lib.tfk_zero_accumulators(self._h))
+
     def set_later_microbatches(self, later):
         check(self.lib.tfk_set_later_microbatches(self._h, int(later)))
 

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tfkaldi_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-NAMES = ["128x128/4w", "128x64/4w", "64x128/4w", "64x64/4w", "128x128/8w", "256x128/8w"]
+NAMES = ["128x128/4w2", "128x64/4wp2", "64x128/4wp2", "64x64/4wp2", "128x128/8w3", "256x128/8w2", "64x128/8wp2", "128x64/8wp2", "64x64/4wp1"]
 LAY = ["NN", "NT", "TN"]
 
 
@@ -47,13 +47,12 @@ def bench(layout, M, N, K, cfg, iters=20):
 
 def main():
     out = {}
-    for tag, (T, F, H, O) in {"cfg2": (1024, 440, 2048, 2000), "cfg4/gpu": (2048, 440, 4096, 8000),
-                              "big": (8192, 440, 2048, 4000)}.items():
+    for tag, (T, F, H, O) in {"cfg2": (1024, 440, 2048, 2000), "cfg4/gpu": (2048, 440, 4096, 8000)}.items():
         print("== %s  T=%d F=%d H=%d O=%d" % (tag, T, F, H, O))
         print("%-6s %-3s %6s %6s %6s | " % ("op", "lay", "M", "N", "K") + " ".join("%11s" % n for n in NAMES))
         for name, layout, M, N, K in shapes(T, F, H, O):
             row = []
-            for cfg in range(6):
+            for cfg in range(len(NAMES)):
                 ms, tf = bench(layout, M, N, K, cfg)
                 row.append((ms, tf))
             out["%s/%s" % (tag, name)] = row
