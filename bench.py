@@ -80,7 +80,7 @@ def main():
     rank, world, local_rank = init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # (init_from_env folds local_rank onto one device under TFK_SHARE_DEVICE)
     dp = DataParallel()
 
     with tempfile.TemporaryDirectory(prefix="tfkaldi_bench_") as workdir:

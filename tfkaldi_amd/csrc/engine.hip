@@ -56,7 +56,7 @@ inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct LayerLayout {
   int d_in, d_out, ld_in, ld_out;
   size_t w_off, b_off, beta_off;  // float offsets inside a P-sized region
-  size_t begin, end;              // bucket span inside a P-sized region
+  size_t w_sz, b_sz, beta_sz;     // span lengths (64-float aligned; beta_sz = 0 without batch norm)
 };
 
 enum KernelFamily {
@@ -99,6 +99,8 @@ struct tfk_engine {
   int32_t* dY[2] = {nullptr, nullptr};
   std::vector<float*> z, a, v, rowscale, mean, rstd;
   float *logits = nullptr, *post = nullptr, *dA[2] = {nullptr, nullptr}, *row_loss = nullptr, *ws = nullptr;
+  float* ws_bwd = nullptr;  // per-layer partial column sums of backward (finalised by one kernel)
+  size_t ws_bwd_stride = 0;
   float* prior = nullptr;
   bool have_prior = false;
 
@@ -173,20 +175,28 @@ void compute_layout(const tfk_config* c, std::vector<LayerLayout>& lay, size_t& 
   const int ldF = (int)up(c->input_dim, 4), ldH = (int)up(c->num_units, 4), ldO = (int)up(c->output_dim, 4);
   lay.resize(L + 1);
   size_t off = 0;
+  // all weight matrices first (one all-reduce bucket each), then every bias / beta vector: the vectors'
+  // gradients are finalised by ONE kernel at the end of backward and travel in the last bucket, right in
+  // front of the scalar + BN tail of the reduce region
   for (int l = 0; l <= L; ++l) {
     LayerLayout& x = lay[l];
     x.d_in = l == 0 ? c->input_dim : c->num_units;
     x.ld_in = l == 0 ? ldF : ldH;
     x.d_out = l == L ? c->output_dim : c->num_units;
     x.ld_out = l == L ? ldO : ldH;
-    x.begin = off;
     x.w_off = off;
-    off += up((size_t)x.d_in * x.ld_out, 64);
-    x.b_off = off;
-    off += up((size_t)x.ld_out, 64);
-    x.beta_off = off;
-    if (c->batch_norm && l < L) off += up((size_t)ldH, 64);
-    x.end = off;
+    x.w_sz = up((size_t)x.d_in * x.ld_out, 64);
+    off += x.w_sz;
+  }
+  for (int l = 0; l <= L; ++l) {
+    lay[l].b_off = off;
+    lay[l].b_sz = up((size_t)lay[l].ld_out, 64);
+    off += lay[l].b_sz;
+  }
+  for (int l = 0; l <= L; ++l) {
+    lay[l].beta_off = off;
+    lay[l].beta_sz = (c->batch_norm && l < L) ? up((size_t)ldH, 64) : 0;
+    off += lay[l].beta_sz;
   }
   P = off;
   E = c->batch_norm ? up((size_t)2 * L * ldH, 64) : 0;
@@ -245,7 +255,7 @@ void free_activations(tfk_engine* e) {
   for (auto& p : e->a) fr(p);
   for (auto& p : e->v) fr(p);
   for (auto& p : e->rowscale) fr(p);
-  fr(e->logits); fr(e->post); fr(e->row_loss); fr(e->ws);
+  fr(e->logits); fr(e->post); fr(e->row_loss); fr(e->ws); fr(e->ws_bwd);
   e->cap = 0;
 }
 
@@ -286,6 +296,8 @@ int reserve(tfk_engine* e, int T) {
   CHK(alloc_zero(&e->row_loss, (size_t)cap));
   const int ldmax = e->ldH > e->ldO ? e->ldH : e->ldO;
   CHK(alloc_zero(&e->ws, (size_t)3 * kMaxRowSplits * ldmax));
+  e->ws_bwd_stride = (size_t)3 * kMaxRowSplits * ldmax;
+  CHK(alloc_zero(&e->ws_bwd, e->ws_bwd_stride * (L + 1)));
   e->cap = cap;
   return 0;
 }
@@ -387,14 +399,24 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   const int acc = e->grads_fresh ? 0 : 1;
   const int epi_w = acc ? EPI_ACCUM : 0;
   if (!acc)  // layers above the active depth are not visited below: their (logically zero) G must be zero
-    for (int l = nact; l < L; ++l)
-      HIPCHK(hipMemsetAsync(G + e->lay[l].begin, 0, (e->lay[l].end - e->lay[l].begin) * sizeof(float), e->stream));
+    for (int l = nact; l < L; ++l) {
+      const LayerLayout& q = e->lay[l];
+      HIPCHK(hipMemsetAsync(G + q.w_off, 0, q.w_sz * sizeof(float), e->stream));
+      HIPCHK(hipMemsetAsync(G + q.b_off, 0, q.b_sz * sizeof(float), e->stream));
+      if (q.beta_sz) HIPCHK(hipMemsetAsync(G + q.beta_off, 0, q.beta_sz * sizeof(float), e->stream));
+    }
   // output layer: dZ = softmax - onehot sits in `logits`
   CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
                epi_w));
+  FinalBatch fin;
+  fin.n = 0;
+  fin.accumulate = acc;
+  const int rs = row_splits(T);
+  auto ws_of = [&](int l) { return e->ws_bwd + (size_t)l * e->ws_bwd_stride; };
   {
     ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
-    colsum_accum(e->stream, e->logits, T, e->O, e->ldO, G + o.b_off, acc, e->ws);
+    colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));
+    fin.it[fin.n++] = {ws_of(L), G + o.b_off, 0, rs, e->O, e->ldO};
   }
   if (fire && e->cb) e->cb(e->cb_user, 0);
   int pp = 0;
@@ -411,8 +433,13 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     }
     {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
-      hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l],
-                      e->cfg.batch_norm ? G + y.beta_off : nullptr, G + y.b_off, acc, T, H, ldH, e->ws);
+      hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l], T, H, ldH, ws_of(l));
+      if (e->cfg.batch_norm) fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, rs, H, ldH};
+      fin.it[fin.n++] = {ws_of(l), G + y.b_off, 2, rs, H, ldH};
+      if (fin.n + 2 > kMaxFinalItems) {  // very deep nets: flush
+        grad_final(e->stream, fin);
+        fin.n = 0;
+      }
     }
     const float* in = l == 0 ? Xd : e->a[l - 1];
     const int ld_in = l == 0 ? ldx : ldH;
@@ -420,6 +447,10 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     if (l > 0) CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, 0));
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
+  }
+  {  // one kernel turns every layer's partial column sums into the bias / beta gradient sums
+    ProfScope ps(e, KF_COLSUM, 0, 0);
+    grad_final(e->stream, fin);
   }
   // layers above the active depth receive no gradient (zero branch of the tf.case); their buckets are
   // still announced so that every rank reduces the same spans.
@@ -764,7 +795,8 @@ int tfk_init_last_layer(tfk_engine* e) {
   // re-run the initialisers of layer L: weights ~ N(0, stddev 0) = 0, biases = 0 (dnn.py:67-68, 114-120)
   const LayerLayout& o = e->lay[e->L];
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipMemsetAsync(e->p_param() + o.begin, 0, (o.end - o.begin) * sizeof(float), e->stream));
+  HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
+  HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
   return 0;
 }
 
@@ -840,13 +872,13 @@ int tfk_num_buckets(tfk_engine* e, int* n) {
 int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* num_floats) {
   if (!e || !offset_floats || !num_floats) return fail(-1, "NULL argument");
   if (bucket < 0 || bucket > e->L + 1) return fail(-1, "bucket %d out of range", bucket);
-  if (bucket == e->L + 1) {
-    *offset_floats = e->P;
-    *num_floats = kScalarFloats + e->E;
+  if (bucket == e->L + 1) {  // every bias / beta gradient + scalars + BN increments: contiguous
+    *offset_floats = e->lay[0].b_off;
+    *num_floats = (e->P - e->lay[0].b_off) + kScalarFloats + e->E;
   } else {
     const LayerLayout& y = e->lay[e->L - bucket];
-    *offset_floats = y.begin;
-    *num_floats = y.end - y.begin;
+    *offset_floats = y.w_off;
+    *num_floats = y.w_sz;
   }
   return 0;
 }

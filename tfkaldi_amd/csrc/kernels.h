@@ -38,14 +38,29 @@ void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, floa
 // L2 chains only: da -> du (gradient w.r.t. the BN output) in place, row-wise.
 void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* v, const float* rowscale, int T,
                        int H, int ld);
-// Column-tiled backward of {dropout, nonlin', batch norm}: da[T,H] -> dz in place;
-// g_beta (+)= sum_t du, g_bias (+)= sum_t dz (accumulate = 0 overwrites: first micro-batch of a step).
-// `pre_du` != 0: da already holds du (after act_backward_rows).  ws: >= 3*kMaxRowSplits*ld floats.
+// Column-tiled backward of {dropout, nonlin', batch norm}: da[T,H] -> dz in place.  Leaves the per-chunk
+// partial column sums in ws (>= 3*kMaxRowSplits*ld floats): slab 0 = sum_t du (-> d beta), slab 1 =
+// sum_t du*xhat, slab 2 = sum_t dz (-> d bias); grad_final() turns them into gradients.
+// `pre_du` != 0: da already holds du (after act_backward_rows).
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int accumulate, int T, int H,
-                     int ld, float* ws);
-// g_out[c] (+)= sum_t x[t,c]   (bias gradient of the output layer).  ws: >= kMaxRowSplits*ld floats.
-void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, int accumulate, float* ws);
+                     const float* mean, const float* rstd, int T, int H, int ld, float* ws);
+// per-chunk partial column sums of x[T, ld] into slab 0 of ws (bias gradient of the output layer)
+void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws);
+int row_splits(int T);  // chunks the column-tiled kernels cut T rows into
+
+// g[c] (+)= sum over the chunks of slab `which` of ws -- for MANY (layer, vector) pairs in one launch
+struct FinalItem {
+  const float* ws;
+  float* g;
+  int which, rs, N, ld;
+};
+constexpr int kMaxFinalItems = 48;
+struct FinalBatch {
+  FinalItem it[kMaxFinalItems];
+  int n;
+  int accumulate;  // 0: first micro-batch of a step overwrites G
+};
+void grad_final(hipStream_t s, const FinalBatch& b);
 
 // ---- softmax cross-entropy (trainer.py:526-531): row_loss[t] = logsumexp(z_t) - z_t[y_t];
 // with_grad: logits <- softmax(z) - onehot(y) in place (sum-reduced loss => no 1/T factor).

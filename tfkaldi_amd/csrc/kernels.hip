@@ -104,6 +104,8 @@ __device__ __forceinline__ float el(const float4& v, int i) { return reinterpret
 // blocks, row splits).  A half-wave reads 512 contiguous bytes of one row.
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_X = 32, CT_Y = 8;
+constexpr int RB = 4;  // rows a thread loads as one batch (its loads are issued back to back: these kernels
+                       // are latency-bound, not bandwidth-bound, on L2-resident [T, H] activations)
 
 struct ColTile {
   int c4;      // float4 column index
@@ -142,12 +144,25 @@ bn_stats_partial_kernel(const float* __restrict__ z, int T, int ld, int rows_per
   __shared__ float4 sm[CT_Y][CT_X];
   __shared__ float4 sm_mean[CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (t.valid)
-    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s = zero4;
+  float4 keep[RB];  // the first row batch stays in registers for the second pass (all of it when T <= 2048)
+#pragma unroll
+  for (int j = 0; j < RB; ++j) keep[j] = zero4;
+  if (t.valid) {
+    const int rfirst = t.r0 + threadIdx.y;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = rfirst + j * CT_Y;
+      if (r < t.r1) keep[j] = ld4(z + (size_t)r * ld + t.col);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) { s.x += keep[j].x; s.y += keep[j].y; s.z += keep[j].z; s.w += keep[j].w; }
+    for (int r = rfirst + RB * CT_Y; r < t.r1; r += CT_Y) {
       const float4 v = ld4(z + (size_t)r * ld + t.col);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
   s = reduce_rows(s, sm);
   const int n = max(t.r1 - t.r0, 0);
   if (threadIdx.y == 0) {
@@ -156,13 +171,22 @@ bn_stats_partial_kernel(const float* __restrict__ z, int T, int ld, int rows_per
   }
   __syncthreads();
   const float4 mu = sm_mean[threadIdx.x];
-  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (t.valid)
-    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+  float4 q = zero4;
+  if (t.valid) {
+    const int rfirst = t.r0 + threadIdx.y;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      if (rfirst + j * CT_Y < t.r1) {
+        const float dx = keep[j].x - mu.x, dy = keep[j].y - mu.y, dz = keep[j].z - mu.z, dw = keep[j].w - mu.w;
+        q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+      }
+    }
+    for (int r = rfirst + RB * CT_Y; r < t.r1; r += CT_Y) {
       const float4 v = ld4(z + (size_t)r * ld + t.col);
       const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
       q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
     }
+  }
   q = reduce_rows(q, sm);
   if (threadIdx.y == 0 && t.valid) {
     st4(ws + ((size_t)0 * rs + blockIdx.y) * ld + t.col, mu);
@@ -361,15 +385,25 @@ hb_stats_kernel(ActDesc d, int pre_du, const float* __restrict__ da, const float
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (t.valid) {
     const float4 mu = ld4(mean + t.col), rsd = ld4(rstd + t.col);
-    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
-      const size_t off = (size_t)r * ld + t.col;
-      const float4 g = ld4(da + off);
-      const float4 av = pre_du ? g : ld4(a + off);
-      const float4 zv = ld4(z + off);
-      const float4 du = compute_du(d, pre_du, g, av, r, t.c4);
-      s1.x += du.x; s1.y += du.y; s1.z += du.z; s1.w += du.w;
-      s2.x += du.x * (zv.x - mu.x) * rsd.x; s2.y += du.y * (zv.y - mu.y) * rsd.y;
-      s2.z += du.z * (zv.z - mu.z) * rsd.z; s2.w += du.w * (zv.w - mu.w) * rsd.w;
+    for (int rb = t.r0 + threadIdx.y; rb < t.r1; rb += CT_Y * RB) {
+      float4 g[RB], av[RB], zv[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int r = rb + j * CT_Y;
+        const size_t off = (size_t)(r < t.r1 ? r : rb) * ld + t.col;
+        g[j] = ld4(da + off);
+        av[j] = pre_du ? g[j] : ld4(a + off);
+        zv[j] = ld4(z + off);
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int r = rb + j * CT_Y;
+        if (r >= t.r1) continue;
+        const float4 du = compute_du(d, pre_du, g[j], av[j], r, t.c4);
+        s1.x += du.x; s1.y += du.y; s1.z += du.z; s1.w += du.w;
+        s2.x += du.x * (zv[j].x - mu.x) * rsd.x; s2.y += du.y * (zv[j].y - mu.y) * rsd.y;
+        s2.z += du.z * (zv[j].z - mu.z) * rsd.z; s2.w += du.w * (zv[j].w - mu.w) * rsd.w;
+      }
     }
   }
   s1 = reduce_rows(s1, sm);
@@ -402,50 +436,60 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
       m1.x *= invT; m1.y *= invT; m1.z *= invT; m1.w *= invT;
       m2.x *= invT; m2.y *= invT; m2.z *= invT; m2.w *= invT;
     }
-    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
-      const size_t off = (size_t)r * ld + t.col;
-      const float4 g = ld4(da + off);
-      const float4 av = pre_du ? g : ld4(a + off);
-      float4 dz = compute_du(d, pre_du, g, av, r, t.c4);
-      if (d.bn) {
-        // dz = rstd * (du - mean(du) - xhat * mean(du * xhat))
-        const float4 zv = ld4(z + off);
-        dz.x = rsd.x * (dz.x - m1.x - (zv.x - mu.x) * rsd.x * m2.x);
-        dz.y = rsd.y * (dz.y - m1.y - (zv.y - mu.y) * rsd.y * m2.y);
-        dz.z = rsd.z * (dz.z - m1.z - (zv.z - mu.z) * rsd.z * m2.z);
-        dz.w = rsd.w * (dz.w - m1.w - (zv.w - mu.w) * rsd.w * m2.w);
+    for (int rb = t.r0 + threadIdx.y; rb < t.r1; rb += CT_Y * RB) {
+      float4 g[RB], av[RB], zv[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {  // all loads of the batch first (da is rewritten in place below)
+        const int r = rb + j * CT_Y;
+        const size_t off = (size_t)(r < t.r1 ? r : rb) * ld + t.col;
+        g[j] = ld4(da + off);
+        av[j] = pre_du ? g[j] : ld4(a + off);
+        zv[j] = d.bn ? ld4(z + off) : g[j];
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (t.col + k >= H) el(dz, k) = 0.f;
-      st4(da + off, dz);
-      sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
+      for (int j = 0; j < RB; ++j) {
+        const int r = rb + j * CT_Y;
+        if (r >= t.r1) continue;
+        float4 dz = compute_du(d, pre_du, g[j], av[j], r, t.c4);
+        if (d.bn) {
+          // dz = rstd * (du - mean(du) - xhat * mean(du * xhat))
+          dz.x = rsd.x * (dz.x - m1.x - (zv[j].x - mu.x) * rsd.x * m2.x);
+          dz.y = rsd.y * (dz.y - m1.y - (zv[j].y - mu.y) * rsd.y * m2.y);
+          dz.z = rsd.z * (dz.z - m1.z - (zv[j].z - mu.z) * rsd.z * m2.z);
+          dz.w = rsd.w * (dz.w - m1.w - (zv[j].w - mu.w) * rsd.w * m2.w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t.col + k >= H) el(dz, k) = 0.f;
+        st4(da + (size_t)r * ld + t.col, dz);
+        sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
+      }
     }
   }
   sz = reduce_rows(sz, sm);
   if (threadIdx.y == 0 && t.valid) st4(ws + ((size_t)2 * rs + blockIdx.y) * ld + t.col, sz);
 }
 
-// g[c] (+)= sum over row splits of slab `which`   (accumulate = 0: first micro-batch of a step overwrites)
-__global__ void __launch_bounds__(FIN_COLS * FIN_KL) colsum_final_kernel(const float* __restrict__ ws, int which, int rs, int N, int ld,
-                                    float* __restrict__ g, int accumulate) {
+// g[c] (+)= sum over row splits of slab `which`, for a batch of (layer, vector) items: blockIdx.y = item
+__global__ void __launch_bounds__(FIN_COLS * FIN_KL) grad_final_kernel(FinalBatch b) {
   __shared__ float sm[FIN_KL][FIN_COLS];
+  const FinalItem it = b.it[blockIdx.y];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x;
   const int ky = threadIdx.y;
   float v[FIN_PER];
 #pragma unroll
   for (int j = 0; j < FIN_PER; ++j) {
     const int k = ky + j * FIN_KL;
-    v[j] = (c < N && k < rs) ? ws[((size_t)which * rs + k) * ld + c] : 0.f;
+    v[j] = (c < it.N && k < it.rs) ? it.ws[((size_t)it.which * it.rs + k) * it.ld + c] : 0.f;
   }
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < FIN_PER; ++j) s += v[j];
   sm[ky][threadIdx.x] = s;
   __syncthreads();
-  if (ky != 0 || c >= N) return;
+  if (ky != 0 || c >= it.N) return;
   s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-  g[c] = accumulate ? g[c] + s : s;
+  it.g[c] = b.accumulate ? it.g[c] + s : s;
 }
 
 __global__ void __launch_bounds__(CT_X * CT_Y)
@@ -616,16 +660,17 @@ __global__ void dropout_mask_kernel(ActDesc d, float* __restrict__ out, int T, i
   st4(out + (size_t)row * ld + (c4 << 2), o);
 }
 
-inline int row_splits(int T) {
+inline dim3 ct_grid(int ld, int rs) { return dim3((ld / 4 + CT_X - 1) / CT_X, rs); }
+inline dim3 ct_block() { return dim3(CT_X, CT_Y); }
+
+}  // namespace
+
+int row_splits(int T) {
   int rs = (T + 31) / 32;
   if (rs < 1) rs = 1;
   if (rs > kMaxRowSplits) rs = kMaxRowSplits;
   return rs;
 }
-inline dim3 ct_grid(int ld, int rs) { return dim3((ld / 4 + CT_X - 1) / CT_X, rs); }
-inline dim3 ct_block() { return dim3(CT_X, CT_Y); }
-
-}  // namespace
 
 void bn_stats_train(hipStream_t s, const float* z, int T, int H, int ld, float eps, float decay, float* mean,
                     float* rstd, float* e_mean, float* e_var, float* ws) {
@@ -659,26 +704,25 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 }
 
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, float* g_beta, float* g_bias, int accumulate, int T, int H,
-                     int ld, float* ws) {
+                     const float* mean, const float* rstd, int T, int H, int ld, float* ws) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   if (d.bn)
     hipLaunchKernelGGL(hb_stats_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, ld,
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
                      rows_per, rs, ws);
-  if (d.bn)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, 0, rs, H, ld, g_beta,
-                       accumulate);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, 2, rs, H, ld, g_bias,
-                     accumulate);
 }
 
-void colsum_accum(hipStream_t s, const float* x, int T, int N, int ld, float* g_out, int accumulate, float* ws) {
+void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   hipLaunchKernelGGL(colsum_partial_kernel, ct_grid(ld, rs), ct_block(), 0, s, x, T, ld, rows_per, rs, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, ws, 0, rs, N, ld, g_out,
-                     accumulate);
+}
+
+void grad_final(hipStream_t s, const FinalBatch& b) {
+  if (b.n <= 0) return;
+  int maxn = 0;
+  for (int i = 0; i < b.n; ++i) maxn = b.it[i].N > maxn ? b.it[i].N : maxn;
+  hipLaunchKernelGGL(grad_final_kernel, dim3((maxn + FIN_COLS - 1) / FIN_COLS, b.n), dim3(FIN_COLS, FIN_KL), 0, s, b);
 }
 
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,

@@ -31,8 +31,17 @@ def init_from_env():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             use_gpu = torch.cuda.is_available()
             if use_gpu:
+                # TFK_SHARE_DEVICE=1 (tests only): several ranks on one GPU -- RCCL refuses that, so pair it
+                # with TFK_DIST_BACKEND=gloo to exercise the host-side bucket / overlap logic on a 1-GPU box
+                if os.environ.get("TFK_SHARE_DEVICE") == "1":
+                    local_rank = local_rank % torch.cuda.device_count()
                 torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+            backend = os.environ.get("TFK_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("TFK_SHARE_DEVICE") == "1":
+        import torch
+        if torch.cuda.is_available():
+            local_rank = local_rank % torch.cuda.device_count()
     return rank, world, local_rank
 
 
