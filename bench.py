@@ -155,6 +155,14 @@ def main():
         achieved = dom["flops"] / dom["total_ms"] / 1e9  # TFLOP/s
         all_gemm_tf = sum(s["flops"] for s in gemms) / sum(s["total_ms"] for s in gemms) / 1e9
         value = world * T * args.steps / elapsed
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tfile):  # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
+            rec = json.load(open(tfile)).get(dom["name"])
+            if rec:
+                traffic = rec["bytes_per_launch"]
+                traffic_src = ("profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                               "(2*FETCH+WRITE)*1024 per MI355X_MICROARCH; L2<->fabric side, Infinity-Cache hits included")
         out = {
             "metric": "acoustic frames/sec (train step)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -166,7 +174,9 @@ def main():
                                    "fp32 MFMA, Adam" % T, "frames_per_gpu": T, "global_frames": world * T,
                        "parallelism": "dp%d" % world, "flop_per_frame": FLOP_PER_FRAME},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                          "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
                          "all_gemm_tflops": all_gemm_tf,
                          "step_tflops": value / world * FLOP_PER_FRAME / 1e12},
