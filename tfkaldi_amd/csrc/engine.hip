@@ -17,6 +17,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -84,6 +85,18 @@ struct tfk_engine {
 
   hipStream_t stream = nullptr, copy_stream = nullptr;
   bool own_stream = false;
+  // Side stream, OFF by default (measured slower on MI355X, profiles/r01_overlap_experiment.txt): (1) the
+  // dW GEMMs of backward only feed Adam, so they can run concurrently with the main chain dA -> BN/activation
+  // backward -> dA; (2) Adam (HBM-bound) can overlap the NEXT step's forward, which then waits per layer on
+  // ev_adam_w[l].  Both lose to plain stream order here: every GEMM already fills all 256 CUs, so concurrent
+  // kernels only evict each other's L2 working set and steal wave slots.
+  hipStream_t side = nullptr;
+  bool overlap = false;     // async Adam on the side stream   (TFK_OVERLAP_ADAM=1)
+  bool overlap_dw = false;  // dW GEMMs on the side stream      (TFK_OVERLAP_DW=1)
+  int adam_blocks = 0;      // grid cap of the async Adam launches (0 = kernel default)
+  std::vector<hipEvent_t> ev_dz, ev_dw, ev_adam_w;
+  hipEvent_t ev_adam_vec = nullptr, ev_adam_done = nullptr, ev_fork = nullptr, ev_loss = nullptr;
+  bool adam_pending = false;  // Adam of the last apply may still be running on the side stream
 
   // persistent state
   float* state = nullptr;
@@ -217,27 +230,43 @@ hipEvent_t get_event(tfk_engine* e) {
 struct ProfScope {
   tfk_engine* e;
   ProfRec r;
-  ProfScope(tfk_engine* e_, int family, double flops, double bytes) : e(e_) {
+  hipStream_t st;
+  ProfScope(tfk_engine* e_, int family, double flops, double bytes, hipStream_t st_ = nullptr)
+      : e(e_), st(st_ ? st_ : e_->stream) {
     if (!e->profiling) return;
     r.family = family; r.flops = flops; r.bytes = bytes;
     r.a = get_event(e); r.b = get_event(e);
-    hipEventRecord(r.a, e->stream);
+    hipEventRecord(r.a, st);
   }
   ~ProfScope() {
     if (!e->profiling) return;
-    hipEventRecord(r.b, e->stream);
+    hipEventRecord(r.b, st);
     e->prof.push_back(r);
   }
 };
 
+// everything this engine has in flight (main, side and copy streams)
+int sync_streams(tfk_engine* e) {
+  HIPCHK(hipStreamSynchronize(e->copy_stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->side));
+  return 0;
+}
+// main stream: do not run ahead of the Adam update still executing on the side stream
+int wait_adam_done(tfk_engine* e) {
+  if (e->adam_pending) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_done, 0));
+  return 0;
+}
+
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-             int M, int N, int K, const float* bias, int epi) {
+             int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr) {
+  if (!st) st = e->stream;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
-  ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)));
-  const int rc = gemm_f32(layout, g, -1, e->stream);
+  ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)), st);
+  const int rc = gemm_f32(layout, g, -1, st);
   if (rc != 0) return fail(rc, "gemm_f32 launch failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
@@ -363,8 +392,11 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   const float* in = Xd;
   int ld_in = ldx;
   const int H = e->H, ldH = e->ldH;
+  const bool gate = e->adam_pending;  // parameters of layer l are ready once ev_adam_w[l] has fired
+  if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_vec, 0));
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
+    if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_w[l], 0));
     CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
                  e->p_param() + y.b_off, EPI_BIAS));
     if (e->cfg.batch_norm) {
@@ -386,8 +418,13 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
     ld_in = ldH;
   }
   const LayerLayout& o = e->lay[e->L];
+  if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_w[e->L], 0));
   CHK(run_gemm(e, GEMM_NN, e->a[nact - 1], ldH, e->p_param() + o.w_off, o.ld_out, e->logits, e->ldO, T, e->O, H,
                e->p_param() + o.b_off, EPI_BIAS));
+  if (gate) {  // the loss accumulators are re-initialised at the very end of the side-stream work
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_done, 0));
+    e->adam_pending = false;  // everything enqueued on the main stream from here on is ordered behind it
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -398,6 +435,10 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   float* G = e->p_grad();
   const int acc = e->grads_fresh ? 0 : 1;
   const int epi_w = acc ? EPI_ACCUM : 0;
+  // With a bucket callback the host launches collectives behind the MAIN stream, so every gradient must be
+  // produced there; otherwise the weight-gradient GEMMs go to the side stream.
+  const bool two = e->overlap_dw && !(fire && e->cb);
+  hipStream_t sw = two ? e->side : e->stream;
   if (!acc)  // layers above the active depth are not visited below: their (logically zero) G must be zero
     for (int l = nact; l < L; ++l) {
       const LayerLayout& q = e->lay[l];
@@ -406,8 +447,13 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
       if (q.beta_sz) HIPCHK(hipMemsetAsync(G + q.beta_off, 0, q.beta_sz * sizeof(float), e->stream));
     }
   // output layer: dZ = softmax - onehot sits in `logits`
+  if (two) {
+    HIPCHK(hipEventRecord(e->ev_dz[L], e->stream));
+    HIPCHK(hipStreamWaitEvent(sw, e->ev_dz[L], 0));
+  }
   CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
-               epi_w));
+               epi_w, sw));
+  if (two) HIPCHK(hipEventRecord(e->ev_dw[L], sw));
   FinalBatch fin;
   fin.n = 0;
   fin.accumulate = acc;
@@ -443,10 +489,23 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     }
     const float* in = l == 0 ? Xd : e->a[l - 1];
     const int ld_in = l == 0 ? ldx : ldH;
-    CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w));
-    if (l > 0) CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, 0));
+    if (two) {  // dz_l (in `da`) is complete on the main stream -> side stream may read it
+      HIPCHK(hipEventRecord(e->ev_dz[l], e->stream));
+      HIPCHK(hipStreamWaitEvent(sw, e->ev_dz[l], 0));
+    }
+    CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w, sw));
+    if (two) HIPCHK(hipEventRecord(e->ev_dw[l], sw));
+    if (l > 0) {
+      // the dA GEMM overwrites dA[pp ^ 1] = dz of layer l + 1, which dW_{l+1} may still be reading
+      if (two && l + 1 <= nact - 1) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l + 1], 0));
+      CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, 0));
+    }
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
+  }
+  if (two) {  // join: every weight gradient is complete (and X / a_l / logits are free again) behind this point
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[L], 0));
+    for (int l = nact - 1; l >= 0; --l) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l], 0));
   }
   {  // one kernel turns every layer's partial column sums into the bias / beta gradient sums
     ProfScope ps(e, KF_COLSUM, 0, 0);
@@ -543,6 +602,25 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     e->own_stream = true;
   }
   HIPB(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  HIPB(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  {
+    const char* v;
+    if ((v = getenv("TFK_OVERLAP_ADAM"))) e->overlap = atoi(v) != 0;
+    if ((v = getenv("TFK_OVERLAP_DW"))) e->overlap_dw = atoi(v) != 0;
+    // few, fat blocks: the optimiser only has to finish within the next forward pass and must leave the
+    // CUs' wave slots to the GEMM blocks it runs beside
+    e->adam_blocks = (v = getenv("TFK_ADAM_BLOCKS")) ? atoi(v) : 512;
+  }
+  e->ev_dz.assign(e->L + 1, nullptr); e->ev_dw.assign(e->L + 1, nullptr); e->ev_adam_w.assign(e->L + 1, nullptr);
+  for (int l = 0; l <= e->L; ++l) {
+    HIPB(hipEventCreateWithFlags(&e->ev_dz[l], hipEventDisableTiming));
+    HIPB(hipEventCreateWithFlags(&e->ev_dw[l], hipEventDisableTiming));
+    HIPB(hipEventCreateWithFlags(&e->ev_adam_w[l], hipEventDisableTiming));
+  }
+  HIPB(hipEventCreateWithFlags(&e->ev_adam_vec, hipEventDisableTiming));
+  HIPB(hipEventCreateWithFlags(&e->ev_adam_done, hipEventDisableTiming));
+  HIPB(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
   for (int s = 0; s < 2; ++s) {
     HIPB(hipEventCreateWithFlags(&e->copy_done[s], hipEventDisableTiming));
     HIPB(hipEventCreateWithFlags(&e->compute_done[s], hipEventDisableTiming));
@@ -599,6 +677,7 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   }
   if (train) {
     const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
+    CHK(wait_adam_done(e));  // (forward already waited; kept for call orders that skip it)
     CHK(backward(e, Xd, ld, T, nact, call, fire));
     if (fire) {
       if (e->cfg.batch_norm && e->later_mb > 0) {
@@ -641,8 +720,14 @@ int tfk_destroy(tfk_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->side) hipStreamSynchronize(e->side);
   if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
   free_activations(e);
+  for (auto ev : e->ev_dz) if (ev) hipEventDestroy(ev);
+  for (auto ev : e->ev_dw) if (ev) hipEventDestroy(ev);
+  for (auto ev : e->ev_adam_w) if (ev) hipEventDestroy(ev);
+  for (hipEvent_t ev : {e->ev_adam_vec, e->ev_adam_done, e->ev_fork, e->ev_loss}) if (ev) hipEventDestroy(ev);
+  if (e->side) hipStreamDestroy(e->side);
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
@@ -678,7 +763,7 @@ int tfk_tensor_get(tfk_engine* e, int kind, int slot, int layer, float* host, si
     memset(host, 0, count * sizeof(float));
     return 0;
   }
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(sync_streams(e));
   HIPCHK(hipMemcpy2D(host, (size_t)t.cols * 4, t.ptr, (size_t)t.ld * 4, (size_t)t.cols * 4, t.rows, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -689,6 +774,7 @@ int tfk_tensor_set(tfk_engine* e, int kind, int slot, int layer, const float* ho
   CHK(tensor_ref(e, kind, slot, layer, &t));
   if (count != (size_t)t.rows * t.cols) return fail(-1, "count %zu != %d x %d", count, t.rows, t.cols);
   HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(sync_streams(e));
   if (slot == TFK_SLOT_GRAD && e->grads_fresh) {
     HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
     e->grads_fresh = false;
@@ -715,7 +801,7 @@ int tfk_scalar_get(tfk_engine* e, int which, double* value) {
     case TFK_BATCH_LOSS:
     case TFK_NUM_FRAMES: {
       HIPCHK(hipSetDevice(e->cfg.device));
-      HIPCHK(hipStreamSynchronize(e->stream));
+      CHK(sync_streams(e));
       float h[2];
       HIPCHK(hipMemcpy(h, e->p_scalars(), sizeof(h), hipMemcpyDeviceToHost));
       *value = which == TFK_BATCH_LOSS ? h[0] : h[1];
@@ -753,17 +839,57 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
   if (e->grads_fresh)  // no micro-batch since the last apply: materialise the zeros Adam is about to read
     HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
-  {
-    ProfScope ps(e, KF_ADAM, 0, 28.0 * e->P);
-    adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
-               e->adam_eps);
-  }
+  // main stream: BN moving averages, the loss read-back, re-initialisation of the BN increments
   if (e->cfg.batch_norm) {
     ProfScope ps(e, KF_EMA, 0, 12.0 * e->E);
     ema_apply(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay);
   }
+  HIPCHK(hipMemcpyAsync(e->h_scalars, e->p_scalars(), 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(e->ev_loss, e->stream));
+  if (e->E) HIPCHK(hipMemsetAsync(e->p_ema(), 0, e->E * sizeof(float), e->stream));
+  // Adam: vectors first, then one launch per weight matrix in FORWARD order, each followed by an event the
+  // next step's forward waits on -- on the side stream, so that the forward GEMMs (matrix-bound) and the
+  // optimiser (HBM-bound) overlap.
+  hipStream_t sa = e->overlap ? e->side : e->stream;
+  const int grid_cap = e->overlap ? e->adam_blocks : 0;
+  if (!e->overlap) {  // one launch over the whole parameter arena, in stream order
+    {
+      ProfScope ps(e, KF_ADAM, 0, 28.0 * e->P);
+      adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
+                 e->adam_eps, 0);
+    }
+    HIPCHK(hipMemsetAsync(e->p_scalars(), 0, kScalarFloats * sizeof(float), e->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(e->ev_loss));
+    e->adam_pending = false;
+    e->grads_fresh = true;
+    e->global_step += 1;
+    if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
+    return 0;
+  }
+  HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+  HIPCHK(hipStreamWaitEvent(sa, e->ev_fork, 0));
+  {
+    const size_t v0 = e->lay[0].b_off;
+    ProfScope ps(e, KF_ADAM, 0, 28.0 * (e->P - v0), sa);
+    adam_apply(sa, e->p_param() + v0, e->p_grad() + v0, e->p_m() + v0, e->p_v() + v0, e->P - v0, e->p_scalars(), lr_t,
+               e->b1, e->b2, e->adam_eps, grid_cap);
+  }
+  HIPCHK(hipEventRecord(e->ev_adam_vec, sa));
+  for (int l = 0; l <= e->L; ++l) {
+    const LayerLayout& y = e->lay[l];
+    {
+      ProfScope ps(e, KF_ADAM, 0, 28.0 * y.w_sz, sa);
+      adam_apply(sa, e->p_param() + y.w_off, e->p_grad() + y.w_off, e->p_m() + y.w_off, e->p_v() + y.w_off, y.w_sz,
+                 e->p_scalars(), lr_t, e->b1, e->b2, e->adam_eps, grid_cap);
+    }
+    HIPCHK(hipEventRecord(e->ev_adam_w[l], sa));
+  }
+  HIPCHK(hipMemsetAsync(e->p_scalars(), 0, kScalarFloats * sizeof(float), sa));  // init_loss / init_num_frames
+  HIPCHK(hipEventRecord(e->ev_adam_done, sa));
   HIPCHK(hipGetLastError());
-  CHK(read_scalars(e, true));
+  e->adam_pending = true;
+  HIPCHK(hipEventSynchronize(e->ev_loss));  // the host only waits for the loss, not for the optimiser
   e->grads_fresh = true;
   e->global_step += 1;
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
@@ -773,6 +899,7 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
 int tfk_eval_finish(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(wait_adam_done(e));
   CHK(read_scalars(e, false));
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
   return 0;
@@ -795,6 +922,7 @@ int tfk_init_last_layer(tfk_engine* e) {
   // re-run the initialisers of layer L: weights ~ N(0, stddev 0) = 0, biases = 0 (dnn.py:67-68, 114-120)
   const LayerLayout& o = e->lay[e->L];
   HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(wait_adam_done(e));
   HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
   return 0;
@@ -885,6 +1013,7 @@ int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* 
 int tfk_zero_accumulators(tfk_engine* e) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(wait_adam_done(e));
   HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->reduce_floats * sizeof(float), e->stream));
   e->grads_fresh = false;  // physically zero now
   return 0;
@@ -905,8 +1034,7 @@ int tfk_set_later_microbatches(tfk_engine* e, int32_t later) {
 int tfk_synchronize(tfk_engine* e) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipStreamSynchronize(e->copy_stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(sync_streams(e));
   return 0;
 }
 int tfk_stream(tfk_engine* e, void** hip_stream) {
@@ -925,7 +1053,7 @@ int tfk_profile_begin(tfk_engine* e) {
 int tfk_profile_end(tfk_engine* e, tfk_kernel_stat* stats, int capacity, int* count) {
   if (!e || !count) return fail(-1, "NULL argument");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(sync_streams(e));
   e->profiling = false;
   tfk_kernel_stat acc[KF_COUNT];
   memset(acc, 0, sizeof(acc));
@@ -953,7 +1081,7 @@ int tfk_profile_end(tfk_engine* e, tfk_kernel_stat* stats, int capacity, int* co
 int tfk_debug_fetch(tfk_engine* e, int what, int layer, float* host, size_t count) {
   if (!e || !host) return fail(-1, "NULL argument");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  CHK(sync_streams(e));
   const int T = e->last_T;
   if (T <= 0) return fail(-1, "no previous call to fetch from");
   if (what == TFK_DBG_LOGITS) {

@@ -73,8 +73,9 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
                   const float* prior);
 
 // ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam (G is left as is) ----
+// grid_cap > 0 limits the number of blocks (grid-stride loop does the rest)
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps);
+                float beta1, float beta2, float eps, int grid_cap);
 // moving <- decay^{num_microbatches} * moving + E
 void ema_apply(hipStream_t s, float* moving, const float* e, size_t n, const float* scalars, float decay);
 void scale_inplace(hipStream_t s, float* x, size_t n, float factor);

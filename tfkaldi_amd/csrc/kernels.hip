@@ -746,10 +746,11 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 }
 
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps) {
+                float beta1, float beta2, float eps, int grid_cap) {
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
+  if (grid_cap > 0 && blocks > (size_t)grid_cap) blocks = grid_cap;
   if (blocks == 0) return;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1, beta2,
                      eps);
