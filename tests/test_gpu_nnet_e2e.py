@@ -149,6 +149,15 @@ def test_nnet_train_and_decode(gpu, tmp_path, capsys):
         assert_close("loglik " + uid, mat, want, 2e-4, 2e-4)
         n += 1
     assert n == len(keep)
+    # the same decode with the splice on the device and small decode batches: identical archive contents
+    reader2 = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, 30,
+                                           splice_on_device=True)
+    reader2.reader.utt_ids = [reader2.reader.utt_ids[i] for i in keep]
+    reader2.reader.scp_data = [reader2.reader.scp_data[i] for i in keep]
+    net.conf["decode_batch_frames"] = "40"
+    writer2 = ark.ArkWriter(str(decodedir / "feats2.scp"), str(decodedir / "likelihoods2.ark"))
+    net.decode(reader2, writer2)
+    assert open(str(decodedir / "likelihoods2.ark"), "rb").read() == open(str(decodedir / "likelihoods.ark"), "rb").read()
 
 
 def test_dnn_call_signature(gpu):

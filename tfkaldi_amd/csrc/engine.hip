@@ -112,6 +112,12 @@ struct tfk_engine {
   int32_t* dY[2] = {nullptr, nullptr};
   std::vector<float*> z, a, v, rowscale, mean, rstd;
   float *logits = nullptr, *post = nullptr, *dA[2] = {nullptr, nullptr}, *row_loss = nullptr, *ws = nullptr;
+  // device-side splice (tfk_*_raw): unspliced frames + utterance offsets, double-buffered like dX
+  float* dRaw[2] = {nullptr, nullptr};
+  int32_t* dSeg[2] = {nullptr, nullptr};
+  float* hRaw[2] = {nullptr, nullptr};
+  int32_t* hSeg[2] = {nullptr, nullptr};
+  int seg_cap = 0;
   float* ws_bwd = nullptr;  // per-layer partial column sums of backward (finalised by one kernel)
   size_t ws_bwd_stride = 0;
   float* prior = nullptr;
@@ -279,6 +285,10 @@ void free_activations(tfk_engine* e) {
     fr(e->dA[s]);
     if (e->hX[s]) { hipHostFree(e->hX[s]); e->hX[s] = nullptr; }
     if (e->hY[s]) { hipHostFree(e->hY[s]); e->hY[s] = nullptr; }
+    fr(e->dRaw[s]);
+    if (e->dSeg[s]) { hipFree(e->dSeg[s]); e->dSeg[s] = nullptr; }
+    if (e->hRaw[s]) { hipHostFree(e->hRaw[s]); e->hRaw[s] = nullptr; }
+    if (e->hSeg[s]) { hipHostFree(e->hSeg[s]); e->hSeg[s] = nullptr; }
   }
   for (auto& p : e->z) fr(p);
   for (auto& p : e->a) fr(p);
@@ -309,6 +319,11 @@ int reserve(tfk_engine* e, int T) {
     CHK(alloc_zero(&e->dA[s], (size_t)cap * e->ldH));
     HIPCHK(hipHostMalloc((void**)&e->hX[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&e->hY[s], (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
+    // raw frames: at most F columns (context 0); one utterance per frame at worst
+    CHK(alloc_zero(&e->dRaw[s], (size_t)cap * e->ldF));
+    HIPCHK(hipMalloc((void**)&e->dSeg[s], (size_t)(cap + 1) * sizeof(int32_t)));
+    HIPCHK(hipHostMalloc((void**)&e->hRaw[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->hSeg[s], (size_t)(cap + 1) * sizeof(int32_t), hipHostMallocDefault));
     e->slot_used[s] = false;
   }
   e->z.assign(L, nullptr); e->a.assign(L, nullptr); e->v.assign(L, nullptr); e->rowscale.assign(L, nullptr);
@@ -365,6 +380,48 @@ int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, in
   if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
   HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
+  e->slot_used[s] = true;
+  *Xd = e->dX[s];
+  *ldx_out = e->ldF;
+  *yd = e->dY[s];
+  e->slot ^= 1;
+  return 0;
+}
+
+// Bring unspliced frames + utterance offsets to HBM and splice them into dX[slot] there.
+int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int T, const int32_t* utt_len, int U,
+              int context, const float** Xd, int* ldx_out, const int32_t** yd) {
+  if (context < 0) return fail(-1, "context_width %d < 0", context);
+  const int win = 2 * context + 1;
+  if (e->F % win != 0) return fail(-1, "input_dim %d is not a multiple of 2*context_width+1 = %d", e->F, win);
+  const int D = e->F / win;
+  if (ldraw < D) return fail(-1, "ldraw %lld < raw dimension %d", (long long)ldraw, D);
+  if (U <= 0 || !utt_len) return fail(-1, "no utterances");
+  if (U > T) return fail(-1, "more utterances (%d) than frames (%d)", U, T);
+  long total = 0;
+  for (int u = 0; u < U; ++u) {
+    if (utt_len[u] < 0) return fail(-1, "negative utterance length");
+    total += utt_len[u];
+  }
+  if (total != T) return fail(-1, "utterance lengths sum to %ld, expected T = %d", total, T);
+  const int s = e->slot;
+  if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
+  for (int t = 0; t < T; ++t) memcpy(e->hRaw[s] + (size_t)t * D, raw + (size_t)t * ldraw, (size_t)D * sizeof(float));
+  e->hSeg[s][0] = 0;
+  for (int u = 0; u < U; ++u) e->hSeg[s][u + 1] = e->hSeg[s][u] + utt_len[u];
+  if (y) memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
+  if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  const int ldD = (D + 3) & ~3;
+  HIPCHK(hipMemcpy2DAsync(e->dRaw[s], (size_t)ldD * 4, e->hRaw[s], (size_t)D * 4, (size_t)D * 4, T,
+                          hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipMemcpyAsync(e->dSeg[s], e->hSeg[s], (size_t)(U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
+  {
+    ProfScope ps(e, KF_MISC, 0, 4.0 * T * (D + e->F));
+    splice_frames(e->stream, e->dRaw[s], ldD, e->dSeg[s], U, T, D, context, e->dX[s], e->ldF);
+  }
   e->slot_used[s] = true;
   *Xd = e->dX[s];
   *ldx_out = e->ldF;
@@ -652,15 +709,22 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   return 0;
 }
 
-int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags, int train) {
+struct RawSpec {  // non-null utt_len selects the device-side splice
+  const int32_t* utt_len;
+  int U, context;
+};
+int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags, int train,
+                  const RawSpec* raw = nullptr) {
   if (!e) return fail(-1, "engine is NULL");
   if (T <= 0) return fail(-1, "empty micro-batch (T = %d)", T);
   if (!X || !y) return fail(-1, "X / y is NULL");
+  if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers");
   HIPCHK(hipSetDevice(e->cfg.device));
   CHK(reserve(e, T));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
-  CHK(stage_input(e, X, ldx, y, T, flags, &Xd, &ld, &yd));
+  if (raw) CHK(stage_raw(e, X, ldx, y, T, raw->utt_len, raw->U, raw->context, &Xd, &ld, &yd));
+  else CHK(stage_input(e, X, ldx, y, T, flags, &Xd, &ld, &yd));
   const uint32_t call = e->call_counter++;
   const int nact = e->nact();
   // train mode evaluates every hidden layer when BN is on: the UPDATE_OPS of all batch-norm layers are
@@ -828,6 +892,18 @@ int tfk_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y,
 int tfk_eval_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags) {
   return train_or_eval(e, X, ldx, y, T, flags & ~TFK_LAST_MICROBATCH, 0);
 }
+int tfk_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
+                       const int32_t* utt_len, int32_t U, int32_t context_width, int flags) {
+  const RawSpec r = {utt_len, U, context_width};
+  if (!utt_len) return fail(-1, "utt_len is NULL");
+  return train_or_eval(e, raw, ldraw, y, T, flags, 1, &r);
+}
+int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
+                            const int32_t* utt_len, int32_t U, int32_t context_width, int flags) {
+  const RawSpec r = {utt_len, U, context_width};
+  if (!utt_len) return fail(-1, "utt_len is NULL");
+  return train_or_eval(e, raw, ldraw, y, T, flags & ~TFK_LAST_MICROBATCH, 0, &r);
+}
 
 int tfk_apply(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
@@ -938,8 +1014,10 @@ int tfk_set_prior(tfk_engine* e, const float* prior, size_t count) {
   return 0;
 }
 
-int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags) {
+static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags,
+                           const RawSpec* raw) {
   if (!e) return fail(-1, "engine is NULL");
+  if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers");
   if (N <= 0) return fail(-1, "empty utterance (N = %d)", N);
   if (!X || !out) return fail(-1, "X / out is NULL");
   if (ldo < e->O) return fail(-1, "ldo %lld < output_dim %d", (long long)ldo, e->O);
@@ -948,14 +1026,15 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
   CHK(reserve(e, N));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
-  CHK(stage_input(e, X, ldx, nullptr, N, flags, &Xd, &ld, &yd));
+  if (raw) CHK(stage_raw(e, X, ldx, nullptr, N, raw->utt_len, raw->U, raw->context, &Xd, &ld, &yd));
+  else CHK(stage_input(e, X, ldx, nullptr, N, flags, &Xd, &ld, &yd));
   const int nact = e->nact();
   const uint32_t call = e->call_counter++;
   CHK(forward(e, Xd, ld, N, 0, nact, nact, call));
   const float* prior = (flags & TFK_LOG_DIV_PRIOR) ? e->prior : nullptr;
-  const bool raw = (flags & TFK_RAW_LOGITS) != 0;
+  const bool want_logits = (flags & TFK_RAW_LOGITS) != 0;
   if (flags & TFK_DEVICE_PTRS) {
-    if (raw) {
+    if (want_logits) {
       HIPCHK(hipMemcpy2DAsync(out, (size_t)ldo * 4, e->logits, (size_t)e->ldO * 4, (size_t)e->O * 4, N,
                               hipMemcpyDeviceToDevice, e->stream));
     } else {
@@ -963,7 +1042,7 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
       softmax_rows(e->stream, e->logits, N, e->O, e->ldO, out, ldo, prior);
     }
   } else {
-    if (!raw) {
+    if (!want_logits) {
       ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * N * e->O);
       softmax_rows(e->stream, e->logits, N, e->O, e->ldO, e->post, e->ldO, prior);
     }
@@ -976,7 +1055,7 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
       HIPCHK(hipHostMalloc((void**)&e->h_post, need * sizeof(float), hipHostMallocDefault));
       e->h_post_floats = need;
     }
-    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, raw ? e->logits : e->post, (size_t)e->ldO * 4,
+    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, want_logits ? e->logits : e->post, (size_t)e->ldO * 4,
                             (size_t)e->O * 4, N, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int t = 0; t < N; ++t) memcpy(out + (size_t)t * ldo, e->h_post + (size_t)t * e->O, (size_t)e->O * sizeof(float));
@@ -984,6 +1063,16 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
   HIPCHK(hipGetLastError());
   e->last_T = N; e->last_nfw = nact; e->last_call = call; e->last_in = Xd;
   return 0;
+}
+
+int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags) {
+  return posteriors_impl(e, X, ldx, N, out, ldo, flags, nullptr);
+}
+int tfk_posteriors_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t N, const int32_t* utt_len, int32_t U,
+                       int32_t context_width, float* out, int64_t ldo, int flags) {
+  const RawSpec r = {utt_len, U, context_width};
+  if (!utt_len) return fail(-1, "utt_len is NULL");
+  return posteriors_impl(e, raw, ldraw, N, out, ldo, flags, &r);
 }
 
 int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {

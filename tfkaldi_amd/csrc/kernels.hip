@@ -422,19 +422,34 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
   __shared__ float4 sm[CT_Y][CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
   float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 m1 = sz, m2 = sz;
+  if (d.bn) {
+    // column means of du and du*xhat from pass A's per-chunk partials: row lane y sums chunks y, y+8, ...
+    // (<= 8 independent loads each), the block combines them through LDS
+    float4 p1 = sz, p2 = sz;
+    if (t.valid)
+      for (int k = threadIdx.y; k < rs; k += CT_Y) {
+        const float4 q1 = ld4(ws + ((size_t)0 * rs + k) * ld + t.col);
+        const float4 q2 = ld4(ws + ((size_t)1 * rs + k) * ld + t.col);
+        p1.x += q1.x; p1.y += q1.y; p1.z += q1.z; p1.w += q1.w;
+        p2.x += q2.x; p2.y += q2.y; p2.z += q2.z; p2.w += q2.w;
+      }
+    __shared__ float4 smm[2][CT_X];
+    p1 = reduce_rows(p1, sm);
+    p2 = reduce_rows(p2, sm);
+    if (threadIdx.y == 0) {
+      const float invT = 1.f / (float)T;
+      smm[0][threadIdx.x] = make_float4(p1.x * invT, p1.y * invT, p1.z * invT, p1.w * invT);
+      smm[1][threadIdx.x] = make_float4(p2.x * invT, p2.y * invT, p2.z * invT, p2.w * invT);
+    }
+    __syncthreads();
+    m1 = smm[0][threadIdx.x];
+    m2 = smm[1][threadIdx.x];
+  }
   if (t.valid) {
-    float4 mu = sz, rsd = sz, m1 = sz, m2 = sz;
+    float4 mu = sz, rsd = sz;
     if (d.bn) {
       mu = ld4(mean + t.col); rsd = ld4(rstd + t.col);
-      for (int k = 0; k < rs; ++k) {
-        const float4 p1 = ld4(ws + ((size_t)0 * rs + k) * ld + t.col);
-        const float4 p2 = ld4(ws + ((size_t)1 * rs + k) * ld + t.col);
-        m1.x += p1.x; m1.y += p1.y; m1.z += p1.z; m1.w += p1.w;
-        m2.x += p2.x; m2.y += p2.y; m2.z += p2.z; m2.w += p2.w;
-      }
-      const float invT = 1.f / (float)T;
-      m1.x *= invT; m1.y *= invT; m1.z *= invT; m1.w *= invT;
-      m2.x *= invT; m2.y *= invT; m2.z *= invT; m2.w *= invT;
     }
     for (int rb = t.r0 + threadIdx.y; rb < t.r1; rb += CT_Y * RB) {
       float4 g[RB], av[RB], zv[RB];
@@ -660,6 +675,37 @@ __global__ void dropout_mask_kernel(ActDesc d, float* __restrict__ out, int T, i
   st4(out + (size_t)row * ld + (c4 << 2), o);
 }
 
+// one thread per output element group of 4 (scalar inside: D need not be a multiple of 4)
+__global__ void __launch_bounds__(256)
+splice_kernel(const float* __restrict__ raw, int ldr, const int32_t* __restrict__ seg, int U, int T, int D, int context,
+              float* __restrict__ out, int ldo) {
+  const int nc4 = ldo >> 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)T * nc4) return;
+  const int t = (int)(idx / nc4), c4 = (int)(idx % nc4);
+  // utterance of frame t: largest u with seg[u] <= t (binary search over U + 1 offsets)
+  int lo = 0, hi = U;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg[mid] <= t) lo = mid; else hi = mid;
+  }
+  const int first = seg[lo], last = seg[lo + 1];
+  const int F = D * (2 * context + 1);
+  float4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int col = (c4 << 2) + k;
+    float v = 0.f;
+    if (col < F) {
+      const int j = col / D, d = col - j * D;
+      const int src = t + j - context;
+      if (src >= first && src < last) v = raw[(size_t)src * ldr + d];
+    }
+    el(o, k) = v;
+  }
+  st4(out + (size_t)t * ldo + (c4 << 2), o);
+}
+
 inline dim3 ct_grid(int ld, int rs) { return dim3((ld / 4 + CT_X - 1) / CT_X, rs); }
 inline dim3 ct_block() { return dim3(CT_X, CT_Y); }
 
@@ -767,6 +813,13 @@ void scale_inplace(hipStream_t s, float* x, size_t n, float factor) {
 void fill(hipStream_t s, float* x, size_t n, float value) {
   if (n == 0) return;
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, value);
+}
+void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg, int U, int T, int D, int context,
+                   float* out, int ldo) {
+  const size_t n = (size_t)T * (ldo / 4);
+  if (n == 0) return;
+  hipLaunchKernelGGL(splice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, ldr, seg, U, T, D, context,
+                     out, ldo);
 }
 void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld) {
   const size_t n = (size_t)T * (ld / 4);

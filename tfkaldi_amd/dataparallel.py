@@ -45,6 +45,28 @@ def init_from_env():
     return rank, world, local_rank
 
 
+class RawMicroBatch(object):
+    """A micro-batch whose +-context splice happens on the device: unspliced frames [T, D], targets [T],
+    utterance lengths [U] and the context width (tfk_accumulate_raw)."""
+
+    def __init__(self, raw, y, lens, context_width):
+        self.raw, self.y, self.lens, self.context_width = raw, y, lens, context_width
+
+
+def _accumulate(engine, mb, last):
+    if isinstance(mb, RawMicroBatch):
+        engine.accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, last=last)
+    else:
+        engine.accumulate(mb[0], mb[1], last=last)
+
+
+def _eval_accumulate(engine, mb):
+    if isinstance(mb, RawMicroBatch):
+        engine.eval_accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width)
+    else:
+        engine.eval_accumulate(mb[0], mb[1])
+
+
 def partition(num_items, world):
     """contiguous [start, end) blocks per rank, sizes differing by at most one (larger blocks first)"""
     base, extra = divmod(num_items, world)
@@ -85,8 +107,8 @@ class DataParallel(object):
         """`microbatches`: the (X[T, F], y[T]) micro-batches of the WHOLE step, identical on every rank.
         Returns the average loss over all of them (reference Trainer.update's return value)."""
         if not self.enabled:
-            for i, (X, y) in enumerate(microbatches):
-                engine.accumulate(X, y, last=(i == len(microbatches) - 1))
+            for i, mb in enumerate(microbatches):
+                _accumulate(engine, mb, i == len(microbatches) - 1)
             return engine.apply()
         import torch.distributed as dist
         start, end = partition(len(microbatches), self.world)[self.rank]
@@ -106,8 +128,8 @@ class DataParallel(object):
 
         engine.set_bucket_callback(on_bucket)
         try:
-            for i, (X, y) in enumerate(mine):
-                engine.accumulate(X, y, last=(i == len(mine) - 1))
+            for i, mb in enumerate(mine):
+                _accumulate(engine, mb, i == len(mine) - 1)
             if not mine:  # more ranks than micro-batches: contribute zeros
                 engine.zero_accumulators()
                 for b in range(len(buckets)):
@@ -124,13 +146,13 @@ class DataParallel(object):
     def eval_step(self, engine, microbatches):
         """average validation loss (reference Trainer.evaluate); only the scalar tail is reduced"""
         if not self.enabled:
-            for X, y in microbatches:
-                engine.eval_accumulate(X, y)
+            for mb in microbatches:
+                _eval_accumulate(engine, mb)
             return engine.eval_finish()
         import torch.distributed as dist
         start, end = partition(len(microbatches), self.world)[self.rank]
-        for X, y in microbatches[start:end]:
-            engine.eval_accumulate(X, y)
+        for mb in microbatches[start:end]:
+            _eval_accumulate(engine, mb)
         off, n = engine.buckets()[-1]
         with self._stream_ctx(engine):
             dist.all_reduce(engine.reduce_view()[off:off + n], op=dist.ReduceOp.SUM, group=self.group)

@@ -147,6 +147,38 @@ class Engine(object):
         flags = _lib.DEVICE_PTRS | (_lib.LAST_MICROBATCH if last else 0)
         check(self.lib.tfk_accumulate(self._h, c_void_p(x_ptr), ldx, c_void_p(y_ptr), T, flags))
 
+    # ---- device-side splice: unspliced frames in, spliced in HBM ----
+    @staticmethod
+    def _raw_batch(raw, lens):
+        raw = _f32(raw)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if raw.ndim != 2 or lens.ndim != 1 or int(lens.sum()) != raw.shape[0]:
+            raise ValueError("raw %s / utterance lengths (sum %d) do not match" % (raw.shape, int(lens.sum())))
+        return raw, lens
+
+    def accumulate_raw(self, raw, y, lens, context_width, last=False):
+        raw, lens = self._raw_batch(raw, lens)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        check(self.lib.tfk_accumulate_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1],
+                                          y.ctypes.data_as(c_void_p), raw.shape[0], lens.ctypes.data_as(c_void_p),
+                                          lens.size, int(context_width), _lib.LAST_MICROBATCH if last else 0))
+
+    def eval_accumulate_raw(self, raw, y, lens, context_width):
+        raw, lens = self._raw_batch(raw, lens)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        check(self.lib.tfk_eval_accumulate_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1],
+                                               y.ctypes.data_as(c_void_p), raw.shape[0],
+                                               lens.ctypes.data_as(c_void_p), lens.size, int(context_width), 0))
+
+    def posteriors_raw(self, raw, lens, context_width, log_div_prior=False, raw_logits=False):
+        raw, lens = self._raw_batch(raw, lens)
+        out = np.empty((raw.shape[0], self.O), dtype=np.float32)
+        flags = (_lib.LOG_DIV_PRIOR if log_div_prior else 0) | (_lib.RAW_LOGITS if raw_logits else 0)
+        check(self.lib.tfk_posteriors_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0],
+                                          lens.ctypes.data_as(c_void_p), lens.size, int(context_width),
+                                          out.ctypes.data_as(c_void_p), self.O, flags))
+        return out
+
     def apply(self):
         loss = c_float()
         check(self.lib.tfk_apply(self._h, byref(loss)))

@@ -3,6 +3,7 @@ import os
 
 import numpy as np
 
+from ..processing.feature_reader import Unspliced
 from .classifiers.dnn import ModelSaver
 
 
@@ -35,13 +36,35 @@ class Decoder(object):
             raise ValueError("negative dimensions are not allowed")
         return inputs
 
+    def _run(self, inputs, **kw):
+        if isinstance(inputs, Unspliced):  # splice on the device
+            self._check(inputs)
+            return self.engine.posteriors_raw(np.asarray(inputs), [inputs.shape[0]], inputs.context_width, **kw)
+        return self.engine.posteriors(self._check(inputs), **kw)
+
     def __call__(self, inputs):
         """NxF features -> NxO state posteriors (reference decoder.py:49-71)"""
-        return self.engine.posteriors(self._check(inputs))
+        return self._run(inputs)
 
     def log_likelihoods(self, inputs):
         """log(posterior / prior), fused in the softmax kernel; needs set_prior (reference nnet.py:280-286)"""
-        return self.engine.posteriors(self._check(inputs), log_div_prior=True)
+        return self._run(inputs, log_div_prior=True)
+
+    def decode_batch(self, utterances, log_div_prior=True):
+        """Several utterances in ONE forward pass: returns a list of per-utterance [N_i, O] arrays.
+        All `Unspliced` -> device-side splice with utterance boundaries; otherwise the spliced matrices are
+        simply stacked (frames are independent once spliced)."""
+        lens = [u.shape[0] for u in utterances]
+        for u in utterances:
+            self._check(u)
+        if all(isinstance(u, Unspliced) for u in utterances):
+            flat = self.engine.posteriors_raw(np.concatenate([np.asarray(u) for u in utterances]), lens,
+                                              utterances[0].context_width, log_div_prior=log_div_prior)
+        else:
+            stack = np.concatenate([u.spliced() if isinstance(u, Unspliced) else np.asarray(u, dtype=np.float32)
+                                    for u in utterances])
+            flat = self.engine.posteriors(stack, log_div_prior=log_div_prior)
+        return np.split(flat, np.cumsum(lens)[:-1])
 
     def set_prior(self, prior):
         self.engine.set_prior(prior)

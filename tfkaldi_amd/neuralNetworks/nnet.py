@@ -184,13 +184,30 @@ class Nnet(object):
         try:
             decoder.restore(self.conf['savedir'] + '/final')
             decoder.set_prior(prior)
+            # The reference evaluates one utterance per session run (nnet.py:270-286).  Frames are independent
+            # in this model, so utterances are grouped into forward passes of up to `decode_batch_frames`
+            # frames (optional [nnet] key, default 8192; 0 = one utterance per pass) and written in order.
+            budget = int(self.conf.get('decode_batch_frames', '8192'))
+            pending, frames = [], 0
+
+            def flush():
+                # log(posterior / prior); the reference's flooring line discards its result (nnet.py:283),
+                # so no flooring is applied there either
+                for (uid, _), like in zip(pending, decoder.decode_batch([m for _, m in pending])):
+                    writer.write_next_utt(uid, like)
+                del pending[:]
+
             while True:
                 utt_id, utt_mat, looped = reader.get_utt()
                 if looped:
                     break
-                # log(posterior / prior); the reference's flooring line discards its result (nnet.py:283),
-                # so no flooring is applied there either
-                writer.write_next_utt(utt_id, decoder.log_likelihoods(utt_mat))
+                if pending and frames + utt_mat.shape[0] > budget:
+                    flush()
+                    frames = 0
+                pending.append((utt_id, utt_mat))
+                frames += utt_mat.shape[0]
+            if pending:
+                flush()
         finally:
             decoder.close()
         writer.close()

@@ -20,8 +20,17 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .. import _lib
-from ..dataparallel import DataParallel
+from ..dataparallel import DataParallel, RawMicroBatch
+from ..processing.feature_reader import Unspliced
 from .classifiers.dnn import ModelSaver
+
+
+def _spliced(utt):
+    """host matrix [N, F] of one utterance (an Unspliced one is spliced on the host when it shares a
+    micro-batch with already-spliced utterances)"""
+    if isinstance(utt, Unspliced):
+        return utt.spliced()
+    return np.asarray(utt, dtype=np.float32)
 
 
 class _Graph(object):
@@ -134,9 +143,16 @@ class Trainer(object, metaclass=ABCMeta):
                 if inputs[i].shape[0] != targets[i].shape[0]:
                     raise ValueError("utterance %d: %d input frames but %d targets (the cross-enthropy trainer "
                                      "needs equal lengths)" % (i, inputs[i].shape[0], targets[i].shape[0]))
-            X = np.concatenate([np.asarray(inputs[i], dtype=np.float32) for i in idx], axis=0)
             y = np.concatenate([np.asarray(targets[i]).astype(np.int32) for i in idx], axis=0)
-            if X.shape[0] > 0:
+            if y.shape[0] == 0:
+                continue
+            if all(isinstance(inputs[i], Unspliced) for i in idx):
+                # splice on the device: ship the unspliced frames + utterance lengths
+                raw = np.concatenate([np.asarray(inputs[i]) for i in idx], axis=0)
+                lens = np.array([inputs[i].shape[0] for i in idx], dtype=np.int32)
+                out.append(RawMicroBatch(raw, y, lens, inputs[idx[0]].context_width))
+            else:
+                X = np.concatenate([_spliced(inputs[i]) for i in idx], axis=0)
                 out.append((X, y))
         return out
 

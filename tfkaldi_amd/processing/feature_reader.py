@@ -5,10 +5,32 @@ import numpy as np
 from . import ark, readfiles
 
 
-class FeatureReader(object):
-    """Reads features from a Kaldi archive, mean/variance-normalises them per speaker and splices them."""
+class Unspliced(np.ndarray):
+    """CMVN-normalised frames [N, D] whose +-context splice is deferred to the GPU.  Trainer and
+    Decoder recognise the type and send only these N x D values over PCIe; `spliced()` gives the host result."""
 
-    def __init__(self, scpfile, cmvnfile, utt2spkfile, context_width, max_input_length):
+    context_width = 0
+
+    def __new__(cls, frames, context_width):
+        obj = np.ascontiguousarray(frames, dtype=np.float32).view(cls)
+        obj.context_width = int(context_width)
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self.context_width = getattr(obj, "context_width", 0)
+
+    def spliced(self):
+        return splice(np.asarray(self), self.context_width)
+
+
+class FeatureReader(object):
+    """Reads features from a Kaldi archive, mean/variance-normalises them per speaker and splices them.
+    With splice_on_device=True get_utt() returns `Unspliced` frames (same None-when-too-short rule) and the
+    splice happens in HBM."""
+
+    def __init__(self, scpfile, cmvnfile, utt2spkfile, context_width, max_input_length, splice_on_device=False):
+        self.splice_on_device = splice_on_device
         self.reader = ark.ArkReader(scpfile)
         self.reader_cmvn = ark.ArkReader(cmvnfile)
         self.utt2spk = readfiles.read_utt2spk(utt2spkfile)
@@ -19,13 +41,12 @@ class FeatureReader(object):
         """(utt_id, spliced features or None if too short, looped) -- reference feature_reader.py:42-60"""
         utt_id, utt_mat, looped = self.reader.read_next_utt()
         stats = self.reader_cmvn.read_utt(self.utt2spk[utt_id])
-        return utt_id, splice(apply_cmvn(utt_mat, stats), self.context_width), looped
-
-    def get_utt_raw(self):
-        """(utt_id, CMVN-normalised UNSPLICED features, looped): for the on-device splice path"""
-        utt_id, utt_mat, looped = self.reader.read_next_utt()
-        stats = self.reader_cmvn.read_utt(self.utt2spk[utt_id])
-        return utt_id, apply_cmvn(utt_mat, stats), looped
+        normalised = apply_cmvn(utt_mat, stats)
+        if self.splice_on_device:
+            if normalised.shape[0] < 1 + 2 * self.context_width:
+                return utt_id, None, looped
+            return utt_id, Unspliced(normalised, self.context_width), looped
+        return utt_id, splice(normalised, self.context_width), looped
 
     def next_id(self):
         return self.reader.read_next_scp()
