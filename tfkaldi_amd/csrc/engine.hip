@@ -118,6 +118,7 @@ struct tfk_engine {
   float* hRaw[2] = {nullptr, nullptr};
   int32_t* hSeg[2] = {nullptr, nullptr};
   int seg_cap = 0;
+  float* ws_stats = nullptr;  // [2, ceil(cap / 64), ldH] per-tile BN statistics from the forward GEMM epilogue
   float* ws_bwd = nullptr;  // per-layer partial column sums of backward (finalised by one kernel)
   size_t ws_bwd_stride = 0;
   float* prior = nullptr;
@@ -265,14 +266,15 @@ int wait_adam_done(tfk_engine* e) {
 }
 
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-             int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr) {
+             int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr, float* stats = nullptr,
+             int cfg = -1) {
   if (!st) st = e->stream;
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.stats = stats;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
   ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)), st);
-  const int rc = gemm_f32(layout, g, -1, st);
+  const int rc = gemm_f32(layout, g, cfg, st);
   if (rc != 0) return fail(rc, "gemm_f32 launch failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
@@ -294,7 +296,7 @@ void free_activations(tfk_engine* e) {
   for (auto& p : e->a) fr(p);
   for (auto& p : e->v) fr(p);
   for (auto& p : e->rowscale) fr(p);
-  fr(e->logits); fr(e->post); fr(e->row_loss); fr(e->ws); fr(e->ws_bwd);
+  fr(e->logits); fr(e->post); fr(e->row_loss); fr(e->ws); fr(e->ws_bwd); fr(e->ws_stats);
   e->cap = 0;
 }
 
@@ -340,6 +342,7 @@ int reserve(tfk_engine* e, int T) {
   CHK(alloc_zero(&e->row_loss, (size_t)cap));
   const int ldmax = e->ldH > e->ldO ? e->ldH : e->ldO;
   CHK(alloc_zero(&e->ws, (size_t)3 * kMaxRowSplits * ldmax));
+  CHK(alloc_zero(&e->ws_stats, (size_t)2 * ((cap + 63) / 64) * e->ldH));
   e->ws_bwd_stride = (size_t)3 * kMaxRowSplits * ldmax;
   CHK(alloc_zero(&e->ws_bwd, e->ws_bwd_stride * (L + 1)));
   e->cap = cap;
@@ -454,6 +457,23 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
     if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_w[l], 0));
+    if (train && e->cfg.batch_norm && !e->cfg.l2_norm) {
+      // fused path: the GEMM epilogue emits the per-tile column statistics, ONE column-tiled kernel merges them
+      // and applies BN + nonlinearity + dropout (4 kernels per layer -> 2)
+      const int cfg = gemm_f32_pick_config(GEMM_NN, T, H, y.d_in);
+      CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
+                   e->p_param() + y.b_off, EPI_BIAS | EPI_COLSTATS, nullptr, e->ws_stats, cfg));
+      {
+        ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * T * H);
+        const ActDesc d = act_desc(e, l, train, call);
+        bn_act_forward(e->stream, d, e->z[l], e->a[l], e->ws_stats, gemm_f32_config_bm(cfg), T, H, ldH, e->bn_eps,
+                       e->bn_decay, e->mean[l], e->rstd[l], e->ema_mean(l), e->ema_var(l),
+                       e->p_param() + y.beta_off);
+      }
+      in = e->a[l];
+      ld_in = ldH;
+      continue;
+    }
     CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
                  e->p_param() + y.b_off, EPI_BIAS));
     if (e->cfg.batch_norm) {
@@ -1203,7 +1223,7 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
                  int N, int K, const float* bias, int epi, int tile_config) {
   if (layout < 0 || layout > 2) return fail(-1, "bad layout %d", layout);
   GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.stats = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int rc = gemm_f32((GemmLayout)layout, g, tile_config, (hipStream_t)stream);
   if (rc != 0) return fail(rc, "gemm_f32 failed: %s", hipGetErrorString((hipError_t)rc));

@@ -23,6 +23,9 @@ enum : int {
   EPI_BIAS = 1,        // C += bias[col]
   EPI_ACCUM = 2,       // C = C_old + result
   EPI_RELU = 4,        // C = max(C, 0)            (non-BN forward with relu)
+  EPI_COLSTATS = 8,    // also emit, per BM-row tile, each column's mean and sum of squared deviations of the
+                       // stored values (the batch-norm statistics of the layer, Chan-mergeable):
+                       // stats[(0 * tiles_m + tile_m) * ldc + col] = mean, stats[(1 * tiles_m + tile_m) * ldc + col] = M2
 };
 
 struct GemmArgs {
@@ -30,6 +33,7 @@ struct GemmArgs {
   const float* B;
   float* C;
   const float* bias;  // [N] when EPI_BIAS
+  float* stats;       // [2, tiles_m, ldc] when EPI_COLSTATS
   int M, N, K;
   int lda, ldb, ldc;
   int epi;
@@ -56,5 +60,6 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K);
 void gemm_f32_force_config(int cfg);
 
 const char* gemm_f32_config_name(int cfg);
+int gemm_f32_config_bm(int cfg);  // rows of a block tile (= rows per EPI_COLSTATS chunk)
 
 }  // namespace tfk

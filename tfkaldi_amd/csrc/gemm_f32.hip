@@ -360,6 +360,55 @@ gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
 
   // ---- epilogue: D reg r of lane (i,h) is row (r&3) + 8*(r>>2) + 4*h, col i of its 32x32 fragment ----
   const bool full_tile = (m0 + T::BM <= p.M) && (n0 + T::BN <= p.N);
+  if constexpr ((EPI & EPI_COLSTATS) != 0) {
+    // Batch-norm statistics of this tile's rows, two-pass (mean, then squared deviations) so that the later
+    // Chan merge over tile rows never subtracts large numbers.  A lane holds 16 rows of one column per fragment,
+    // its partner lane ^ 32 the interleaved other 16; the WAVES_M waves stacked along m meet in LDS (the K loop
+    // has ended behind a barrier, so the ring is free).
+    float* red = smem;  // [WAVES_M][BN]
+    const int n_tile = min(T::BM, p.M - m0);
+    float cmean[T::FN];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int b = 0; b < T::FN; ++b) {
+        const int colc = min(n0 + wn * T::WN + b * 32 + i, p.N - 1);
+        const float bv = (EPI & EPI_BIAS) ? p.bias[colc] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < T::FM; ++a) {
+          const int rbase = m0 + wm * T::WM + a * 32 + 4 * h;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[0][a][b][r];
+#pragma unroll
+            for (int q = 1; q < T::KS; ++q) v += acc[q][a][b][r];
+            v += bv;
+            if (rbase + (r & 3) + 8 * (r >> 2) < p.M) s += pass == 0 ? v : (v - cmean[b]) * (v - cmean[b]);
+          }
+        }
+        s += __shfl_xor(s, 32);
+        if (h == 0) red[wm * T::BN + wn * T::WN + b * 32 + i] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < T::FN; ++b) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < T::WAVES_M; ++w) t += red[w * T::BN + wn * T::WN + b * 32 + i];
+        if (pass == 0) {
+          cmean[b] = t / (float)n_tile;
+        } else if (wm == 0 && h == 0) {
+          const int col = n0 + wn * T::WN + b * 32 + i;
+          if (col < p.N) {
+            p.stats[((size_t)0 * tiles_m + tm) * p.ldc + col] = cmean[b];
+            p.stats[((size_t)1 * tiles_m + tm) * p.ldc + col] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
 #pragma unroll
   for (int b = 0; b < T::FN; ++b) {
     const int col = n0 + wn * T::WN + b * 32 + i;
@@ -473,6 +522,7 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
         case 0: return dispatch_cfg<true, false, 0>(p, cfg, s);
         case EPI_BIAS: return dispatch_cfg<true, false, EPI_BIAS>(p, cfg, s);
         case EPI_BIAS | EPI_RELU: return dispatch_cfg<true, false, EPI_BIAS | EPI_RELU>(p, cfg, s);
+        case EPI_BIAS | EPI_COLSTATS: return dispatch_cfg<true, false, EPI_BIAS | EPI_COLSTATS>(p, cfg, s);
       }
       break;
     case GEMM_NT:
@@ -494,9 +544,18 @@ const char* gemm_f32_config_name(int cfg) {
   return (cfg >= 0 && cfg < kNumGemmConfigs) ? kCfg[cfg].name : "?";
 }
 
+int gemm_f32_config_bm(int cfg) { return (cfg >= 0 && cfg < kNumGemmConfigs) ? kCfg[cfg].bm : 0; }
+
 void gemm_f32_force_config(int cfg) { g_forced_cfg = cfg; }
 
 int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
+  if (g_forced_cfg == -2) {
+    const char* e = getenv("TFK_GEMM_CFG");
+    g_forced_cfg = e ? atoi(e) : -1;
+    if ((e = getenv("TFK_GEMM_MIN_LDS"))) g_min_lds = atoi(e);
+    if ((e = getenv("TFK_GEMM_EVEN_SPREAD"))) g_even_spread = atoi(e);
+  }
+  if (g_forced_cfg >= 0) return g_forced_cfg;
   (void)K;
   (void)layout;
   // Measured on MI355X (profiles/r01_gemm_sweep_v3.txt): the 128x128 tile (4 waves of 64x64: half the LDS
@@ -507,13 +566,7 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
 }
 
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream) {
-  if (g_forced_cfg == -2) {
-    const char* e = getenv("TFK_GEMM_CFG");
-    g_forced_cfg = e ? atoi(e) : -1;
-    if ((e = getenv("TFK_GEMM_MIN_LDS"))) g_min_lds = atoi(e);
-    if ((e = getenv("TFK_GEMM_EVEN_SPREAD"))) g_even_spread = atoi(e);
-  }
-  if (cfg < 0) cfg = (g_forced_cfg >= 0) ? g_forced_cfg : gemm_f32_pick_config(layout, args.M, args.N, args.K);
+  if (cfg < 0) cfg = gemm_f32_pick_config(layout, args.M, args.N, args.K);
   if ((args.lda & 3) || (args.ldb & 3)) return (int)hipErrorInvalidValue;
   if (args.M <= 0 || args.N <= 0 || args.K <= 0) return (int)hipErrorInvalidValue;
   {  // operands are addressed with 32-bit byte offsets through buffer resources

@@ -30,6 +30,15 @@ void bn_stats_train(hipStream_t s, const float* z, int T, int H, int ld, float e
 void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, int H, float eps, float* mean,
                    float* rstd);
 
+// ---- fused training-mode batch norm + activation chain forward (no L2Norm) ----
+// stats = per-chunk (mean, M2) of z's columns as written by the forward GEMM's EPI_COLSTATS epilogue
+// ([2, nchunk, ld], chunk k = rows [k*chunk_rows, ...)).  Merges them (Chan), publishes mean / rstd for the
+// backward pass, advances the moving-average increments E <- decay*E + (1-decay)*stat, and writes
+// a = dropout(nonlin((z - mean) * rstd + beta)).
+void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, const float* stats, int chunk_rows,
+                    int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
+                    float* e_var, const float* beta);
+
 // ---- activation chain forward: z -> a (v: post-nonlin copy, rowscale: L2 mean-square; both only if l2) ----
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
                  const float* mean, const float* rstd, const float* beta, int T, int H, int ld);

@@ -308,6 +308,98 @@ act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a
   }
 }
 
+// ---- fused BN (training) + nonlinearity + dropout, column-tiled; statistics from the GEMM epilogue ----
+__global__ void __launch_bounds__(CT_X * CT_Y)
+bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a, const float* __restrict__ st,
+                      int nchunk, int chunk_rows, int T, int H, int ld, int rows_per, float eps, float decay,
+                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ e_mean,
+                      float* __restrict__ e_var, const float* __restrict__ beta) {
+  __shared__ float4 sm[CT_Y][CT_X];
+  __shared__ float4 smm[CT_X];
+  const ColTile t = col_tile(T, ld, rows_per);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Chan merge of the per-chunk (n, mean, M2): row lane y takes chunks y, y + 8, ...
+  float4 tot = zero4;
+  if (t.valid)
+    for (int k = threadIdx.y; k < nchunk; k += CT_Y) {
+      const float n = (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0);
+      const float4 m = ld4(st + ((size_t)0 * nchunk + k) * ld + t.col);
+      tot.x += n * m.x; tot.y += n * m.y; tot.z += n * m.z; tot.w += n * m.w;
+    }
+  tot = reduce_rows(tot, sm);
+  if (threadIdx.y == 0) {
+    const float inv = 1.f / (float)T;
+    smm[threadIdx.x] = make_float4(tot.x * inv, tot.y * inv, tot.z * inv, tot.w * inv);
+  }
+  __syncthreads();
+  const float4 mu = smm[threadIdx.x];
+  float4 m2 = zero4;
+  if (t.valid)
+    for (int k = threadIdx.y; k < nchunk; k += CT_Y) {
+      const float n = (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0);
+      const float4 m = ld4(st + ((size_t)0 * nchunk + k) * ld + t.col);
+      const float4 q = ld4(st + ((size_t)1 * nchunk + k) * ld + t.col);
+      m2.x += q.x + n * (m.x - mu.x) * (m.x - mu.x); m2.y += q.y + n * (m.y - mu.y) * (m.y - mu.y);
+      m2.z += q.z + n * (m.z - mu.z) * (m.z - mu.z); m2.w += q.w + n * (m.w - mu.w) * (m.w - mu.w);
+    }
+  m2 = reduce_rows(m2, sm);
+  if (threadIdx.y == 0) {
+    const float inv = 1.f / (float)T;  // biased variance, as tf.nn.moments
+    float4 var = make_float4(m2.x * inv, m2.y * inv, m2.z * inv, m2.w * inv);
+    float4 rs4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) el(rs4, k) = (t.col + k < H) ? rsqrtf(el(var, k) + eps) : 0.f;
+    smm[threadIdx.x] = rs4;
+    if (blockIdx.y == 0 && t.valid) {  // one block per column tile publishes the statistics
+      float4 mu_w = mu;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t.col + k >= H) el(mu_w, k) = 0.f;
+      st4(mean + t.col, mu_w);
+      st4(rstd + t.col, rs4);
+      float4 em = ld4(e_mean + t.col), ev = ld4(e_var + t.col);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t.col + k < H) {
+          el(em, k) = decay * el(em, k) + (1.f - decay) * el(mu, k);
+          el(ev, k) = decay * el(ev, k) + (1.f - decay) * el(var, k);
+        }
+      st4(e_mean + t.col, em);
+      st4(e_var + t.col, ev);
+    }
+  }
+  __syncthreads();
+  if (!t.valid) return;
+  const float4 rsd = smm[threadIdx.x];
+  const float4 be = ld4(beta + t.col);
+  const bool drop = d.train && d.keep < 1.f;
+  const float inv_keep = drop ? 1.f / d.keep : 1.f;
+  for (int rb = t.r0 + threadIdx.y; rb < t.r1; rb += CT_Y * RB) {
+    float4 zv[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = rb + j * CT_Y;
+      zv[j] = ld4(z + (size_t)(r < t.r1 ? r : rb) * ld + t.col);
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = rb + j * CT_Y;
+      if (r >= t.r1) continue;
+      float4 v;
+      v.x = (zv[j].x - mu.x) * rsd.x + be.x; v.y = (zv[j].y - mu.y) * rsd.y + be.y;
+      v.z = (zv[j].z - mu.z) * rsd.z + be.z; v.w = (zv[j].w - mu.w) * rsd.w + be.w;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) el(v, k) = (t.col + k < H) ? nonlin_fwd(el(v, k), d.nonlin) : 0.f;
+      if (drop) {
+        const Keep4 m = keep_mask(d, r, t.c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
+      }
+      st4(a + (size_t)r * ld + t.col, v);
+    }
+  }
+}
+
 // ---- L2 chains: da -> du in place (row-wise) ----
 __global__ void __launch_bounds__(256)
 act_backward_rows_kernel(ActDesc d, float* __restrict__ da, const float* __restrict__ vbuf,
@@ -730,6 +822,15 @@ void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, i
                    float* rstd) {
   hipLaunchKernelGGL(bn_stats_eval_kernel, dim3((H + 255) / 256), dim3(256), 0, s, mov_mean, mov_var, H, eps, mean,
                      rstd);
+}
+
+void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, const float* stats, int chunk_rows,
+                    int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
+                    float* e_var, const float* beta) {
+  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
+  const int nchunk = (T + chunk_rows - 1) / chunk_rows;
+  hipLaunchKernelGGL(bn_act_forward_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, z, a, stats, nchunk, chunk_rows, T, H,
+                     ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta);
 }
 
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,

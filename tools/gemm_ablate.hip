@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
   hipMemcpy(a, h.data(), na * 4, hipMemcpyHostToDevice); hipMemcpy(b, h.data(), nb * 4, hipMemcpyHostToDevice);
   tfk::GemmArgs g;
-  g.A = a; g.B = b; g.C = c; g.bias = nullptr; g.M = M; g.N = N; g.K = K; g.epi = 0;
+  g.A = a; g.B = b; g.C = c; g.bias = nullptr; g.stats = nullptr; g.M = M; g.N = N; g.K = K; g.epi = 0;
   g.lda = (((layout == 2 ? M : K) + 3) & ~3) + pad; g.ldb = (((layout == 1 ? K : N) + 3) & ~3) + pad; g.ldc = ((N + 3) & ~3) + pad;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
