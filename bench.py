@@ -72,6 +72,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: libraries that chat on stdout (RCCL prints its library
+    # path from C stdio at teardown) are diverted to stderr until the record is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from tfkaldi_amd import _lib
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
@@ -185,10 +191,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, y, hidden)
-        print(json.dumps(out))
     eng.close()
     if dp.enabled:
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # C stdio buffers still point at the diverted fd
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

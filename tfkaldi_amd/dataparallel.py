@@ -23,7 +23,9 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # TFK_FORCE_DP=1 (tests only): run the exchange step even with a single rank, so that the RCCL call path
+    # (async all-reduce of engine-state views from the bucket callback) is exercised on a 1-GPU box
+    if world > 1 or os.environ.get("TFK_FORCE_DP") == "1":
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -37,7 +39,11 @@ def init_from_env():
                     local_rank = local_rank % torch.cuda.device_count()
                 torch.cuda.set_device(local_rank)
             backend = os.environ.get("TFK_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if os.environ.get("TFK_SHARE_DEVICE") == "1":
         import torch
         if torch.cuda.is_available():
@@ -84,16 +90,18 @@ class DataParallel(object):
     def __init__(self, group=None):
         self.group = group
         self.rank, self.world = 0, 1
+        self._forced = False
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+                self._forced = os.environ.get("TFK_FORCE_DP") == "1"
         except ImportError:
             pass
 
     @property
     def enabled(self):
-        return self.world > 1
+        return self.world > 1 or self._forced
 
     @staticmethod
     def _stream_ctx(engine):
