@@ -131,16 +131,20 @@ enum { /* flags */
  * G += g, batch_loss += loss, num_frames += T, BN moving-average updates (UPDATE_OPS). */
 int tfk_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags);
 
-/* The step BEFORE the path, moved onto the device: the +-context splice of
- * processing/feature_reader.py:117-156.  raw [T, ldraw] = the CMVN-normalised UNSPLICED frames (raw_dim columns,
- * input_dim = raw_dim * (2*context_width + 1)) of U utterances back to back, utt_len[U] their frame counts
- * (sum = T).  Frames beyond an utterance's edges splice in as zeros, exactly like the host splice.  Only the
- * unspliced frames cross PCIe (11x less at context 5) and the spliced matrix is produced in HBM.  Host pointers
- * only (raw, y, utt_len); TFK_DEVICE_PTRS is not accepted. */
+/* The step BEFORE the path, moved onto the device: per-speaker mean/variance normalisation and the
+ * +-context splice of processing/feature_reader.py:91-156 (apply_cmvn :109-115, splice :117-156).
+ * raw [T, ldraw] = the UNSPLICED frames (raw_dim columns, input_dim = raw_dim * (2*context_width + 1)) of U
+ * utterances back to back, utt_len[U] their frame counts (sum = T).
+ * cmvn = NULL: raw is already normalised.  cmvn = [U, 2, raw_dim] fp32: row 0 of utterance u is its speaker's
+ * mean, row 1 the standard deviation sqrt(E[x^2] - mean^2); the device computes (raw - mean) / std with the same
+ * IEEE roundings as numpy's float32 subtract and divide, so the result is bit-identical to the host path.
+ * Frames beyond an utterance's edges splice in as zeros, exactly like the host splice.  Only the unspliced frames
+ * cross PCIe (11x less at context 5) and the spliced matrix is produced in HBM.  Host pointers only (raw, y,
+ * utt_len, cmvn); TFK_DEVICE_PTRS is not accepted. */
 int tfk_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
-                       const int32_t* utt_len, int32_t U, int32_t context_width, int flags);
+                       const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags);
 int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
-                            const int32_t* utt_len, int32_t U, int32_t context_width, int flags);
+                            const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags);
 
 /* Replaces `[average_loss, apply_gradients_op]` + the three re-initialisations (trainer.py:336-352):
  * g = clip(G / num_frames, -1, 1); Adam; global_step += 1; returns batch_loss / num_frames (the
@@ -163,10 +167,10 @@ int tfk_init_last_layer(tfk_engine* e);     /* control_ops['init'] (dnn.py:114-1
  * X [N, ldx] -> out [N, ldo] posteriors (or log(posterior/prior) with TFK_LOG_DIV_PRIOR). */
 int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags);
 int tfk_set_prior(tfk_engine* e, const float* prior, size_t count); /* prior.npy (nnet.py:241-244) */
-/* As tfk_posteriors on unspliced frames of U utterances (device-side splice; several utterances per call =
- * the batched decode of SURVEY 8f-2). */
+/* As tfk_posteriors on unspliced frames of U utterances (device-side CMVN + splice as tfk_accumulate_raw;
+ * several utterances per call = the batched decode of SURVEY 8f-2). */
 int tfk_posteriors_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t N, const int32_t* utt_len, int32_t U,
-                       int32_t context_width, float* out, int64_t ldo, int flags);
+                       int32_t context_width, const float* cmvn, float* out, int64_t ldo, int flags);
 
 /* ---- data parallelism (one engine per rank; the host owns the collective) --------------------- */
 

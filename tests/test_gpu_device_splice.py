@@ -61,9 +61,55 @@ def test_raw_accumulate_is_bit_identical(gpu):
     with pytest.raises(_lib.EngineError, match="sum to"):
         b.lib  # noqa: B018
         _lib.check(b.lib.tfk_accumulate_raw(b._h, raw.ctypes.data, D, y.ctypes.data, T,
-                                            np.array([3, 4], dtype=np.int32).ctypes.data, 2, C, 0))
+                                            np.array([3, 4], dtype=np.int32).ctypes.data, 2, C, None, 0))
     with pytest.raises(_lib.EngineError, match="multiple"):
         b.accumulate_raw(raw, y, lens, 3)  # F = 40 is not a multiple of 7
+    a.close(); b.close()
+
+
+def test_device_cmvn_is_bit_identical(gpu):
+    """raw frames + per-utterance (mean, std) table: the device's (x - mean) / std then splice == numpy's"""
+    from tfkaldi_amd import _lib
+    from tfkaldi_amd.processing.feature_reader import apply_cmvn, cmvn_params
+    rng = np.random.default_rng(5)
+    lens = [12, 3, 25, 7]
+    utts = [(rng.standard_normal((n, D)) * rng.uniform(0.5, 30.0, size=D) + rng.uniform(-50, 50, size=D))
+            .astype(np.float32) for n in lens]
+    stats = []
+    for u in utts:  # Kaldi-style accumulated statistics, float32 as ArkWriter stores them
+        st = np.zeros((2, D + 1), dtype=np.float32)
+        pool = np.concatenate([u, rng.standard_normal((40, D)).astype(np.float32) * 5 + u.mean(0)])
+        st[0, :-1], st[0, -1], st[1, :-1] = pool.sum(0), pool.shape[0], np.square(pool).sum(0)
+        stats.append(st)
+    normalised = [apply_cmvn(u, st) for u, st in zip(utts, stats)]
+    assert all(n.dtype == np.float32 for n in normalised)
+    X = np.concatenate([host_splice(n, C) for n in normalised])
+    raw = np.concatenate(utts)
+    table = np.stack([np.stack(cmvn_params(st)) for st in stats])
+    T = raw.shape[0]
+    y = rng.integers(0, KW["output_dim"], size=T).astype(np.int32)
+    a, _ = make_pair(np.random.default_rng(1), **KW)
+    b, _ = make_pair(np.random.default_rng(1), **KW)
+    for step in range(2):
+        a.accumulate(X, y)
+        b.accumulate_raw(raw, y, lens, C, cmvn=table)
+        for l in range(a.L):
+            assert (a.debug_fetch(_lib.DBG_HIDDEN, l, T) == b.debug_fetch(_lib.DBG_HIDDEN, l, T)).all()
+        assert a.apply() == b.apply()
+    a.eval_accumulate(X, y)
+    b.eval_accumulate_raw(raw, y, lens, C, cmvn=table)
+    assert a.eval_finish() == b.eval_finish()
+    assert (a.posteriors(X) == b.posteriors_raw(raw, lens, C, cmvn=table)).all()
+    # a larger table than the first one (buffers grow) and then none at all
+    lens2 = [4] * 9
+    raw2 = rng.standard_normal((36, D)).astype(np.float32)
+    table2 = np.stack([np.stack([rng.standard_normal(D), rng.uniform(0.5, 2, D)]) for _ in lens2]).astype(np.float32)
+    want = np.concatenate([host_splice((raw2[4 * i:4 * i + 4] - table2[i, 0]) / table2[i, 1], C) for i in range(9)])
+    assert (a.posteriors(want) == b.posteriors_raw(raw2, lens2, C, cmvn=table2)).all()
+    assert (a.posteriors(np.concatenate([host_splice(raw2[4 * i:4 * i + 4], C) for i in range(9)]))
+            == b.posteriors_raw(raw2, lens2, C)).all()
+    with pytest.raises(ValueError, match="cmvn table"):
+        b.posteriors_raw(raw2, lens2, C, cmvn=table2[:3])
     a.close(); b.close()
 
 
@@ -82,7 +128,7 @@ def test_feature_reader_to_trainer_and_decoder(gpu, tmp_path):
 
     def run(on_device):
         reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], C, 40,
-                                              splice_on_device=on_device)
+                                              splice_on_device=on_device == 1, cmvn_on_device=on_device == 2)
         disp = batchdispenser.AlignmentBatchDispenser(reader, target_coder.AlignmentCoder(lambda x, y: x, O), 4,
                                                       paths["alignments"])
         dnn = DNN(O, 2, 32, act.TfActivation(act.Batchnorm(None), "relu"), False)
@@ -102,10 +148,11 @@ def test_feature_reader_to_trainer_and_decoder(gpu, tmp_path):
         dec.close()
         return losses, single, batched, post, type(val[0][0]).__name__
 
-    l0, s0, b0, p0, t0 = run(False)
-    l1, s1, b1, p1, t1 = run(True)
-    assert (t0, t1) == ("ndarray", "Unspliced")
-    assert l0 == l1
-    assert (p0 == p1).all()
-    for x0, x1, y0, y1 in zip(s0, s1, b0, b1):
-        assert (x0 == x1).all() and (y0 == y1).all() and (x0 == y0).all()
+    l0, s0, b0, p0, t0 = run(0)
+    for mode in (1, 2):  # 1: splice on the device, 2: CMVN + splice on the device
+        l1, s1, b1, p1, t1 = run(mode)
+        assert (t0, t1) == ("ndarray", "Unspliced")
+        assert l0 == l1
+        assert (p0 == p1).all()
+        for x0, x1, y0, y1 in zip(s0, s1, b0, b1):
+            assert (x0 == x1).all() and (y0 == y1).all() and (x0 == y0).all()

@@ -57,9 +57,12 @@ SYMBOLS = {
     "tfk_scalar_get": (c_int, [_E, c_int, POINTER(c_double)]),
     "tfk_scalar_set": (c_int, [_E, c_int, c_double]),
     "tfk_accumulate": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_int]),
-    "tfk_accumulate_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int]),
-    "tfk_eval_accumulate_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int]),
-    "tfk_posteriors_raw": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int]),
+    "tfk_accumulate_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                   c_int]),
+    "tfk_eval_accumulate_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                        c_void_p, c_int]),
+    "tfk_posteriors_raw": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                   c_int64, c_int]),
     "tfk_apply": (c_int, [_E, POINTER(c_float)]),
     "tfk_eval_accumulate": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_int]),
     "tfk_eval_finish": (c_int, [_E, POINTER(c_float)]),

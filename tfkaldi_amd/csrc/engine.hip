@@ -117,6 +117,9 @@ struct tfk_engine {
   int32_t* dSeg[2] = {nullptr, nullptr};
   float* hRaw[2] = {nullptr, nullptr};
   int32_t* hSeg[2] = {nullptr, nullptr};
+  float* dCmvn[2] = {nullptr, nullptr};  // per-utterance (mean, std) tables of the raw entry points, grown on demand
+  float* hCmvn[2] = {nullptr, nullptr};
+  size_t cmvn_cap = 0;
   int seg_cap = 0;
   float* ws_stats = nullptr;  // [2, ceil(cap / 64), ldH] per-tile BN statistics from the forward GEMM epilogue
   float* ws_bwd = nullptr;  // per-layer partial column sums of backward (finalised by one kernel)
@@ -291,7 +294,10 @@ void free_activations(tfk_engine* e) {
     if (e->dSeg[s]) { hipFree(e->dSeg[s]); e->dSeg[s] = nullptr; }
     if (e->hRaw[s]) { hipHostFree(e->hRaw[s]); e->hRaw[s] = nullptr; }
     if (e->hSeg[s]) { hipHostFree(e->hSeg[s]); e->hSeg[s] = nullptr; }
+    fr(e->dCmvn[s]);
+    if (e->hCmvn[s]) { hipHostFree(e->hCmvn[s]); e->hCmvn[s] = nullptr; }
   }
+  e->cmvn_cap = 0;
   for (auto& p : e->z) fr(p);
   for (auto& p : e->a) fr(p);
   for (auto& p : e->v) fr(p);
@@ -393,7 +399,7 @@ int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, in
 
 // Bring unspliced frames + utterance offsets to HBM and splice them into dX[slot] there.
 int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int T, const int32_t* utt_len, int U,
-              int context, const float** Xd, int* ldx_out, const int32_t** yd) {
+              int context, const float* cmvn, const float** Xd, int* ldx_out, const int32_t** yd) {
   if (context < 0) return fail(-1, "context_width %d < 0", context);
   const int win = 2 * context + 1;
   if (e->F % win != 0) return fail(-1, "input_dim %d is not a multiple of 2*context_width+1 = %d", e->F, win);
@@ -408,8 +414,21 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
   }
   if (total != T) return fail(-1, "utterance lengths sum to %ld, expected T = %d", total, T);
   const int s = e->slot;
+  const size_t cmvn_floats = cmvn ? (size_t)2 * U * D : 0;
+  if (cmvn_floats > e->cmvn_cap) {
+    HIPCHK(hipStreamSynchronize(e->copy_stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int k = 0; k < 2; ++k) {
+      if (e->dCmvn[k]) { hipFree(e->dCmvn[k]); e->dCmvn[k] = nullptr; }
+      if (e->hCmvn[k]) { hipHostFree(e->hCmvn[k]); e->hCmvn[k] = nullptr; }
+      HIPCHK(hipMalloc((void**)&e->dCmvn[k], 2 * cmvn_floats * sizeof(float)));
+      HIPCHK(hipHostMalloc((void**)&e->hCmvn[k], 2 * cmvn_floats * sizeof(float), hipHostMallocDefault));
+    }
+    e->cmvn_cap = 2 * cmvn_floats;
+  }
   if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
   for (int t = 0; t < T; ++t) memcpy(e->hRaw[s] + (size_t)t * D, raw + (size_t)t * ldraw, (size_t)D * sizeof(float));
+  if (cmvn) memcpy(e->hCmvn[s], cmvn, cmvn_floats * sizeof(float));
   e->hSeg[s][0] = 0;
   for (int u = 0; u < U; ++u) e->hSeg[s][u + 1] = e->hSeg[s][u] + utt_len[u];
   if (y) memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
@@ -419,11 +438,14 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
                           hipMemcpyHostToDevice, e->copy_stream));
   HIPCHK(hipMemcpyAsync(e->dSeg[s], e->hSeg[s], (size_t)(U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
   if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  if (cmvn)
+    HIPCHK(hipMemcpyAsync(e->dCmvn[s], e->hCmvn[s], cmvn_floats * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
   HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
   {
     ProfScope ps(e, KF_MISC, 0, 4.0 * T * (D + e->F));
-    splice_frames(e->stream, e->dRaw[s], ldD, e->dSeg[s], U, T, D, context, e->dX[s], e->ldF);
+    splice_frames(e->stream, e->dRaw[s], ldD, e->dSeg[s], U, T, D, context, cmvn ? e->dCmvn[s] : nullptr, e->dX[s],
+                  e->ldF);
   }
   e->slot_used[s] = true;
   *Xd = e->dX[s];
@@ -732,6 +754,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
 struct RawSpec {  // non-null utt_len selects the device-side splice
   const int32_t* utt_len;
   int U, context;
+  const float* cmvn;  // nullable [U, 2, raw_dim]
 };
 int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags, int train,
                   const RawSpec* raw = nullptr) {
@@ -743,7 +766,7 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   CHK(reserve(e, T));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
-  if (raw) CHK(stage_raw(e, X, ldx, y, T, raw->utt_len, raw->U, raw->context, &Xd, &ld, &yd));
+  if (raw) CHK(stage_raw(e, X, ldx, y, T, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd));
   else CHK(stage_input(e, X, ldx, y, T, flags, &Xd, &ld, &yd));
   const uint32_t call = e->call_counter++;
   const int nact = e->nact();
@@ -913,14 +936,14 @@ int tfk_eval_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_
   return train_or_eval(e, X, ldx, y, T, flags & ~TFK_LAST_MICROBATCH, 0);
 }
 int tfk_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
-                       const int32_t* utt_len, int32_t U, int32_t context_width, int flags) {
-  const RawSpec r = {utt_len, U, context_width};
+                       const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags) {
+  const RawSpec r = {utt_len, U, context_width, cmvn};
   if (!utt_len) return fail(-1, "utt_len is NULL");
   return train_or_eval(e, raw, ldraw, y, T, flags, 1, &r);
 }
 int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
-                            const int32_t* utt_len, int32_t U, int32_t context_width, int flags) {
-  const RawSpec r = {utt_len, U, context_width};
+                            const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags) {
+  const RawSpec r = {utt_len, U, context_width, cmvn};
   if (!utt_len) return fail(-1, "utt_len is NULL");
   return train_or_eval(e, raw, ldraw, y, T, flags & ~TFK_LAST_MICROBATCH, 0, &r);
 }
@@ -1046,7 +1069,7 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
   CHK(reserve(e, N));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
-  if (raw) CHK(stage_raw(e, X, ldx, nullptr, N, raw->utt_len, raw->U, raw->context, &Xd, &ld, &yd));
+  if (raw) CHK(stage_raw(e, X, ldx, nullptr, N, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd));
   else CHK(stage_input(e, X, ldx, nullptr, N, flags, &Xd, &ld, &yd));
   const int nact = e->nact();
   const uint32_t call = e->call_counter++;
@@ -1089,8 +1112,8 @@ int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float*
   return posteriors_impl(e, X, ldx, N, out, ldo, flags, nullptr);
 }
 int tfk_posteriors_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t N, const int32_t* utt_len, int32_t U,
-                       int32_t context_width, float* out, int64_t ldo, int flags) {
-  const RawSpec r = {utt_len, U, context_width};
+                       int32_t context_width, const float* cmvn, float* out, int64_t ldo, int flags) {
+  const RawSpec r = {utt_len, U, context_width, cmvn};
   if (!utt_len) return fail(-1, "utt_len is NULL");
   return posteriors_impl(e, raw, ldraw, N, out, ldo, flags, &r);
 }

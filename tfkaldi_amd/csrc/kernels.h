@@ -92,8 +92,10 @@ void fill(hipStream_t s, float* x, size_t n, float value);
 // +-context splicing on the device (reference processing/feature_reader.py:117-156): raw[T, ldr] holds the
 // unspliced frames of the utterances back to back, seg[U+1] their start offsets; out[t, j*D + d] =
 // raw[t + j - c, d] when that frame belongs to the same utterance, else 0.  Pad columns of out are zeroed.
+// cmvn (nullable) = per-utterance [U, 2, D] (mean, standard deviation): the spliced value is
+// (raw - mean) / std, IEEE-rounded like numpy's float32 subtract / divide (feature_reader.py:109-115).
 void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg, int U, int T, int D, int context,
-                   float* out, int ldo);
+                   const float* cmvn, float* out, int ldo);
 // debug: regenerate the keep mask of a layer as 0/1 floats [T, ld]
 void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld);
 

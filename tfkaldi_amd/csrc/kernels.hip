@@ -770,7 +770,7 @@ __global__ void dropout_mask_kernel(ActDesc d, float* __restrict__ out, int T, i
 // one thread per output element group of 4 (scalar inside: D need not be a multiple of 4)
 __global__ void __launch_bounds__(256)
 splice_kernel(const float* __restrict__ raw, int ldr, const int32_t* __restrict__ seg, int U, int T, int D, int context,
-              float* __restrict__ out, int ldo) {
+              const float* __restrict__ cmvn, float* __restrict__ out, int ldo) {
   const int nc4 = ldo >> 2;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)T * nc4) return;
@@ -791,7 +791,10 @@ splice_kernel(const float* __restrict__ raw, int ldr, const int32_t* __restrict_
     if (col < F) {
       const int j = col / D, d = col - j * D;
       const int src = t + j - context;
-      if (src >= first && src < last) v = raw[(size_t)src * ldr + d];
+      if (src >= first && src < last) {
+        v = raw[(size_t)src * ldr + d];
+        if (cmvn) v = __fdiv_rn(__fsub_rn(v, cmvn[(size_t)(2 * lo) * D + d]), cmvn[(size_t)(2 * lo + 1) * D + d]);
+      }
     }
     el(o, k) = v;
   }
@@ -916,11 +919,11 @@ void fill(hipStream_t s, float* x, size_t n, float value) {
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, value);
 }
 void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg, int U, int T, int D, int context,
-                   float* out, int ldo) {
+                   const float* cmvn, float* out, int ldo) {
   const size_t n = (size_t)T * (ldo / 4);
   if (n == 0) return;
   hipLaunchKernelGGL(splice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, ldr, seg, U, T, D, context,
-                     out, ldo);
+                     cmvn, out, ldo);
 }
 void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld) {
   const size_t n = (size_t)T * (ld / 4);

@@ -52,23 +52,24 @@ def init_from_env():
 
 
 class RawMicroBatch(object):
-    """A micro-batch whose +-context splice happens on the device: unspliced frames [T, D], targets [T],
-    utterance lengths [U] and the context width (tfk_accumulate_raw)."""
+    """A micro-batch whose +-context splice (and optionally CMVN) happens on the device: unspliced frames
+    [T, D], targets [T], utterance lengths [U], the context width and the optional [U, 2, D] (mean, std) table
+    (tfk_accumulate_raw)."""
 
-    def __init__(self, raw, y, lens, context_width):
-        self.raw, self.y, self.lens, self.context_width = raw, y, lens, context_width
+    def __init__(self, raw, y, lens, context_width, cmvn=None):
+        self.raw, self.y, self.lens, self.context_width, self.cmvn = raw, y, lens, context_width, cmvn
 
 
 def _accumulate(engine, mb, last):
     if isinstance(mb, RawMicroBatch):
-        engine.accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, last=last)
+        engine.accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, last=last, cmvn=mb.cmvn)
     else:
         engine.accumulate(mb[0], mb[1], last=last)
 
 
 def _eval_accumulate(engine, mb):
     if isinstance(mb, RawMicroBatch):
-        engine.eval_accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width)
+        engine.eval_accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, cmvn=mb.cmvn)
     else:
         engine.eval_accumulate(mb[0], mb[1])
 

@@ -156,26 +156,41 @@ class Engine(object):
             raise ValueError("raw %s / utterance lengths (sum %d) do not match" % (raw.shape, int(lens.sum())))
         return raw, lens
 
-    def accumulate_raw(self, raw, y, lens, context_width, last=False):
+    @staticmethod
+    def _cmvn_table(cmvn, raw, lens):
+        """None or the [U, 2, D] (mean, std) table -> (keep-alive array, pointer)"""
+        if cmvn is None:
+            return None, c_void_p(None)
+        cmvn = np.ascontiguousarray(cmvn, dtype=np.float32)
+        if cmvn.shape != (lens.size, 2, raw.shape[1]):
+            raise ValueError("cmvn table %s, expected %s" % (cmvn.shape, (lens.size, 2, raw.shape[1])))
+        return cmvn, cmvn.ctypes.data_as(c_void_p)
+
+    def accumulate_raw(self, raw, y, lens, context_width, last=False, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
         y = np.ascontiguousarray(y, dtype=np.int32)
+        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
         check(self.lib.tfk_accumulate_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1],
                                           y.ctypes.data_as(c_void_p), raw.shape[0], lens.ctypes.data_as(c_void_p),
-                                          lens.size, int(context_width), _lib.LAST_MICROBATCH if last else 0))
+                                          lens.size, int(context_width), cmvn_ptr,
+                                          _lib.LAST_MICROBATCH if last else 0))
 
-    def eval_accumulate_raw(self, raw, y, lens, context_width):
+    def eval_accumulate_raw(self, raw, y, lens, context_width, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
         y = np.ascontiguousarray(y, dtype=np.int32)
+        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
         check(self.lib.tfk_eval_accumulate_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1],
                                                y.ctypes.data_as(c_void_p), raw.shape[0],
-                                               lens.ctypes.data_as(c_void_p), lens.size, int(context_width), 0))
+                                               lens.ctypes.data_as(c_void_p), lens.size, int(context_width),
+                                               cmvn_ptr, 0))
 
-    def posteriors_raw(self, raw, lens, context_width, log_div_prior=False, raw_logits=False):
+    def posteriors_raw(self, raw, lens, context_width, log_div_prior=False, raw_logits=False, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
         out = np.empty((raw.shape[0], self.O), dtype=np.float32)
         flags = (_lib.LOG_DIV_PRIOR if log_div_prior else 0) | (_lib.RAW_LOGITS if raw_logits else 0)
+        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
         check(self.lib.tfk_posteriors_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0],
-                                          lens.ctypes.data_as(c_void_p), lens.size, int(context_width),
+                                          lens.ctypes.data_as(c_void_p), lens.size, int(context_width), cmvn_ptr,
                                           out.ctypes.data_as(c_void_p), self.O, flags))
         return out
 

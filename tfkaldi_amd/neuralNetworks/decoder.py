@@ -3,7 +3,7 @@ import os
 
 import numpy as np
 
-from ..processing.feature_reader import Unspliced
+from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
 
 
@@ -39,7 +39,8 @@ class Decoder(object):
     def _run(self, inputs, **kw):
         if isinstance(inputs, Unspliced):  # splice on the device
             self._check(inputs)
-            return self.engine.posteriors_raw(np.asarray(inputs), [inputs.shape[0]], inputs.context_width, **kw)
+            return self.engine.posteriors_raw(np.asarray(inputs), [inputs.shape[0]], inputs.context_width,
+                                              cmvn=cmvn_table([inputs]), **kw)
         return self.engine.posteriors(self._check(inputs), **kw)
 
     def __call__(self, inputs):
@@ -59,7 +60,8 @@ class Decoder(object):
             self._check(u)
         if all(isinstance(u, Unspliced) for u in utterances):
             flat = self.engine.posteriors_raw(np.concatenate([np.asarray(u) for u in utterances]), lens,
-                                              utterances[0].context_width, log_div_prior=log_div_prior)
+                                              utterances[0].context_width, log_div_prior=log_div_prior,
+                                              cmvn=cmvn_table(utterances))
         else:
             stack = np.concatenate([u.spliced() if isinstance(u, Unspliced) else np.asarray(u, dtype=np.float32)
                                     for u in utterances])

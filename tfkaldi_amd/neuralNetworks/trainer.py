@@ -21,7 +21,7 @@ import numpy as np
 
 from .. import _lib
 from ..dataparallel import DataParallel, RawMicroBatch
-from ..processing.feature_reader import Unspliced
+from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
 
 
@@ -150,7 +150,8 @@ class Trainer(object, metaclass=ABCMeta):
                 # splice on the device: ship the unspliced frames + utterance lengths
                 raw = np.concatenate([np.asarray(inputs[i]) for i in idx], axis=0)
                 lens = np.array([inputs[i].shape[0] for i in idx], dtype=np.int32)
-                out.append(RawMicroBatch(raw, y, lens, inputs[idx[0]].context_width))
+                out.append(RawMicroBatch(raw, y, lens, inputs[idx[0]].context_width,
+                                         cmvn_table([inputs[i] for i in idx])))
             else:
                 X = np.concatenate([_spliced(inputs[i]) for i in idx], axis=0)
                 out.append((X, y))
