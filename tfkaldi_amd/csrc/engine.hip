@@ -132,7 +132,10 @@ struct tfk_engine {
   int32_t* hY[2] = {nullptr, nullptr};
   float* h_post = nullptr;
   size_t h_post_floats = 0;
-  float* h_scalars = nullptr;
+  float* h_scalars = nullptr;    // mapped pinned memory: kernels write the step's (loss, frames, #mb) here
+  float* h_scalars_dev = nullptr;
+  bool scalars_fresh = true;
+  bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   hipEvent_t copy_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
   bool slot_used[2] = {false, false};
   int slot = 0;
@@ -268,12 +271,20 @@ int wait_adam_done(tfk_engine* e) {
   return 0;
 }
 
+struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient the GEMM produces
+  const float *a, *z, *mean, *rstd;
+  int nonlin;
+};
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr, float* stats = nullptr,
-             int cfg = -1) {
+             int cfg = -1, const ActEpi* act = nullptr) {
   if (!st) st = e->stream;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.stats = stats;
+  g.act_a = act ? act->a : nullptr; g.act_z = act ? act->z : nullptr;
+  g.act_mean = act ? act->mean : nullptr; g.act_rstd = act ? act->rstd : nullptr;
+  g.act_nonlin = act ? act->nonlin : 0;
+  g.stats_stride = kMaxRowSplits;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
   ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)), st);
@@ -565,12 +576,27 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   }
   if (fire && e->cb) e->cb(e->cb_user, 0);
   int pp = 0;
-  CHK(run_gemm(e, GEMM_NT, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O, nullptr, 0));
+  // BN chains without L2Norm / dropout: the GEMM that produces a layer's output gradient also applies f' and
+  // reduces the two column sums of batch-norm's backward in its epilogue (EPI_DACT), which removes one pass
+  // over [T, H] per layer.  The per-tile partial sums must fit the kMaxRowSplits chunk slots of the workspace.
+  const int cfg_h = gemm_f32_pick_config(GEMM_NT, T, H, H), cfg_o = gemm_f32_pick_config(GEMM_NT, T, H, e->O);
+  const int chunks_h = (T + gemm_f32_config_bm(cfg_h) - 1) / gemm_f32_config_bm(cfg_h);
+  const int chunks_o = (T + gemm_f32_config_bm(cfg_o) - 1) / gemm_f32_config_bm(cfg_o);
+  const bool fuse_hb = e->cfg.batch_norm && !e->cfg.l2_norm && !(e->cfg.keep_prob < 1.f) && e->fuse_hb_enabled &&
+                       chunks_h <= kMaxRowSplits && chunks_o <= kMaxRowSplits;
+  auto dact_gemm = [&](const float* dz, int ld_dz, const float* W, int ldw, float* out, int K, int target, int cfg) {
+    if (!fuse_hb) return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, 0);
+    const ActEpi act = {e->a[target], e->z[target], e->mean[target], e->rstd[target], e->cfg.nonlin};
+    return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, EPI_DACT, nullptr, ws_of(target), cfg,
+                    &act);
+  };
+  CHK(dact_gemm(e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], e->O, nact - 1, cfg_o));
+  int chunks_in = chunks_o;
   for (int l = nact - 1; l >= 0; --l) {
     const LayerLayout& y = e->lay[l];
     float* da = e->dA[pp];
     const ActDesc d = act_desc(e, l, 1, call);
-    int pre_du = 0;
+    int pre_du = fuse_hb ? 1 : 0;
     if (e->cfg.l2_norm) {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, 12.0 * T * H);
       act_backward_rows(e->stream, d, da, e->v[l], e->rowscale[l], T, H, ldH);
@@ -578,8 +604,9 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     }
     {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
-      hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l], T, H, ldH, ws_of(l));
-      if (e->cfg.batch_norm) fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, rs, H, ldH};
+      hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l], T, H, ldH, ws_of(l),
+                      fuse_hb ? chunks_in : 0);
+      if (e->cfg.batch_norm) fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, fuse_hb ? chunks_in : rs, H, ldH};
       fin.it[fin.n++] = {ws_of(l), G + y.b_off, 2, rs, H, ldH};
       if (fin.n + 2 > kMaxFinalItems) {  // very deep nets: flush
         grad_final(e->stream, fin);
@@ -597,7 +624,8 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     if (l > 0) {
       // the dA GEMM overwrites dA[pp ^ 1] = dz of layer l + 1, which dW_{l+1} may still be reading
       if (two && l + 1 <= nact - 1) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l + 1], 0));
-      CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, 0));
+      CHK(dact_gemm(da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], H, l - 1, cfg_h));
+      chunks_in = chunks_h;
     }
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
@@ -618,11 +646,19 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   return 0;
 }
 
-int read_scalars(tfk_engine* e, bool zero_ema) {
+// materialise the logical zeros of the scalar accumulators (only when something reads them before a micro-batch)
+int settle_scalars(tfk_engine* e) {
+  if (e->scalars_fresh) {
+    HIPCHK(hipMemsetAsync(e->p_scalars(), 0, kScalarFloats * sizeof(float), e->stream));
+    e->scalars_fresh = false;
+  }
+  return 0;
+}
+int read_scalars(tfk_engine* e) {
+  CHK(settle_scalars(e));
   HIPCHK(hipMemcpyAsync(e->h_scalars, e->p_scalars(), 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  const size_t n = kScalarFloats + (zero_ema ? e->E : 0);
-  HIPCHK(hipMemsetAsync(e->p_scalars(), 0, n * sizeof(float), e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->scalars_fresh = true;  // init_loss / init_num_frames
   return 0;
 }
 
@@ -706,6 +742,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     const char* v;
     if ((v = getenv("TFK_OVERLAP_ADAM"))) e->overlap = atoi(v) != 0;
     if ((v = getenv("TFK_OVERLAP_DW"))) e->overlap_dw = atoi(v) != 0;
+    if ((v = getenv("TFK_FUSE_HB"))) e->fuse_hb_enabled = atoi(v) != 0;
     // few, fat blocks: the optimiser only has to finish within the next forward pass and must leave the
     // CUs' wave slots to the GEMM blocks it runs beside
     e->adam_blocks = (v = getenv("TFK_ADAM_BLOCKS")) ? atoi(v) : 512;
@@ -736,7 +773,8 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   HIPB(hipMemsetAsync(e->state, 0, e->state_floats * sizeof(float), e->stream));
   if (cfg->batch_norm)  // moving_variance initialises to 1, moving_mean to 0
     for (int l = 0; l < e->L; ++l) fill(e->stream, e->mov_var(l), (size_t)e->H, 1.0f);
-  HIPB(hipHostMalloc((void**)&e->h_scalars, 16 * sizeof(float), hipHostMallocDefault));
+  HIPB(hipHostMalloc((void**)&e->h_scalars, 16 * sizeof(float), hipHostMallocMapped));
+  HIPB(hipHostGetDevicePointer((void**)&e->h_scalars_dev, e->h_scalars, 0));
   e->mean.assign(e->L, nullptr);
   e->rstd.assign(e->L, nullptr);
   for (int l = 0; l < e->L; ++l) {
@@ -780,7 +818,8 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   }
   {
     ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
-    loss_reduce(e->stream, e->row_loss, T, e->p_scalars());
+    loss_reduce(e->stream, e->row_loss, T, e->p_scalars(), e->scalars_fresh);
+    e->scalars_fresh = false;
   }
   if (train) {
     const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
@@ -908,6 +947,7 @@ int tfk_scalar_get(tfk_engine* e, int which, double* value) {
     case TFK_BATCH_LOSS:
     case TFK_NUM_FRAMES: {
       HIPCHK(hipSetDevice(e->cfg.device));
+      if (e->scalars_fresh) { *value = 0.0; return 0; }
       CHK(sync_streams(e));
       float h[2];
       HIPCHK(hipMemcpy(h, e->p_scalars(), sizeof(h), hipMemcpyDeviceToHost));
@@ -958,14 +998,13 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
   if (e->grads_fresh)  // no micro-batch since the last apply: materialise the zeros Adam is about to read
     HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
-  // main stream: BN moving averages, the loss read-back, re-initialisation of the BN increments
-  if (e->cfg.batch_norm) {
-    ProfScope ps(e, KF_EMA, 0, 12.0 * e->E);
-    ema_apply(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay);
+  CHK(settle_scalars(e));
+  // main stream: BN moving averages + re-initialisation of their increments + the loss hand-over, one launch
+  {
+    ProfScope ps(e, KF_EMA, 0, 16.0 * e->E);
+    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev);
   }
-  HIPCHK(hipMemcpyAsync(e->h_scalars, e->p_scalars(), 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipEventRecord(e->ev_loss, e->stream));
-  if (e->E) HIPCHK(hipMemsetAsync(e->p_ema(), 0, e->E * sizeof(float), e->stream));
   // Adam: vectors first, then one launch per weight matrix in FORWARD order, each followed by an event the
   // next step's forward waits on -- on the side stream, so that the forward GEMMs (matrix-bound) and the
   // optimiser (HBM-bound) overlap.
@@ -977,11 +1016,11 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
       adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
                  e->adam_eps, 0);
     }
-    HIPCHK(hipMemsetAsync(e->p_scalars(), 0, kScalarFloats * sizeof(float), e->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventSynchronize(e->ev_loss));
     e->adam_pending = false;
     e->grads_fresh = true;
+    e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
     e->global_step += 1;
     if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
     return 0;
@@ -1004,12 +1043,12 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
     }
     HIPCHK(hipEventRecord(e->ev_adam_w[l], sa));
   }
-  HIPCHK(hipMemsetAsync(e->p_scalars(), 0, kScalarFloats * sizeof(float), sa));  // init_loss / init_num_frames
   HIPCHK(hipEventRecord(e->ev_adam_done, sa));
   HIPCHK(hipGetLastError());
   e->adam_pending = true;
   HIPCHK(hipEventSynchronize(e->ev_loss));  // the host only waits for the loss, not for the optimiser
   e->grads_fresh = true;
+  e->scalars_fresh = true;  // (the side stream still reads num_frames: wait_adam_done precedes the next overwrite)
   e->global_step += 1;
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
   return 0;
@@ -1019,7 +1058,7 @@ int tfk_eval_finish(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
   CHK(wait_adam_done(e));
-  CHK(read_scalars(e, false));
+  CHK(read_scalars(e));
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
   return 0;
 }
@@ -1148,6 +1187,7 @@ int tfk_zero_accumulators(tfk_engine* e) {
   CHK(wait_adam_done(e));
   HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->reduce_floats * sizeof(float), e->stream));
   e->grads_fresh = false;  // physically zero now
+  e->scalars_fresh = false;
   return 0;
 }
 int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user) {
@@ -1247,6 +1287,7 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
   if (layout < 0 || layout > 2) return fail(-1, "bad layout %d", layout);
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.stats = nullptr;
+  g.act_a = g.act_z = g.act_mean = g.act_rstd = nullptr; g.act_nonlin = 0; g.stats_stride = 0;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int rc = gemm_f32((GemmLayout)layout, g, tile_config, (hipStream_t)stream);
   if (rc != 0) return fail(rc, "gemm_f32 failed: %s", hipGetErrorString((hipError_t)rc));

@@ -26,6 +26,10 @@ enum : int {
   EPI_COLSTATS = 8,    // also emit, per BM-row tile, each column's mean and sum of squared deviations of the
                        // stored values (the batch-norm statistics of the layer, Chan-mergeable):
                        // stats[(0 * tiles_m + tile_m) * ldc + col] = mean, stats[(1 * tiles_m + tile_m) * ldc + col] = M2
+  EPI_DACT = 16,       // C = du = result * f'(act_a) (derivative through the layer output act_a = f(u)), and per
+                       // BM-row tile the column sums batch-norm's backward needs:
+                       // stats[(0 * stats_stride + tile_m) * ldc + col] = sum du,
+                       // stats[(1 * stats_stride + tile_m) * ldc + col] = sum du * (act_z - mean) * rstd
 };
 
 struct GemmArgs {
@@ -33,7 +37,14 @@ struct GemmArgs {
   const float* B;
   float* C;
   const float* bias;  // [N] when EPI_BIAS
-  float* stats;       // [2, tiles_m, ldc] when EPI_COLSTATS
+  float* stats;       // [2, tiles_m, ldc] when EPI_COLSTATS; [2, stats_stride, ldc] when EPI_DACT
+  // EPI_DACT: the layer whose output gradient this GEMM produces (all [M, ldc] / [N])
+  const float* act_a;     // layer output a = f(u)
+  const float* act_z;     // pre-batch-norm affine output
+  const float* act_mean;  // batch mean / rstd of act_z's columns
+  const float* act_rstd;
+  int act_nonlin;         // TFK_NONLIN_*
+  int stats_stride;
   int M, N, K;
   int lda, ldb, ldc;
   int epi;

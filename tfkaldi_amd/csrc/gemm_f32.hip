@@ -409,6 +409,74 @@ gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
       __syncthreads();
     }
   }
+  if constexpr ((EPI & EPI_DACT) != 0) {
+    // The result is da of a hidden layer: turn it into du = da * f'(a) in the accumulators and reduce, over this
+    // tile's rows, the two column sums of batch-norm's backward (same lane / wave reduction as above).
+    float* red = smem;  // [2][WAVES_M][BN]
+#pragma unroll
+    for (int b = 0; b < T::FN; ++b) {
+      const int col = n0 + wn * T::WN + b * 32 + i;
+      const int colc = min(col, p.N - 1);
+      const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < T::FM; ++a) {
+        const int rbase = m0 + wm * T::WM + a * 32 + 4 * h;
+        float av[16], zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+          av[r] = p.act_a[(size_t)row * p.ldc + colc];
+          zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[0][a][b][r];
+#pragma unroll
+          for (int q = 1; q < T::KS; ++q) {
+            v += acc[q][a][b][r];
+            acc[q][a][b][r] = 0.f;
+          }
+          float d1;  // f' through the output, as kernels.hip nonlin_bwd
+          switch (p.act_nonlin) {
+            case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+            case 1: d1 = av[r] * (1.f - av[r]); break;
+            case 2: d1 = 1.f - av[r] * av[r]; break;
+            default: d1 = 1.f;
+          }
+          const float du = v * d1;
+          acc[0][a][b][r] = du;
+          if (rbase + (r & 3) + 8 * (r >> 2) < p.M) {
+            s1 += du;
+            s2 += du * (zv[r] - mu) * rsd;
+          }
+        }
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        red[(0 * T::WAVES_M + wm) * T::BN + wn * T::WN + b * 32 + i] = s1;
+        red[(1 * T::WAVES_M + wm) * T::BN + wn * T::WN + b * 32 + i] = s2;
+      }
+    }
+    __syncthreads();
+    if (wm == 0 && h == 0) {
+#pragma unroll
+      for (int b = 0; b < T::FN; ++b) {
+        const int col = n0 + wn * T::WN + b * 32 + i;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < T::WAVES_M; ++w) {
+          t1 += red[(0 * T::WAVES_M + w) * T::BN + wn * T::WN + b * 32 + i];
+          t2 += red[(1 * T::WAVES_M + w) * T::BN + wn * T::WN + b * 32 + i];
+        }
+        if (col < p.N) {
+          p.stats[((size_t)0 * p.stats_stride + tm) * p.ldc + col] = t1;
+          p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = t2;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int b = 0; b < T::FN; ++b) {
     const int col = n0 + wn * T::WN + b * 32 + i;
@@ -527,6 +595,7 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
       break;
     case GEMM_NT:
       if (p.epi == 0) return dispatch_cfg<true, true, 0>(p, cfg, s);
+      if (p.epi == EPI_DACT) return dispatch_cfg<true, true, EPI_DACT>(p, cfg, s);
       break;
     case GEMM_TN:
       if (p.epi == 0) return dispatch_cfg<false, false, 0>(p, cfg, s);

@@ -50,9 +50,11 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 // Column-tiled backward of {dropout, nonlin', batch norm}: da[T,H] -> dz in place.  Leaves the per-chunk
 // partial column sums in ws (>= 3*kMaxRowSplits*ld floats): slab 0 = sum_t du (-> d beta), slab 1 =
 // sum_t du*xhat, slab 2 = sum_t dz (-> d bias); grad_final() turns them into gradients.
-// `pre_du` != 0: da already holds du (after act_backward_rows).
+// Slab k starts at row k*kMaxRowSplits of ws ([., ld]).
+// `pre_du` != 0: da already holds du (after act_backward_rows, or from the dA GEMM's EPI_DACT epilogue).
+// `stats_chunks` > 0: slabs 0 / 1 already hold that many chunks (EPI_DACT): the statistics pass is skipped.
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, int T, int H, int ld, float* ws);
+                     const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks = 0);
 // per-chunk partial column sums of x[T, ld] into slab 0 of ws (bias gradient of the output layer)
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws);
 int row_splits(int T);  // chunks the column-tiled kernels cut T rows into
@@ -76,7 +78,8 @@ void grad_final(hipStream_t s, const FinalBatch& b);
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
                   int with_grad);
 // scalars[0] += sum(row_loss), scalars[1] += T, scalars[2] += 1
-void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars);
+// overwrite: the accumulators were logically re-initialised since the last call (no memset needed)
+void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite);
 // decoder.py:44 softmax; prior != null: out = log(softmax / prior) (nnet.py:280-286)
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
                   const float* prior);
@@ -85,8 +88,9 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 // grid_cap > 0 limits the number of blocks (grid-stride loop does the rest)
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
                 float beta1, float beta2, float eps, int grid_cap);
-// moving <- decay^{num_microbatches} * moving + E
-void ema_apply(hipStream_t s, float* moving, const float* e, size_t n, const float* scalars, float decay);
+// end of a step in one launch: moving <- decay^{num_microbatches} * moving + E, E <- 0, and
+// host[0..3] <- scalars[0..3] (host = device address of mapped pinned memory)
+void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host);
 void scale_inplace(hipStream_t s, float* x, size_t n, float factor);
 void fill(hipStream_t s, float* x, size_t n, float value);
 // +-context splicing on the device (reference processing/feature_reader.py:117-156): raw[T, ldr] holds the

@@ -501,16 +501,17 @@ hb_stats_kernel(ActDesc d, int pre_du, const float* __restrict__ da, const float
   s1 = reduce_rows(s1, sm);
   s2 = reduce_rows(s2, sm);
   if (threadIdx.y == 0 && t.valid) {
-    st4(ws + ((size_t)0 * rs + blockIdx.y) * ld + t.col, s1);
-    st4(ws + ((size_t)1 * rs + blockIdx.y) * ld + t.col, s2);
+    st4(ws + ((size_t)0 * kMaxRowSplits + blockIdx.y) * ld + t.col, s1);
+    st4(ws + ((size_t)1 * kMaxRowSplits + blockIdx.y) * ld + t.col, s2);
   }
 }
 
-// pass B: dz in place (+ partial column sums of dz)
+// pass B: dz in place (+ partial column sums of dz).  rs_in = number of pass-A chunks in slabs 0 / 1 (written by
+// hb_stats_kernel, or by the dA GEMM's EPI_DACT epilogue: then pre_du = 1 and `da` already holds du)
 __global__ void __launch_bounds__(CT_X * CT_Y)
 hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __restrict__ a,
                 const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd, int T,
-                int H, int ld, int rows_per, int rs, float* __restrict__ ws) {
+                int H, int ld, int rows_per, int rs_in, float* __restrict__ ws) {
   __shared__ float4 sm[CT_Y][CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
   float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -520,9 +521,9 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
     // (<= 8 independent loads each), the block combines them through LDS
     float4 p1 = sz, p2 = sz;
     if (t.valid)
-      for (int k = threadIdx.y; k < rs; k += CT_Y) {
-        const float4 q1 = ld4(ws + ((size_t)0 * rs + k) * ld + t.col);
-        const float4 q2 = ld4(ws + ((size_t)1 * rs + k) * ld + t.col);
+      for (int k = threadIdx.y; k < rs_in; k += CT_Y) {
+        const float4 q1 = ld4(ws + ((size_t)0 * kMaxRowSplits + k) * ld + t.col);
+        const float4 q2 = ld4(ws + ((size_t)1 * kMaxRowSplits + k) * ld + t.col);
         p1.x += q1.x; p1.y += q1.y; p1.z += q1.z; p1.w += q1.w;
         p2.x += q2.x; p2.y += q2.y; p2.z += q2.z; p2.w += q2.w;
       }
@@ -574,7 +575,7 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
     }
   }
   sz = reduce_rows(sz, sm);
-  if (threadIdx.y == 0 && t.valid) st4(ws + ((size_t)2 * rs + blockIdx.y) * ld + t.col, sz);
+  if (threadIdx.y == 0 && t.valid) st4(ws + ((size_t)2 * kMaxRowSplits + blockIdx.y) * ld + t.col, sz);
 }
 
 // g[c] (+)= sum over row splits of slab `which`, for a batch of (layer, vector) items: blockIdx.y = item
@@ -587,7 +588,7 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_KL) grad_final_kernel(FinalBatc
 #pragma unroll
   for (int j = 0; j < FIN_PER; ++j) {
     const int k = ky + j * FIN_KL;
-    v[j] = (c < it.N && k < it.rs) ? it.ws[((size_t)it.which * it.rs + k) * it.ld + c] : 0.f;
+    v[j] = (c < it.N && k < it.rs) ? it.ws[((size_t)it.which * kMaxRowSplits + k) * it.ld + c] : 0.f;
   }
   float s = 0.f;
 #pragma unroll
@@ -683,15 +684,16 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
 }
 
 __global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restrict__ row_loss, int T,
-                                                           float* __restrict__ scalars) {
+                                                           float* __restrict__ scalars, int overwrite) {
   __shared__ float sm[16];
   float s = 0.f;
   for (int i = threadIdx.x; i < T; i += 1024) s += row_loss[i];
   s = block_sum(s, sm);
   if (threadIdx.x == 0) {
-    scalars[0] += s;
-    scalars[1] += (float)T;
-    scalars[2] += 1.f;
+    // overwrite: first micro-batch since the accumulators were (logically) re-initialised -- saves the memset
+    scalars[0] = overwrite ? s : scalars[0] + s;
+    scalars[1] = overwrite ? (float)T : scalars[1] + (float)T;
+    scalars[2] = overwrite ? 1.f : scalars[2] + 1.f;
   }
 }
 
@@ -718,13 +720,34 @@ softmax_rows_kernel(const float* __restrict__ logits, int O, int ld, float* __re
 }
 
 // ---- mean -> clip -> Adam (TF formulation), zeroing the gradient sum on the way out ----
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4s(const float* p) {
+  if constexpr (NT) {
+    const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+  } else {
+    return ld4(p);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void st4s(float* p, float4 v) {
+  if constexpr (NT) {
+    v4f q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(p));
+  } else {
+    st4(p, v);
+  }
+}
+// NT: streaming (non-temporal) accesses for g / m / v, which nothing re-reads before the next optimiser step
+template <bool NT>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
             const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps) {
   const float inv_n = 1.f / scalars[1];  // G / float(num_frames): trainer.py:174-175
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 gv = ld4(g + 4 * i), mv = ld4(m + 4 * i), vv = ld4(v + 4 * i), wv = ld4(w + 4 * i);
+    float4 gv = ld4s<NT>(g + 4 * i), mv = ld4s<NT>(m + 4 * i), vv = ld4s<NT>(v + 4 * i), wv = ld4(w + 4 * i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gk = fminf(fmaxf(el(gv, k) * inv_n, -1.f), 1.f);  // clip_by_value: trainer.py:178-179
@@ -734,18 +757,27 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
       el(vv, k) = vk;
       el(wv, k) -= lr_t * mk / (sqrtf(vk) + eps);
     }
-    st4(m + 4 * i, mv);
-    st4(v + 4 * i, vv);
+    st4s<NT>(m + 4 * i, mv);
+    st4s<NT>(v + 4 * i, vv);
     st4(w + 4 * i, wv);
     // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
   }
 }
 
-__global__ void ema_kernel(float* __restrict__ mov, const float* __restrict__ e, size_t n,
-                           const float* __restrict__ scalars, float decay) {
+// End of an optimiser step, one launch: BN moving averages mov = decay^k * mov + increments (k = micro-batches of
+// the step), re-initialisation of the increments, and the step's (loss, frames, k) handed to the host through
+// mapped pinned memory (no copy kernel, no memset).
+__global__ void step_finish_kernel(float* __restrict__ mov, float* __restrict__ e, size_t n,
+                                   const float* __restrict__ scalars, float decay, float* __restrict__ host) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  mov[i] = powf(decay, scalars[2]) * mov[i] + e[i];
+  if (i < n) {
+    mov[i] = powf(decay, scalars[2]) * mov[i] + e[i];
+    e[i] = 0.f;
+  }
+  if (i < 4) {
+    host[i] = scalars[i];
+    __threadfence_system();
+  }
 }
 __global__ void scale_kernel(float* __restrict__ x, size_t n, float f) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -854,13 +886,13 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 }
 
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, int T, int H, int ld, float* ws) {
+                     const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
-  if (d.bn)
+  if (d.bn && stats_chunks <= 0)
     hipLaunchKernelGGL(hb_stats_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, ld,
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
-                     rows_per, rs, ws);
+                     rows_per, stats_chunks > 0 ? stats_chunks : rs, ws);
 }
 
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws) {
@@ -886,8 +918,8 @@ void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, 
   else hipLaunchKernelGGL(softmax_xent_kernel<0>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
 }
 
-void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, row_loss, T, scalars);
+void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, row_loss, T, scalars, overwrite ? 1 : 0);
 }
 
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
@@ -902,13 +934,19 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (grid_cap > 0 && blocks > (size_t)grid_cap) blocks = grid_cap;
   if (blocks == 0) return;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1, beta2,
-                     eps);
+  // streaming accesses measured 116.7 -> 107.8 us on cfg2 (6.75 TB/s); TFK_ADAM_NT=0 restores cached ones
+  static const bool nt = [] { const char* q = getenv("TFK_ADAM_NT"); return !q || atoi(q) != 0; }();
+  if (nt)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1,
+                       beta2, eps);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1,
+                       beta2, eps);
 }
 
-void ema_apply(hipStream_t s, float* moving, const float* e, size_t n, const float* scalars, float decay) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, moving, e, n, scalars, decay);
+void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host) {
+  const size_t blocks = n ? (n + 255) / 256 : 1;
+  hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host);
 }
 void scale_inplace(hipStream_t s, float* x, size_t n, float factor) {
   if (n == 0) return;

@@ -162,6 +162,8 @@ class DataParallel(object):
         start, end = partition(len(microbatches), self.world)[self.rank]
         for mb in microbatches[start:end]:
             _eval_accumulate(engine, mb)
+        if start == end:  # nothing on this rank: contribute physical zeros (the accumulators reset lazily)
+            engine.zero_accumulators()
         off, n = engine.buckets()[-1]
         with self._stream_ctx(engine):
             dist.all_reduce(engine.reduce_view()[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
