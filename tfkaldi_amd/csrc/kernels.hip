@@ -318,10 +318,38 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
   __shared__ float4 smm[CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Everything this block reads is requested up front -- the chunk statistics (up to KREG chunk pairs per thread
+  // stay in registers) and the first batch of z rows -- so that the kernel pays ONE memory round trip before its
+  // two LDS reductions instead of three dependent ones (these launches are latency-bound: ~7 us for 16 MB).
+  constexpr int KREG = 2;
+  const bool in_regs = nchunk <= KREG * CT_Y;  // block-uniform
+  float4 mreg[KREG], qreg[KREG];
+  float nreg[KREG];
+#pragma unroll
+  for (int j = 0; j < KREG; ++j) {
+    const int k = threadIdx.y + j * CT_Y;
+    const bool ok = t.valid && k < nchunk;
+    nreg[j] = ok ? (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0) : 0.f;
+    mreg[j] = ok ? ld4(st + ((size_t)0 * nchunk + k) * ld + t.col) : zero4;
+    qreg[j] = ok ? ld4(st + ((size_t)1 * nchunk + k) * ld + t.col) : zero4;
+  }
+  const int rb0 = t.r0 + threadIdx.y;
+  float4 zv[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int r = rb0 + j * CT_Y;
+    zv[j] = (t.valid && rb0 < t.r1) ? ld4(z + (size_t)(r < t.r1 ? r : rb0) * ld + t.col) : zero4;
+  }
+  const float4 be = t.valid ? ld4(beta + t.col) : zero4;
   // Chan merge of the per-chunk (n, mean, M2): row lane y takes chunks y, y + 8, ...
   float4 tot = zero4;
-  if (t.valid)
-    for (int k = threadIdx.y; k < nchunk; k += CT_Y) {
+#pragma unroll
+  for (int j = 0; j < KREG; ++j) {
+    tot.x += nreg[j] * mreg[j].x; tot.y += nreg[j] * mreg[j].y;
+    tot.z += nreg[j] * mreg[j].z; tot.w += nreg[j] * mreg[j].w;
+  }
+  if (!in_regs && t.valid)
+    for (int k = threadIdx.y + KREG * CT_Y; k < nchunk; k += CT_Y) {
       const float n = (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0);
       const float4 m = ld4(st + ((size_t)0 * nchunk + k) * ld + t.col);
       tot.x += n * m.x; tot.y += n * m.y; tot.z += n * m.z; tot.w += n * m.w;
@@ -334,8 +362,15 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
   __syncthreads();
   const float4 mu = smm[threadIdx.x];
   float4 m2 = zero4;
-  if (t.valid)
-    for (int k = threadIdx.y; k < nchunk; k += CT_Y) {
+#pragma unroll
+  for (int j = 0; j < KREG; ++j) {
+    const float4 m = mreg[j], q = qreg[j];
+    const float n = nreg[j];
+    m2.x += q.x + n * (m.x - mu.x) * (m.x - mu.x); m2.y += q.y + n * (m.y - mu.y) * (m.y - mu.y);
+    m2.z += q.z + n * (m.z - mu.z) * (m.z - mu.z); m2.w += q.w + n * (m.w - mu.w) * (m.w - mu.w);
+  }
+  if (!in_regs && t.valid)
+    for (int k = threadIdx.y + KREG * CT_Y; k < nchunk; k += CT_Y) {
       const float n = (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0);
       const float4 m = ld4(st + ((size_t)0 * nchunk + k) * ld + t.col);
       const float4 q = ld4(st + ((size_t)1 * nchunk + k) * ld + t.col);
@@ -371,15 +406,15 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
   __syncthreads();
   if (!t.valid) return;
   const float4 rsd = smm[threadIdx.x];
-  const float4 be = ld4(beta + t.col);
   const bool drop = d.train && d.keep < 1.f;
   const float inv_keep = drop ? 1.f / d.keep : 1.f;
-  for (int rb = t.r0 + threadIdx.y; rb < t.r1; rb += CT_Y * RB) {
-    float4 zv[RB];
+  for (int rb = rb0; rb < t.r1; rb += CT_Y * RB) {
+    float4 zn[RB];  // next batch in flight while this one is finished
+    const int rbn = rb + CT_Y * RB;
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      const int r = rb + j * CT_Y;
-      zv[j] = ld4(z + (size_t)(r < t.r1 ? r : rb) * ld + t.col);
+      const int r = rbn + j * CT_Y;
+      zn[j] = rbn < t.r1 ? ld4(z + (size_t)(r < t.r1 ? r : rbn) * ld + t.col) : zero4;
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
@@ -397,6 +432,8 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
       }
       st4(a + (size_t)r * ld + t.col, v);
     }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) zv[j] = zn[j];
   }
 }
 
@@ -515,7 +552,24 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
   __shared__ float4 sm[CT_Y][CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
   float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 zero4 = sz;
   float4 m1 = sz, m2 = sz;
+  // first batch of rows requested before the statistics prologue: one memory round trip, not two
+  const int rb0 = t.r0 + threadIdx.y;
+  float4 g[RB], av[RB], zv[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int r = rb0 + j * CT_Y;
+    const bool ok = t.valid && rb0 < t.r1;
+    const size_t off = (size_t)(r < t.r1 ? r : rb0) * ld + t.col;
+    g[j] = ok ? ld4(da + off) : zero4;
+    av[j] = (ok && !pre_du) ? ld4(a + off) : g[j];
+    zv[j] = (ok && d.bn) ? ld4(z + off) : g[j];
+  }
+  float4 mu = sz, rsd = sz;
+  if (d.bn && t.valid) {
+    mu = ld4(mean + t.col); rsd = ld4(rstd + t.col);
+  }
   if (d.bn) {
     // column means of du and du*xhat from pass A's per-chunk partials: row lane y sums chunks y, y+8, ...
     // (<= 8 independent loads each), the block combines them through LDS
@@ -540,19 +594,17 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
     m2 = smm[1][threadIdx.x];
   }
   if (t.valid) {
-    float4 mu = sz, rsd = sz;
-    if (d.bn) {
-      mu = ld4(mean + t.col); rsd = ld4(rstd + t.col);
-    }
-    for (int rb = t.r0 + threadIdx.y; rb < t.r1; rb += CT_Y * RB) {
-      float4 g[RB], av[RB], zv[RB];
+    for (int rb = rb0; rb < t.r1; rb += CT_Y * RB) {
+      float4 gn[RB], an[RB], zn[RB];  // next batch in flight (other rows: da is rewritten in place below)
+      const int rbn = rb + CT_Y * RB;
 #pragma unroll
-      for (int j = 0; j < RB; ++j) {  // all loads of the batch first (da is rewritten in place below)
-        const int r = rb + j * CT_Y;
-        const size_t off = (size_t)(r < t.r1 ? r : rb) * ld + t.col;
-        g[j] = ld4(da + off);
-        av[j] = pre_du ? g[j] : ld4(a + off);
-        zv[j] = d.bn ? ld4(z + off) : g[j];
+      for (int j = 0; j < RB; ++j) {
+        const int r = rbn + j * CT_Y;
+        const bool ok = rbn < t.r1;
+        const size_t off = (size_t)(r < t.r1 ? r : rbn) * ld + t.col;
+        gn[j] = ok ? ld4(da + off) : zero4;
+        an[j] = (ok && !pre_du) ? ld4(a + off) : gn[j];
+        zn[j] = (ok && d.bn) ? ld4(z + off) : gn[j];
       }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
@@ -571,6 +623,10 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
           if (t.col + k >= H) el(dz, k) = 0.f;
         st4(da + (size_t)r * ld + t.col, dz);
         sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        g[j] = gn[j]; av[j] = an[j]; zv[j] = zn[j];
       }
     }
   }
