@@ -28,6 +28,12 @@ extern "C" {
 
 typedef struct tfk_engine tfk_engine;
 
+/* Arithmetic of the affine / gradient contractions.  TFK_DTYPE_F32 is the reference's (exact-fp32 MFMA).
+ * TFK_DTYPE_BF16 is mixed precision (BASELINE cfg3 / cfg4): GEMM operands -- layer inputs, weights, dZ -- are
+ * rounded to bfloat16 (round to nearest even), products accumulate in fp32; master parameters, batch-norm
+ * statistics, the loss, gradient sums and the Adam update stay fp32. */
+enum { TFK_DTYPE_F32 = 0, TFK_DTYPE_BF16 = 1 };
+
 /* nonlinearity of the hidden layers: neuralNetworks/nnet.py:48-65 */
 enum { TFK_NONLIN_RELU = 0, TFK_NONLIN_SIGMOID = 1, TFK_NONLIN_TANH = 2, TFK_NONLIN_LINEAR = 3 };
 
@@ -59,6 +65,7 @@ typedef struct tfk_config {
   float adam_beta1;            /* [0.9]   tf.train.AdamOptimizer */
   float adam_beta2;            /* [0.999] */
   float adam_epsilon;          /* [1e-8] */
+  int32_t compute_dtype;       /* TFK_DTYPE_*: arithmetic of the three contractions (0 = fp32, the reference's) */
 } tfk_config;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -224,6 +231,10 @@ int tfk_debug_fetch(tfk_engine* e, int what, int layer, float* host, size_t coun
 /* Stand-alone fp32 GEMM on device pointers (tests / tools): layout 0 NN, 1 NT, 2 TN (gemm_f32.h). */
 int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                  int M, int N, int K, const float* bias, int epi, int tile_config);
+/* Stand-alone bf16 GEMM (fp32 accumulate / result) on device pointers: A, B hold bfloat16 bit patterns with
+ * leading dimensions (in elements) that are multiples of 8 and zero padding (gemm_bf16.h). */
+int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                  int M, int N, int K, const float* bias, int epi);
 
 #ifdef __cplusplus
 }

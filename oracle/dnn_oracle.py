@@ -55,14 +55,25 @@ def _nonlin_grad(v, kind):
     return np.ones_like(v)
 
 
+def round_bf16(x):
+    """float -> nearest bfloat16 (ties to even), returned as float64; as the engine rounds its fp32 values"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32).astype(np.float64)
+
+
 class OracleDNN(object):
     """State + ops of Trainer (trainer.py:13-218) around DNN (dnn.py:10-131), in float64."""
 
     def __init__(self, input_dim, num_layers, num_units, output_dim, nonlin="relu", batch_norm=False,
                  l2_norm=False, keep_prob=1.0, layerwise_init=False, init_learning_rate=1e-3,
                  learning_rate_decay=1.0, num_steps=1, bn_decay=0.999, bn_epsilon=1e-3, beta1=0.9, beta2=0.999,
-                 adam_epsilon=1e-8):
+                 adam_epsilon=1e-8, gemm_dtype="float32"):
         assert nonlin in NONLINS
+        # "bfloat16": restates the engine's mixed-precision mode (TFK_DTYPE_BF16, not a reference behaviour): the
+        # operands of the three contractions are rounded to bfloat16, everything else keeps full precision
+        assert gemm_dtype in ("float32", "bfloat16")
+        self.gemm_dtype = gemm_dtype
         assert 0 < keep_prob  # activation.py:126 (values > 1 never reach Dropout: nnet.py:70-72)
         self.F, self.L, self.H, self.O = input_dim, num_layers, num_units, output_dim
         self.nonlin, self.bn, self.l2 = nonlin, bool(batch_norm), bool(l2_norm)
@@ -87,6 +98,12 @@ class OracleDNN(object):
         self._zero_accumulators()
         self.m = self._like_params()
         self.v = self._like_params()
+
+    def _mm(self, a, b):
+        """a . b in the arithmetic of the contractions"""
+        if self.gemm_dtype == "bfloat16":
+            return round_bf16(a).dot(round_bf16(b))
+        return a.dot(b)
 
     # ---- parameter bookkeeping ----
     def params(self):
@@ -141,7 +158,7 @@ class OracleDNN(object):
         T = inp.shape[0]
         for l in range(nfw):
             c = {"in": inp}
-            z = inp.dot(self.W[l]) + self.b[l]                       # layer.py:52
+            z = self._mm(inp, self.W[l]) + self.b[l]                 # layer.py:52
             u = z
             if self.bn:                                               # activation.py:159-161 (A1)
                 if train:
@@ -169,7 +186,7 @@ class OracleDNN(object):
             c["a"] = a
             cache.append(c)
             inp = a
-        logits = cache[nact - 1]["a"].dot(self.W[self.L]) + self.b[self.L]  # dnn.py:108, identity activation
+        logits = self._mm(cache[nact - 1]["a"], self.W[self.L]) + self.b[self.L]  # dnn.py:108, identity activation
         return logits, cache, nact
 
     @staticmethod
@@ -197,9 +214,9 @@ class OracleDNN(object):
         g = self._like_params()
         dz = prob.copy()
         dz[np.arange(T), y] -= 1.0                                    # d(sum CE)/dlogits
-        g["W%d" % self.L] = cache[nact - 1]["a"].T.dot(dz)
+        g["W%d" % self.L] = self._mm(cache[nact - 1]["a"].T, dz)
         g["b%d" % self.L] = dz.sum(axis=0)
-        da = dz.dot(self.W[self.L].T)
+        da = self._mm(dz, self.W[self.L].T)
         for l in range(nact - 1, -1, -1):
             c = cache[l]
             dw = da
@@ -217,10 +234,10 @@ class OracleDNN(object):
                 dzl = rstd * (du - du.mean(axis=0) - xhat * (du * xhat).mean(axis=0))
             else:
                 dzl = du
-            g["W%d" % l] = c["in"].T.dot(dzl)
+            g["W%d" % l] = self._mm(c["in"].T, dzl)
             g["b%d" % l] = dzl.sum(axis=0)
             if l > 0:
-                da = dzl.dot(self.W[l].T)
+                da = self._mm(dzl, self.W[l].T)
         for k in g:                                                   # trainer.py:165-169
             self.G[k] = self.G[k] + g[k]
         self.batch_loss += loss

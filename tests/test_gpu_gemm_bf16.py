@@ -1,0 +1,88 @@
+"""bf16 MFMA GEMM (tfkaldi_amd/csrc/gemm_bf16.hip) against float64 numpy on the SAME bf16-rounded operands,
+through the C ABI.  Products of two bf16 values are exact in fp32, so the only error is the fp32 accumulation:
+|err| <= 4e-7 * sum_k |a_k b_k| + 1e-6, the bound of the fp32 kernel's test.  Inputs are random and not symmetric,
+so a transposed operand or a wrong k order inside ds_read_b64_tr_b16 / the MFMA operand cannot pass."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPI_BIAS, EPI_ACCUM = 1, 2
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def _bf16_dev(torch, a):
+    """host float [rows, cols] -> (device bf16 buffer with ld = pad8(cols) and zero padding, ld, rounded values)"""
+    rows, cols = a.shape
+    ld = _pad(cols, 8)
+    buf = torch.zeros((rows, ld), dtype=torch.bfloat16)
+    buf[:, :cols] = torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)
+    rounded = buf[:, :cols].to(torch.float64).numpy()
+    return buf.cuda(), ld, rounded
+
+
+def _run(lib, torch, layout, M, N, K, epi=0, seed=0):
+    rng = np.random.default_rng(seed)
+    shapes = {0: ((M, K), (K, N)), 1: ((M, K), (N, K)), 2: ((K, M), (K, N))}[layout]
+    A = rng.standard_normal(shapes[0]); B = rng.standard_normal(shapes[1])
+    dA, lda, Ar = _bf16_dev(torch, A)
+    dB, ldb, Br = _bf16_dev(torch, B)
+    if layout == 0:
+        ref, absref = Ar @ Br, np.abs(Ar) @ np.abs(Br)
+    elif layout == 1:
+        ref, absref = Ar @ Br.T, np.abs(Ar) @ np.abs(Br).T
+    else:
+        ref, absref = Ar.T @ Br, np.abs(Ar).T @ np.abs(Br)
+    ldc = _pad(N, 4)
+    C0 = np.zeros((M, ldc), dtype=np.float32)
+    C0[:, :N] = rng.standard_normal((M, N))
+    dC = torch.from_numpy(C0.copy()).cuda()
+    bias = rng.standard_normal(N).astype(np.float32)
+    dbias = torch.from_numpy(bias).cuda()
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.tfk_gemm_bf16(ctypes.c_void_p(st), layout, ctypes.c_void_p(dA.data_ptr()), lda,
+                           ctypes.c_void_p(dB.data_ptr()), ldb, ctypes.c_void_p(dC.data_ptr()), ldc, M, N, K,
+                           ctypes.c_void_p(dbias.data_ptr()), epi)
+    assert rc == 0, lib.tfk_last_error()
+    torch.cuda.synchronize()
+    out = dC.cpu().numpy()
+    if epi & EPI_BIAS:
+        ref = ref + bias
+        absref = absref + np.abs(bias)
+    if epi & EPI_ACCUM:
+        ref = ref + C0[:, :N]
+        absref = absref + np.abs(C0[:, :N])
+    err = np.abs(out[:, :N] - ref)
+    bound = 4e-7 * absref + 1e-6
+    assert (err <= bound).all(), "layout %d %dx%dx%d epi %d: max err/bound %.2f" % (
+        layout, M, N, K, epi, float((err / bound).max()))
+    assert (out[:, N:] == C0[:, N:]).all()  # padding columns untouched
+
+
+SHAPES = [(64, 64, 64), (128, 192, 256), (1, 1, 1), (37, 29, 13), (65, 63, 130), (100, 250, 72), (256, 2000, 440),
+          (1024, 2048, 2048)]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_bf16(gpu, layout, shape):
+    import torch
+    from tfkaldi_amd import _lib
+    M, N, K = shape
+    if layout == 2:
+        M, K = K, M  # TN: the long dimension is the contraction (frames)
+    _run(_lib.load(), torch, layout, M, N, K, seed=layout * 100 + M)
+
+
+@pytest.mark.parametrize("layout,epi", [(0, EPI_BIAS), (2, EPI_ACCUM)])
+def test_gemm_bf16_epilogues(gpu, layout, epi):
+    import torch
+    from tfkaldi_amd import _lib
+    for M, N, K in ((70, 90, 200), (256, 128, 64)):
+        _run(_lib.load(), torch, layout, M, N, K, epi=epi, seed=7)

@@ -43,9 +43,11 @@ def make_pair(rng, output_too=True, **kw):
     """(Engine, OracleDNN) of the same shape holding the same parameters."""
     from tfkaldi_amd import _lib
     from tfkaldi_amd.engine import Engine
-    oracle = OracleDNN(**oracle_kwargs(kw))
+    dtype = kw.get("compute_dtype", "float32")  # "bfloat16": engine in mixed precision, oracle rounding GEMM operands
+    oracle = OracleDNN(gemm_dtype=dtype, **oracle_kwargs(kw))
     randomize(oracle, rng, output_too)
-    cfg = _lib.make_config(max_frames=kw.get("max_frames", 256), seed=kw.get("seed", 1234), **oracle_kwargs(kw))
+    cfg = _lib.make_config(max_frames=kw.get("max_frames", 256), seed=kw.get("seed", 1234), compute_dtype=dtype,
+                           **oracle_kwargs(kw))
     eng = Engine(cfg, torch_state=kw.get("torch_state", False))
     copy_oracle_to_engine(oracle, eng)
     return eng, oracle

@@ -14,6 +14,7 @@ ABI_VERSION = 1
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
+DTYPES = {"float32": 0, "bfloat16": 1}  # TFK_DTYPE_*: arithmetic of the GEMMs (bfloat16 = mixed precision)
 WEIGHTS, BIASES, BN_BETA, BN_MOVING_MEAN, BN_MOVING_VAR = range(5)
 SLOT_PARAM, SLOT_GRAD, SLOT_ADAM_M, SLOT_ADAM_V = range(4)
 (GLOBAL_STEP, LEARNING_RATE_FACT, INITIALISED_LAYERS, ADAM_STEPS, BATCH_LOSS, NUM_FRAMES,
@@ -32,6 +33,7 @@ class TfkConfig(Structure):
         ("init_learning_rate", c_float), ("learning_rate_decay", c_float), ("num_steps", c_int32),
         ("max_frames", c_int32), ("seed", c_uint64), ("bn_decay", c_float), ("bn_epsilon", c_float),
         ("adam_beta1", c_float), ("adam_beta2", c_float), ("adam_epsilon", c_float),
+        ("compute_dtype", c_int32),
     ]
 
 
@@ -84,6 +86,8 @@ SYMBOLS = {
     "tfk_debug_fetch": (c_int, [_E, c_int, c_int, c_void_p, c_size_t]),
     "tfk_gemm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_int]),
+    "tfk_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                              c_int, c_void_p, c_int]),
 }
 
 _lib = None
@@ -128,9 +132,11 @@ def check(rc):
 
 def make_config(input_dim, num_layers, num_units, output_dim, nonlin="relu", batch_norm=False, l2_norm=False,
                 keep_prob=1.0, layerwise_init=False, init_learning_rate=1e-3, learning_rate_decay=1.0,
-                num_steps=1, max_frames=1024, seed=0, device=0):
+                num_steps=1, max_frames=1024, seed=0, device=0, compute_dtype="float32"):
     if nonlin not in NONLIN:
         raise Exception('unkown nonlinearity')  # spelling as neuralNetworks/nnet.py:65
+    if compute_dtype not in DTYPES:
+        raise ValueError("compute_dtype must be one of %s" % sorted(DTYPES))
     c = TfkConfig()
     c.struct_size = ctypes.sizeof(TfkConfig)
     c.device = device
@@ -140,4 +146,5 @@ def make_config(input_dim, num_layers, num_units, output_dim, nonlin="relu", bat
     c.keep_prob = float(keep_prob)
     c.init_learning_rate, c.learning_rate_decay = float(init_learning_rate), float(learning_rate_decay)
     c.num_steps, c.max_frames, c.seed = int(num_steps), int(max_frames), int(seed)
+    c.compute_dtype = DTYPES[compute_dtype]
     return c

@@ -10,6 +10,7 @@
 //   activations (engine-owned, grow on demand): X, per hidden layer z_l (pre-BN) and a_l (layer output),
 //     logits, two ping-pong gradient buffers, BN batch statistics, reduction workspace.
 #include "../../include/tfkaldi_hip.h"
+#include "gemm_bf16.h"
 #include "gemm_f32.h"
 #include "kernels.h"
 
@@ -134,8 +135,22 @@ struct tfk_engine {
   size_t h_post_floats = 0;
   float* h_scalars = nullptr;    // mapped pinned memory: kernels write the step's (loss, frames, #mb) here
   float* h_scalars_dev = nullptr;
-  bool scalars_fresh = true;
-  bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
+  bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
+  bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
+
+  // mixed precision (cfg.compute_dtype == TFK_DTYPE_BF16): every fp32 buffer that is a GEMM operand has a bf16
+  // twin written by its producer; master parameters, statistics, gradients and the optimiser stay fp32
+  bool bf16 = false;
+  int ldFb = 0, ldHb = 0, ldOb = 0;  // leading dimensions of the twins (multiples of 8 elements)
+  bf16_t* Xb[2] = {nullptr, nullptr};
+  std::vector<bf16_t*> ab;
+  bf16_t* logb = nullptr;
+  bf16_t* dAb[2] = {nullptr, nullptr};
+  bf16_t* Wb = nullptr;              // shadow of the weight matrices
+  std::vector<size_t> wb_off;
+  std::vector<int> wb_ld;
+  bool wb_aligned = false;           // shadow offsets == fp32 arena offsets: Adam writes it with the update
+  bool shadow_dirty = true;
   hipEvent_t copy_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
   bool slot_used[2] = {false, false};
   int slot = 0;
@@ -193,6 +208,8 @@ int validate(const tfk_config* c) {
     return fail(-1, "bad dimensions F=%d L=%d H=%d O=%d", c->input_dim, c->num_layers, c->num_units, c->output_dim);
   if (c->nonlin < 0 || c->nonlin > 3) return fail(-1, "unkown nonlinearity %d", c->nonlin);
   if (!(c->keep_prob > 0.f)) return fail(-1, "dropout keep probability must be in (0, 1], got %g", c->keep_prob);
+  if (c->compute_dtype != TFK_DTYPE_F32 && c->compute_dtype != TFK_DTYPE_BF16)
+    return fail(-1, "unknown compute_dtype %d", c->compute_dtype);
   return 0;
 }
 
@@ -271,6 +288,37 @@ int wait_adam_done(tfk_engine* e) {
   return 0;
 }
 
+// bf16 twin of an fp32 GEMM operand buffer (mixed-precision mode)
+const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
+  for (int s = 0; s < 2; ++s) {
+    if (p == e->dX[s]) { *ld = e->ldFb; return e->Xb[s]; }
+    if (p == e->dA[s]) { *ld = e->ldHb; return e->dAb[s]; }
+  }
+  if (p == e->logits) { *ld = e->ldOb; return e->logb; }
+  for (size_t l = 0; l < e->a.size(); ++l)
+    if (p == e->a[l]) { *ld = e->ldHb; return e->ab[l]; }
+  for (int l = 0; l <= e->L; ++l)
+    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; return e->Wb + e->wb_off[l]; }
+  return nullptr;
+}
+// rows a GEMM's per-tile statistics (EPI_COLSTATS / EPI_DACT) are chunked by
+int gemm_chunk_rows(tfk_engine* e, GemmLayout layout, int M, int N, int K, int* cfg) {
+  if (e->bf16) { *cfg = -1; return kGemmBf16TileRows; }
+  *cfg = gemm_f32_pick_config(layout, M, N, K);
+  return gemm_f32_config_bm(*cfg);
+}
+// (re)build the bf16 shadow of the weight matrices after the parameters were written from outside the optimiser
+int refresh_shadow(tfk_engine* e) {
+  if (!e->bf16 || !e->shadow_dirty) return 0;
+  for (int l = 0; l <= e->L; ++l) {
+    const LayerLayout& y = e->lay[l];
+    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->wb_off[l], e->wb_ld[l], y.d_in, y.d_out);
+  }
+  HIPCHK(hipGetLastError());
+  e->shadow_dirty = false;
+  return 0;
+}
+
 struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient the GEMM produces
   const float *a, *z, *mean, *rstd;
   int nonlin;
@@ -279,6 +327,25 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
              int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr, float* stats = nullptr,
              int cfg = -1, const ActEpi* act = nullptr) {
   if (!st) st = e->stream;
+  if (e->bf16) {
+    GemmArgsB b = {};
+    int lda8 = 0, ldb8 = 0;
+    b.A = twin_of(e, A, &lda8);
+    b.B = twin_of(e, B, &ldb8);
+    if (!b.A || !b.B) return fail(-1, "internal: GEMM operand without a bf16 twin");
+    b.C = C; b.bias = bias; b.stats = stats;
+    b.act_a = act ? act->a : nullptr; b.act_z = act ? act->z : nullptr;
+    b.act_mean = act ? act->mean : nullptr; b.act_rstd = act ? act->rstd : nullptr;
+    b.act_nonlin = act ? act->nonlin : 0;
+    b.stats_stride = kMaxRowSplits;
+    b.M = M; b.N = N; b.K = K; b.lda = lda8; b.ldb = ldb8; b.ldc = ldc; b.epi = epi;
+    const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
+    ProfScope ps(e, fam, 2.0 * M * N * K,
+                 2.0 * ((double)M * K + (double)K * N) + 4.0 * (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1), st);
+    const int rc = gemm_bf16(layout, b, st);
+    if (rc != 0) return fail(rc, "gemm_bf16 launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return 0;
+  }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.stats = stats;
   g.act_a = act ? act->a : nullptr; g.act_z = act ? act->z : nullptr;
@@ -309,6 +376,10 @@ void free_activations(tfk_engine* e) {
     if (e->hCmvn[s]) { hipHostFree(e->hCmvn[s]); e->hCmvn[s] = nullptr; }
   }
   e->cmvn_cap = 0;
+  auto frb = [](bf16_t*& p) { if (p) { hipFree(p); p = nullptr; } };
+  for (int s = 0; s < 2; ++s) { frb(e->Xb[s]); frb(e->dAb[s]); }
+  for (auto& p : e->ab) frb(p);
+  frb(e->logb);
   for (auto& p : e->z) fr(p);
   for (auto& p : e->a) fr(p);
   for (auto& p : e->v) fr(p);
@@ -320,6 +391,11 @@ void free_activations(tfk_engine* e) {
 int alloc_zero(float** p, size_t floats) {
   HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
   HIPCHK(hipMemset(*p, 0, floats * sizeof(float)));
+  return 0;
+}
+int alloc_zero_b(bf16_t** p, size_t elems) {
+  HIPCHK(hipMalloc((void**)p, elems * sizeof(bf16_t)));
+  HIPCHK(hipMemset(*p, 0, elems * sizeof(bf16_t)));
   return 0;
 }
 
@@ -353,6 +429,15 @@ int reserve(tfk_engine* e, int T) {
       CHK(alloc_zero(&e->v[l], (size_t)cap * e->ldH));
       CHK(alloc_zero(&e->rowscale[l], (size_t)cap));
     }
+  }
+  if (e->bf16) {
+    for (int s = 0; s < 2; ++s) {
+      CHK(alloc_zero_b(&e->Xb[s], (size_t)cap * e->ldFb));
+      CHK(alloc_zero_b(&e->dAb[s], (size_t)cap * e->ldHb));
+    }
+    e->ab.assign(L, nullptr);
+    for (int l = 0; l < L; ++l) CHK(alloc_zero_b(&e->ab[l], (size_t)cap * e->ldHb));
+    CHK(alloc_zero_b(&e->logb, (size_t)cap * e->ldOb));
   }
   CHK(alloc_zero(&e->logits, (size_t)cap * e->ldO));
   CHK(alloc_zero(&e->post, (size_t)cap * e->ldO));
@@ -466,6 +551,23 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
   return 0;
 }
 
+// Mixed precision: the bf16 twin of the staged input.  A caller-owned device matrix adopted in place has no
+// slot of its own: it is converted into the current slot's twin and that slot's (unused) fp32 buffer becomes
+// the key under which the GEMMs find it.
+int twin_input(tfk_engine* e, const float** Xd, int* ld, int T) {
+  int s = (*Xd == e->dX[0]) ? 0 : (*Xd == e->dX[1]) ? 1 : -1;
+  const float* src = *Xd;
+  const int ld_src = *ld;
+  if (s < 0) {
+    s = e->slot;
+    *Xd = e->dX[s];
+    *ld = e->ldF;
+  }
+  to_bf16_rows(e->stream, src, ld_src, e->Xb[s], e->ldFb, T, e->F);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int finish_slot(tfk_engine* e, int flags, int slot_before) {
   if (!(flags & TFK_DEVICE_PTRS) && e->slot != slot_before) HIPCHK(hipEventRecord(e->compute_done[slot_before], e->stream));
   return 0;
@@ -487,21 +589,27 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   const int H = e->H, ldH = e->ldH;
   const bool gate = e->adam_pending;  // parameters of layer l are ready once ev_adam_w[l] has fired
   if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_vec, 0));
+  if (e->bf16 && e->shadow_dirty) {
+    CHK(wait_adam_done(e));
+    CHK(refresh_shadow(e));
+  }
+  auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; } return t; };
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
     if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_w[l], 0));
     if (train && e->cfg.batch_norm && !e->cfg.l2_norm) {
       // fused path: the GEMM epilogue emits the per-tile column statistics, ONE column-tiled kernel merges them
       // and applies BN + nonlinearity + dropout (4 kernels per layer -> 2)
-      const int cfg = gemm_f32_pick_config(GEMM_NN, T, H, y.d_in);
+      int cfg;
+      const int chunk = gemm_chunk_rows(e, GEMM_NN, T, H, y.d_in, &cfg);
       CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
                    e->p_param() + y.b_off, EPI_BIAS | EPI_COLSTATS, nullptr, e->ws_stats, cfg));
       {
         ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * T * H);
         const ActDesc d = act_desc(e, l, train, call);
-        bn_act_forward(e->stream, d, e->z[l], e->a[l], e->ws_stats, gemm_f32_config_bm(cfg), T, H, ldH, e->bn_eps,
+        bn_act_forward(e->stream, d, e->z[l], e->a[l], e->ws_stats, chunk, T, H, ldH, e->bn_eps,
                        e->bn_decay, e->mean[l], e->rstd[l], e->ema_mean(l), e->ema_var(l),
-                       e->p_param() + y.beta_off);
+                       e->p_param() + y.beta_off, twin_a(l));
       }
       in = e->a[l];
       ld_in = ldH;
@@ -522,7 +630,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
       const ActDesc d = act_desc(e, l, train, call);
       act_forward(e->stream, d, e->z[l], e->a[l], e->cfg.l2_norm ? e->v[l] : nullptr,
                   e->cfg.l2_norm ? e->rowscale[l] : nullptr, e->mean[l], e->rstd[l],
-                  e->cfg.batch_norm ? e->p_param() + y.beta_off : nullptr, T, H, ldH);
+                  e->cfg.batch_norm ? e->p_param() + y.beta_off : nullptr, T, H, ldH, twin_a(l));
     }
     in = e->a[l];
     ld_in = ldH;
@@ -579,9 +687,9 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   // BN chains without L2Norm / dropout: the GEMM that produces a layer's output gradient also applies f' and
   // reduces the two column sums of batch-norm's backward in its epilogue (EPI_DACT), which removes one pass
   // over [T, H] per layer.  The per-tile partial sums must fit the kMaxRowSplits chunk slots of the workspace.
-  const int cfg_h = gemm_f32_pick_config(GEMM_NT, T, H, H), cfg_o = gemm_f32_pick_config(GEMM_NT, T, H, e->O);
-  const int chunks_h = (T + gemm_f32_config_bm(cfg_h) - 1) / gemm_f32_config_bm(cfg_h);
-  const int chunks_o = (T + gemm_f32_config_bm(cfg_o) - 1) / gemm_f32_config_bm(cfg_o);
+  int cfg_h, cfg_o;
+  const int rows_h = gemm_chunk_rows(e, GEMM_NT, T, H, H, &cfg_h), rows_o = gemm_chunk_rows(e, GEMM_NT, T, H, e->O, &cfg_o);
+  const int chunks_h = (T + rows_h - 1) / rows_h, chunks_o = (T + rows_o - 1) / rows_o;
   const bool fuse_hb = e->cfg.batch_norm && !e->cfg.l2_norm && !(e->cfg.keep_prob < 1.f) && e->fuse_hb_enabled &&
                        chunks_h <= kMaxRowSplits && chunks_o <= kMaxRowSplits;
   auto dact_gemm = [&](const float* dz, int ld_dz, const float* W, int ldw, float* out, int K, int target, int cfg) {
@@ -604,8 +712,10 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     }
     {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
+      Twin tw;
+      if (e->bf16) { tw.p = e->dAb[pp]; tw.ld = e->ldHb; }
       hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l], T, H, ldH, ws_of(l),
-                      fuse_hb ? chunks_in : 0);
+                      fuse_hb ? chunks_in : 0, tw);
       if (e->cfg.batch_norm) fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, fuse_hb ? chunks_in : rs, H, ldH};
       fin.it[fin.n++] = {ws_of(l), G + y.b_off, 2, rs, H, ldH};
       if (fin.n + 2 > kMaxFinalItems) {  // very deep nets: flush
@@ -707,6 +817,8 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   e->cfg = *cfg;
   e->F = cfg->input_dim; e->L = cfg->num_layers; e->H = cfg->num_units; e->O = cfg->output_dim;
   e->ldF = (int)up(e->F, 4); e->ldH = (int)up(e->H, 4); e->ldO = (int)up(e->O, 4);
+  e->bf16 = cfg->compute_dtype == TFK_DTYPE_BF16;
+  e->ldFb = (int)up(e->F, 8); e->ldHb = (int)up(e->H, 8); e->ldOb = (int)up(e->O, 8);
   e->bn_decay = cfg->bn_decay > 0.f ? cfg->bn_decay : 0.999f;
   e->bn_eps = cfg->bn_epsilon > 0.f ? cfg->bn_epsilon : 1e-3f;
   e->b1 = cfg->adam_beta1 > 0.f ? cfg->adam_beta1 : 0.9f;
@@ -781,6 +893,24 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if (alloc_zero(&e->mean[l], (size_t)e->ldH) || alloc_zero(&e->rstd[l], (size_t)e->ldH)) return bail(-1);
   }
   if (alloc_zero(&e->prior, (size_t)e->ldO)) return bail(-1);
+  if (e->bf16) {
+    // shadow arena: when every weight matrix has a leading dimension that is already a multiple of 8 it mirrors
+    // the fp32 arena element for element (the optimiser then writes it with the update), else it is packed
+    e->wb_aligned = true;
+    for (int l = 0; l <= e->L; ++l) e->wb_aligned = e->wb_aligned && (e->lay[l].ld_out % 8 == 0);
+    e->wb_off.assign(e->L + 1, 0);
+    e->wb_ld.assign(e->L + 1, 0);
+    size_t off = 0;
+    for (int l = 0; l <= e->L; ++l) {
+      const LayerLayout& y = e->lay[l];
+      e->wb_ld[l] = (int)up(y.d_out, 8);
+      e->wb_off[l] = e->wb_aligned ? y.w_off : off;
+      off += up((size_t)y.d_in * e->wb_ld[l], 64);
+    }
+    const size_t elems = e->wb_aligned ? e->lay[0].b_off : off;
+    if (alloc_zero_b(&e->Wb, elems)) return bail(-1);
+    e->shadow_dirty = true;
+  }
   const int cap0 = cfg->max_frames > 0 ? cfg->max_frames : 1024;
   { const int rc = reserve(e, cap0); if (rc) return bail(rc); }
   HIPB(hipStreamSynchronize(e->stream));
@@ -806,6 +936,7 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   const int slot_before = e->slot;
   if (raw) CHK(stage_raw(e, X, ldx, y, T, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd));
   else CHK(stage_input(e, X, ldx, y, T, flags, &Xd, &ld, &yd));
+  if (e->bf16) CHK(twin_input(e, &Xd, &ld, T));
   const uint32_t call = e->call_counter++;
   const int nact = e->nact();
   // train mode evaluates every hidden layer when BN is on: the UPDATE_OPS of all batch-norm layers are
@@ -814,7 +945,9 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   CHK(forward(e, Xd, ld, T, train, nact, nfw, call));
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
-    softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train);
+    Twin tw;
+    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
+    softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw);
   }
   {
     ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
@@ -877,6 +1010,7 @@ int tfk_destroy(tfk_engine* e) {
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
+  if (e->Wb) hipFree(e->Wb);
   if (e->h_scalars) hipHostFree(e->h_scalars);
   if (e->h_post) hipHostFree(e->h_post);
   if (e->own_state && e->state) hipFree(e->state);
@@ -927,6 +1061,7 @@ int tfk_tensor_set(tfk_engine* e, int kind, int slot, int layer, const float* ho
   }
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy2D(t.ptr, (size_t)t.ld * 4, host, (size_t)t.cols * 4, (size_t)t.cols * 4, t.rows, hipMemcpyHostToDevice));
+  if (slot == TFK_SLOT_PARAM) e->shadow_dirty = true;
   return 0;
 }
 
@@ -1013,8 +1148,10 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   if (!e->overlap) {  // one launch over the whole parameter arena, in stream order
     {
       ProfScope ps(e, KF_ADAM, 0, 28.0 * e->P);
+      const bool direct = e->bf16 && e->wb_aligned && !e->shadow_dirty;
       adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
-                 e->adam_eps, 0);
+                 e->adam_eps, 0, direct ? e->Wb : nullptr, direct ? e->lay[0].b_off : 0);
+      if (!direct) e->shadow_dirty = true;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventSynchronize(e->ev_loss));
@@ -1025,6 +1162,7 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
     if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
     return 0;
   }
+  e->shadow_dirty = true;  // the side-stream optimiser does not maintain the bf16 shadow
   HIPCHK(hipEventRecord(e->ev_fork, e->stream));
   HIPCHK(hipStreamWaitEvent(sa, e->ev_fork, 0));
   {
@@ -1083,6 +1221,7 @@ int tfk_init_last_layer(tfk_engine* e) {
   CHK(wait_adam_done(e));
   HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
+  e->shadow_dirty = true;
   return 0;
 }
 
@@ -1110,6 +1249,7 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
   const int slot_before = e->slot;
   if (raw) CHK(stage_raw(e, X, ldx, nullptr, N, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd));
   else CHK(stage_input(e, X, ldx, nullptr, N, flags, &Xd, &ld, &yd));
+  if (e->bf16) CHK(twin_input(e, &Xd, &ld, N));
   const int nact = e->nact();
   const uint32_t call = e->call_counter++;
   CHK(forward(e, Xd, ld, N, 0, nact, nact, call));
@@ -1291,6 +1431,17 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int rc = gemm_f32((GemmLayout)layout, g, tile_config, (hipStream_t)stream);
   if (rc != 0) return fail(rc, "gemm_f32 failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                  int M, int N, int K, const float* bias, int epi) {
+  if (layout < 0 || layout > 2) return fail(-1, "bad layout %d", layout);
+  GemmArgsB g = {};
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  const int rc = gemm_bf16((GemmLayout)layout, g, (hipStream_t)stream);
+  if (rc != 0) return fail(rc, "gemm_bf16 failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 

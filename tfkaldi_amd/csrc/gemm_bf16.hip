@@ -1,0 +1,297 @@
+// bf16 MFMA GEMM for gfx950 (CDNA4): v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//
+// Replaces the same reference lines as gemm_f32.hip (neuralNetworks/classifiers/layer.py:52 and its tf.gradients,
+// neuralNetworks/trainer.py:155) when the engine runs in mixed precision.
+//
+// One 64x64 output tile per 256-thread block (4 waves, 32x32 each), K in steps of 64:
+//   * global -> registers -> LDS through buffer resources (out-of-range chunks come back as zeros, no branches);
+//     two LDS stages, the next tile's loads are in flight under the current tile's MFMAs;
+//   * a k-contiguous operand ([ext][k] in memory) is kept as rows of 64 + 8 bf16 (144 B: conflict-free
+//     ds_read_b128) and a lane's MFMA operand -- 8 consecutive k of one row -- is ONE ds_read_b128;
+//   * a k-strided operand ([k][ext] in memory: the weight matrix in the forward GEMM, BOTH operands of the
+//     weight-gradient GEMM) is kept as it lies, rows of 64 + 32 bf16 (192 B), and transposed on the way out of LDS by
+//     ds_read_b64_tr_b16: each 16-lane group reads a [4 k][16 ext] block and every lane receives the 4 k-values of
+//     its own column, two reads per operand.  No transposed copy of weights or activations exists anywhere.
+// At the sizes of this path (1024 rows per GPU) the bf16 contractions are no longer matrix-bound: a step is
+// dominated by the HBM-bound optimiser and the latency-bound elementwise kernels, which is why this kernel is
+// kept simple (no ring, no split accumulators beyond two).
+#include "gemm_bf16.h"
+
+namespace tfk {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 64, NT = 256;
+constexpr int KC_LD = BK + 8;   // elements per LDS row of a k-contiguous operand
+constexpr int MC_LD = 64 + 32;  // elements per LDS row (one k) of a k-strided operand
+constexpr int kOOB = (int)0x80000000;
+constexpr int NUM_XCD = 8;
+
+template <bool KC>
+struct Operand {
+  static constexpr int LD = KC ? KC_LD : MC_LD;
+  static constexpr int SZ = 64 * LD;  // elements per stage (64 rows of ext, or 64 rows of k)
+};
+
+// This thread's two 16-byte chunks of an operand tile.
+template <bool KC>
+struct Loader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[2];  // byte offset inside the matrix without the k-tile term; kOOB if outside along ext
+  int kidx[2];  // first k of the chunk inside a tile
+  int kstride;  // bytes per unit of k
+  int k_lim;
+
+  __device__ __forceinline__ void init(const bf16_t* base, int ld, int rows, int ext0, int ext_lim, int k_lim_,
+                                       int tid) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ld * 2, 0x00020000);
+    k_lim = k_lim_;
+    kstride = KC ? 2 : ld * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + j * NT;
+      const int r = c >> 3, q = (c & 7) << 3;
+      if (KC) {  // memory [ext][k]: row r of ext, k chunk q
+        voff[j] = (ext0 + r < ext_lim) ? ((ext0 + r) * ld + q) * 2 : kOOB;
+        kidx[j] = q;
+      } else {   // memory [k][ext]: k row r, ext chunk q
+        voff[j] = (ext0 + q < ext_lim) ? (r * ld + ext0 + q) * 2 : kOOB;
+        kidx[j] = r;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(u32x4 (&v)[2], int k0) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int off = (k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
+      v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, k0 * kstride, 0);
+    }
+  }
+  __device__ __forceinline__ void store(const u32x4 (&v)[2], bf16_t* s, int tid) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = tid + j * NT;
+      const int r = c >> 3, q = (c & 7) << 3;
+      *reinterpret_cast<u32x4*>(s + r * Operand<KC>::LD + q) = v[j];
+    }
+  }
+};
+
+// MFMA operand of k-step ks for the 32 rows (or columns) starting at ext_base.
+template <bool KC>
+__device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks, int lane) {
+  if (KC) {
+    const int i = lane & 31, kb = lane >> 5;
+    return *reinterpret_cast<const bf16x8*>(s + (ext_base + i) * KC_LD + 16 * ks + 8 * kb);
+  } else {
+    const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
+    const bf16_t* p = s + (16 * ks + 8 * kb + j) * MC_LD + ext_base + 16 * half + 4 * q;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * MC_LD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(NT)
+gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  constexpr int A_SZ = Operand<A_KC>::SZ, B_SZ = Operand<B_KC>::SZ, STAGE = A_SZ + B_SZ;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware order: block b runs on XCD b % 8; each XCD takes a contiguous run of the column-major tile
+  // sequence, so the tiles sharing a B panel (and neighbouring A panels) meet in one L2.
+  int tm, tn;
+  {
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid % NUM_XCD, loc = bid / NUM_XCD;
+    const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
+    const int seq = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    tm = seq % tiles_m;
+    tn = seq / tiles_m;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int K8 = (p.K + 7) & ~7;
+  Loader<A_KC> la;
+  Loader<B_KC> lb;
+  // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
+  // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
+  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid);
+  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  u32x4 ra[2], rb[2];
+  la.load(ra, 0);
+  lb.load(rb, 0);
+  la.store(ra, smem, tid);
+  lb.store(rb, smem + A_SZ, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bf16_t* cur = smem + (kt & 1) * STAGE;
+    bf16_t* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const bool more = kt + 1 < nk;  // block-uniform
+    if (more) {
+      la.load(ra, (kt + 1) * BK);
+      lb.load(rb, (kt + 1) * BK);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const bf16x8 fa = fragment<A_KC>(cur, wm * 32, ks, lane);
+      const bf16x8 fb = fragment<B_KC>(cur + A_SZ, wn * 32, ks, lane);
+      acc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[ks & 1], 0, 0, 0);
+    }
+    if (more) {
+      la.store(ra, nxt, tid);
+      lb.store(rb, nxt + A_SZ, tid);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
+
+  // ---- epilogue: D reg r of lane (i, h) is row (r&3) + 8*(r>>2) + 4*h, column i of the wave's 32x32 tile ----
+  float* red = reinterpret_cast<float*>(smem);  // [2][2 waves along m][BN]; the K loop ended behind a barrier
+  const int col = n0 + wn * 32 + i;
+  const bool col_ok = col < p.N;
+  const int colc = col_ok ? col : p.N - 1;
+  const int rbase = m0 + wm * 32 + 4 * h;
+  const int cidx = wn * 32 + i;
+  const float bv = (EPI & EPI_BIAS) ? p.bias[colc] : 0.f;
+  if constexpr ((EPI & EPI_BIAS) != 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] += bv;
+  }
+  if constexpr ((EPI & EPI_COLSTATS) != 0) {
+    // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
+    const int n_tile = min(BM, p.M - m0);
+    float cmean = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[0][r];
+        if (rbase + (r & 3) + 8 * (r >> 2) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
+      }
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wm * BN + cidx] = s;
+      __syncthreads();
+      const float t = red[cidx] + red[BN + cidx];
+      if (pass == 0) {
+        cmean = t / (float)n_tile;
+      } else if (wm == 0 && h == 0 && col_ok) {
+        p.stats[((size_t)0 * tiles_m + tm) * p.ldc + col] = cmean;
+        p.stats[((size_t)1 * tiles_m + tm) * p.ldc + col] = t;
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr ((EPI & EPI_DACT) != 0) {
+    // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
+    const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
+    float av[16], zv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+      av[r] = p.act_a[(size_t)row * p.ldc + colc];
+      zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float d1;
+      switch (p.act_nonlin) {
+        case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+        case 1: d1 = av[r] * (1.f - av[r]); break;
+        case 2: d1 = 1.f - av[r] * av[r]; break;
+        default: d1 = 1.f;
+      }
+      const float du = acc[0][r] * d1;
+      acc[0][r] = du;
+      if (rbase + (r & 3) + 8 * (r >> 2) < p.M) {
+        s1 += du;
+        s2 += du * (zv[r] - mu) * rsd;
+      }
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (h == 0) {
+      red[(0 * 2 + wm) * BN + cidx] = s1;
+      red[(1 * 2 + wm) * BN + cidx] = s2;
+    }
+    __syncthreads();
+    if (wm == 0 && h == 0 && col_ok) {
+      p.stats[((size_t)0 * p.stats_stride + tm) * p.ldc + col] = red[(0 * 2 + 0) * BN + cidx] + red[(0 * 2 + 1) * BN + cidx];
+      p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = red[(1 * 2 + 0) * BN + cidx] + red[(1 * 2 + 1) * BN + cidx];
+    }
+  }
+  float old[16];
+  if constexpr ((EPI & EPI_ACCUM) != 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+      old[r] = p.C[(size_t)row * p.ldc + colc];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    float v = acc[0][r];
+    if (EPI & EPI_ACCUM) v += old[r];
+    if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = v;
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+int launch(const GemmArgsB& p, hipStream_t stream) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (Operand<A_KC>::SZ + Operand<B_KC>::SZ) * sizeof(bf16_t);
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p, tiles_m,
+                     tiles_n);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int gemm_bf16(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
+  if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 3)) return (int)hipErrorInvalidValue;
+  switch (layout) {
+    case GEMM_NN:
+      switch (p.epi) {
+        case 0: return launch<true, false, 0>(p, stream);
+        case EPI_BIAS: return launch<true, false, EPI_BIAS>(p, stream);
+        case EPI_BIAS | EPI_COLSTATS: return launch<true, false, EPI_BIAS | EPI_COLSTATS>(p, stream);
+      }
+      break;
+    case GEMM_NT:
+      if (p.epi == 0) return launch<true, true, 0>(p, stream);
+      if (p.epi == EPI_DACT) return launch<true, true, EPI_DACT>(p, stream);
+      break;
+    case GEMM_TN:
+      if (p.epi == 0) return launch<false, false, 0>(p, stream);
+      if (p.epi == EPI_ACCUM) return launch<false, false, EPI_ACCUM>(p, stream);
+      break;
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+}  // namespace tfk

@@ -21,6 +21,13 @@ struct ActDesc {
 
 constexpr int kMaxRowSplits = 64;
 
+// Mixed-precision mode: kernels that produce a GEMM operand also store its bf16 twin (p == nullptr: fp32 mode).
+// ld in bf16 elements, a multiple of 8; padding columns of the twin stay zero from its allocation.
+struct Twin {
+  uint16_t* p = nullptr;
+  int ld = 0;
+};
+
 // ---- batch norm statistics ----
 // train: per-column mean / biased variance of z[T,H] (two-level, Chan-merged), rstd = rsqrt(var+eps);
 // the moving-average increments follow E <- decay*E + (1-decay)*stat.  ws: >= 2*kMaxRowSplits*ld floats.
@@ -37,11 +44,11 @@ void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, i
 // a = dropout(nonlin((z - mean) * rstd + beta)).
 void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, const float* stats, int chunk_rows,
                     int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
-                    float* e_var, const float* beta);
+                    float* e_var, const float* beta, Twin tw = Twin());
 
 // ---- activation chain forward: z -> a (v: post-nonlin copy, rowscale: L2 mean-square; both only if l2) ----
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
-                 const float* mean, const float* rstd, const float* beta, int T, int H, int ld);
+                 const float* mean, const float* rstd, const float* beta, int T, int H, int ld, Twin tw = Twin());
 
 // ---- activation chain backward ----
 // L2 chains only: da -> du (gradient w.r.t. the BN output) in place, row-wise.
@@ -54,7 +61,8 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 // `pre_du` != 0: da already holds du (after act_backward_rows, or from the dA GEMM's EPI_DACT epilogue).
 // `stats_chunks` > 0: slabs 0 / 1 already hold that many chunks (EPI_DACT): the statistics pass is skipped.
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks = 0);
+                     const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks = 0,
+                     Twin tw = Twin());
 // per-chunk partial column sums of x[T, ld] into slab 0 of ws (bias gradient of the output layer)
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws);
 int row_splits(int T);  // chunks the column-tiled kernels cut T rows into
@@ -76,7 +84,7 @@ void grad_final(hipStream_t s, const FinalBatch& b);
 // ---- softmax cross-entropy (trainer.py:526-531): row_loss[t] = logsumexp(z_t) - z_t[y_t];
 // with_grad: logits <- softmax(z) - onehot(y) in place (sum-reduced loss => no 1/T factor).
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
-                  int with_grad);
+                  int with_grad, Twin tw = Twin());
 // scalars[0] += sum(row_loss), scalars[1] += T, scalars[2] += 1
 // overwrite: the accumulators were logically re-initialised since the last call (no memset needed)
 void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite);
@@ -87,7 +95,10 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 // ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam (G is left as is) ----
 // grid_cap > 0 limits the number of blocks (grid-stride loop does the rest)
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap);
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0);
+// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update
+// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns
+void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols);
 // end of a step in one launch: moving <- decay^{num_microbatches} * moving + E, E <- 0, and
 // host[0..3] <- scalars[0..3] (host = device address of mapped pinned memory)
 void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host);

@@ -95,6 +95,15 @@ __device__ __forceinline__ float nonlin_bwd(float v, int nonlin) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// bf16 twin of a GEMM operand (mixed-precision mode): the same 4 values, round-to-nearest-even, 8 bytes
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ __forceinline__ void st4_twin(const Twin& t, size_t row, int col, float4 v) {
+  if (!t.p) return;
+  u16x4 q;
+  q.x = to_bf16(v.x); q.y = to_bf16(v.y); q.z = to_bf16(v.z); q.w = to_bf16(v.w);
+  *reinterpret_cast<u16x4*>(t.p + row * t.ld + col) = q;
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float& el(float4& v, int i) { return reinterpret_cast<float*>(&v)[i]; }
 __device__ __forceinline__ float el(const float4& v, int i) { return reinterpret_cast<const float*>(&v)[i]; }
@@ -257,7 +266,7 @@ template <bool L2>
 __global__ void __launch_bounds__(256)
 act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a, float* __restrict__ vbuf,
                    float* __restrict__ rowscale, const float* __restrict__ mean, const float* __restrict__ rstd,
-                   const float* __restrict__ beta, int T, int H, int ld) {
+                   const float* __restrict__ beta, int T, int H, int ld, Twin tw) {
   __shared__ float sm[4];
   const int nc4 = ld >> 2;
   const bool drop = d.train && d.keep < 1.f;
@@ -287,6 +296,7 @@ act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a
           for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
         }
         st4(ar + col, v);
+        st4_twin(tw, row, col, v);
       }
     }
     if (L2) {
@@ -303,6 +313,7 @@ act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a
           for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
         }
         st4(ar + col, v);
+        st4_twin(tw, row, col, v);
       }
     }
   }
@@ -313,7 +324,7 @@ __global__ void __launch_bounds__(CT_X * CT_Y)
 bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a, const float* __restrict__ st,
                       int nchunk, int chunk_rows, int T, int H, int ld, int rows_per, float eps, float decay,
                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ e_mean,
-                      float* __restrict__ e_var, const float* __restrict__ beta) {
+                      float* __restrict__ e_var, const float* __restrict__ beta, Twin tw) {
   __shared__ float4 sm[CT_Y][CT_X];
   __shared__ float4 smm[CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
@@ -431,6 +442,7 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
         for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
       }
       st4(a + (size_t)r * ld + t.col, v);
+      st4_twin(tw, r, t.col, v);
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) zv[j] = zn[j];
@@ -548,7 +560,7 @@ hb_stats_kernel(ActDesc d, int pre_du, const float* __restrict__ da, const float
 __global__ void __launch_bounds__(CT_X * CT_Y)
 hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __restrict__ a,
                 const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd, int T,
-                int H, int ld, int rows_per, int rs_in, float* __restrict__ ws) {
+                int H, int ld, int rows_per, int rs_in, float* __restrict__ ws, Twin tw) {
   __shared__ float4 sm[CT_Y][CT_X];
   const ColTile t = col_tile(T, ld, rows_per);
   float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -622,6 +634,7 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
         for (int k = 0; k < 4; ++k)
           if (t.col + k >= H) el(dz, k) = 0.f;
         st4(da + (size_t)r * ld + t.col, dz);
+        st4_twin(tw, r, t.col, dz);
         sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
       }
 #pragma unroll
@@ -674,7 +687,7 @@ colsum_partial_kernel(const float* __restrict__ x, int T, int ld, int rows_per, 
 template <int NV>  // float4 per thread; NV == 0: generic (re-reads global)
 __global__ void __launch_bounds__(256)
 softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, int O, int ld,
-                    float* __restrict__ row_loss, int with_grad) {
+                    float* __restrict__ row_loss, int with_grad, Twin tw) {
   __shared__ float sm[4];
   const int row = blockIdx.x;
   float* zr = logits + (size_t)row * ld;
@@ -732,10 +745,15 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
           el(g, k) = c < O ? el(v[j], k) * inv - (c == label ? 1.f : 0.f) : 0.f;
         }
         st4(zr + (c4 << 2), g);
+        st4_twin(tw, row, c4 << 2, g);
       }
     }
   } else {
-    for (int c = threadIdx.x; c < O; c += 256) zr[c] = expf(zr[c] - mx) * inv - (c == label ? 1.f : 0.f);
+    for (int c = threadIdx.x; c < O; c += 256) {
+      const float g = expf(zr[c] - mx) * inv - (c == label ? 1.f : 0.f);
+      zr[c] = g;
+      if (tw.p) tw.p[(size_t)row * tw.ld + c] = to_bf16(g);
+    }
   }
 }
 
@@ -799,7 +817,8 @@ __device__ __forceinline__ void st4s(float* p, float4 v) {
 template <bool NT>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
-            const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps) {
+            const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps, uint16_t* __restrict__ wb,
+            size_t n4_wb) {
   const float inv_n = 1.f / scalars[1];  // G / float(num_frames): trainer.py:174-175
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -816,6 +835,11 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
     st4s<NT>(m + 4 * i, mv);
     st4s<NT>(v + 4 * i, vv);
     st4(w + 4 * i, wv);
+    if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices (same element offsets as the fp32 arena)
+      u16x4 q;
+      q.x = to_bf16(wv.x); q.y = to_bf16(wv.y); q.z = to_bf16(wv.z); q.w = to_bf16(wv.w);
+      *reinterpret_cast<u16x4*>(wb + 4 * i) = q;
+    }
     // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
   }
 }
@@ -834,6 +858,22 @@ __global__ void step_finish_kernel(float* __restrict__ mov, float* __restrict__ 
     host[i] = scalars[i];
     __threadfence_system();
   }
+}
+// fp32 [rows, lds] -> bf16 [rows, ldd] (ldd multiple of 8): one thread per 8-column chunk, padding columns zero
+__global__ void __launch_bounds__(256)
+to_bf16_rows_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict__ dst, int ldd, int rows, int cols) {
+  const int nc8 = ldd >> 3;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)rows * nc8) return;
+  const int r = (int)(idx / nc8), c = (int)(idx % nc8) << 3;
+  uint16_t o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (c + k < cols) ? to_bf16(src[(size_t)r * lds + c + k]) : (uint16_t)0;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 q;
+  q.x = o[0] | ((uint32_t)o[1] << 16); q.y = o[2] | ((uint32_t)o[3] << 16);
+  q.z = o[4] | ((uint32_t)o[5] << 16); q.w = o[6] | ((uint32_t)o[7] << 16);
+  *reinterpret_cast<u32x4*>(dst + (size_t)r * ldd + c) = q;
 }
 __global__ void scale_kernel(float* __restrict__ x, size_t n, float f) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -917,22 +957,22 @@ void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, i
 
 void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, const float* stats, int chunk_rows,
                     int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
-                    float* e_var, const float* beta) {
+                    float* e_var, const float* beta, Twin tw) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   const int nchunk = (T + chunk_rows - 1) / chunk_rows;
   hipLaunchKernelGGL(bn_act_forward_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, z, a, stats, nchunk, chunk_rows, T, H,
-                     ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta);
+                     ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta, tw);
 }
 
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
-                 const float* mean, const float* rstd, const float* beta, int T, int H, int ld) {
+                 const float* mean, const float* rstd, const float* beta, int T, int H, int ld, Twin tw) {
   const int grid = T < 4096 ? T : 4096;
   if (d.l2)
     hipLaunchKernelGGL(act_forward_kernel<true>, dim3(grid), dim3(256), 0, s, d, z, a, v, rowscale, mean, rstd, beta,
-                       T, H, ld);
+                       T, H, ld, tw);
   else
     hipLaunchKernelGGL(act_forward_kernel<false>, dim3(grid), dim3(256), 0, s, d, z, a, v, rowscale, mean, rstd, beta,
-                       T, H, ld);
+                       T, H, ld, tw);
 }
 
 void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* v, const float* rowscale, int T,
@@ -942,13 +982,14 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 }
 
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
-                     const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks) {
+                     const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks,
+                     Twin tw) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
   if (d.bn && stats_chunks <= 0)
     hipLaunchKernelGGL(hb_stats_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, ld,
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
-                     rows_per, stats_chunks > 0 ? stats_chunks : rs, ws);
+                     rows_per, stats_chunks > 0 ? stats_chunks : rs, ws, tw);
 }
 
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws) {
@@ -964,14 +1005,14 @@ void grad_final(hipStream_t s, const FinalBatch& b) {
 }
 
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
-                  int with_grad) {
+                  int with_grad, Twin tw) {
   const int nc4 = ld / 4;
   const dim3 g(T), b(256);
-  if (nc4 <= 256) hipLaunchKernelGGL(softmax_xent_kernel<1>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
-  else if (nc4 <= 512) hipLaunchKernelGGL(softmax_xent_kernel<2>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
-  else if (nc4 <= 1024) hipLaunchKernelGGL(softmax_xent_kernel<4>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
-  else if (nc4 <= 2048) hipLaunchKernelGGL(softmax_xent_kernel<8>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
-  else hipLaunchKernelGGL(softmax_xent_kernel<0>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad);
+  if (nc4 <= 256) hipLaunchKernelGGL(softmax_xent_kernel<1>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw);
+  else if (nc4 <= 512) hipLaunchKernelGGL(softmax_xent_kernel<2>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw);
+  else if (nc4 <= 1024) hipLaunchKernelGGL(softmax_xent_kernel<4>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw);
+  else if (nc4 <= 2048) hipLaunchKernelGGL(softmax_xent_kernel<8>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw);
+  else hipLaunchKernelGGL(softmax_xent_kernel<0>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw);
 }
 
 void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite) {
@@ -984,7 +1025,7 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 }
 
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap) {
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb) {
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -994,15 +1035,21 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
   static const bool nt = [] { const char* q = getenv("TFK_ADAM_NT"); return !q || atoi(q) != 0; }();
   if (nt)
     hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1,
-                       beta2, eps);
+                       beta2, eps, wb, n_wb / 4);
   else
     hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1,
-                       beta2, eps);
+                       beta2, eps, wb, n_wb / 4);
 }
 
 void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host) {
   const size_t blocks = n ? (n + 255) / 256 : 1;
   hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host);
+}
+void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols) {
+  const size_t n = (size_t)rows * (ldd / 8);
+  if (n == 0) return;
+  hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds, dst, ldd, rows,
+                     cols);
 }
 void scale_inplace(hipStream_t s, float* x, size_t n, float factor) {
   if (n == 0) return;

@@ -41,12 +41,16 @@ class ControlOp(object):
 class DNN(Classifier):
     """feed-forward fully connected network"""
 
-    def __init__(self, output_dim, num_layers, num_units, activation, layerwise_init=True):
+    def __init__(self, output_dim, num_layers, num_units, activation, layerwise_init=True,
+                 compute_dtype="float32"):
+        """(reference dnn.py:17-35) + compute_dtype: "float32" = the reference's arithmetic, "bfloat16" = mixed
+        precision (bf16 MFMA contractions, everything else fp32; BASELINE cfg3 / cfg4)"""
         super(DNN, self).__init__(output_dim)
         self.num_layers = num_layers
         self.num_units = num_units
         self.activation = activation
         self.layerwise_init = layerwise_init
+        self.compute_dtype = compute_dtype
         self._scopes = {}
 
     # ---- structure ----
@@ -63,7 +67,7 @@ class DNN(Classifier):
         return _lib.make_config(input_dim, self.num_layers, self.num_units, self.output_dim,
                                 layerwise_init=self.layerwise_init, init_learning_rate=init_learning_rate,
                                 learning_rate_decay=learning_rate_decay, num_steps=num_steps, max_frames=max_frames,
-                                seed=seed, device=device, **opts)
+                                seed=seed, device=device, compute_dtype=self.compute_dtype, **opts)
 
     def create_engine(self, input_dim, torch_state=False, **options):
         return Engine(self.engine_config(input_dim, **options), torch_state=torch_state)

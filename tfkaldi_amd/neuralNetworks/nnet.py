@@ -45,8 +45,10 @@ class Nnet(object):
         if float(self.conf['dropout']) < 1:
             activation = act.Dropout(activation, float(self.conf['dropout']))
 
+        # optional [nnet] key compute_dtype = float32 (default, the reference's arithmetic) | bfloat16
         self.dnn = DNN(num_labels, int(self.conf['num_hidden_layers']), int(self.conf['num_hidden_units']),
-                       activation, int(self.conf['add_layer_period']) > 0)
+                       activation, int(self.conf['add_layer_period']) > 0,
+                       compute_dtype=self.conf.get('compute_dtype', 'float32'))
 
     def _say(self, text):
         if self.rank == 0:

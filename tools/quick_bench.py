@@ -14,7 +14,9 @@ from tfkaldi_amd.engine import Engine  # noqa: E402
 
 def main():
     T, F, L, H, O = 1024, 440, 6, 2048, 2000
-    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, max_frames=T, num_steps=1000)
+    dtype = os.environ.get("TFK_QB_DTYPE", "float32")  # bfloat16: mixed-precision mode
+    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, max_frames=T, num_steps=1000,
+                           compute_dtype=dtype)
     eng = Engine(cfg)
     rng = np.random.default_rng(7)
     eng.init_hidden_weights(rng)
