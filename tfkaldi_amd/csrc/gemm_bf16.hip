@@ -5,17 +5,18 @@
 //
 // One 64x64 output tile per 256-thread block (4 waves, 32x32 each), K in steps of 64:
 //   * global -> registers -> LDS through buffer resources (out-of-range chunks come back as zeros, no branches);
-//     two LDS stages, the next tile's loads are in flight under the current tile's MFMAs;
+//     three LDS stages fed from a register ring that keeps PF tiles of loads in flight;
 //   * a k-contiguous operand ([ext][k] in memory) is kept as rows of 64 + 8 bf16 (144 B: conflict-free
 //     ds_read_b128) and a lane's MFMA operand -- 8 consecutive k of one row -- is ONE ds_read_b128;
 //   * a k-strided operand ([k][ext] in memory: the weight matrix in the forward GEMM, BOTH operands of the
 //     weight-gradient GEMM) is kept as it lies, rows of 64 + 32 bf16 (192 B), and transposed on the way out of LDS by
 //     ds_read_b64_tr_b16: each 16-lane group reads a [4 k][16 ext] block and every lane receives the 4 k-values of
 //     its own column, two reads per operand.  No transposed copy of weights or activations exists anywhere.
-// At the sizes of this path (1024 rows per GPU) the bf16 contractions are no longer matrix-bound: a step is
-// dominated by the HBM-bound optimiser and the latency-bound elementwise kernels, which is why this kernel is
-// kept simple (no ring, no split accumulators beyond two).
+// At the sizes of this path (1024 rows per GPU) the bf16 contractions are not matrix-bound (8.6 GFLOP = 3.4 us at
+// peak against ~20 MB of operands and a launch): what matters is load latency, hence the deep register ring.
 #include "gemm_bf16.h"
+
+#include <stdlib.h>
 
 namespace tfk {
 namespace {
@@ -97,7 +98,14 @@ __device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI>
+// TFK_ABLB (tools/gemm_bf16_ablate.hip only): timing-only variants with pieces of the K loop removed --
+// 1 global loads, 2 LDS writes, 4 fragment reads, 8 barrier.  Results are wrong by construction.
+#ifndef TFK_ABLB
+#define TFK_ABLB 0
+#endif
+
+// PF: tiles of global loads in flight per block (even)
+template <bool A_KC, bool B_KC, int EPI, int PF>
 __global__ void __launch_bounds__(NT)
 gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -137,32 +145,67 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
+  // Pipeline (one barrier per K step, nothing on the critical path but the MFMAs):
+  //   registers: a ring of PF tiles of global loads in flight (a K step computes for ~130 cycles per wave, a load
+  //              takes over a thousand);
+  //   LDS:       three stages -- while tile t is multiplied, tile t+1 (made visible by the previous barrier) is
+  //              read into the second fragment set and tile t+2 is written;
+  //   fragments: all four k-steps of a tile in registers, double-buffered.
   const int nk = (p.K + BK - 1) / BK;
-  u32x4 ra[2], rb[2];
-  la.load(ra, 0);
-  lb.load(rb, 0);
-  la.store(ra, smem, tid);
-  lb.store(rb, smem + A_SZ, tid);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bf16_t* cur = smem + (kt & 1) * STAGE;
-    bf16_t* nxt = smem + ((kt + 1) & 1) * STAGE;
-    const bool more = kt + 1 < nk;  // block-uniform
-    if (more) {
-      la.load(ra, (kt + 1) * BK);
-      lb.load(rb, (kt + 1) * BK);
-    }
+  u32x4 ra[PF][2], rb[PF][2];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const bf16x8 fa = fragment<A_KC>(cur, wm * 32, ks, lane);
-      const bf16x8 fb = fragment<B_KC>(cur + A_SZ, wn * 32, ks, lane);
-      acc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[ks & 1], 0, 0, 0);
+  for (int j = 0; j < PF; ++j) {
+    la.load(ra[j], j * BK);  // tiles beyond K come back as zeros without touching memory
+    lb.load(rb[j], j * BK);
+  }
+  bf16_t* st0 = smem;              // stage of tile t
+  bf16_t* st1 = smem + STAGE;      // tile t + 1
+  bf16_t* st2 = smem + 2 * STAGE;  // tile t + 2
+  la.store(ra[0], st0, tid);
+  lb.store(rb[0], st0 + A_SZ, tid);
+  la.store(ra[1], st1, tid);
+  lb.store(rb[1], st1 + A_SZ, tid);
+  la.load(ra[0], PF * BK);
+  lb.load(rb[0], PF * BK);
+  la.load(ra[1], (PF + 1) * BK);
+  lb.load(rb[1], (PF + 1) * BK);
+  __syncthreads();
+  bf16x8 fa[2][BK / 16], fb[2][BK / 16];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    fa[0][ks] = fragment<A_KC>(st0, wm * 32, ks, lane);
+    fb[0][ks] = fragment<B_KC>(st0 + A_SZ, wn * 32, ks, lane);
+  }
+#pragma unroll 1
+  for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      // No guard on kt < nk: the trip count is rounded up to a multiple of PF and the surplus steps multiply zero
+      // tiles.  A guard would make the compiler assume that earlier steps of the unrolled body may not have issued
+      // their loads, and it then waits for (nearly) ALL outstanding loads before each LDS write.
+      const int kt = kt0 + j;
+      const int s2 = (j + 2) % PF;  // register set holding tile kt + 2
+      if (!(TFK_ABLB & 2)) {
+        la.store(ra[s2], st2, tid);
+        lb.store(rb[s2], st2 + A_SZ, tid);
+      }
+      if (!(TFK_ABLB & 1)) {
+        la.load(ra[s2], (kt + 2 + PF) * BK);
+        lb.load(rb[s2], (kt + 2 + PF) * BK);
+      }
+      if (!(TFK_ABLB & 4)) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          fa[(j + 1) & 1][ks] = fragment<A_KC>(st1, wm * 32, ks, lane);
+          fb[(j + 1) & 1][ks] = fragment<B_KC>(st1 + A_SZ, wn * 32, ks, lane);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks)
+        acc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j & 1][ks], fb[j & 1][ks], acc[ks & 1], 0, 0, 0);
+      if (!(TFK_ABLB & 8)) __syncthreads();
+      bf16_t* t = st0; st0 = st1; st1 = st2; st2 = t;
     }
-    if (more) {
-      la.store(ra, nxt, tid);
-      lb.store(rb, nxt + A_SZ, tid);
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
@@ -263,9 +306,14 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgsB& p, hipStream_t stream) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)2 * (Operand<A_KC>::SZ + Operand<B_KC>::SZ) * sizeof(bf16_t);
-  hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p, tiles_m,
-                     tiles_n);
+  const size_t lds = (size_t)3 * (Operand<A_KC>::SZ + Operand<B_KC>::SZ) * sizeof(bf16_t);
+  static const int pf = [] { const char* q = getenv("TFK_BF16_PF"); return q ? atoi(q) : 4; }();
+  if (pf == 4)
+    hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, 4>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
+                       tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, 8>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
+                       tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 

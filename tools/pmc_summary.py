@@ -5,7 +5,7 @@ agg = collections.defaultdict(list)
 dur = []
 for f in glob.glob("gpurun_out/pmc_%s/p*/*/*_counter_collection.csv" % tag):
     for r in csv.DictReader(open(f)):
-        if "gemm_f32_kernel" in r["Kernel_Name"]:
+        if "gemm_f32_kernel" in r["Kernel_Name"] or "gemm_bf16_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("kernel duration under PMC: mean %.1f us" % (sum(dur) / max(len(dur), 1)))
