@@ -28,6 +28,7 @@ T = UTT_PER_GPU * UTT_LEN
 M_MACS = F * H + (L - 1) * H * H + H * O
 FLOP_PER_FRAME = 6 * M_MACS - 2 * F * H  # fwd 2M, dW 2M, dA 2M minus the unneeded layer-0 dA
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # v_mfma_f32_32x32x16_bf16, dense (--dtype bfloat16 only)
 
 
 def make_batch(rank, world, workdir):
@@ -70,6 +71,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["float32", "bfloat16"], default="float32",
+                    help="float32 (default) is BASELINE cfg2's arithmetic and the only valid headline; bfloat16 runs "
+                         "the same workload in the engine's mixed-precision mode (cfg3/cfg4 arithmetic) for reference")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: libraries that chat on stdout (RCCL prints its library
@@ -94,7 +98,8 @@ def main():
     assert X.shape == (T, F) and X.dtype == np.float32 and y.shape == (T,)
 
     cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, init_learning_rate=1e-3,
-                           num_steps=args.steps + args.warmup, max_frames=T, device=local_rank)
+                           num_steps=args.steps + args.warmup, max_frames=T, device=local_rank,
+                           compute_dtype=args.dtype)
     eng = Engine(cfg, torch_state=dp.enabled)
     rng = np.random.default_rng(7)
     hidden = [(rng.standard_normal((F if l == 0 else H, H)) / np.sqrt(F if l == 0 else H)).astype(np.float32)
@@ -161,9 +166,10 @@ def main():
         achieved = dom["flops"] / dom["total_ms"] / 1e9  # TFLOP/s
         all_gemm_tf = sum(s["flops"] for s in gemms) / sum(s["total_ms"] for s in gemms) / 1e9
         value = world * T * args.steps / elapsed
+        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "float32" else PEAK_BF16_MFMA_TFLOPS
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tfile):  # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
+        if os.path.exists(tfile) and args.dtype == "float32":  # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
             rec = json.load(open(tfile)).get(dom["name"])
             if rec:
                 traffic = rec["bytes_per_launch"]
@@ -173,14 +179,16 @@ def main():
             "metric": "acoustic frames/sec (train step)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_with_event_profiling": 1e3 * elapsed_profiled / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "float32" else "bf16 operands, f32 accumulate / master / optimiser",
             "data": "synthetic ark/scp/alignment files (SURVEY 8d) read through the feature reader + dispenser; "
                     "random-init weights N(0,1/sqrt(d_in)), zero output layer",
             "config": {"workload": "cfg2: 6x2048 ReLU+BN DNN, 440-in (40 fbank +-5), 2000 pdf, %d frames/GPU/step, "
-                                   "fp32 MFMA, Adam" % T, "frames_per_gpu": T, "global_frames": world * T,
+                                   "%s, Adam" % (T, "fp32 MFMA" if args.dtype == "float32" else "bf16 MFMA (mixed precision)"),
+                       "frames_per_gpu": T, "global_frames": world * T,
                        "parallelism": "dp%d" % world, "flop_per_frame": FLOP_PER_FRAME},
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                          "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
