@@ -112,3 +112,28 @@ def test_large_and_growing_micro_batches(gpu):
             assert_close("T=%d G[%s]" % (T, k), got[k], want, rtol=5e-4, atol=5e-5 * max(np.abs(want).max(), 1e-3))
         assert_close("loss T=%d" % T, eng.apply(), oracle.apply(), 5e-5, 0)
     eng.close()
+
+
+def test_cfg3_per_gpu_size_bf16_against_oracle(gpu):
+    """BASELINE configs[2] as one rank sees it: 6x2048 + BN, 440 -> 4000 pdfs, 1024 frames, bf16 MFMA contractions.
+    Checked against the oracle that rounds every matmul operand to bfloat16 (tanh: no ReLU-kink sign flips)."""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(23)
+    kw = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=4000, nonlin="tanh", batch_norm=True,
+              init_learning_rate=1e-3, num_steps=100, max_frames=1024, compute_dtype="bfloat16")
+    eng, oracle = make_pair(rng, **kw)
+    T = 1024
+    X, y = batch(rng, T, 440, 4000)
+    eng.accumulate(X, y)
+    oracle.accumulate(X, y)
+    np.testing.assert_allclose(eng.scalar(_lib.BATCH_LOSS), oracle.batch_loss, rtol=5e-4)
+    rel = lambda got, want: float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    for l in (0, 5):
+        assert rel(eng.debug_fetch(_lib.DBG_HIDDEN, l, T), oracle.last_cache[l]["a"]) < 2e-3, l
+    got = engine_grads(eng)
+    # operands within fp32 round-off of a bf16 rounding boundary round to different neighbours on the two sides
+    # (one bf16 ulp = 0.4 % of that operand); the handful of such flips per GEMM compounds through the six layers
+    for k in ("W6", "b6", "W5", "beta5", "W3", "beta2", "W0", "beta0"):
+        assert rel(got[k], oracle.G[k]) < (5e-3 if k in ("W6", "b6") else 2e-2), (k, rel(got[k], oracle.G[k]))
+    np.testing.assert_allclose(eng.apply(), oracle.apply(), rtol=5e-4)
+    eng.close()
