@@ -1,6 +1,11 @@
-"""Kaldi-style neural network with the reference's interface (neuralNetworks/nnet.py): configuration ->
-DNN, the training loop with validation / learning-rate halving / rollback / layer-wise growth /
-checkpoints, and the decoding loop that writes pseudo-log-likelihoods for Kaldi."""
+"""Kaldi-style neural network with the reference's interface (neuralNetworks/nnet.py): `[nnet]` configuration
+-> DNN; `train` = the optimisation schedule (held-out validation, learning-rate halving with rollback, layer-wise
+growth, periodic checkpoints, state prior); `decode` = pseudo-log-likelihoods for Kaldi.
+
+The reference keeps the whole schedule in one method around a tf.Session (nnet.py:80-244); here the engine
+lifetime belongs to the Trainer / Decoder objects and the schedule is a small state object (`_Schedule`), one method
+per decision the reference takes.  Printed lines and file names are the reference's.
+"""
 import itertools
 import os
 import shutil
@@ -13,208 +18,198 @@ from .classifiers.dnn import DNN
 from .decoder import Decoder
 from .trainer import CrossEnthropyTrainer
 
+_NONLINEARITIES = ('relu', 'sigmoid', 'tanh', 'linear')  # nnet.py:48-62
+
+
+def _activation_chain(conf):
+    """Batchnorm -> nonlinearity -> L2Norm -> Dropout, each present only if configured; the flags are compared as
+    the strings the config file holds (reference nnet.py:42-72)"""
+    chain = act.Batchnorm(None) if conf['batch_norm'] == 'True' else None
+    if conf['nonlin'] not in _NONLINEARITIES:
+        raise Exception('unkown nonlinearity')
+    chain = act.TfActivation(chain, conf['nonlin'])
+    if conf['l2_norm'] == 'True':
+        chain = act.L2Norm(chain)
+    keep = float(conf['dropout'])
+    return act.Dropout(chain, keep) if keep < 1 else chain
+
 
 class Nnet(object):
     """a class for a neural network that can be used together with Kaldi"""
 
     def __init__(self, conf, input_dim, num_labels):
-        """
-        Args:
-            conf: nnet configuration (a ConfigParser holding the [nnet] and [directories] sections,
-                config/config_AURORA4.cfg:102-153)
-            input_dim: network input dimension (unspliced features)
-            num_labels: number of target labels
-        """
+        """conf: ConfigParser with the [nnet] and [directories] sections (config/config_AURORA4.cfg:102-153);
+        input_dim: dimension of the UNSPLICED features; num_labels: number of pdf-ids"""
         self.conf = dict(conf.items('nnet'))
-        self.conf['savedir'] = conf.get('directories', 'expdir') + '/' + self.conf['name']
+        self.conf['savedir'] = '/'.join((conf.get('directories', 'expdir'), self.conf['name']))
         self.rank, self.world, _ = init_from_env()
-        for d in (self.conf['savedir'], self.conf['savedir'] + '/training'):
-            os.makedirs(d, exist_ok=True)
-
-        # the input dimension of the spliced features (reference nnet.py:39)
-        self.input_dim = input_dim * (2 * int(self.conf['context_width']) + 1)
-
-        # activation chain, built exactly as reference nnet.py:42-72 (string compares included)
-        activation = act.Batchnorm(None) if self.conf['batch_norm'] == 'True' else None
-        if self.conf['nonlin'] in ('relu', 'sigmoid', 'tanh', 'linear'):
-            activation = act.TfActivation(activation, self.conf['nonlin'])
-        else:
-            raise Exception('unkown nonlinearity')
-        if self.conf['l2_norm'] == 'True':
-            activation = act.L2Norm(activation)
-        if float(self.conf['dropout']) < 1:
-            activation = act.Dropout(activation, float(self.conf['dropout']))
-
-        # optional [nnet] key compute_dtype = float32 (default, the reference's arithmetic) | bfloat16
+        os.makedirs(os.path.join(self.conf['savedir'], 'training'), exist_ok=True)
+        self.input_dim = (1 + 2 * int(self.conf['context_width'])) * input_dim  # after the +-context splice
+        grows = int(self.conf['add_layer_period']) > 0
+        # optional key compute_dtype = float32 (default, the reference's arithmetic) | bfloat16 (mixed precision)
         self.dnn = DNN(num_labels, int(self.conf['num_hidden_layers']), int(self.conf['num_hidden_units']),
-                       activation, int(self.conf['add_layer_period']) > 0,
-                       compute_dtype=self.conf.get('compute_dtype', 'float32'))
+                       _activation_chain(self.conf), grows, compute_dtype=self.conf.get('compute_dtype', 'float32'))
 
+    # ---- helpers shared with the schedule ----
     def _say(self, text):
         if self.rank == 0:
             print(text)
-
-    def train(self, dispenser):
-        """
-        Train the neural network (control flow of reference nnet.py:80-244)
-
-        Args:
-            dispenser: a batchdispenser for training
-        """
-        conf = self.conf
-        savedir = conf['savedir']
-        # the validation set is read first and split off
-        val_batches = [dispenser.get_batch() for _ in range(int(conf['valid_batches']))]
-        if val_batches:
-            val_data, val_labels = zip(*val_batches)
-            val_data = list(itertools.chain.from_iterable(val_data))
-            val_labels = list(itertools.chain.from_iterable(val_labels))
-        else:
-            val_data = val_labels = None
-        dispenser.split()
-
-        num_steps = int(dispenser.num_batches * int(conf['num_epochs']))
-
-        # the saving point closest to the starting step, and the matching position in the data
-        step = int(conf['starting_step']) - int(conf['starting_step']) % int(conf['check_freq'])
-        for _ in range(step):
-            dispenser.skip_batch()
-
-        if conf['numutterances_per_minibatch'] == '-1':
-            numutterances_per_minibatch = dispenser.size
-        else:
-            numutterances_per_minibatch = int(conf['numutterances_per_minibatch'])
-
-        trainer = CrossEnthropyTrainer(
-            self.dnn, self.input_dim, dispenser.max_input_length, dispenser.max_target_length,
-            float(conf['initial_learning_rate']), float(conf['learning_rate_decay']), num_steps,
-            numutterances_per_minibatch)
-
-        if conf['visualise'] == 'True' and self.rank == 0:
-            if os.path.isdir(savedir + '/logdir'):
-                shutil.rmtree(savedir + '/logdir')
-            trainer.start_visualization(savedir + '/logdir')
-
-        def save_trainer(name):  # every rank holds the same state: rank 0 writes, all wait
-            if self.rank == 0:
-                trainer.save_trainer(savedir + '/training/' + name)
-            self._barrier()
-
-        try:
-            trainer.initialize()
-            if step > 0:
-                trainer.restore_trainer(savedir + '/training/step' + str(step))
-
-            if val_data is not None:
-                validation_loss = trainer.evaluate(val_data, val_labels)
-                self._say('validation loss at step %d: %f' % (step, validation_loss))
-                validation_step = step
-                save_trainer('validated')
-                num_retries = 0
-
-            while step < num_steps:
-                batch_data, batch_labels = dispenser.get_batch()
-                loss = trainer.update(batch_data, batch_labels)
-                self._say('step %d/%d loss: %f' % (step, num_steps, loss))
-                step += 1
-
-                if step % int(conf['valid_frequency']) == 0 and val_data is not None:
-                    current_loss = trainer.evaluate(val_data, val_labels)
-                    self._say('validation loss at step %d: %f' % (step, current_loss))
-
-                    if conf['valid_adapt'] == 'True':
-                        if current_loss > validation_loss:
-                            # worse: rewind the data, reload the validated model, halve the learning rate
-                            for _ in range(step - validation_step):
-                                dispenser.return_batch()
-                            trainer.restore_trainer(savedir + '/training/validated')
-                            trainer.halve_learning_rate()
-                            step = validation_step
-                            if num_retries == int(conf['valid_retries']):
-                                self._say('the validation loss is worse, terminating training')
-                                break
-                            self._say('the validation loss is worse, returning to the previously validated '
-                                      'model with halved learning rate')
-                            num_retries += 1
-                            continue
-                        else:
-                            validation_loss = current_loss
-                            validation_step = step
-                            num_retries = 0
-                            save_trainer('validated')
-
-                # layer-wise growth
-                period = int(conf['add_layer_period'])
-                if period > 0:
-                    if step % period == 0 and step // period < int(conf['num_hidden_layers']):
-                        self._say('adding layer, the model now holds %d/%d layers' % (
-                            step // period + 1, int(conf['num_hidden_layers'])))
-                        trainer.control_ops['add'].run()
-                        trainer.control_ops['init'].run()
-                        validation_loss = trainer.evaluate(val_data, val_labels)
-                        self._say('validation loss at step %d: %f' % (step, validation_loss))
-                        validation_step = step
-                        save_trainer('validated')
-                        num_retries = 0
-
-                if step % int(conf['check_freq']) == 0:
-                    save_trainer('step' + str(step))
-
-            if self.rank == 0:
-                trainer.save_model(savedir + '/final')
-            self._barrier()
-        finally:
-            trainer.close()
-
-        # the state prior (over ALL alignment targets, validation utterances included)
-        prior = dispenser.compute_target_count().astype(np.float32)
-        prior = prior / prior.sum()
-        if self.rank == 0:
-            np.save(savedir + '/prior.npy', prior)
-        self._barrier()
-
-    def decode(self, reader, writer):
-        """
-        compute pseudo likelihoods of the testing set (reference nnet.py:246-289)
-
-        Args:
-            reader: a feature reader object to read features to decode
-            writer: a writer object to write likelihoods
-        """
-        decoder = Decoder(self.dnn, self.input_dim, reader.max_input_length)
-        prior = np.load(self.conf['savedir'] + '/prior.npy')
-        try:
-            decoder.restore(self.conf['savedir'] + '/final')
-            decoder.set_prior(prior)
-            # The reference evaluates one utterance per session run (nnet.py:270-286).  Frames are independent
-            # in this model, so utterances are grouped into forward passes of up to `decode_batch_frames`
-            # frames (optional [nnet] key, default 8192; 0 = one utterance per pass) and written in order.
-            budget = int(self.conf.get('decode_batch_frames', '8192'))
-            pending, frames = [], 0
-
-            def flush():
-                # log(posterior / prior); the reference's flooring line discards its result (nnet.py:283),
-                # so no flooring is applied there either
-                for (uid, _), like in zip(pending, decoder.decode_batch([m for _, m in pending])):
-                    writer.write_next_utt(uid, like)
-                del pending[:]
-
-            while True:
-                utt_id, utt_mat, looped = reader.get_utt()
-                if looped:
-                    break
-                if pending and frames + utt_mat.shape[0] > budget:
-                    flush()
-                    frames = 0
-                pending.append((utt_id, utt_mat))
-                frames += utt_mat.shape[0]
-            if pending:
-                flush()
-        finally:
-            decoder.close()
-        writer.close()
 
     def _barrier(self):
         if self.world > 1:
             import torch.distributed as dist
             dist.barrier()
+
+    def train(self, dispenser):
+        """Train the neural network on the batches of `dispenser` (schedule of reference nnet.py:80-244)"""
+        _Schedule(self, dispenser).run()
+        # the state prior counts ALL alignment targets, validation utterances included (nnet.py:241-244)
+        counts = dispenser.compute_target_count().astype(np.float32)
+        if self.rank == 0:
+            np.save(os.path.join(self.conf['savedir'], 'prior.npy'), counts / counts.sum())
+        self._barrier()
+
+    def decode(self, reader, writer):
+        """log(posterior / prior) of every utterance `reader` yields, written through `writer`
+        (reference nnet.py:246-289)"""
+        decoder = Decoder(self.dnn, self.input_dim, reader.max_input_length)
+        try:
+            decoder.restore(self.conf['savedir'] + '/final')
+            decoder.set_prior(np.load(self.conf['savedir'] + '/prior.npy'))
+            # The reference evaluates one utterance per session run (nnet.py:270-286).  Frames are independent in
+            # this model, so utterances are grouped into forward passes of up to `decode_batch_frames` frames
+            # (optional [nnet] key, default 8192; 0 = one utterance per pass) and written in their order.
+            # The reference's flooring line discards its result (nnet.py:283): nothing is floored here either.
+            budget = int(self.conf.get('decode_batch_frames', '8192'))
+            group, frames = [], 0
+            for utt_id, features in _utterances(reader):
+                if group and frames + features.shape[0] > budget:
+                    _write_group(decoder, writer, group)
+                    group, frames = [], 0
+                group.append((utt_id, features))
+                frames += features.shape[0]
+            if group:
+                _write_group(decoder, writer, group)
+        finally:
+            decoder.close()
+        writer.close()
+
+
+def _utterances(reader):
+    """one pass over the reader: it reports `looped` when it has wrapped around (nnet.py:272-277)"""
+    while True:
+        utt_id, features, looped = reader.get_utt()
+        if looped:
+            return
+        yield utt_id, features
+
+
+def _write_group(decoder, writer, group):
+    likelihoods = decoder.decode_batch([features for _, features in group])
+    for (utt_id, _), like in zip(group, likelihoods):
+        writer.write_next_utt(utt_id, like)
+
+
+class _Schedule(object):
+    """One call of Nnet.train: owns the trainer and the position in the data."""
+
+    def __init__(self, net, dispenser):
+        self.net, self.conf, self.dispenser = net, net.conf, dispenser
+        self.training_dir = net.conf['savedir'] + '/training/'
+        n_valid = int(self.conf['valid_batches'])
+        # the first batches of the data are held out for validation, then cut off (nnet.py:88-96)
+        held_out = [dispenser.get_batch() for _ in range(n_valid)]
+        self.valid = tuple(list(itertools.chain.from_iterable(part)) for part in zip(*held_out)) if held_out else None
+        dispenser.split()
+        self.total_steps = int(dispenser.num_batches * int(self.conf['num_epochs']))
+        # resume from the checkpoint at or below starting_step, at the matching position in the data (:101-108)
+        start, every = int(self.conf['starting_step']), int(self.conf['check_freq'])
+        self.step = start - start % every
+        for _ in range(self.step):
+            dispenser.skip_batch()
+        per_minibatch = self.conf['numutterances_per_minibatch']
+        per_minibatch = dispenser.size if per_minibatch == '-1' else int(per_minibatch)
+        self.trainer = CrossEnthropyTrainer(
+            net.dnn, net.input_dim, dispenser.max_input_length, dispenser.max_target_length,
+            float(self.conf['initial_learning_rate']), float(self.conf['learning_rate_decay']), self.total_steps,
+            per_minibatch)
+        self.best_loss = self.best_step = None
+        self.retries = 0
+
+    # ---- persistence: every rank holds the same state, rank 0 writes, all wait ----
+    def save(self, name):
+        if self.net.rank == 0:
+            self.trainer.save_trainer(self.training_dir + name)
+        self.net._barrier()
+
+    def accept(self, loss):
+        """the current model becomes the one to fall back to"""
+        self.best_loss, self.best_step, self.retries = loss, self.step, 0
+        self.save('validated')
+
+    def validate(self):
+        loss = self.trainer.evaluate(*self.valid)
+        self.net._say('validation loss at step %d: %f' % (self.step, loss))
+        return loss
+
+    def fall_back(self):
+        """worse than the validated model: rewind the data, reload it, halve the learning rate (nnet.py:180-199).
+        Returns False when the retries are used up."""
+        for _ in range(self.step - self.best_step):
+            self.dispenser.return_batch()
+        self.trainer.restore_trainer(self.training_dir + 'validated')
+        self.trainer.halve_learning_rate()
+        self.step = self.best_step
+        if self.retries == int(self.conf['valid_retries']):
+            self.net._say('the validation loss is worse, terminating training')
+            return False
+        self.net._say('the validation loss is worse, returning to the previously validated model with halved '
+                      'learning rate')
+        self.retries += 1
+        return True
+
+    def grow(self):
+        """layer-wise growth (nnet.py:209-229): a new hidden layer every add_layer_period steps"""
+        period, depth = int(self.conf['add_layer_period']), int(self.conf['num_hidden_layers'])
+        if period <= 0 or self.step % period or self.step // period >= depth:
+            return
+        self.net._say('adding layer, the model now holds %d/%d layers' % (self.step // period + 1, depth))
+        self.trainer.control_ops['add'].run()
+        self.trainer.control_ops['init'].run()
+        if self.valid is not None:
+            self.accept(self.validate())
+
+    def run(self):
+        conf, trainer = self.conf, self.trainer
+        if conf['visualise'] == 'True' and self.net.rank == 0:
+            logdir = conf['savedir'] + '/logdir'
+            if os.path.isdir(logdir):
+                shutil.rmtree(logdir)
+            trainer.start_visualization(logdir)
+        try:
+            trainer.initialize()
+            if self.step > 0:
+                trainer.restore_trainer(self.training_dir + 'step%d' % self.step)
+            if self.valid is not None:
+                self.accept(self.validate())
+            adaptive = conf['valid_adapt'] == 'True'
+            while self.step < self.total_steps:
+                loss = trainer.update(*self.dispenser.get_batch())
+                self.net._say('step %d/%d loss: %f' % (self.step, self.total_steps, loss))
+                self.step += 1
+                if self.valid is not None and self.step % int(conf['valid_frequency']) == 0:
+                    current = self.validate()
+                    if adaptive and current > self.best_loss:
+                        if not self.fall_back():
+                            break
+                        continue
+                    if adaptive:
+                        self.accept(current)
+                self.grow()
+                if self.step % int(conf['check_freq']) == 0:
+                    self.save('step%d' % self.step)
+            if self.net.rank == 0:
+                trainer.save_model(conf['savedir'] + '/final')
+            self.net._barrier()
+        finally:
+            trainer.close()
