@@ -153,6 +153,20 @@ int tfk_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int
 int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
                             const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags);
 
+/* CTC loss instead of the frame-level cross-entropy (BASELINE configs[4]): what the reference's
+ * CTCTrainer.compute_loss means to build with tf.nn.ctc_loss (trainer.py:533-570; its code cannot run, so this is a
+ * clean-room implementation of the published forward-backward algorithm with that op's conventions: the blank is
+ * the LAST class, repeated labels are merged).  X [T, ldx] = the flat utterance-major frames of U utterances,
+ * utt_len[U] their frame counts (sum = T), labels = their label sequences back to back (values in [0, output_dim-1)),
+ * label_len[U] the sequence lengths (at most 511 labels per utterance).  batch_loss += sum_u -log p(labels_u | X_u),
+ * num_frames += number of labels (the reference counts TARGET lengths, trainer.py:126-133), then backward as
+ * tfk_accumulate.  An utterance too short for its labels contributes +inf to the loss and a zero gradient.
+ * Host pointers for utt_len / labels / label_len; X as tfk_accumulate (TFK_DEVICE_PTRS allowed). */
+int tfk_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,
+                       const int32_t* labels, const int32_t* label_len, int flags);
+int tfk_eval_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,
+                            const int32_t* labels, const int32_t* label_len, int flags);
+
 /* Replaces `[average_loss, apply_gradients_op]` + the three re-initialisations (trainer.py:336-352):
  * g = clip(G / num_frames, -1, 1); Adam; global_step += 1; returns batch_loss / num_frames (the
  * pre-update, train-mode loss); zeroes G, batch_loss, num_frames.  With data parallelism the host

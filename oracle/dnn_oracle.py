@@ -206,14 +206,32 @@ class OracleDNN(object):
         micro-batch's gradients (tf.gradients, trainer.py:155) for inspection."""
         y = np.asarray(y).astype(np.int64)
         T = len(y)
+        logits, cache, nact = self._train_forward(X, masks)
+        loss, prob = self._xent(logits, y)
+        dz = prob.copy()
+        dz[np.arange(T), y] -= 1.0                                    # d(sum CE)/dlogits
+        return self._backward_and_accumulate(dz, loss, T, logits, cache, nact)
+
+    def _train_forward(self, X, masks=None):
         # All BN layers' UPDATE_OPS are fetched (trainer.py:164-169), so with layer-wise growth the
         # hidden layers above the active depth are still evaluated in training mode.
         nfw = self.L if (self.layerwise and self.bn) else None
-        logits, cache, nact = self._forward(X, True, masks, nfw)
-        loss, prob = self._xent(logits, y)
+        return self._forward(X, True, masks, nfw)
+
+    # Loss-agnostic entry points (used with the CTC oracle, oracle/ctc_oracle.py): the training-mode logits of a
+    # micro-batch, then the rest of update_gradients_op from a given d loss / d logits.
+    def forward_logits(self, X, train=True, masks=None):
+        if not train:
+            return self._forward(X, False)[0]
+        self._pending = self._train_forward(X, masks)
+        return self._pending[0]
+
+    def backward_from_dlogits(self, dlogits, loss, num_frames):
+        logits, cache, nact = self._pending
+        return self._backward_and_accumulate(np.asarray(dlogits, dtype=np.float64), loss, num_frames, logits, cache, nact)
+
+    def _backward_and_accumulate(self, dz, loss, num_frames, logits, cache, nact):
         g = self._like_params()
-        dz = prob.copy()
-        dz[np.arange(T), y] -= 1.0                                    # d(sum CE)/dlogits
         g["W%d" % self.L] = self._mm(cache[nact - 1]["a"].T, dz)
         g["b%d" % self.L] = dz.sum(axis=0)
         da = self._mm(dz, self.W[self.L].T)
@@ -241,7 +259,7 @@ class OracleDNN(object):
         for k in g:                                                   # trainer.py:165-169
             self.G[k] = self.G[k] + g[k]
         self.batch_loss += loss
-        self.num_frames += T
+        self.num_frames += num_frames
         if self.bn:                                                   # UPDATE_OPS (A1)
             for l in range(len(cache)):
                 d = self.bn_decay

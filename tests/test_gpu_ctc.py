@@ -1,0 +1,103 @@
+"""CTC loss on the device (tfkaldi_amd/csrc/ctc.hip through tfk_accumulate_ctc) against the float64 oracle
+(oracle/ctc_oracle.py, itself pinned against torch's ctc_loss in tests/test_ctc_oracle.py).
+
+The kernel works in fp32 log space; tolerances: loss rtol 2e-5, dLogits atol 2e-5 (values are O(1) probabilities),
+parameter gradients as in the cross-entropy parity test (rtol 2e-4 + 2e-5 * max)."""
+import numpy as np
+import pytest
+
+from oracle.ctc_oracle import ctc_batch
+from util import assert_close, engine_grads, make_pair
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(input_dim=20, num_layers=2, num_units=32, output_dim=9, nonlin="tanh", batch_norm=True,
+          init_learning_rate=1e-3, num_steps=50)
+
+
+def _batch(rng, utt_lens, label_lens, F, O, repeat_heavy=False):
+    X = (rng.standard_normal((int(np.sum(utt_lens)), F)) * 1.5).astype(np.float32)
+    hi = 2 if repeat_heavy else O - 1   # few distinct labels -> many repeats
+    labels = np.concatenate([rng.integers(0, hi, size=n) for n in label_lens] + [np.zeros(0, dtype=np.int64)])
+    return X, labels.astype(np.int32)
+
+
+def _oracle_step(oracle, X, utt_lens, labels, label_lens):
+    """oracle forward, CTC loss + dLogits from the CTC oracle, oracle backward from those dLogits"""
+    logits = oracle.forward_logits(X)
+    loss, dlog, n_labels = ctc_batch(logits, utt_lens, labels, label_lens)
+    oracle.backward_from_dlogits(dlog, loss, n_labels)
+    return loss, dlog
+
+
+@pytest.mark.parametrize("case", [
+    dict(utt=[30, 17, 44, 9], lab=[5, 3, 11, 0]),                       # incl. an empty label sequence
+    dict(utt=[25, 40], lab=[12, 19], repeat=True),                      # repeated labels: blanks are mandatory
+    dict(utt=[7, 60], lab=[7, 2], repeat=False),                        # T == S: every frame emits a label
+    dict(utt=[300], lab=[140]),                                         # 281 states: 8 states per lane
+], ids=["mixed", "repeats", "tight", "long"])
+def test_ctc_accumulate_matches_oracle(gpu, case):
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(41)
+    eng, oracle = make_pair(rng, max_frames=512, **KW)
+    X, labels = _batch(rng, case["utt"], case["lab"], KW["input_dim"], KW["output_dim"], case.get("repeat", False))
+    if case["utt"][0] == 7:  # the tight case must be feasible: no repeats in the 7-label utterance
+        labels[:7] = np.arange(7) % (KW["output_dim"] - 1)
+    T = X.shape[0]
+    eng.accumulate_ctc(X, case["utt"], labels, case["lab"])
+    loss, dlog = _oracle_step(oracle, X, case["utt"], labels, case["lab"])
+    assert np.isfinite(loss)
+    assert_close("batch_loss", eng.scalar(_lib.BATCH_LOSS), loss, 2e-5, 0)
+    assert eng.scalar(_lib.NUM_FRAMES) == sum(case["lab"])
+    # the posteriors come out of a T-step fp32 log-space recursion: round-off grows with the utterance length
+    assert_close("dlogits", eng.debug_fetch(_lib.DBG_LOGITS, 0, T), dlog, rtol=1e-4, atol=2e-5 if T < 200 else 2e-4)
+    got = engine_grads(eng)
+    for k, want in oracle.G.items():
+        if k.startswith("b") and not k.startswith("beta") and k != "b%d" % oracle.L:
+            continue  # bias under batch norm: true gradient 0
+        assert_close("G[%s]" % k, got[k], want, rtol=2e-4 if T < 200 else 1e-3,
+                     atol=(2e-5 if T < 200 else 2e-4) * max(np.abs(want).max(), 1e-3))
+    assert_close("avg loss", eng.apply(), oracle.apply(), 2e-5, 0)
+    # evaluation mode (moving-average batch norm), loss only; the parameters now carry Adam's round-off amplification
+    # (see test_gpu_engine_parity.test_multi_step_training), hence the wider tolerance
+    eng.eval_accumulate_ctc(X, case["utt"], labels, case["lab"])
+    want = ctc_batch(oracle.forward_logits(X, train=False), case["utt"], labels, case["lab"])[0] / max(sum(case["lab"]), 1)
+    assert_close("eval loss", eng.eval_finish(), want, 5e-4, 0)
+    eng.close()
+
+
+def test_ctc_infeasible_utterance_and_errors(gpu):
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(42)
+    eng, oracle = make_pair(rng, max_frames=128, **KW)
+    X = rng.standard_normal((3 + 20, KW["input_dim"])).astype(np.float32)
+    labels = np.array([1, 1, 2, 0, 3, 4], dtype=np.int32)  # first utterance: 3 frames for "1 1 2" needs 4
+    eng.accumulate_ctc(X, [3, 20], labels, [3, 3])
+    assert eng.scalar(_lib.BATCH_LOSS) == np.inf
+    dlog = eng.debug_fetch(_lib.DBG_LOGITS, 0, 23)
+    assert not dlog[:3].any() and dlog[3:].any()           # zero gradient for the impossible utterance only
+    _, want, _ = ctc_batch(oracle.forward_logits(X), [3, 20], labels, [3, 3])
+    assert_close("dlogits", dlog, want, rtol=1e-4, atol=2e-5)
+    with pytest.raises(_lib.EngineError, match="outside"):
+        eng.accumulate_ctc(X, [3, 20], np.array([1, 1, 2, 0, 3, 8], dtype=np.int32), [3, 3])  # 8 = the blank
+    with pytest.raises(ValueError, match="do not match"):
+        eng.accumulate_ctc(X, [3, 19], labels, [3, 3])
+    eng.close()
+
+
+def test_ctc_training_reduces_loss_and_is_deterministic(gpu):
+    rng = np.random.default_rng(43)
+    traces = []
+    for rep in range(2):
+        eng, _ = make_pair(np.random.default_rng(5), output_too=False, max_frames=256, **dict(KW, init_learning_rate=3e-3))
+        r = np.random.default_rng(44)
+        utt, lab = [40, 35, 50, 28], [6, 4, 9, 3]
+        X, labels = _batch(r, utt, lab, KW["input_dim"], KW["output_dim"])
+        trace = []
+        for _ in range(80):
+            eng.accumulate_ctc(X, utt, labels, lab, last=True)
+            trace.append(eng.apply())
+        traces.append(trace)
+        eng.close()
+    assert traces[0] == traces[1]
+    assert traces[0][-1] < 0.7 * traces[0][0]

@@ -1,0 +1,253 @@
+// CTC loss and its gradient w.r.t. the logits, gfx950 (wave64).  See ctc.h for what it restates.
+//
+//   ctc_softmax      one block per frame: softmax row (kept for the gradient) and its log-sum-exp
+//   ctc_gather       log p_t(state) for the 2S+1 states of the frame's utterance, contiguous per frame
+//   ctc_alpha_beta   ONE WAVE PER UTTERANCE: every lane owns R consecutive states in registers, the s-1 / s-2
+//                    neighbours of a lane's first states come from the previous lane by DPP shuffles -- the time
+//                    recursion runs without LDS and without barriers; alpha rows go to HBM, the backward sweep
+//                    turns them into state posteriors in place
+//   ctc_grad         one wave per frame: folds the state posteriors onto the classes in LABEL ORDER (repeated labels
+//                    and the S+1 blanks are summed in a fixed order, so the result is bitwise reproducible)
+// Log space, fp32, with a large finite "minus infinity" so that no inf - inf can arise.
+#include "ctc.h"
+
+#include <math.h>
+
+namespace tfk {
+namespace {
+
+constexpr float NEG = -1e30f;
+
+__device__ __forceinline__ float lse2(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+__device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+
+// utterance of frame t: largest u with seg[u] <= t
+__device__ __forceinline__ int utt_of(const int32_t* __restrict__ seg, int U, int t) {
+  int lo = 0, hi = U;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+ctc_softmax_kernel(const float* __restrict__ logits, int O, int ld, float* __restrict__ post, float* __restrict__ lse) {
+  __shared__ float sm[8];
+  const int row = blockIdx.x;
+  const float* zr = logits + (size_t)row * ld;
+  float* pr = post + (size_t)row * ld;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < O; c += 256) mx = fmaxf(mx, zr[c]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float se = 0.f;
+  for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  if ((threadIdx.x & 63) == 0) sm[4 + (threadIdx.x >> 6)] = se;
+  __syncthreads();
+  se = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+  const float inv = 1.f / se;
+  for (int c = threadIdx.x; c < ld; c += 256) pr[c] = c < O ? expf(zr[c] - mx) * inv : 0.f;
+  if (threadIdx.x == 0) lse[row] = mx + logf(se);
+}
+
+__global__ void __launch_bounds__(256)
+ctc_gather_kernel(CtcBatch b) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)b.T * b.sext) return;
+  const int t = (int)(idx / b.sext), s = (int)(idx % b.sext);
+  const int u = utt_of(b.seg, b.U, t);
+  const int l0 = b.lab_off[u], n = 2 * (b.lab_off[u + 1] - l0) + 1;
+  float v = NEG;
+  if (s < n) {
+    const int k = (s & 1) ? b.labels[l0 + (s >> 1)] : b.O - 1;
+    v = b.logits[(size_t)t * b.ld + k] - b.lse[t];
+  }
+  b.lp[idx] = v;
+}
+
+template <int R>
+__global__ void __launch_bounds__(64)
+ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
+  const int u = blockIdx.x, lane = threadIdx.x;
+  const int r0 = b.seg[u], Tn = b.seg[u + 1] - r0;
+  const int l0 = b.lab_off[u], S = b.lab_off[u + 1] - l0, n = 2 * S + 1;
+  if (Tn <= 0) {  // an utterance without frames: only the empty labelling is possible
+    if (lane == 0) b.utt_loss[u] = S == 0 ? 0.f : INFINITY;
+    return;
+  }
+  const int s0 = lane * R;
+  // transitions: `skip_in[r]`  s-2 -> s allowed (s is a label state whose label differs from the previous label)
+  //              `skip_out[r]` s -> s+2 allowed (the same test for state s+2)
+  bool skip_in[R], skip_out[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int s = s0 + r, j = s >> 1;
+    const bool lab = (s & 1) && s < n;
+    skip_in[r] = lab && j >= 1 && b.labels[l0 + j] != b.labels[l0 + j - 1];
+    skip_out[r] = lab && j + 1 < S && b.labels[l0 + j + 1] != b.labels[l0 + j];
+  }
+  const float* lp = b.lp + (size_t)r0 * b.sext + s0;
+  float* ab = b.ab + (size_t)r0 * b.sext + s0;
+  float a[R], cur[R], nxt[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cur[r] = lp[r];
+    a[r] = (s0 + r < 2 && s0 + r < n) ? cur[r] : NEG;
+    ab[r] = a[r];
+  }
+  for (int t = 1; t < Tn; ++t) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) nxt[r] = lp[(size_t)t * b.sext + r];  // in flight under the shuffles below
+    float up1 = __shfl_up(a[R - 1], 1), up2 = __shfl_up(R >= 2 ? a[R - 2] : a[0], R >= 2 ? 1 : 2);
+    if (lane == 0) up1 = NEG;
+    if (lane < (R >= 2 ? 1 : 2)) up2 = NEG;
+    float na[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float p1 = r >= 1 ? a[r - 1] : up1;
+      const float p2 = r >= 2 ? a[r - 2] : (r == 1 ? up1 : up2);
+      na[r] = (s0 + r < n) ? lse3(a[r], p1, skip_in[r] ? p2 : NEG) + nxt[r] : NEG;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      a[r] = na[r];
+      ab[(size_t)t * b.sext + r] = a[r];
+    }
+  }
+  // log p(labels) = alpha_T(n-1) (+) alpha_T(n-2)
+  float m = NEG;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (s0 + r == n - 1 || s0 + r == n - 2) m = fmaxf(m, a[r]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float se = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (s0 + r == n - 1 || s0 + r == n - 2) se += expf(a[r] - m);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  const float log_z = m + logf(se);
+  const bool feasible = log_z > -1e29f;
+  if (lane == 0) b.utt_loss[u] = feasible ? -log_z : INFINITY;
+  if (!with_grad) return;
+  // backward sweep: beta in registers, alpha row t read back and replaced by the state posterior
+  float bt[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int s = s0 + r;
+    cur[r] = lp[(size_t)(Tn - 1) * b.sext + r];
+    bt[r] = (s == n - 1 || s == n - 2) ? cur[r] : NEG;
+    const float al = ab[(size_t)(Tn - 1) * b.sext + r];
+    ab[(size_t)(Tn - 1) * b.sext + r] = (feasible && s < n) ? expf(al + bt[r] - cur[r] - log_z) : 0.f;
+  }
+  for (int t = Tn - 2; t >= 0; --t) {
+    float al[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      nxt[r] = lp[(size_t)t * b.sext + r];
+      al[r] = ab[(size_t)t * b.sext + r];
+    }
+    float dn1 = __shfl_down(bt[0], 1), dn2 = __shfl_down(R >= 2 ? bt[1] : bt[0], R >= 2 ? 1 : 2);
+    if (lane == 63) dn1 = NEG;
+    if (lane > 63 - (R >= 2 ? 1 : 2)) dn2 = NEG;
+    float nb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float q1 = r + 1 < R ? bt[r + 1] : dn1;
+      const float q2 = r + 2 < R ? bt[r + 2] : (r + 1 < R ? dn1 : (R >= 2 ? dn2 : dn2));
+      nb[r] = (s0 + r < n) ? lse3(bt[r], q1, skip_out[r] ? q2 : NEG) + nxt[r] : NEG;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      bt[r] = nb[r];
+      ab[(size_t)t * b.sext + r] = (feasible && s0 + r < n) ? expf(al[r] + bt[r] - nxt[r] - log_z) : 0.f;
+    }
+  }
+}
+
+// one wave per frame; dynamic LDS: the class row
+__global__ void __launch_bounds__(64)
+ctc_grad_kernel(CtcBatch b, float* __restrict__ dlogits, Twin tw) {
+  extern __shared__ float row[];
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int u = utt_of(b.seg, b.U, t);
+  const int l0 = b.lab_off[u], S = b.lab_off[u + 1] - l0, n = 2 * S + 1;
+  const bool live = b.utt_loss[u] < INFINITY;
+  const float* pr = b.post + (size_t)t * b.ld;
+  for (int c = lane; c < b.ld; c += 64) row[c] = live ? pr[c] : 0.f;
+  const float* g = b.ab + (size_t)t * b.sext;
+  float blank = 0.f;
+  for (int s = 2 * lane; s < n; s += 128) blank += g[s];
+  for (int o = 32; o > 0; o >>= 1) blank += __shfl_xor(blank, o);
+  __syncthreads();
+  if (lane == 0 && live) {
+    row[b.O - 1] -= blank;
+    for (int j = 0; j < S; ++j) row[b.labels[l0 + j]] -= g[2 * j + 1];  // label order: deterministic for repeats
+  }
+  __syncthreads();
+  float* dr = dlogits + (size_t)t * b.ld;
+  for (int c = lane; c < b.ld; c += 64) dr[c] = row[c];
+  if (tw.p)
+    for (int c = lane; c < b.ld; c += 64) tw.p[(size_t)t * tw.ld + c] = to_bf16(row[c]);
+}
+
+__global__ void __launch_bounds__(256)
+ctc_loss_reduce_kernel(const float* __restrict__ utt_loss, const int32_t* __restrict__ lab_off, int U,
+                       float* __restrict__ scalars, int overwrite) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < U; i += 256) s += utt_loss[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    const float labels = (float)(lab_off[U] - lab_off[0]);
+    scalars[0] = overwrite ? s : scalars[0] + s;
+    scalars[1] = overwrite ? labels : scalars[1] + labels;
+    scalars[2] = overwrite ? 1.f : scalars[2] + 1.f;
+  }
+}
+
+int regs_for(int max_labels) {
+  const int n = 2 * max_labels + 1;
+  int r = 2;
+  while (64 * r < n) r *= 2;
+  return r;
+}
+
+}  // namespace
+
+int ctc_state_stride(int max_labels) { return 64 * regs_for(max_labels); }
+
+void ctc_loss_grad(hipStream_t s, const CtcBatch& b, float* dlogits, int with_grad, Twin tw) {
+  if (b.T <= 0 || b.U <= 0) return;
+  hipLaunchKernelGGL(ctc_softmax_kernel, dim3(b.T), dim3(256), 0, s, b.logits, b.O, b.ld, b.post, b.lse);
+  const size_t n = (size_t)b.T * b.sext;
+  hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b);
+  switch (b.sext / 64) {
+    case 2: hipLaunchKernelGGL(ctc_alpha_beta_kernel<2>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
+    case 4: hipLaunchKernelGGL(ctc_alpha_beta_kernel<4>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
+    case 8: hipLaunchKernelGGL(ctc_alpha_beta_kernel<8>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
+    default: hipLaunchKernelGGL(ctc_alpha_beta_kernel<16>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
+  }
+  if (with_grad)
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(b.T), dim3(64), (size_t)b.ld * sizeof(float), s, b, dlogits, tw);
+}
+
+void ctc_loss_reduce(hipStream_t s, const float* utt_loss, const int32_t* lab_off, int U, float* scalars,
+                     bool overwrite) {
+  hipLaunchKernelGGL(ctc_loss_reduce_kernel, dim3(1), dim3(256), 0, s, utt_loss, lab_off, U, scalars, overwrite ? 1 : 0);
+}
+
+}  // namespace tfk

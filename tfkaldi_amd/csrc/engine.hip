@@ -10,6 +10,7 @@
 //   activations (engine-owned, grow on demand): X, per hidden layer z_l (pre-BN) and a_l (layer output),
 //     logits, two ping-pong gradient buffers, BN batch statistics, reduction workspace.
 #include "../../include/tfkaldi_hip.h"
+#include "ctc.h"
 #include "gemm_bf16.h"
 #include "gemm_f32.h"
 #include "kernels.h"
@@ -137,6 +138,13 @@ struct tfk_engine {
   float* h_scalars_dev = nullptr;
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
+
+  // CTC loss (tfk_accumulate_ctc): device copies of the utterance / label offsets and the state workspaces,
+  // grown on demand
+  int32_t *ctc_seg = nullptr, *ctc_lab_off = nullptr, *ctc_lab = nullptr;
+  float *ctc_lp = nullptr, *ctc_ab = nullptr, *ctc_utt_loss = nullptr, *ctc_lse = nullptr;
+  size_t ctc_cap_seg = 0, ctc_cap_off = 0, ctc_cap_loss = 0, ctc_cap_lab = 0, ctc_cap_lp = 0, ctc_cap_ab = 0,
+         ctc_cap_rows = 0;
 
   // mixed precision (cfg.compute_dtype == TFK_DTYPE_BF16): every fp32 buffer that is a GEMM operand has a bf16
   // twin written by its producer; master parameters, statistics, gradients and the optimiser stay fp32
@@ -919,16 +927,84 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   return 0;
 }
 
+struct CtcSpec {  // CTC loss instead of the frame-level cross-entropy
+  const int32_t* utt_len;    // [U] frames per utterance (sum = T)
+  int U;
+  const int32_t* labels;     // concatenated label sequences
+  const int32_t* label_len;  // [U]
+};
+template <class Tp>
+int grow(Tp** p, size_t* cap, size_t need) {
+  if (need <= *cap) return 0;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr;
+  const size_t n = need + need / 2;
+  HIPCHK(hipMalloc((void**)p, n * sizeof(Tp)));
+  *cap = n;
+  return 0;
+}
+// Loss + dLogits of one CTC micro-batch (logits already in e->logits).  Replaces compute_loss of the reference's
+// CTCTrainer (trainer.py:533-570); batch_loss += sum of -log p, num_frames += number of labels (trainer.py:126-133).
+int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
+  if (c.U <= 0 || !c.utt_len || !c.label_len) return fail(-1, "CTC: no utterances");
+  std::vector<int32_t> seg(c.U + 1, 0), off(c.U + 1, 0);
+  int max_labels = 0;
+  for (int u = 0; u < c.U; ++u) {
+    if (c.utt_len[u] < 0 || c.label_len[u] < 0) return fail(-1, "CTC: negative length");
+    seg[u + 1] = seg[u] + c.utt_len[u];
+    off[u + 1] = off[u] + c.label_len[u];
+    max_labels = c.label_len[u] > max_labels ? c.label_len[u] : max_labels;
+  }
+  if (seg[c.U] != T) return fail(-1, "CTC: utterance lengths sum to %d, expected T = %d", seg[c.U], T);
+  if (max_labels > kCtcMaxLabels) return fail(-1, "CTC: %d labels in one utterance (limit %d)", max_labels, kCtcMaxLabels);
+  const int total = off[c.U];
+  if (total > 0 && !c.labels) return fail(-1, "CTC: labels is NULL");
+  for (int i = 0; i < total; ++i)  // the blank is the LAST class (tf.nn.ctc_loss): labels live in [0, O - 1)
+    if (c.labels[i] < 0 || c.labels[i] >= e->O - 1) return fail(-1, "CTC: label %d outside [0, %d)", c.labels[i], e->O - 1);
+  const int sext = ctc_state_stride(max_labels);
+  HIPCHK(hipStreamSynchronize(e->stream));  // the workspaces below may still be read by the previous micro-batch
+  CHK(grow(&e->ctc_seg, &e->ctc_cap_seg, (size_t)c.U + 1));
+  CHK(grow(&e->ctc_lab_off, &e->ctc_cap_off, (size_t)c.U + 1));
+  CHK(grow(&e->ctc_utt_loss, &e->ctc_cap_loss, (size_t)c.U));
+  CHK(grow(&e->ctc_lab, &e->ctc_cap_lab, (size_t)(total > 0 ? total : 1)));
+  CHK(grow(&e->ctc_lp, &e->ctc_cap_lp, (size_t)T * sext));
+  CHK(grow(&e->ctc_ab, &e->ctc_cap_ab, (size_t)T * sext));
+  CHK(grow(&e->ctc_lse, &e->ctc_cap_rows, (size_t)T));
+  HIPCHK(hipMemcpyAsync(e->ctc_seg, seg.data(), (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(e->ctc_lab_off, off.data(), (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  if (total > 0)
+    HIPCHK(hipMemcpyAsync(e->ctc_lab, c.labels, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // seg / off are stack-lifetime host buffers
+  CtcBatch b;
+  b.logits = e->logits; b.ld = e->ldO; b.post = e->post; b.lse = e->ctc_lse;
+  b.seg = e->ctc_seg; b.labels = e->ctc_lab; b.lab_off = e->ctc_lab_off;
+  b.U = c.U; b.T = T; b.O = e->O; b.sext = sext;
+  b.lp = e->ctc_lp; b.ab = e->ctc_ab; b.utt_loss = e->ctc_utt_loss;
+  {
+    ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * T * e->O + 16.0 * T * sext);
+    Twin tw;
+    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
+    ctc_loss_grad(e->stream, b, e->logits, train, tw);
+  }
+  {
+    ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * c.U);
+    ctc_loss_reduce(e->stream, e->ctc_utt_loss, e->ctc_lab_off, c.U, e->p_scalars(), e->scalars_fresh);
+    e->scalars_fresh = false;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 struct RawSpec {  // non-null utt_len selects the device-side splice
   const int32_t* utt_len;
   int U, context;
   const float* cmvn;  // nullable [U, 2, raw_dim]
 };
 int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags, int train,
-                  const RawSpec* raw = nullptr) {
+                  const RawSpec* raw = nullptr, const CtcSpec* ctc = nullptr) {
   if (!e) return fail(-1, "engine is NULL");
   if (T <= 0) return fail(-1, "empty micro-batch (T = %d)", T);
-  if (!X || !y) return fail(-1, "X / y is NULL");
+  if (!X || (!y && !ctc)) return fail(-1, "X / y is NULL");
   if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers");
   HIPCHK(hipSetDevice(e->cfg.device));
   CHK(reserve(e, T));
@@ -943,16 +1019,20 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   // fetched by update_gradients_op (trainer.py:164-169) even for layers the tf.case does not select.
   const int nfw = (train && e->cfg.layerwise_init && e->cfg.batch_norm) ? e->L : nact;
   CHK(forward(e, Xd, ld, T, train, nact, nfw, call));
-  {
-    ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
-    Twin tw;
-    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
-    softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw);
-  }
-  {
-    ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
-    loss_reduce(e->stream, e->row_loss, T, e->p_scalars(), e->scalars_fresh);
-    e->scalars_fresh = false;
+  if (ctc) {
+    CHK(ctc_loss(e, *ctc, T, train));
+  } else {
+    {
+      ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
+      Twin tw;
+      if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
+      softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw);
+    }
+    {
+      ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
+      loss_reduce(e->stream, e->row_loss, T, e->p_scalars(), e->scalars_fresh);
+      e->scalars_fresh = false;
+    }
   }
   if (train) {
     const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
@@ -1011,6 +1091,9 @@ int tfk_destroy(tfk_engine* e) {
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
   if (e->Wb) hipFree(e->Wb);
+  for (void* p : {(void*)e->ctc_seg, (void*)e->ctc_lab_off, (void*)e->ctc_lab, (void*)e->ctc_lp, (void*)e->ctc_ab,
+                  (void*)e->ctc_utt_loss, (void*)e->ctc_lse})
+    if (p) hipFree(p);
   if (e->h_scalars) hipHostFree(e->h_scalars);
   if (e->h_post) hipHostFree(e->h_post);
   if (e->own_state && e->state) hipFree(e->state);
@@ -1121,6 +1204,17 @@ int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, cons
   const RawSpec r = {utt_len, U, context_width, cmvn};
   if (!utt_len) return fail(-1, "utt_len is NULL");
   return train_or_eval(e, raw, ldraw, y, T, flags & ~TFK_LAST_MICROBATCH, 0, &r);
+}
+
+int tfk_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,
+                       const int32_t* labels, const int32_t* label_len, int flags) {
+  const CtcSpec c = {utt_len, U, labels, label_len};
+  return train_or_eval(e, X, ldx, nullptr, T, flags, 1, nullptr, &c);
+}
+int tfk_eval_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,
+                            const int32_t* labels, const int32_t* label_len, int flags) {
+  const CtcSpec c = {utt_len, U, labels, label_len};
+  return train_or_eval(e, X, ldx, nullptr, T, flags & ~TFK_LAST_MICROBATCH, 0, nullptr, &c);
 }
 
 int tfk_apply(tfk_engine* e, float* average_loss) {

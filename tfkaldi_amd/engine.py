@@ -194,6 +194,30 @@ class Engine(object):
                                           out.ctypes.data_as(c_void_p), self.O, flags))
         return out
 
+    # ---- CTC loss: frames [T, F] of U utterances + their label sequences ----
+    def _ctc_args(self, X, utt_lens, labels, label_lens):
+        X = _f32(X)
+        utt_lens = np.ascontiguousarray(utt_lens, dtype=np.int32)
+        label_lens = np.ascontiguousarray(label_lens, dtype=np.int32)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if int(utt_lens.sum()) != X.shape[0] or int(label_lens.sum()) != labels.size or utt_lens.size != label_lens.size:
+            raise ValueError("CTC micro-batch: frames %s / utterance lengths / labels do not match" % (X.shape,))
+        return X, utt_lens, labels, label_lens
+
+    def accumulate_ctc(self, X, utt_lens, labels, label_lens, last=False):
+        X, utt_lens, labels, label_lens = self._ctc_args(X, utt_lens, labels, label_lens)
+        check(self.lib.tfk_accumulate_ctc(self._h, X.ctypes.data_as(c_void_p), X.shape[1], X.shape[0],
+                                          utt_lens.ctypes.data_as(c_void_p), utt_lens.size,
+                                          labels.ctypes.data_as(c_void_p), label_lens.ctypes.data_as(c_void_p),
+                                          _lib.LAST_MICROBATCH if last else 0))
+
+    def eval_accumulate_ctc(self, X, utt_lens, labels, label_lens):
+        X, utt_lens, labels, label_lens = self._ctc_args(X, utt_lens, labels, label_lens)
+        check(self.lib.tfk_eval_accumulate_ctc(self._h, X.ctypes.data_as(c_void_p), X.shape[1], X.shape[0],
+                                               utt_lens.ctypes.data_as(c_void_p), utt_lens.size,
+                                               labels.ctypes.data_as(c_void_p), label_lens.ctypes.data_as(c_void_p),
+                                               0))
+
     def apply(self):
         loss = c_float()
         check(self.lib.tfk_apply(self._h, byref(loss)))
