@@ -101,3 +101,45 @@ def test_ctc_training_reduces_loss_and_is_deterministic(gpu):
         eng.close()
     assert traces[0] == traces[1]
     assert traces[0][-1] < 0.7 * traces[0][0]
+
+
+def test_ctc_trainer_end_to_end(gpu, tmp_path):
+    """TextBatchDispenser (character targets through TextCoder + aurora4_normalizer) -> CTCTrainer -> engine:
+    the first update's loss equals the CTC oracle's on the oracle DNN's logits, training reduces it, evaluate runs"""
+    from oracle.dnn_oracle import OracleDNN
+    from tfkaldi_amd import _lib, synthetic
+    from tfkaldi_amd.neuralNetworks.classifiers import activation as act
+    from tfkaldi_amd.neuralNetworks.classifiers.dnn import DNN
+    from tfkaldi_amd.neuralNetworks.trainer import CTCTrainer
+    from tfkaldi_amd.processing import batchdispenser, feature_reader, target_coder, target_normalizers
+    D, C, U = 8, 2, 4
+    F = D * (2 * C + 1)
+    lengths = [90, 70, 120, 80, 100, 60, 75, 110]
+    paths = synthetic.write_corpus(str(tmp_path), len(lengths), 10, feat_dim=D, lengths=lengths, num_speakers=2)
+    text = synthetic.write_text_targets(str(tmp_path), len(lengths))
+    reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], C, max(lengths))
+    coder = target_coder.TextCoder(target_normalizers.aurora4_normalizer)
+    disp = batchdispenser.TextBatchDispenser(reader, coder, U, text)
+    O = coder.num_labels + 1  # + the blank, last class
+    dnn = DNN(O, 2, 48, act.TfActivation(act.Batchnorm(None), "relu"), False)
+    tr = CTCTrainer(dnn, F, max(lengths), disp.max_target_length, 3e-3, 1.0, 100, 2, seed=11)
+    tr.initialize()
+    xs, ys = disp.get_batch()
+    assert all(y.dtype == np.uint32 for y in ys) and all(len(y) < len(x) for x, y in zip(xs, ys))
+    # oracle: same parameters, the two micro-batches of this batch
+    oracle = OracleDNN(F, 2, 48, O, nonlin="relu", batch_norm=True, init_learning_rate=3e-3, num_steps=100)
+    for l in range(3):
+        oracle.W[l] = tr.engine.get(_lib.WEIGHTS, l).astype(np.float64)
+    for k in range(0, U, 2):
+        X = np.concatenate(xs[k:k + 2])
+        labels = np.concatenate(ys[k:k + 2]).astype(np.int64)
+        logits = oracle.forward_logits(X)
+        loss, dlog, n = ctc_batch(logits, [len(x) for x in xs[k:k + 2]], labels, [len(y) for y in ys[k:k + 2]])
+        oracle.backward_from_dlogits(dlog, loss, n)
+    want = oracle.apply()
+    first = tr.update(xs, ys)
+    assert_close("first loss", first, want, 2e-5, 0)
+    losses = [first] + [tr.update(xs, ys) for _ in range(60)]
+    assert losses[-1] < 0.6 * losses[0]
+    assert np.isfinite(tr.evaluate(xs, ys))
+    tr.close()

@@ -149,3 +149,19 @@ def test_batch_dispenser_matches_reference(gold, datadir):
 def test_read_utt2spk(gold, datadir):
     got = readfiles.read_utt2spk(os.path.join(datadir, "utt2spk"))
     assert sorted(got.items()) == [tuple(x) for x in gold["utt2spk_keys"]]
+
+
+def test_text_targets_match_reference():
+    """aurora4_normalizer + TextCoder against tests/golden/text_golden.json (oracle/make_golden_text.py: the
+    reference's own code run on these transcriptions)"""
+    import json
+    from tfkaldi_amd.processing import target_normalizers
+    with open(os.path.join(GOLD, "text_golden.json")) as fid:
+        gold = json.load(fid)
+    coder = target_coder.TextCoder(target_normalizers.aurora4_normalizer)
+    assert coder.alphabet == gold["alphabet"] and coder.num_labels == gold["num_labels"] == 35
+    for case in gold["cases"]:
+        assert target_normalizers.aurora4_normalizer(case["text"], coder.lookup.keys()) == case["normalized"]
+        got = coder.encode(case["text"])
+        assert got.dtype == np.uint32 and got.tolist() == case["encoded"]
+    assert coder.decode(coder.encode("AB C")) == "<sos> a b <space> c <eos>"

@@ -60,15 +60,27 @@ class RawMicroBatch(object):
         self.raw, self.y, self.lens, self.context_width, self.cmvn = raw, y, lens, context_width, cmvn
 
 
+class CtcMicroBatch(object):
+    """A micro-batch for the CTC loss: spliced frames [T, F] of U utterances, their frame counts, their label
+    sequences back to back and the label counts (tfk_accumulate_ctc)."""
+
+    def __init__(self, X, utt_lens, labels, label_lens):
+        self.X, self.utt_lens, self.labels, self.label_lens = X, utt_lens, labels, label_lens
+
+
 def _accumulate(engine, mb, last):
-    if isinstance(mb, RawMicroBatch):
+    if isinstance(mb, CtcMicroBatch):
+        engine.accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens, last=last)
+    elif isinstance(mb, RawMicroBatch):
         engine.accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, last=last, cmvn=mb.cmvn)
     else:
         engine.accumulate(mb[0], mb[1], last=last)
 
 
 def _eval_accumulate(engine, mb):
-    if isinstance(mb, RawMicroBatch):
+    if isinstance(mb, CtcMicroBatch):
+        engine.eval_accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens)
+    elif isinstance(mb, RawMicroBatch):
         engine.eval_accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, cmvn=mb.cmvn)
     else:
         engine.eval_accumulate(mb[0], mb[1])

@@ -20,7 +20,7 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .. import _lib
-from ..dataparallel import DataParallel, RawMicroBatch
+from ..dataparallel import CtcMicroBatch, DataParallel, RawMicroBatch
 from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
 
@@ -88,8 +88,8 @@ class Trainer(object, metaclass=ABCMeta):
         self.graph = _Graph()
         # the loss is part of the graph: abstract in the base class (trainer.py:219-242)
         self.loss_kind = self.compute_loss(None, None, None, None)
-        if self.loss_kind != "cross_enthropy":
-            raise NotImplementedError("the HIP engine implements the cross-enthropy loss only")
+        if self.loss_kind not in ("cross_enthropy", "ctc"):
+            raise NotImplementedError("the HIP engine implements the cross-enthropy and CTC losses")
         max_frames = max(1, int(numutterances_per_minibatch)) * max(1, int(max_input_length))
         self.engine = classifier.create_engine(
             input_dim, torch_state=self.dp.enabled, init_learning_rate=init_learning_rate,
@@ -138,6 +138,15 @@ class Trainer(object, metaclass=ABCMeta):
         out = []
         for idx in microbatch_indices(len(inputs), self.numutterances_per_minibatch):
             if not idx:
+                continue
+            if self.loss_kind == "ctc":  # label sequences of their own length; frames spliced on the host
+                X = np.concatenate([_spliced(inputs[i]) for i in idx], axis=0)
+                if X.shape[0] == 0:
+                    continue
+                out.append(CtcMicroBatch(
+                    X, np.array([inputs[i].shape[0] for i in idx], dtype=np.int32),
+                    np.concatenate([np.asarray(targets[i]).astype(np.int32).reshape(-1) for i in idx]),
+                    np.array([np.asarray(targets[i]).size for i in idx], dtype=np.int32)))
                 continue
             for i in idx:
                 if inputs[i].shape[0] != targets[i].shape[0]:
@@ -221,9 +230,13 @@ class CrossEnthropyTrainer(Trainer):
 
 
 class CTCTrainer(Trainer):
-    """The reference's CTCTrainer.compute_loss (trainer.py:533-570) cannot run: it iterates over
-    range(len(batch_size)) of an int, fills the sparse targets from the logits and returns nothing, and
-    the repository has no recurrent classifier to train with it.  There is no behaviour to reproduce."""
+    """A trainer that minimises the CTC loss (reference trainer.py:533-570).  The reference's compute_loss cannot
+    run -- it iterates over range(len(batch_size)) of an int, fills the sparse label values from the logits and
+    returns nothing -- so this is what that method means to build: tf.nn.ctc_loss on the time-major logits with the
+    op's conventions (the blank is the LAST class, so the classifier needs num_labels + 1 outputs; repeated labels
+    are merged), summed over the utterances.  As everywhere in the Trainer, num_frames counts TARGET lengths
+    (trainer.py:126-133): the reported loss and the mean gradient are per label.  Checked against
+    oracle/ctc_oracle.py (pinned to torch's ctc_loss), not against the reference: parity unpinned."""
 
     def compute_loss(self, targets, logits, logit_seq_length, target_seq_length):
-        raise NotImplementedError("CTC training is not functional in the reference (trainer.py:558-570)")
+        return "ctc"

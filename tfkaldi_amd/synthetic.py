@@ -8,6 +8,19 @@ import numpy as np
 from .processing import ark
 
 
+def write_text_targets(directory, num_utt, words_per_utt=(1, 4), seed=99):
+    """text.txt with "<utt> WORD WORD ..." lines (upper-case words over a small vocabulary) for the utterance ids
+    of write_corpus; returns the path"""
+    rng = np.random.default_rng(seed)
+    vocab = ["THE", "CAT", "SAT", "ON", "A", "MAT", "DOG", "RAN", ",COMMA", ".PERIOD", "IT'S", "<NOISE>"]
+    path = os.path.join(directory, "text.txt")
+    with open(path, "w") as fid:
+        for i in range(num_utt):
+            n = int(rng.integers(words_per_utt[0], words_per_utt[1] + 1))
+            fid.write("utt%06d %s\n" % (i, " ".join(vocab[int(k)] for k in rng.integers(0, len(vocab), size=n))))
+    return path
+
+
 def write_corpus(directory, num_utt, num_pdfs, feat_dim=40, utt_len=64, num_speakers=4, feat_seed=1234,
                  ali_seed=4321, lengths=None):
     """feats.scp/.ark (float32 N(0,1)*2+5), cmvn.scp/.ark (per-speaker stats), utt2spk, maxlength and
