@@ -258,3 +258,25 @@ def test_data_parallel_equivalence(gpu):
     assert sum(c for _, c in buckets) == n  # the buckets tile the reduce region exactly
     for e in ranks + [serial]:
         e.close()
+
+
+def test_narrow_net_many_frames_split_k(gpu):
+    """3000 frames through a 48-unit net: the weight-gradient GEMMs have ONE output tile and a long contraction, so
+    they run split-K (gemm_f32.h): partial results per chunk, summed in chunk order.  First micro-batch overwrites
+    G, the second accumulates on top; two engines give identical bits."""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(29)
+    kw = dict(input_dim=24, num_layers=2, num_units=48, output_dim=20, nonlin="relu", batch_norm=True,
+              init_learning_rate=1e-3, num_steps=100, max_frames=3000)
+    eng, oracle = make_pair(rng, **kw)
+    twin, _ = make_pair(np.random.default_rng(29), **kw)
+    for T in (3000, 2500):
+        X, y = batch(rng, T, 24, 20)
+        eng.accumulate(X, y)
+        twin.accumulate(X, y)
+        oracle.accumulate(X, y)
+        _check_grads(eng, oracle)
+    a, b = engine_grads(eng), engine_grads(twin)
+    assert all((a[k] == b[k]).all() for k in a)
+    assert_close("avg loss", eng.apply(), oracle.apply(), 2e-5, 0)
+    eng.close(); twin.close()

@@ -125,6 +125,8 @@ struct tfk_engine {
   int seg_cap = 0;
   float* ws_stats = nullptr;  // [2, ceil(cap / 64), ldH] per-tile BN statistics from the forward GEMM epilogue
   float* ws_bwd = nullptr;  // per-layer partial column sums of backward (finalised by one kernel)
+  float* ws_splitk = nullptr;  // split-K partials of narrow weight-gradient GEMMs (grown on demand)
+  size_t ws_splitk_floats = 0;
   size_t ws_bwd_stride = 0;
   float* prior = nullptr;
   bool have_prior = false;
@@ -361,6 +363,19 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   g.act_nonlin = act ? act->nonlin : 0;
   g.stats_stride = kMaxRowSplits;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  if (layout == GEMM_TN && K >= 2048 && (size_t)M * N < ((size_t)1 << 20)) {
+    // narrow layer, many frames: the weight gradient may run split-K (gemm_f32.h) -- partials of up to 32 chunks
+    const size_t need = (size_t)32 * M * ldc;
+    if (need > e->ws_splitk_floats) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (e->ws_splitk) HIPCHK(hipFree(e->ws_splitk));
+      e->ws_splitk = nullptr;
+      HIPCHK(hipMalloc((void**)&e->ws_splitk, need * sizeof(float)));
+      e->ws_splitk_floats = need;
+    }
+    g.splitk_ws = e->ws_splitk;
+    g.splitk_ws_floats = e->ws_splitk_floats;
+  }
   const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
   ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)), st);
   const int rc = gemm_f32(layout, g, cfg, st);
@@ -1091,6 +1106,7 @@ int tfk_destroy(tfk_engine* e) {
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
   if (e->Wb) hipFree(e->Wb);
+  if (e->ws_splitk) hipFree(e->ws_splitk);
   for (void* p : {(void*)e->ctc_seg, (void*)e->ctc_lab_off, (void*)e->ctc_lab, (void*)e->ctc_lp, (void*)e->ctc_ab,
                   (void*)e->ctc_utt_loss, (void*)e->ctc_lse})
     if (p) hipFree(p);

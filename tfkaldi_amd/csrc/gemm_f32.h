@@ -48,6 +48,14 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldb, ldc;
   int epi;
+  // Split-K (optional; epi 0 / EPI_ACCUM only): when the output has too few tiles to fill the chip and K is long
+  // -- the weight gradient of a narrow layer over many frames -- the contraction is cut into chunks that run as
+  // extra blocks into partial results in `splitk_ws`, summed in chunk order by a second kernel (deterministic).
+  float* splitk_ws = nullptr;
+  size_t splitk_ws_floats = 0;
+  // filled by gemm_f32() for the kernel
+  int nsplit = 1, ksplit = 0;
+  size_t split_stride = 0;
 };
 
 // Tile configurations (compile-time instantiated); index = config id.

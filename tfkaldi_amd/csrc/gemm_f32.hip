@@ -156,6 +156,13 @@ template <class T, int EPI>
 __global__ void __launch_bounds__(T::NT)
 gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (p.nsplit > 1) {  // split-K: this block contracts k in [k0, k0 + ksplit) into its own partial result
+    const int k0 = blockIdx.y * p.ksplit;
+    p.A += T::A_KC ? (size_t)k0 : (size_t)k0 * p.lda;
+    p.B += T::B_KC ? (size_t)k0 : (size_t)k0 * p.ldb;
+    p.K = min(p.ksplit, p.K - k0);
+    p.C += (size_t)blockIdx.y * p.split_stride;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -542,7 +549,7 @@ int launch(const GemmArgs& p, hipStream_t stream) {
   // block sets the kernel time.
   int lds = T::LDS_BYTES;
   const int tiles = tiles_m * tiles_n;
-  const int per_cu = (tiles + 255) / 256;  // blocks per CU of an even spread
+  const int per_cu = (tiles * p.nsplit + 255) / 256;  // blocks per CU of an even spread
   if (g_even_spread && per_cu <= 4) {
     const int cap = (160 * 1024 / per_cu) & ~1023;
     const int floor_next = (160 * 1024 / (per_cu + 1) / 1024 + 1) * 1024;  // just too big for per_cu + 1 blocks
@@ -550,7 +557,7 @@ int launch(const GemmArgs& p, hipStream_t stream) {
   }
   if (g_min_lds > lds) lds = g_min_lds;
   if (lds > 160 * 1024) lds = 160 * 1024;
-  hipLaunchKernelGGL((gemm_f32_kernel<T, EPI>), dim3(tiles), dim3(T::NT), lds, stream, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_f32_kernel<T, EPI>), dim3(tiles, p.nsplit), dim3(T::NT), lds, stream, p, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 
@@ -605,6 +612,24 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
   return (int)hipErrorInvalidValue;
 }
 
+// C (+)= sum over the split-K partials, in chunk order
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t stride, float* __restrict__ C, size_t n4,
+                     int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+  for (int k = 1; k < nsplit; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + 4 * i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (accumulate) {
+    const float4 c = *reinterpret_cast<const float4*>(C + 4 * i);
+    s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+  }
+  *reinterpret_cast<float4*>(C + 4 * i) = s;
+}
+
 int g_forced_cfg = -2;  // -2: env not read yet; -1: heuristic
 
 }  // namespace
@@ -642,6 +667,29 @@ int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t strea
     const long a_rows = layout == GEMM_TN ? args.K : args.M;
     const long b_rows = layout == GEMM_NT ? args.N : args.K;
     if (a_rows * args.lda * 4 >= (1L << 31) || b_rows * args.ldb * 4 >= (1L << 31)) return (int)hipErrorInvalidValue;
+  }
+  // split-K for chip-starved, long contractions (only the plain / accumulating epilogues)
+  const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
+  const int tiles = ((args.M + bm - 1) / bm) * ((args.N + bn - 1) / bn);
+  if (args.splitk_ws && (args.epi == 0 || args.epi == EPI_ACCUM) && tiles < 256 && args.K >= 2048) {
+    int nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > args.K / 512) nsplit = args.K / 512;
+    if (nsplit > 32) nsplit = 32;
+    const size_t stride = (size_t)args.M * args.ldc;
+    if (nsplit > 1 && stride * nsplit <= args.splitk_ws_floats) {
+      GemmArgs q = args;
+      q.ksplit = ((args.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+      q.nsplit = (args.K + q.ksplit - 1) / q.ksplit;
+      q.split_stride = stride;
+      q.C = args.splitk_ws;
+      q.epi = 0;
+      const int rc = dispatch_epi(layout, q, cfg, stream);
+      if (rc != 0) return rc;
+      const size_t n4 = stride / 4;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, args.splitk_ws,
+                         q.nsplit, stride, args.C, n4, (args.epi & EPI_ACCUM) ? 1 : 0);
+      return (int)hipGetLastError();
+    }
   }
   return dispatch_epi(layout, args, cfg, stream);
 }
