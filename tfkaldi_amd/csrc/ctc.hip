@@ -3,7 +3,7 @@
 //   ctc_softmax      one block per frame: softmax row (kept for the gradient) and its log-sum-exp
 //   ctc_gather       log p_t(state) for the 2S+1 states of the frame's utterance, contiguous per frame
 //   ctc_alpha_beta   ONE WAVE PER UTTERANCE: every lane owns R consecutive states in registers, the s-1 / s-2
-//                    neighbours of a lane's first states come from the previous lane by DPP shuffles -- the time
+//                    neighbours of a lane's first states come from the previous lane by DPP wave shifts -- the time
 //                    recursion runs without LDS and without barriers; alpha rows go to HBM, the backward sweep
 //                    turns them into state posteriors in place
 //   ctc_grad         one wave per frame: folds the state posteriors onto the classes in LABEL ORDER (repeated labels
@@ -18,13 +18,22 @@ namespace {
 
 constexpr float NEG = -1e30f;
 
-__device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  return m + logf(expf(a - m) + expf(b - m));
-}
+// log(e^a + e^b + e^c) on the hardware exp2 / log2 units: the arguments are <= 0 and the sum lies in [1, 3], where
+// v_exp_f32 / v_log_f32 are good to ~1 ulp -- the recursion is a chain of Tn dependent evaluations of this on ONE
+// wave, so its instruction count is the kernel's run time
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(a, fmaxf(b, c));
-  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+// value of the previous / next lane (wave64 shift by one lane as a DPP move, no LDS round trip); the lane shifted
+// in at the end gets `fill`
+__device__ __forceinline__ float lane_prev(float v, float fill, int lane) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  return lane == 0 ? fill : __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float lane_next(float v, float fill, int lane) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  return lane == 63 ? fill : __builtin_bit_cast(float, r);
 }
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 
@@ -99,30 +108,48 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
   }
   const float* lp = b.lp + (size_t)r0 * b.sext + s0;
   float* ab = b.ab + (size_t)r0 * b.sext + s0;
-  float a[R], cur[R], nxt[R];
+  // The recursion is a chain of Tn dependent steps of ~100 cycles each, while a row of lp takes ~1000 cycles to
+  // arrive: PFD rows are kept in flight in a register ring.  The ring is advanced with clamped row indices instead
+  // of guards (a surplus step re-does the last row with the state held), so the unrolled body has no branches and
+  // the compiler's wait counts stay exact.
+  constexpr int PFD = 8;
+  float a[R], pre[PFD][R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    cur[r] = lp[r];
-    a[r] = (s0 + r < 2 && s0 + r < n) ? cur[r] : NEG;
+    const float v = lp[r];
+    a[r] = (s0 + r < 2 && s0 + r < n) ? v : NEG;
     ab[r] = a[r];
   }
-  for (int t = 1; t < Tn; ++t) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) nxt[r] = lp[(size_t)t * b.sext + r];  // in flight under the shuffles below
-    float up1 = __shfl_up(a[R - 1], 1), up2 = __shfl_up(R >= 2 ? a[R - 2] : a[0], R >= 2 ? 1 : 2);
-    if (lane == 0) up1 = NEG;
-    if (lane < (R >= 2 ? 1 : 2)) up2 = NEG;
-    float na[R];
+  for (int j = 0; j < PFD; ++j)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float p1 = r >= 1 ? a[r - 1] : up1;
-      const float p2 = r >= 2 ? a[r - 2] : (r == 1 ? up1 : up2);
-      na[r] = (s0 + r < n) ? lse3(a[r], p1, skip_in[r] ? p2 : NEG) + nxt[r] : NEG;
-    }
+    for (int r = 0; r < R; ++r) pre[j][r] = lp[(size_t)min(1 + j, Tn - 1) * b.sext + r];
+  for (int t0 = 1; t0 < Tn; t0 += PFD) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      a[r] = na[r];
-      ab[(size_t)t * b.sext + r] = a[r];
+    for (int j = 0; j < PFD; ++j) {
+      const int t = t0 + j;
+      const bool live = t < Tn;
+      const int row = min(t, Tn - 1);
+      float cur[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        cur[r] = pre[j][r];
+        pre[j][r] = lp[(size_t)min(t + PFD, Tn - 1) * b.sext + r];
+      }
+      const float up1 = lane_prev(a[R - 1], NEG, lane), up2 = lane_prev(a[R - 2], NEG, lane);
+      float na[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float p1 = r >= 1 ? a[r - 1] : up1;
+        const float p2 = r >= 2 ? a[r - 2] : (r == 1 ? up1 : up2);
+        const float v = (s0 + r < n) ? lse3(a[r], p1, skip_in[r] ? p2 : NEG) + cur[r] : NEG;
+        na[r] = live ? v : a[r];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        a[r] = na[r];
+        ab[(size_t)row * b.sext + r] = a[r];
+      }
     }
   }
   // log p(labels) = alpha_T(n-1) (+) alpha_T(n-2)
@@ -140,37 +167,60 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
   const bool feasible = log_z > -1e29f;
   if (lane == 0) b.utt_loss[u] = feasible ? -log_z : INFINITY;
   if (!with_grad) return;
-  // backward sweep: beta in registers, alpha row t read back and replaced by the state posterior
+  // backward sweep: beta in registers, alpha row t read back and replaced by the state posterior; the same ring
   float bt[R];
+  {
+    float cur[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int s = s0 + r;
-    cur[r] = lp[(size_t)(Tn - 1) * b.sext + r];
-    bt[r] = (s == n - 1 || s == n - 2) ? cur[r] : NEG;
-    const float al = ab[(size_t)(Tn - 1) * b.sext + r];
-    ab[(size_t)(Tn - 1) * b.sext + r] = (feasible && s < n) ? expf(al + bt[r] - cur[r] - log_z) : 0.f;
+    for (int r = 0; r < R; ++r) {
+      const int s = s0 + r;
+      cur[r] = lp[(size_t)(Tn - 1) * b.sext + r];
+      bt[r] = (s == n - 1 || s == n - 2) ? cur[r] : NEG;
+      const float al = ab[(size_t)(Tn - 1) * b.sext + r];
+      ab[(size_t)(Tn - 1) * b.sext + r] = (feasible && s < n) ? expf(al + bt[r] - cur[r] - log_z) : 0.f;
+    }
   }
-  for (int t = Tn - 2; t >= 0; --t) {
-    float al[R];
+  float prel[PFD][R], prea[PFD][R];
+#pragma unroll
+  for (int j = 0; j < PFD; ++j)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      nxt[r] = lp[(size_t)t * b.sext + r];
-      al[r] = ab[(size_t)t * b.sext + r];
+      const size_t row = (size_t)max(Tn - 2 - j, 0) * b.sext + r;
+      prel[j][r] = lp[row];
+      prea[j][r] = ab[row];
     }
-    float dn1 = __shfl_down(bt[0], 1), dn2 = __shfl_down(R >= 2 ? bt[1] : bt[0], R >= 2 ? 1 : 2);
-    if (lane == 63) dn1 = NEG;
-    if (lane > 63 - (R >= 2 ? 1 : 2)) dn2 = NEG;
-    float nb[R];
+  for (int t0 = Tn - 2; t0 >= 0; t0 -= PFD) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float q1 = r + 1 < R ? bt[r + 1] : dn1;
-      const float q2 = r + 2 < R ? bt[r + 2] : (r + 1 < R ? dn1 : (R >= 2 ? dn2 : dn2));
-      nb[r] = (s0 + r < n) ? lse3(bt[r], q1, skip_out[r] ? q2 : NEG) + nxt[r] : NEG;
-    }
+    for (int j = 0; j < PFD; ++j) {
+      const int t = t0 - j;
+      const bool live = t >= 0;
+      float cur[R], al[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      bt[r] = nb[r];
-      ab[(size_t)t * b.sext + r] = (feasible && s0 + r < n) ? expf(al[r] + bt[r] - nxt[r] - log_z) : 0.f;
+      for (int r = 0; r < R; ++r) {
+        cur[r] = prel[j][r];
+        al[r] = prea[j][r];
+        // rows below 0 are clamped to row 0, which a surplus step must not read after it was rewritten: the ring
+        // slot of a dead step is never consumed again, so the clamped value is simply unused
+        const size_t row = (size_t)max(t - PFD, 0) * b.sext + r;
+        prel[j][r] = lp[row];
+        prea[j][r] = ab[row];
+      }
+      const float dn1 = lane_next(bt[0], NEG, lane), dn2 = lane_next(bt[1], NEG, lane);
+      float nb[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float q1 = r + 1 < R ? bt[r + 1] : dn1;
+        const float q2 = r + 2 < R ? bt[r + 2] : (r + 1 < R ? dn1 : dn2);
+        const float v = (s0 + r < n) ? lse3(bt[r], q1, skip_out[r] ? q2 : NEG) + cur[r] : NEG;
+        nb[r] = live ? v : bt[r];
+      }
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          bt[r] = nb[r];
+          ab[(size_t)t * b.sext + r] = (feasible && s0 + r < n) ? expf(al[r] + bt[r] - cur[r] - log_z) : 0.f;
+        }
+      }
     }
   }
 }
