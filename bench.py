@@ -84,7 +84,7 @@ def main():
 
     import torch
     from tfkaldi_amd import _lib
-    from tfkaldi_amd.dataparallel import DataParallel, init_from_env
+    from tfkaldi_amd.dataparallel import BucketReducer, DataParallel, init_from_env
     from tfkaldi_amd.engine import Engine
 
     rank, world, local_rank = init_from_env()
@@ -113,23 +113,16 @@ def main():
 
     if dp.enabled:
         import torch.distributed as dist
-        view, buckets = eng.reduce_view(), eng.buckets()
-        handles = []
-
-        def on_bucket(b):
-            off, n = buckets[b]
-            with torch.cuda.stream(eng.torch_stream):
-                handles.append(dist.all_reduce(view[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
-        eng.set_bucket_callback(on_bucket)
+        # the product's exchange step: per-layer bucket announcements from backward, coalesced into a few large
+        # asynchronous all-reduces (tfkaldi_amd/dataparallel.py)
+        reducer = BucketReducer(eng, stream_ctx=lambda: torch.cuda.stream(eng.torch_stream))
+        eng.set_bucket_callback(reducer.on_bucket)
         eng.set_later_microbatches(world - 1 - rank)
 
     def step():
         eng.accumulate_device(dX.data_ptr(), F, dy.data_ptr(), T, last=True)
         if dp.enabled:
-            with torch.cuda.stream(eng.torch_stream):
-                for h in handles:
-                    h.wait()
-            del handles[:]
+            reducer.finish()
         return eng.apply()
 
     def fence():

@@ -275,3 +275,52 @@ def test_feature_reader_device_modes_defer_exactly(tmp_path):
     assert table.shape == (2, 2, 6) and (table[0, 0] == 0).all() and (table[0, 1] == 1).all()
     assert (table[1] == seen[1][1].cmvn).all()
     assert feature_reader.cmvn_table([s[0] for s in seen]) is None
+
+
+def test_bucket_reducer_coalesces_adjacent_announcements():
+    """DataParallel's BucketReducer: the engine announces W_L .. W_0 (adjacent, descending) and then the tail that
+    lies behind W_L; announcements are merged until a collective carries min_bytes, every float of the reduce
+    region is reduced exactly once, and a non-adjacent announcement starts a new collective."""
+    from tfkaldi_amd.dataparallel import BucketReducer
+
+    class FakeHandle(object):
+        def wait(self):
+            pass
+
+    class FakeDist(object):
+        class ReduceOp(object):
+            SUM = "sum"
+
+        def __init__(self):
+            self.calls = []
+
+        def all_reduce(self, view, op, group, async_op):
+            self.calls.append(view)
+            return FakeHandle()
+
+    class FakeEngine(object):
+        # arena: W_0 (3 units) | W_1 .. W_3 (16 each) | vectors + scalars + E (1); bucket b = W_{L-b}, last = the tail
+        sizes = [3, 16, 16, 16]
+
+        def buckets(self):
+            offs = np.concatenate([[0], np.cumsum(self.sizes)])
+            w = [(int(offs[l]) * 1024, self.sizes[l] * 1024) for l in range(4)]
+            return w[::-1] + [(int(offs[4]) * 1024, 1024)]
+
+        def reduce_view(self):
+            return np.zeros(52 * 1024, dtype=np.float32)
+
+    for min_bytes, want in ((1, [16, 16, 16, 3, 1]), (20 * 4096, [32, 19, 1]), (40 * 4096, [48, 3, 1]),
+                            (1 << 30, [52])):  # the tail is adjacent to the end of W_L: one collective
+        red = BucketReducer.__new__(BucketReducer)
+        BucketReducer.__init__(red, FakeEngine(), min_bytes=min_bytes)
+        red._dist = FakeDist()
+        for b in range(5):
+            red.on_bucket(b)
+        launched = red.finish()
+        assert [n // 1024 for _, n in launched] == want, (min_bytes, launched)
+        covered = np.zeros(52 * 1024, dtype=np.int32)
+        for off, n in launched:
+            covered[off:off + n] += 1
+        assert (covered == 1).all()
+        assert [v.size for v in red._dist.calls] == [n for _, n in launched]

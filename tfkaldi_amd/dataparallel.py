@@ -97,6 +97,65 @@ def partition(num_items, world):
     return out
 
 
+class BucketReducer(object):
+    """Turns the engine's bucket announcements (one per weight matrix, in backward order, then the vector / scalar
+    tail) into asynchronous SUM all-reduces launched while backward is still being enqueued.
+
+    Consecutive announcements are adjacent in the reduce region (the arena is W_0 .. W_L and they arrive as
+    W_L .. W_0), so they are COALESCED until a collective carries at least `min_bytes`: xGMI is point-to-point and a
+    ring / tree step is bound by one link, so a few large collectives reach a much higher bus bandwidth than one
+    per 16 MB layer, at the price of starting a little later.  TFK_DP_BUCKET_MB (default 48) sets the size."""
+
+    def __init__(self, engine, group=None, min_bytes=None, stream_ctx=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.view, self.buckets = engine.reduce_view(), engine.buckets()
+        if min_bytes is None:
+            min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", "48")) * (1 << 20))
+        self.min_floats = max(1, min_bytes // 4)
+        self._stream_ctx = stream_ctx or contextlib.nullcontext
+        self.handles, self.errors = [], []
+        self._lo = self._hi = None
+        self.launched = []  # (offset, floats) of every collective of the current step (tests / diagnostics)
+
+    def _launch(self):
+        if self._lo is None:
+            return
+        lo, hi, self._lo, self._hi = self._lo, self._hi, None, None
+        with self._stream_ctx():
+            self.handles.append(self._dist.all_reduce(self.view[lo:hi], op=self._dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+        self.launched.append((lo, hi - lo))
+
+    def on_bucket(self, b):
+        try:  # exceptions cannot propagate through the C callback
+            off, n = self.buckets[b]
+            if self._lo is not None and off + n == self._lo:
+                self._lo = off
+            elif self._lo is not None and off == self._hi:
+                self._hi = off + n
+            else:
+                self._launch()
+                self._lo, self._hi = off, off + n
+            if self._hi - self._lo >= self.min_floats:
+                self._launch()
+        except Exception as exc:  # noqa: BLE001
+            self.errors.append(exc)
+
+    def finish(self):
+        """launch what is still pending, make the engine's stream wait for every collective of the step"""
+        self._launch()
+        if self.errors:
+            raise self.errors[0]
+        with self._stream_ctx():
+            for h in self.handles:
+                h.wait()
+        del self.handles[:]
+        launched, self.launched = self.launched, []
+        return launched
+
+
 class DataParallel(object):
     """Shards the micro-batches of one optimiser step over the ranks of a process group."""
 
@@ -135,33 +194,18 @@ class DataParallel(object):
         start, end = partition(len(microbatches), self.world)[self.rank]
         mine = microbatches[start:end]
         engine.set_later_microbatches(len(microbatches) - end)
-        view, buckets = engine.reduce_view(), engine.buckets()
-        handles, errors = [], []
-
-        def on_bucket(b):
-            try:  # exceptions cannot propagate through the C callback
-                off, n = buckets[b]
-                with self._stream_ctx(engine):
-                    handles.append(dist.all_reduce(view[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
-                                                   async_op=True))
-            except Exception as exc:  # noqa: BLE001
-                errors.append(exc)
-
-        engine.set_bucket_callback(on_bucket)
+        reducer = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(engine))
+        engine.set_bucket_callback(reducer.on_bucket)
         try:
             for i, mb in enumerate(mine):
                 _accumulate(engine, mb, i == len(mine) - 1)
             if not mine:  # more ranks than micro-batches: contribute zeros
                 engine.zero_accumulators()
-                for b in range(len(buckets)):
-                    on_bucket(b)
+                for b in range(len(reducer.buckets)):
+                    reducer.on_bucket(b)
         finally:
             engine.set_bucket_callback(None)
-        if errors:
-            raise errors[0]
-        with self._stream_ctx(engine):
-            for h in handles:
-                h.wait()
+        self.last_collectives = reducer.finish()
         return engine.apply()
 
     def eval_step(self, engine, microbatches):
