@@ -79,8 +79,9 @@ def test_trainer_update_matches_oracle(gpu, tmp_path):
     with pytest.raises(ValueError):
         trainer.update([xs[0]], [ys[0][:-1]])
     trainer.close()
-    with pytest.raises(NotImplementedError):
-        CTCTrainer(dnn, F, 30, 30, 1e-3, 1.0, 10, 2)
+    ctc = CTCTrainer(dnn, F, 30, 30, 1e-3, 1.0, 10, 2)  # the CTC loss has its own tests (test_gpu_ctc.py)
+    assert ctc.loss_kind == "ctc"
+    ctc.close()
 
 
 def test_nnet_train_and_decode(gpu, tmp_path, capsys):
