@@ -122,7 +122,7 @@ def main():
     def step():
         eng.accumulate_device(dX.data_ptr(), F, dy.data_ptr(), T, last=True)
         if dp.enabled:
-            reducer.finish()
+            return reducer.finish_and_apply(eng)  # Adam per reduced span, behind the collectives still in flight
         return eng.apply()
 
     def fence():

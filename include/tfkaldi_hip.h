@@ -198,8 +198,10 @@ int tfk_posteriors_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t N
 /* The reduce region is one contiguous fp32 span of the state: [ G (all layers) | batch_loss,
  * num_frames, num_microbatches, pad | BN moving-average increments ].  A SUM all-reduce of it across
  * ranks before tfk_apply makes B/U serial micro-batches on one GPU (trainer.py:310-332) and
- * one micro-batch on each of B/U GPUs the same computation.  Buckets: b in [0, L] is the
- * gradient span of layer L - b (the order backward produces them), bucket L + 1 the scalars + BN tail. */
+ * one micro-batch on each of B/U GPUs the same computation.  Buckets: b in [0, L] is the weight-gradient span of
+ * layer L - b (the order backward produces them), L + 1 every bias / beta gradient, L + 2 the scalars + the BN
+ * increments.  With TFK_LAST_MICROBATCH they are announced in the order L + 2 (right after the loss, before
+ * backward), 0 .. L, L + 1. */
 int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
 /* `init_grads` / `init_loss` / `init_num_frames` (trainer.py:350-352) done eagerly: writes zeros over the whole
  * reduce region.  tfk_apply re-initialises lazily (the next step's first micro-batch overwrites G), so a rank
@@ -213,6 +215,15 @@ int tfk_num_buckets(tfk_engine* e, int* n);
  * remaining backward keeps the GPU busy. */
 typedef void (*tfk_bucket_fn)(void* user, int bucket);
 int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user);
+
+/* tfk_apply in three parts, for a host that overlaps the optimiser with its collectives: tfk_apply_begin needs
+ * bucket L + 2 reduced (learning rate, BN moving averages, loss hand-over); tfk_apply_span runs mean -> clip ->
+ * Adam on the parameters [offset, offset + n) of the arena (same offsets as the reduce region), callable as soon as
+ * THAT span of G is reduced; tfk_apply_end returns the average loss and re-initialises the accumulators.
+ * tfk_apply == begin, span(0, P), end. */
+int tfk_apply_begin(tfk_engine* e);
+int tfk_apply_span(tfk_engine* e, size_t offset_floats, size_t num_floats);
+int tfk_apply_end(tfk_engine* e, float* average_loss);
 
 /* Number of micro-batches of this optimiser step that ranks AFTER this one process: weights this
  * rank's BN moving-average increment by bn_decay^later so the all-reduced result equals the

@@ -229,7 +229,10 @@ def test_data_parallel_equivalence(gpu):
             eng.set_later_microbatches(k - 1 - r)
             eng.set_bucket_callback(lambda b, r=r: fired.append((r, b)))
             eng.accumulate(mbs[r][0], mbs[r][1], last=True)
-        assert [b for (r, b) in fired if r == 0] == list(range(ranks[0].L + 2))  # reverse-layer bucket order
+        # announcement order: scalars + BN increments first (final after the loss), weights in reverse-layer order,
+        # then the bias / beta gradients
+        L = ranks[0].L
+        assert [b for (r, b) in fired if r == 0] == [L + 2] + list(range(L + 1)) + [L + 1]
         for eng in ranks:
             eng.synchronize()
         total = sum(eng.reduce_view().clone() for eng in ranks)

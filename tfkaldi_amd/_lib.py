@@ -80,6 +80,9 @@ SYMBOLS = {
     "tfk_zero_accumulators": (c_int, [_E]),
     "tfk_reduce_bucket": (c_int, [_E, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "tfk_num_buckets": (c_int, [_E, POINTER(c_int)]),
+    "tfk_apply_begin": (c_int, [_E]),
+    "tfk_apply_span": (c_int, [_E, c_size_t, c_size_t]),
+    "tfk_apply_end": (c_int, [_E, POINTER(c_float)]),
     "tfk_set_bucket_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
     "tfk_set_later_microbatches": (c_int, [_E, c_int32]),
     "tfk_synchronize": (c_int, [_E]),

@@ -138,6 +138,8 @@ struct tfk_engine {
   size_t h_post_floats = 0;
   float* h_scalars = nullptr;    // mapped pinned memory: kernels write the step's (loss, frames, #mb) here
   float* h_scalars_dev = nullptr;
+  bool apply_open = false, apply_direct = false;  // between tfk_apply_begin and tfk_apply_end
+  float cur_lr_t = 0.f;
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
 
@@ -1052,14 +1054,18 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   if (train) {
     const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
     CHK(wait_adam_done(e));  // (forward already waited; kept for call orders that skip it)
-    CHK(backward(e, Xd, ld, T, nact, call, fire));
     if (fire) {
+      // loss, frame count and the BN moving-average increments of the step are final once the last micro-batch's
+      // forward + loss have run: their (tiny) bucket is announced FIRST, so that its all-reduce is long done when
+      // the optimiser needs the frame count
       if (e->cfg.batch_norm && e->later_mb > 0) {
         ProfScope ps(e, KF_MISC, 0, 8.0 * e->E);
         scale_inplace(e->stream, e->p_ema(), e->E, (float)pow((double)e->bn_decay, (double)e->later_mb));
       }
-      if (e->cb) e->cb(e->cb_user, e->L + 1);
+      if (e->cb) e->cb(e->cb_user, e->L + 2);
     }
+    CHK(backward(e, Xd, ld, T, nact, call, fire));
+    if (fire && e->cb) e->cb(e->cb_user, e->L + 1);  // bias / beta gradients: finalised by backward's last kernel
     e->grads_fresh = false;
   }
   HIPCHK(hipGetLastError());
@@ -1233,18 +1239,90 @@ int tfk_eval_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t 
   return train_or_eval(e, X, ldx, nullptr, T, flags & ~TFK_LAST_MICROBATCH, 0, nullptr, &c);
 }
 
-int tfk_apply(tfk_engine* e, float* average_loss) {
-  if (!e) return fail(-1, "engine is NULL");
-  HIPCHK(hipSetDevice(e->cfg.device));
+// The optimiser step in three parts, so that a data-parallel host can run Adam on each span of parameters as soon
+// as ITS gradients are reduced while later collectives are still in flight:
+//   begin  needs the reduced scalars / BN increments: learning rate, moving averages, loss hand-over
+//   span   mean -> clip -> Adam on parameters [offset, offset + n)
+//   end    waits for the loss on the host, re-initialises the accumulators (lazily), global_step += 1
+int apply_begin(tfk_engine* e) {
+  if (e->apply_open) return fail(-1, "tfk_apply_begin called twice without tfk_apply_end");
   const double lr = current_lr(e);
   e->adam_t += 1;
   // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); w -= lr_t * m / (sqrt(v) + eps)
   const double t = (double)e->adam_t;
-  const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
+  e->cur_lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
   if (e->grads_fresh)  // no micro-batch since the last apply: materialise the zeros Adam is about to read
     HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
   CHK(settle_scalars(e));
-  // main stream: BN moving averages + re-initialisation of their increments + the loss hand-over, one launch
+  // BN moving averages + re-initialisation of their increments + the loss hand-over, one launch
+  {
+    ProfScope ps(e, KF_EMA, 0, 16.0 * e->E);
+    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev);
+  }
+  HIPCHK(hipEventRecord(e->ev_loss, e->stream));
+  e->apply_direct = e->bf16 && e->wb_aligned && !e->shadow_dirty;
+  e->apply_open = true;
+  return 0;
+}
+int apply_span(tfk_engine* e, size_t off, size_t n) {
+  if (!e->apply_open) return fail(-1, "tfk_apply_span outside tfk_apply_begin / tfk_apply_end");
+  if (off >= e->P || n == 0) return 0;
+  if (off + n > e->P) n = e->P - off;
+  if ((off | n) & 3) return fail(-1, "parameter span [%zu, +%zu) is not a multiple of 4 floats", off, n);
+  const size_t w_end = e->lay[0].b_off;  // the weight matrices (and their bf16 shadow) come first
+  const size_t n_wb = (e->apply_direct && off < w_end) ? ((off + n < w_end ? off + n : w_end) - off) : 0;
+  ProfScope ps(e, KF_ADAM, 0, 28.0 * n);
+  adam_apply(e->stream, e->p_param() + off, e->p_grad() + off, e->p_m() + off, e->p_v() + off, n, e->p_scalars(),
+             e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0, n_wb ? e->Wb + off : nullptr, n_wb);
+  return 0;
+}
+int apply_end(tfk_engine* e, float* average_loss) {
+  if (!e->apply_open) return fail(-1, "tfk_apply_end without tfk_apply_begin");
+  e->apply_open = false;
+  if (!e->apply_direct) e->shadow_dirty = true;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventSynchronize(e->ev_loss));
+  e->adam_pending = false;
+  e->grads_fresh = true;
+  e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
+  e->global_step += 1;
+  if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
+  return 0;
+}
+
+int tfk_apply_begin(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (e->overlap) return fail(-1, "the split optimiser step is not available with TFK_OVERLAP_ADAM");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  return apply_begin(e);
+}
+int tfk_apply_span(tfk_engine* e, size_t offset_floats, size_t num_floats) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  return apply_span(e, offset_floats, num_floats);
+}
+int tfk_apply_end(tfk_engine* e, float* average_loss) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  return apply_end(e, average_loss);
+}
+
+int tfk_apply(tfk_engine* e, float* average_loss) {
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (!e->overlap) {  // one Adam launch over the whole parameter arena, in stream order
+    CHK(apply_begin(e));
+    CHK(apply_span(e, 0, e->P));
+    return apply_end(e, average_loss);
+  }
+  if (e->apply_open) return fail(-1, "tfk_apply inside tfk_apply_begin / tfk_apply_end");
+  const double lr = current_lr(e);
+  e->adam_t += 1;
+  const double t = (double)e->adam_t;
+  const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
+  if (e->grads_fresh)
+    HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
+  CHK(settle_scalars(e));
   {
     ProfScope ps(e, KF_EMA, 0, 16.0 * e->E);
     step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev);
@@ -1253,25 +1331,8 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   // Adam: vectors first, then one launch per weight matrix in FORWARD order, each followed by an event the
   // next step's forward waits on -- on the side stream, so that the forward GEMMs (matrix-bound) and the
   // optimiser (HBM-bound) overlap.
-  hipStream_t sa = e->overlap ? e->side : e->stream;
-  const int grid_cap = e->overlap ? e->adam_blocks : 0;
-  if (!e->overlap) {  // one launch over the whole parameter arena, in stream order
-    {
-      ProfScope ps(e, KF_ADAM, 0, 28.0 * e->P);
-      const bool direct = e->bf16 && e->wb_aligned && !e->shadow_dirty;
-      adam_apply(e->stream, e->p_param(), e->p_grad(), e->p_m(), e->p_v(), e->P, e->p_scalars(), lr_t, e->b1, e->b2,
-                 e->adam_eps, 0, direct ? e->Wb : nullptr, direct ? e->lay[0].b_off : 0);
-      if (!direct) e->shadow_dirty = true;
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventSynchronize(e->ev_loss));
-    e->adam_pending = false;
-    e->grads_fresh = true;
-    e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
-    e->global_step += 1;
-    if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
-    return 0;
-  }
+  hipStream_t sa = e->side;
+  const int grid_cap = e->adam_blocks;
   e->shadow_dirty = true;  // the side-stream optimiser does not maintain the bf16 shadow
   HIPCHK(hipEventRecord(e->ev_fork, e->stream));
   HIPCHK(hipStreamWaitEvent(sa, e->ev_fork, 0));
@@ -1415,15 +1476,18 @@ int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {
 }
 int tfk_num_buckets(tfk_engine* e, int* n) {
   if (!e || !n) return fail(-1, "NULL argument");
-  *n = e->L + 2;
+  *n = e->L + 3;
   return 0;
 }
 int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* num_floats) {
   if (!e || !offset_floats || !num_floats) return fail(-1, "NULL argument");
-  if (bucket < 0 || bucket > e->L + 1) return fail(-1, "bucket %d out of range", bucket);
-  if (bucket == e->L + 1) {  // every bias / beta gradient + scalars + BN increments: contiguous
+  if (bucket < 0 || bucket > e->L + 2) return fail(-1, "bucket %d out of range", bucket);
+  if (bucket == e->L + 1) {  // every bias / beta gradient
     *offset_floats = e->lay[0].b_off;
-    *num_floats = (e->P - e->lay[0].b_off) + kScalarFloats + e->E;
+    *num_floats = e->P - e->lay[0].b_off;
+  } else if (bucket == e->L + 2) {  // batch_loss, num_frames, #micro-batches + the BN moving-average increments
+    *offset_floats = e->P;
+    *num_floats = kScalarFloats + e->E;
   } else {
     const LayerLayout& y = e->lay[e->L - bucket];
     *offset_floats = y.w_off;

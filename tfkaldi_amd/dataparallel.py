@@ -155,6 +155,37 @@ class BucketReducer(object):
         launched, self.launched = self.launched, []
         return launched
 
+    def finish_and_apply(self, engine):
+        """The optimiser step pipelined behind the collectives: the engine's stream waits for the (small, early)
+        collective that carries the scalars, starts the step (tfk_apply_begin), then waits for each remaining
+        collective in launch order and runs Adam on exactly that span of parameters (tfk_apply_span) while the later
+        collectives are still in flight.  Returns the average loss (tfk_apply_end)."""
+        if not hasattr(engine, "apply_span"):
+            self.finish()
+            return engine.apply()
+        self._launch()
+        if self.errors:
+            raise self.errors[0]
+        head_off, head_n = self.buckets[-1]
+        waited = set()
+
+        def wait(i):
+            if i not in waited:
+                with self._stream_ctx():
+                    self.handles[i].wait()
+                waited.add(i)
+
+        for i, (off, n) in enumerate(self.launched):
+            if off < head_off + head_n and off + n > head_off:
+                wait(i)
+        engine.apply_begin()
+        for i, (off, n) in enumerate(self.launched):
+            wait(i)
+            engine.apply_span(off, n)  # (spans beyond the parameter arena are clipped by the engine)
+        del self.handles[:]
+        self.last_launched, self.launched = self.launched, []
+        return engine.apply_end()
+
 
 class DataParallel(object):
     """Shards the micro-batches of one optimiser step over the ranks of a process group."""
@@ -199,14 +230,16 @@ class DataParallel(object):
         try:
             for i, mb in enumerate(mine):
                 _accumulate(engine, mb, i == len(mine) - 1)
-            if not mine:  # more ranks than micro-batches: contribute zeros
-                engine.zero_accumulators()
-                for b in range(len(reducer.buckets)):
+            if not mine:  # more ranks than micro-batches: contribute zeros, announced in the engine's own order
+                engine.zero_accumulators()  # (every rank must launch the same collectives in the same order)
+                order = engine.bucket_order() if hasattr(engine, "bucket_order") else range(len(reducer.buckets))
+                for b in order:
                     reducer.on_bucket(b)
         finally:
             engine.set_bucket_callback(None)
-        self.last_collectives = reducer.finish()
-        return engine.apply()
+        loss = reducer.finish_and_apply(engine)
+        self.last_collectives = getattr(reducer, "last_launched", None)
+        return loss
 
     def eval_step(self, engine, microbatches):
         """average validation loss (reference Trainer.evaluate); only the scalar tail is reduced"""

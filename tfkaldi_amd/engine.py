@@ -218,6 +218,18 @@ class Engine(object):
                                                labels.ctypes.data_as(c_void_p), label_lens.ctypes.data_as(c_void_p),
                                                0))
 
+    # ---- the optimiser step in parts (data parallel: Adam per reduced span, see dataparallel.BucketReducer) ----
+    def apply_begin(self):
+        check(self.lib.tfk_apply_begin(self._h))
+
+    def apply_span(self, offset_floats, num_floats):
+        check(self.lib.tfk_apply_span(self._h, int(offset_floats), int(num_floats)))
+
+    def apply_end(self):
+        loss = c_float()
+        check(self.lib.tfk_apply_end(self._h, byref(loss)))
+        return float(loss.value)
+
     def apply(self):
         loss = c_float()
         check(self.lib.tfk_apply(self._h, byref(loss)))
@@ -260,6 +272,12 @@ class Engine(object):
         ptr, n = c_void_p(), c_size_t()
         check(self.lib.tfk_reduce_region(self._h, byref(ptr), byref(n)))
         return ptr.value, n.value
+
+    def bucket_order(self):
+        """the order in which accumulate(last=True) announces the buckets: scalars + BN increments, the weight
+        matrices from the output layer down, the bias / beta gradients (include/tfkaldi_hip.h)"""
+        L = self.L
+        return [L + 2] + list(range(L + 1)) + [L + 1]
 
     def buckets(self):
         nb = c_int()
