@@ -22,11 +22,11 @@ def _data(num_mb, seed):
              rng.integers(0, KW["output_dim"], size=50 + 9 * i).astype(np.int32)) for i in range(num_mb)]
 
 
-def _engine(torch_state):
+def _engine(torch_state, dtype="float32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import make_pair
-    eng, _ = make_pair(np.random.default_rng(3), torch_state=torch_state, **KW)
+    eng, _ = make_pair(np.random.default_rng(3), torch_state=torch_state, compute_dtype=dtype, **KW)
     return eng
 
 
@@ -42,7 +42,7 @@ def _collect(eng, losses):
     return out
 
 
-def _worker(rank, world, port, num_mb, out_dir):
+def _worker(rank, world, port, num_mb, out_dir, dtype="float32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo")
     sys.path.insert(0, ROOT)
@@ -51,7 +51,7 @@ def _worker(rank, world, port, num_mb, out_dir):
     init_from_env()
     dp = DataParallel()
     assert dp.enabled
-    eng = _engine(torch_state=True)
+    eng = _engine(torch_state=True, dtype=dtype)
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **_collect(eng, losses))
@@ -59,12 +59,12 @@ def _worker(rank, world, port, num_mb, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_mb", [4, 3, 1])
-def test_two_ranks_match_serial(gpu, tmp_path, num_mb):
+@pytest.mark.parametrize("num_mb,dtype", [(4, "float32"), (3, "float32"), (1, "float32"), (3, "bfloat16")])
+def test_two_ranks_match_serial(gpu, tmp_path, num_mb, dtype):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, num_mb, str(tmp_path)), nprocs=2, join=True)
-    eng = _engine(torch_state=False)
+    mp.spawn(_worker, args=(2, port, num_mb, str(tmp_path), dtype), nprocs=2, join=True)
+    eng = _engine(torch_state=False, dtype=dtype)
     want = []
     for step in range(3):
         mbs = _data(num_mb, step)
