@@ -315,7 +315,7 @@ const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
 }
 // rows a GEMM's per-tile statistics (EPI_COLSTATS / EPI_DACT) are chunked by
 int gemm_chunk_rows(tfk_engine* e, GemmLayout layout, int M, int N, int K, int* cfg) {
-  if (e->bf16) { *cfg = -1; return kGemmBf16TileRows; }
+  if (e->bf16) { *cfg = -1; return gemm_bf16_tile_rows(M, N); }
   *cfg = gemm_f32_pick_config(layout, M, N, K);
   return gemm_f32_config_bm(*cfg);
 }

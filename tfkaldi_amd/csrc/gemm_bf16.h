@@ -37,6 +37,7 @@ struct GemmArgsB {
 // Returns hipError_t as int.
 int gemm_bf16(GemmLayout layout, const GemmArgsB& args, hipStream_t stream);
 
-constexpr int kGemmBf16TileRows = 64;  // rows of a block tile (= rows per EPI_COLSTATS / EPI_DACT chunk)
+// rows of the block tile gemm_bf16 uses for an [M, N] result (= rows per EPI_COLSTATS / EPI_DACT chunk)
+int gemm_bf16_tile_rows(int M, int N);
 
 }  // namespace tfk

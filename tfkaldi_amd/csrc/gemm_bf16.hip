@@ -3,7 +3,7 @@
 // Replaces the same reference lines as gemm_f32.hip (neuralNetworks/classifiers/layer.py:52 and its tf.gradients,
 // neuralNetworks/trainer.py:155) when the engine runs in mixed precision.
 //
-// One 64x64 output tile per 256-thread block (4 waves, 32x32 each), K in steps of 64:
+// One 64x64 or 128x64 output tile per 256-thread block (4 waves as 2 x 2), K in steps of 64:
 //   * global -> registers -> LDS through buffer resources (out-of-range chunks come back as zeros, no branches);
 //     three LDS stages fed from a register ring that keeps PF tiles of loads in flight;
 //   * a k-contiguous operand ([ext][k] in memory) is kept as rows of 64 + 8 bf16 (144 B: conflict-free
@@ -26,74 +26,80 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 64, NT = 256;
-constexpr int KC_LD = BK + 8;   // elements per LDS row of a k-contiguous operand
-constexpr int MC_LD = 64 + 32;  // elements per LDS row (one k) of a k-strided operand
+constexpr int BN = 64, BK = 64, NT = 256, PF = 4;  // PF: tiles of global loads in flight per block (even)
+constexpr int KC_LD = BK + 8;  // elements per LDS row of a k-contiguous operand (144 B)
 constexpr int kOOB = (int)0x80000000;
 constexpr int NUM_XCD = 8;
 
-template <bool KC>
+// EXT = tile extent along m (64 or 128) or n (64)
+template <bool KC, int EXT>
 struct Operand {
-  static constexpr int LD = KC ? KC_LD : MC_LD;
-  static constexpr int SZ = 64 * LD;  // elements per stage (64 rows of ext, or 64 rows of k)
+  static constexpr int LD = KC ? KC_LD : EXT + 32;   // k-strided: one k per row of EXT + 32 elements (192 / 320 B)
+  static constexpr int SZ = (KC ? EXT : BK) * LD;    // elements per stage
+  static constexpr int NCH = EXT * BK / 8 / NT;      // 16-byte chunks per thread per tile
 };
 
-// This thread's two 16-byte chunks of an operand tile.
-template <bool KC>
+template <bool KC, int EXT>
 struct Loader {
+  static constexpr int NCH = Operand<KC, EXT>::NCH;
   __amdgpu_buffer_rsrc_t rsrc;
-  int voff[2];  // byte offset inside the matrix without the k-tile term; kOOB if outside along ext
-  int kidx[2];  // first k of the chunk inside a tile
-  int kstride;  // bytes per unit of k
+  int voff[NCH];  // byte offset inside the matrix without the k-tile term; kOOB if outside along ext
+  int kidx[NCH];  // first k of the chunk inside a tile
+  int kstride;    // bytes per unit of k
   int k_lim;
 
+  // chunk c of the tile: (row, 8-element column) in the memory order of the operand
+  static __device__ __forceinline__ void coords(int c, int& r, int& q) {
+    if (KC) { r = c >> 3; q = (c & 7) << 3; }                       // [ext][k]: 8 chunks per 64-k row
+    else { r = c / (EXT / 8); q = (c % (EXT / 8)) << 3; }           // [k][ext]: EXT / 8 chunks per k row
+  }
   __device__ __forceinline__ void init(const bf16_t* base, int ld, int rows, int ext0, int ext_lim, int k_lim_,
                                        int tid) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ld * 2, 0x00020000);
     k_lim = k_lim_;
     kstride = KC ? 2 : ld * 2;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = tid + j * NT;
-      const int r = c >> 3, q = (c & 7) << 3;
-      if (KC) {  // memory [ext][k]: row r of ext, k chunk q
+    for (int j = 0; j < NCH; ++j) {
+      int r, q;
+      coords(tid + j * NT, r, q);
+      if (KC) {
         voff[j] = (ext0 + r < ext_lim) ? ((ext0 + r) * ld + q) * 2 : kOOB;
         kidx[j] = q;
-      } else {   // memory [k][ext]: k row r, ext chunk q
+      } else {
         voff[j] = (ext0 + q < ext_lim) ? (r * ld + ext0 + q) * 2 : kOOB;
         kidx[j] = r;
       }
     }
   }
-  __device__ __forceinline__ void load(u32x4 (&v)[2], int k0) const {
+  __device__ __forceinline__ void load(u32x4 (&v)[NCH], int k0) const {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int off = (k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
       v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, k0 * kstride, 0);
     }
   }
-  __device__ __forceinline__ void store(const u32x4 (&v)[2], bf16_t* s, int tid) const {
+  __device__ __forceinline__ void store(const u32x4 (&v)[NCH], bf16_t* s, int tid) const {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = tid + j * NT;
-      const int r = c >> 3, q = (c & 7) << 3;
-      *reinterpret_cast<u32x4*>(s + r * Operand<KC>::LD + q) = v[j];
+    for (int j = 0; j < NCH; ++j) {
+      int r, q;
+      coords(tid + j * NT, r, q);
+      *reinterpret_cast<u32x4*>(s + r * Operand<KC, EXT>::LD + q) = v[j];
     }
   }
 };
 
-// MFMA operand of k-step ks for the 32 rows (or columns) starting at ext_base.
-template <bool KC>
+// MFMA operand of k-step ks for the 32 rows (or columns) starting at ext_base; LD = LDS row length in elements.
+template <bool KC, int LD>
 __device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks, int lane) {
   if (KC) {
     const int i = lane & 31, kb = lane >> 5;
-    return *reinterpret_cast<const bf16x8*>(s + (ext_base + i) * KC_LD + 16 * ks + 8 * kb);
+    return *reinterpret_cast<const bf16x8*>(s + (ext_base + i) * LD + 16 * ks + 8 * kb);
   } else {
     const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
-    const bf16_t* p = s + (16 * ks + 8 * kb + j) * MC_LD + ext_base + 16 * half + 4 * q;
+    const bf16_t* p = s + (16 * ks + 8 * kb + j) * LD + ext_base + 16 * half + 4 * q;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * MC_LD));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * LD));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
@@ -104,12 +110,18 @@ __device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks
 #define TFK_ABLB 0
 #endif
 
-// PF: tiles of global loads in flight per block (even)
-template <bool A_KC, bool B_KC, int EPI, int PF>
+// FM: 32-row MFMA fragments per wave along m.  Block tile = (64 * FM) x 64, four waves as 2 x 2, wave tile
+// (32 * FM) x 32.  FM = 2 stages 25 % fewer bytes through LDS per flop and doubles the MFMAs per barrier; it is
+// used when 128 x 64 tiles still cover the chip.
+template <bool A_KC, bool B_KC, int EPI, int FM>
 __global__ void __launch_bounds__(NT)
 gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-  constexpr int A_SZ = Operand<A_KC>::SZ, B_SZ = Operand<B_KC>::SZ, STAGE = A_SZ + B_SZ;
+  constexpr int BM = 64 * FM;
+  typedef Operand<A_KC, BM> OA;
+  typedef Operand<B_KC, BN> OB;
+  constexpr int A_SZ = OA::SZ, B_SZ = OB::SZ, STAGE = A_SZ + B_SZ;
+  constexpr int KSTEPS = BK / 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -132,27 +144,29 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
-  Loader<A_KC> la;
-  Loader<B_KC> lb;
+  Loader<A_KC, BM> la;
+  Loader<B_KC, BN> lb;
   // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
   // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
   la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid);
   lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid);
 
-  f32x16 acc[2];
+  f32x16 acc[FM][2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int a = 0; a < FM; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
 
   // Pipeline (one barrier per K step, nothing on the critical path but the MFMAs):
-  //   registers: a ring of PF tiles of global loads in flight (a K step computes for ~130 cycles per wave, a load
-  //              takes over a thousand);
+  //   registers: a ring of PF tiles of global loads in flight (a K step computes for a few hundred cycles per
+  //              wave, a load takes over a thousand);
   //   LDS:       three stages -- while tile t is multiplied, tile t+1 (made visible by the previous barrier) is
   //              read into the second fragment set and tile t+2 is written;
   //   fragments: all four k-steps of a tile in registers, double-buffered.
   const int nk = (p.K + BK - 1) / BK;
-  u32x4 ra[PF][2], rb[PF][2];
+  u32x4 ra[PF][OA::NCH], rb[PF][OB::NCH];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     la.load(ra[j], j * BK);  // tiles beyond K come back as zeros without touching memory
@@ -170,11 +184,12 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   la.load(ra[1], (PF + 1) * BK);
   lb.load(rb[1], (PF + 1) * BK);
   __syncthreads();
-  bf16x8 fa[2][BK / 16], fb[2][BK / 16];
+  bf16x8 fa[2][FM][KSTEPS], fb[2][KSTEPS];
 #pragma unroll
-  for (int ks = 0; ks < BK / 16; ++ks) {
-    fa[0][ks] = fragment<A_KC>(st0, wm * 32, ks, lane);
-    fb[0][ks] = fragment<B_KC>(st0 + A_SZ, wn * 32, ks, lane);
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a) fa[0][a][ks] = fragment<A_KC, OA::LD>(st0, wm * 32 * FM + a * 32, ks, lane);
+    fb[0][ks] = fragment<B_KC, OB::LD>(st0 + A_SZ, wn * 32, ks, lane);
   }
 #pragma unroll 1
   for (int kt0 = 0; kt0 < nk; kt0 += PF) {
@@ -195,32 +210,40 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
       }
       if (!(TFK_ABLB & 4)) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-          fa[(j + 1) & 1][ks] = fragment<A_KC>(st1, wm * 32, ks, lane);
-          fb[(j + 1) & 1][ks] = fragment<B_KC>(st1 + A_SZ, wn * 32, ks, lane);
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+            fa[(j + 1) & 1][a][ks] = fragment<A_KC, OA::LD>(st1, wm * 32 * FM + a * 32, ks, lane);
+          fb[(j + 1) & 1][ks] = fragment<B_KC, OB::LD>(st1 + A_SZ, wn * 32, ks, lane);
         }
       }
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks)
-        acc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j & 1][ks], fb[j & 1][ks], acc[ks & 1], 0, 0, 0);
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+          acc[a][ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j & 1][a][ks], fb[j & 1][ks], acc[a][ks & 1], 0, 0, 0);
       if (!(TFK_ABLB & 8)) __syncthreads();
       bf16_t* t = st0; st0 = st1; st1 = st2; st2 = t;
     }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][r] += acc[1][r];
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][0][r] += acc[a][1][r];
 
-  // ---- epilogue: D reg r of lane (i, h) is row (r&3) + 8*(r>>2) + 4*h, column i of the wave's 32x32 tile ----
+  // ---- epilogue: D reg r of lane (i, h) is row (r&3) + 8*(r>>2) + 4*h, column i of a 32x32 fragment ----
   float* red = reinterpret_cast<float*>(smem);  // [2][2 waves along m][BN]; the K loop ended behind a barrier
   const int col = n0 + wn * 32 + i;
   const bool col_ok = col < p.N;
   const int colc = col_ok ? col : p.N - 1;
-  const int rbase = m0 + wm * 32 + 4 * h;
   const int cidx = wn * 32 + i;
-  const float bv = (EPI & EPI_BIAS) ? p.bias[colc] : 0.f;
+  auto row_of = [&](int a, int r) { return m0 + wm * 32 * FM + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2); };
   if constexpr ((EPI & EPI_BIAS) != 0) {
+    const float bv = p.bias[colc];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] += bv;
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][0][r] += bv;
   }
   if constexpr ((EPI & EPI_COLSTATS) != 0) {
     // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
@@ -230,10 +253,12 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
     for (int pass = 0; pass < 2; ++pass) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[0][r];
-        if (rbase + (r & 3) + 8 * (r >> 2) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
-      }
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[a][0][r];
+          if (row_of(a, r) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
+        }
       s += __shfl_xor(s, 32);
       if (h == 0) red[wm * BN + cidx] = s;
       __syncthreads();
@@ -250,28 +275,31 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   if constexpr ((EPI & EPI_DACT) != 0) {
     // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
     const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
-    float av[16], zv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-      av[r] = p.act_a[(size_t)row * p.ldc + colc];
-      zv[r] = p.act_z[(size_t)row * p.ldc + colc];
-    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float d1;
-      switch (p.act_nonlin) {
-        case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
-        case 1: d1 = av[r] * (1.f - av[r]); break;
-        case 2: d1 = 1.f - av[r] * av[r]; break;
-        default: d1 = 1.f;
+    for (int a = 0; a < FM; ++a) {
+      float av[16], zv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row_of(a, r), p.M - 1);
+        av[r] = p.act_a[(size_t)row * p.ldc + colc];
+        zv[r] = p.act_z[(size_t)row * p.ldc + colc];
       }
-      const float du = acc[0][r] * d1;
-      acc[0][r] = du;
-      if (rbase + (r & 3) + 8 * (r >> 2) < p.M) {
-        s1 += du;
-        s2 += du * (zv[r] - mu) * rsd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float d1;
+        switch (p.act_nonlin) {
+          case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+          case 1: d1 = av[r] * (1.f - av[r]); break;
+          case 2: d1 = 1.f - av[r] * av[r]; break;
+          default: d1 = 1.f;
+        }
+        const float du = acc[a][0][r] * d1;
+        acc[a][0][r] = du;
+        if (row_of(a, r) < p.M) {
+          s1 += du;
+          s2 += du * (zv[r] - mu) * rsd;
+        }
       }
     }
     s1 += __shfl_xor(s1, 32);
@@ -286,38 +314,55 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
       p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = red[(1 * 2 + 0) * BN + cidx] + red[(1 * 2 + 1) * BN + cidx];
     }
   }
-  float old[16];
-  if constexpr ((EPI & EPI_ACCUM) != 0) {
+#pragma unroll
+  for (int a = 0; a < FM; ++a) {
+    float old[16];
+    if constexpr ((EPI & EPI_ACCUM) != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = p.C[(size_t)min(row_of(a, r), p.M - 1) * p.ldc + colc];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
-      old[r] = p.C[(size_t)row * p.ldc + colc];
+      const int row = row_of(a, r);
+      float v = acc[a][0][r];
+      if (EPI & EPI_ACCUM) v += old[r];
+      if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = v;
     }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = rbase + (r & 3) + 8 * (r >> 2);
-    float v = acc[0][r];
-    if (EPI & EPI_ACCUM) v += old[r];
-    if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = v;
   }
 }
 
+// 128 x 64 tiles when they still give (nearly) every CU a block, else 64 x 64
+int pick_fm(int M, int N) {
+  static const int forced = [] { const char* q = getenv("TFK_BF16_FM"); return q ? atoi(q) : 0; }();
+  if (forced == 1 || forced == 2) return forced;
+  const int tiles128 = ((M + 127) / 128) * ((N + BN - 1) / BN);
+  return tiles128 >= 192 ? 2 : 1;
+}
+
+template <bool A_KC, bool B_KC, int EPI, int FM>
+int launch_fm(const GemmArgsB& p, hipStream_t stream) {
+  constexpr int BM = 64 * FM;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const size_t lds = (size_t)3 * (Operand<A_KC, BM>::SZ + Operand<B_KC, BN>::SZ) * sizeof(bf16_t);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, FM>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
+                     tiles_m, tiles_n);
+  return (int)hipGetLastError();
+}
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgsB& p, hipStream_t stream) {
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)3 * (Operand<A_KC>::SZ + Operand<B_KC>::SZ) * sizeof(bf16_t);
-  static const int pf = [] { const char* q = getenv("TFK_BF16_PF"); return q ? atoi(q) : 4; }();
-  if (pf == 4)
-    hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, 4>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
-                       tiles_m, tiles_n);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, 8>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
-                       tiles_m, tiles_n);
-  return (int)hipGetLastError();
+  return pick_fm(p.M, p.N) == 2 ? launch_fm<A_KC, B_KC, EPI, 2>(p, stream) : launch_fm<A_KC, B_KC, EPI, 1>(p, stream);
 }
 
 }  // namespace
+
+int gemm_bf16_tile_rows(int M, int N) { return 64 * pick_fm(M, N); }
 
 int gemm_bf16(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
