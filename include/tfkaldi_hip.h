@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 1
+#define TFK_ABI_VERSION 2
 
 typedef struct tfk_engine tfk_engine;
 

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_flo
 
 from .build import lib_path
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
