@@ -814,33 +814,46 @@ __device__ __forceinline__ void st4s(float* p, float4 v) {
   }
 }
 // NT: streaming (non-temporal) accesses for g / m / v, which nothing re-reads before the next optimiser step
-template <bool NT>
+// UN: float4 groups per thread per trip (their loads are all issued before the first is consumed)
+template <bool NT, int UN>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
             const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps, uint16_t* __restrict__ wb,
             size_t n4_wb) {
   const float inv_n = 1.f / scalars[1];  // G / float(num_frames): trainer.py:174-175
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 gv = ld4s<NT>(g + 4 * i), mv = ld4s<NT>(m + 4 * i), vv = ld4s<NT>(v + 4 * i), wv = ld4(w + 4 * i);
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * UN) {
+    float4 gv[UN], mv[UN], vv[UN], wv[UN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = fminf(fmaxf(el(gv, k) * inv_n, -1.f), 1.f);  // clip_by_value: trainer.py:178-179
-      const float mk = b1 * el(mv, k) + (1.f - b1) * gk;
-      const float vk = b2 * el(vv, k) + (1.f - b2) * gk * gk;
-      el(mv, k) = mk;
-      el(vv, k) = vk;
-      el(wv, k) -= lr_t * mk / (sqrtf(vk) + eps);
+    for (int u = 0; u < UN; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < n4) {
+        gv[u] = ld4s<NT>(g + 4 * i); mv[u] = ld4s<NT>(m + 4 * i); vv[u] = ld4s<NT>(v + 4 * i); wv[u] = ld4(w + 4 * i);
+      }
     }
-    st4s<NT>(m + 4 * i, mv);
-    st4s<NT>(v + 4 * i, vv);
-    st4(w + 4 * i, wv);
-    if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices (same element offsets as the fp32 arena)
-      u16x4 q;
-      q.x = to_bf16(wv.x); q.y = to_bf16(wv.y); q.z = to_bf16(wv.z); q.w = to_bf16(wv.w);
-      *reinterpret_cast<u16x4*>(wb + 4 * i) = q;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i >= n4) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = fminf(fmaxf(el(gv[u], k) * inv_n, -1.f), 1.f);  // clip_by_value: trainer.py:178-179
+        const float mk = b1 * el(mv[u], k) + (1.f - b1) * gk;
+        const float vk = b2 * el(vv[u], k) + (1.f - b2) * gk * gk;
+        el(mv[u], k) = mk;
+        el(vv[u], k) = vk;
+        el(wv[u], k) -= lr_t * mk / (sqrtf(vk) + eps);
+      }
+      st4s<NT>(m + 4 * i, mv[u]);
+      st4s<NT>(v + 4 * i, vv[u]);
+      st4(w + 4 * i, wv[u]);
+      if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices (same element offsets as the fp32 arena)
+        u16x4 q;
+        q.x = to_bf16(wv[u].x); q.y = to_bf16(wv[u].y); q.z = to_bf16(wv[u].z); q.w = to_bf16(wv[u].w);
+        *reinterpret_cast<u16x4*>(wb + 4 * i) = q;
+      }
+      // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
     }
-    // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
   }
 }
 
@@ -1028,17 +1041,22 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
                 float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb) {
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  static const size_t max_blocks = [] { const char* q = getenv("TFK_ADAM_GRID"); return (size_t)(q ? atoi(q) : 256 * 32); }();  // measured: 2 groups per thread x 8192 blocks, cfg2 111 -> 107 us, cfg4 789 -> 723 us
+  if (blocks > max_blocks) blocks = max_blocks;
   if (grid_cap > 0 && blocks > (size_t)grid_cap) blocks = grid_cap;
   if (blocks == 0) return;
   // streaming accesses measured 116.7 -> 107.8 us on cfg2 (6.75 TB/s); TFK_ADAM_NT=0 restores cached ones
   static const bool nt = [] { const char* q = getenv("TFK_ADAM_NT"); return !q || atoi(q) != 0; }();
-  if (nt)
-    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1,
-                       beta2, eps, wb, n_wb / 4);
-  else
-    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, beta1,
-                       beta2, eps, wb, n_wb / 4);
+  static const int un = [] { const char* q = getenv("TFK_ADAM_UNROLL"); return q ? atoi(q) : 2; }();
+#define TFK_ADAM_LAUNCH(NTV, UNV)                                                                                  \
+  hipLaunchKernelGGL((adam_kernel<NTV, UNV>), dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, \
+                     beta1, beta2, eps, wb, n_wb / 4)
+  if (nt) {
+    if (un == 4) TFK_ADAM_LAUNCH(true, 4); else if (un == 2) TFK_ADAM_LAUNCH(true, 2); else TFK_ADAM_LAUNCH(true, 1);
+  } else {
+    TFK_ADAM_LAUNCH(false, 1);
+  }
+#undef TFK_ADAM_LAUNCH
 }
 
 void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host) {

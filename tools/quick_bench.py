@@ -13,9 +13,11 @@ from tfkaldi_amd.engine import Engine  # noqa: E402
 
 
 def main():
-    T, F, L, H, O = 1024, 440, 6, 2048, 2000
+    # TFK_QB_SHAPE="T,F,L,H,O" (default BASELINE cfg2), TFK_QB_KEEP=<dropout keep prob>, TFK_QB_BN=0 disables BN
+    T, F, L, H, O = [int(x) for x in os.environ.get("TFK_QB_SHAPE", "1024,440,6,2048,2000").split(",")]
     dtype = os.environ.get("TFK_QB_DTYPE", "float32")  # bfloat16: mixed-precision mode
-    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, max_frames=T, num_steps=1000,
+    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=os.environ.get("TFK_QB_BN", "1") != "0",
+                           keep_prob=float(os.environ.get("TFK_QB_KEEP", "1")), max_frames=T, num_steps=1000,
                            compute_dtype=dtype)
     eng = Engine(cfg)
     rng = np.random.default_rng(7)
