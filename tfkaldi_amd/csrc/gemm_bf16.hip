@@ -3,7 +3,7 @@
 // Replaces the same reference lines as gemm_f32.hip (neuralNetworks/classifiers/layer.py:52 and its tf.gradients,
 // neuralNetworks/trainer.py:155) when the engine runs in mixed precision.
 //
-// One 64x64 or 128x64 output tile per 256-thread block (4 waves as 2 x 2), K in steps of 64:
+// One 64x64, 128x64 or 128x128 output tile per 256-thread block (4 waves as 2 x 2), K in steps of 64:
 //   * global -> registers -> LDS through buffer resources (out-of-range chunks come back as zeros, no branches);
 //     three LDS stages fed from a register ring that keeps PF tiles of loads in flight;
 //   * a k-contiguous operand ([ext][k] in memory) is kept as rows of 64 + 8 bf16 (144 B: conflict-free
@@ -26,7 +26,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 64, BK = 64, NT = 256, PF = 4;  // PF: tiles of global loads in flight per block (even)
+constexpr int BK = 64, NT = 256, PF = 4;  // PF: tiles of global loads in flight per block (even)
 constexpr int KC_LD = BK + 8;  // elements per LDS row of a k-contiguous operand (144 B)
 constexpr int kOOB = (int)0x80000000;
 constexpr int NUM_XCD = 8;
@@ -110,14 +110,14 @@ __device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks
 #define TFK_ABLB 0
 #endif
 
-// FM: 32-row MFMA fragments per wave along m.  Block tile = (64 * FM) x 64, four waves as 2 x 2, wave tile
-// (32 * FM) x 32.  FM = 2 stages 25 % fewer bytes through LDS per flop and doubles the MFMAs per barrier; it is
-// used when 128 x 64 tiles still cover the chip.
-template <bool A_KC, bool B_KC, int EPI, int FM>
+// FM / FN: 32-row / 32-column MFMA fragments per wave.  Block tile = (64 * FM) x (64 * FN), four waves as 2 x 2, wave
+// tile (32 * FM) x (32 * FN).  Larger wave tiles stage fewer bytes AND fewer staging instructions per MFMA (a
+// ds_write_b128 holds its wave ~13 cycles, an MFMA lasts 32): 64x64 -> 128x64 -> 128x128 as the problem allows.
+template <bool A_KC, bool B_KC, int EPI, int FM, int FN>
 __global__ void __launch_bounds__(NT)
 gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-  constexpr int BM = 64 * FM;
+  constexpr int BM = 64 * FM, BN = 64 * FN;
   typedef Operand<A_KC, BM> OA;
   typedef Operand<B_KC, BN> OB;
   constexpr int A_SZ = OA::SZ, B_SZ = OB::SZ, STAGE = A_SZ + B_SZ;
@@ -151,20 +151,25 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid);
   lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid);
 
-  f32x16 acc[FM][2];
+  // a wave owns FM * FN accumulator fragments; with a single fragment the k-steps alternate between two
+  // accumulators so that consecutive MFMAs never depend on each other
+  constexpr int KS = (FM * FN == 1) ? 2 : 1;
+  f32x16 acc[FM][FN][KS];
 #pragma unroll
   for (int a = 0; a < FM; ++a)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int b = 0; b < FN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
+      for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][q][r] = 0.f;
 
-  // Pipeline (one barrier per K step, nothing on the critical path but the MFMAs):
+  // Pipeline (one barrier per K step of 64, nothing on the critical path but the MFMAs):
   //   registers: a ring of PF tiles of global loads in flight (a K step computes for a few hundred cycles per
   //              wave, a load takes over a thousand);
   //   LDS:       three stages -- while tile t is multiplied, tile t+1 (made visible by the previous barrier) is
-  //              read into the second fragment set and tile t+2 is written;
-  //   fragments: all four k-steps of a tile in registers, double-buffered.
+  //              already readable and tile t+2 is written;
+  //   fragments: double-buffered per 16-k step; the last step of a tile prefetches the first of the next.
   const int nk = (p.K + BK - 1) / BK;
   u32x4 ra[PF][OA::NCH], rb[PF][OB::NCH];
 #pragma unroll
@@ -184,13 +189,14 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   la.load(ra[1], (PF + 1) * BK);
   lb.load(rb[1], (PF + 1) * BK);
   __syncthreads();
-  bf16x8 fa[2][FM][KSTEPS], fb[2][KSTEPS];
+  bf16x8 fa[2][FM], fb[2][FN];
+  auto read_frags = [&](int buf, const bf16_t* st, int ks) {
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
+    for (int a = 0; a < FM; ++a) fa[buf][a] = fragment<A_KC, OA::LD>(st, wm * 32 * FM + a * 32, ks, lane);
 #pragma unroll
-    for (int a = 0; a < FM; ++a) fa[0][a][ks] = fragment<A_KC, OA::LD>(st0, wm * 32 * FM + a * 32, ks, lane);
-    fb[0][ks] = fragment<B_KC, OB::LD>(st0 + A_SZ, wn * 32, ks, lane);
-  }
+    for (int b = 0; b < FN; ++b) fb[buf][b] = fragment<B_KC, OB::LD>(st + A_SZ, wn * 32 * FN + b * 32, ks, lane);
+  };
+  read_frags(0, st0, 0);
 #pragma unroll 1
   for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
@@ -208,161 +214,171 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
         la.load(ra[s2], (kt + 2 + PF) * BK);
         lb.load(rb[s2], (kt + 2 + PF) * BK);
       }
-      if (!(TFK_ABLB & 4)) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-          for (int a = 0; a < FM; ++a)
-            fa[(j + 1) & 1][a][ks] = fragment<A_KC, OA::LD>(st1, wm * 32 * FM + a * 32, ks, lane);
-          fb[(j + 1) & 1][ks] = fragment<B_KC, OB::LD>(st1 + A_SZ, wn * 32, ks, lane);
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int cur = ks & 1;  // KSTEPS is even: every tile starts in buffer 0
+        if (!(TFK_ABLB & 4)) {
+          if (ks + 1 < KSTEPS) read_frags(cur ^ 1, st0, ks + 1);
+          else read_frags(cur ^ 1, st1, 0);
         }
-      }
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
         for (int a = 0; a < FM; ++a)
-          acc[a][ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j & 1][a][ks], fb[j & 1][ks], acc[a][ks & 1], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+            acc[a][b][ks % KS] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b][ks % KS], 0, 0, 0);
+      }
       if (!(TFK_ABLB & 8)) __syncthreads();
       bf16_t* t = st0; st0 = st1; st1 = st2; st2 = t;
     }
   }
+  if constexpr (KS == 2) {
 #pragma unroll
-  for (int a = 0; a < FM; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][0][r] += acc[a][1][r];
+    for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[0][0][1][r];
+  }
 
   // ---- epilogue: D reg r of lane (i, h) is row (r&3) + 8*(r>>2) + 4*h, column i of a 32x32 fragment ----
   float* red = reinterpret_cast<float*>(smem);  // [2][2 waves along m][BN]; the K loop ended behind a barrier
-  const int col = n0 + wn * 32 + i;
-  const bool col_ok = col < p.N;
-  const int colc = col_ok ? col : p.N - 1;
-  const int cidx = wn * 32 + i;
   auto row_of = [&](int a, int r) { return m0 + wm * 32 * FM + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2); };
-  if constexpr ((EPI & EPI_BIAS) != 0) {
-    const float bv = p.bias[colc];
 #pragma unroll
-    for (int a = 0; a < FM; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][0][r] += bv;
-  }
-  if constexpr ((EPI & EPI_COLSTATS) != 0) {
-    // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
-    const int n_tile = min(BM, p.M - m0);
-    float cmean = 0.f;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      float s = 0.f;
+  for (int b = 0; b < FN; ++b) {
+    const int col = n0 + wn * 32 * FN + b * 32 + i;
+    const bool col_ok = col < p.N;
+    const int colc = col_ok ? col : p.N - 1;
+    const int cidx = wn * 32 * FN + b * 32 + i;
+    if constexpr ((EPI & EPI_BIAS) != 0) {
+      const float bv = p.bias[colc];
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[a][0][r];
-          if (row_of(a, r) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
+        for (int r = 0; r < 16; ++r) acc[a][b][0][r] += bv;
+    }
+    if constexpr ((EPI & EPI_COLSTATS) != 0) {
+      // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
+      const int n_tile = min(BM, p.M - m0);
+      float cmean = 0.f;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[a][b][0][r];
+            if (row_of(a, r) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
+          }
+        s += __shfl_xor(s, 32);
+        if (h == 0) red[wm * BN + cidx] = s;
+        __syncthreads();
+        const float t = red[cidx] + red[BN + cidx];
+        if (pass == 0) {
+          cmean = t / (float)n_tile;
+        } else if (wm == 0 && h == 0 && col_ok) {
+          p.stats[((size_t)0 * tiles_m + tm) * p.ldc + col] = cmean;
+          p.stats[((size_t)1 * tiles_m + tm) * p.ldc + col] = t;
         }
-      s += __shfl_xor(s, 32);
-      if (h == 0) red[wm * BN + cidx] = s;
+        __syncthreads();
+      }
+    }
+    if constexpr ((EPI & EPI_DACT) != 0) {
+      // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
+      const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        float av[16], zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row_of(a, r), p.M - 1);
+          av[r] = p.act_a[(size_t)row * p.ldc + colc];
+          zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float d1;
+          switch (p.act_nonlin) {
+            case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+            case 1: d1 = av[r] * (1.f - av[r]); break;
+            case 2: d1 = 1.f - av[r] * av[r]; break;
+            default: d1 = 1.f;
+          }
+          const float du = acc[a][b][0][r] * d1;
+          acc[a][b][0][r] = du;
+          if (row_of(a, r) < p.M) {
+            s1 += du;
+            s2 += du * (zv[r] - mu) * rsd;
+          }
+        }
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        red[(0 * 2 + wm) * BN + cidx] = s1;
+        red[(1 * 2 + wm) * BN + cidx] = s2;
+      }
       __syncthreads();
-      const float t = red[cidx] + red[BN + cidx];
-      if (pass == 0) {
-        cmean = t / (float)n_tile;
-      } else if (wm == 0 && h == 0 && col_ok) {
-        p.stats[((size_t)0 * tiles_m + tm) * p.ldc + col] = cmean;
-        p.stats[((size_t)1 * tiles_m + tm) * p.ldc + col] = t;
+      if (wm == 0 && h == 0 && col_ok) {
+        p.stats[((size_t)0 * p.stats_stride + tm) * p.ldc + col] = red[(0 * 2 + 0) * BN + cidx] + red[(0 * 2 + 1) * BN + cidx];
+        p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = red[(1 * 2 + 0) * BN + cidx] + red[(1 * 2 + 1) * BN + cidx];
       }
       __syncthreads();
     }
-  }
-  if constexpr ((EPI & EPI_DACT) != 0) {
-    // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
-    const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
-      float av[16], zv[16];
+      float old[16];
+      if constexpr ((EPI & EPI_ACCUM) != 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(row_of(a, r), p.M - 1);
-        av[r] = p.act_a[(size_t)row * p.ldc + colc];
-        zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+        for (int r = 0; r < 16; ++r) old[r] = p.C[(size_t)min(row_of(a, r), p.M - 1) * p.ldc + colc];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float d1;
-        switch (p.act_nonlin) {
-          case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
-          case 1: d1 = av[r] * (1.f - av[r]); break;
-          case 2: d1 = 1.f - av[r] * av[r]; break;
-          default: d1 = 1.f;
-        }
-        const float du = acc[a][0][r] * d1;
-        acc[a][0][r] = du;
-        if (row_of(a, r) < p.M) {
-          s1 += du;
-          s2 += du * (zv[r] - mu) * rsd;
-        }
+        const int row = row_of(a, r);
+        float v = acc[a][b][0][r];
+        if (EPI & EPI_ACCUM) v += old[r];
+        if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = v;
       }
-    }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    if (h == 0) {
-      red[(0 * 2 + wm) * BN + cidx] = s1;
-      red[(1 * 2 + wm) * BN + cidx] = s2;
-    }
-    __syncthreads();
-    if (wm == 0 && h == 0 && col_ok) {
-      p.stats[((size_t)0 * p.stats_stride + tm) * p.ldc + col] = red[(0 * 2 + 0) * BN + cidx] + red[(0 * 2 + 1) * BN + cidx];
-      p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = red[(1 * 2 + 0) * BN + cidx] + red[(1 * 2 + 1) * BN + cidx];
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < FM; ++a) {
-    float old[16];
-    if constexpr ((EPI & EPI_ACCUM) != 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) old[r] = p.C[(size_t)min(row_of(a, r), p.M - 1) * p.ldc + colc];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row_of(a, r);
-      float v = acc[a][0][r];
-      if (EPI & EPI_ACCUM) v += old[r];
-      if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = v;
     }
   }
 }
 
-// 128 x 64 tiles when they still give (nearly) every CU a block, else 64 x 64
-int pick_fm(int M, int N) {
-  static const int forced = [] { const char* q = getenv("TFK_BF16_FM"); return q ? atoi(q) : 0; }();
-  if (forced == 1 || forced == 2) return forced;
-  const int tiles128 = ((M + 127) / 128) * ((N + BN - 1) / BN);
-  return tiles128 >= 192 ? 2 : 1;
+// tile shape: the largest of 128x128 / 128x64 / 64x64 that still gives (nearly) every CU a block
+int pick_tile(int M, int N) {  // returns 10 * FM + FN
+  static const int forced = [] { const char* q = getenv("TFK_BF16_TILE"); return q ? atoi(q) : 0; }();
+  if (forced == 11 || forced == 21 || forced == 22) return forced;
+  const int m128 = (M + 127) / 128;
+  if (m128 * ((N + 127) / 128) >= 192) return 22;
+  if (m128 * ((N + 63) / 64) >= 192) return 21;
+  return 11;
 }
 
-template <bool A_KC, bool B_KC, int EPI, int FM>
-int launch_fm(const GemmArgsB& p, hipStream_t stream) {
-  constexpr int BM = 64 * FM;
+template <bool A_KC, bool B_KC, int EPI, int FM, int FN>
+int launch_tile(const GemmArgsB& p, hipStream_t stream) {
+  constexpr int BM = 64 * FM, BN = 64 * FN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)3 * (Operand<A_KC, BM>::SZ + Operand<B_KC, BN>::SZ) * sizeof(bf16_t);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, FM>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
+  hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
                      tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgsB& p, hipStream_t stream) {
-  return pick_fm(p.M, p.N) == 2 ? launch_fm<A_KC, B_KC, EPI, 2>(p, stream) : launch_fm<A_KC, B_KC, EPI, 1>(p, stream);
+  switch (pick_tile(p.M, p.N)) {
+    case 22: return launch_tile<A_KC, B_KC, EPI, 2, 2>(p, stream);
+    case 21: return launch_tile<A_KC, B_KC, EPI, 2, 1>(p, stream);
+    default: return launch_tile<A_KC, B_KC, EPI, 1, 1>(p, stream);
+  }
 }
 
 }  // namespace
 
-int gemm_bf16_tile_rows(int M, int N) { return 64 * pick_fm(M, N); }
+int gemm_bf16_tile_rows(int M, int N) { return 64 * (pick_tile(M, N) / 10); }
 
 int gemm_bf16(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
