@@ -166,3 +166,49 @@ def test_bf16_trainer_end_to_end(gpu, tmp_path):
     post = dec(batch_[0][0])
     assert post.shape == (30, O) and np.allclose(post.sum(1), 1, atol=1e-5)
     dec.close()
+
+
+def test_bf16_input_paths_and_layerwise_growth(gpu):
+    """mixed precision on the other entry points: device-resident X, unspliced frames (+ CMVN table), layer-wise
+    growth (the weight shadow is rebuilt after control_ops['init'] zeroes the output layer)"""
+    import torch
+    from tfkaldi_amd import _lib
+    D, C = 8, 2
+    F = D * (2 * C + 1)
+    kw = dict(input_dim=F, num_layers=3, num_units=40, output_dim=16, nonlin="relu", batch_norm=True,
+              init_learning_rate=1e-3, num_steps=100, compute_dtype="bfloat16")
+    rng = np.random.default_rng(8)
+    lens = [20, 9, 31]
+    utts = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    spliced = []
+    for u in utts:
+        pad = np.zeros((u.shape[0] + 2 * C, D), dtype=np.float32)
+        pad[C:C + u.shape[0]] = u
+        spliced.append(np.concatenate([pad[j:j + u.shape[0]] for j in range(2 * C + 1)], axis=1))
+    X = np.concatenate(spliced)
+    T = X.shape[0]
+    y = rng.integers(0, 16, size=T).astype(np.int32)
+    engines = [make_pair(np.random.default_rng(2), **kw)[0] for _ in range(3)]
+    a, b, c = engines
+    dX = torch.from_numpy(X).cuda(); dy = torch.from_numpy(y).cuda()
+    for _ in range(2):
+        a.accumulate(X, y, last=True)
+        b.accumulate_device(dX.data_ptr(), F, dy.data_ptr(), T, last=True)
+        c.accumulate_raw(np.concatenate(utts), y, lens, C, last=True)
+        la, lb, lc = a.apply(), b.apply(), c.apply()
+        assert la == lb == lc
+    assert (a.posteriors(X) == c.posteriors_raw(np.concatenate(utts), lens, C)).all()
+    for e in engines:
+        e.close()
+    # layer-wise growth against the bf16 oracle
+    eng, oracle = make_pair(np.random.default_rng(3), output_too=False, layerwise_init=True, **kw)
+    for step in range(4):
+        eng.accumulate(X, y, last=True)
+        oracle.accumulate(X, y)
+        np.testing.assert_allclose(eng.apply(), oracle.apply(), rtol=2e-3)
+        if step in (0, 2):
+            eng.add_layer(); oracle.add_layer()
+            eng.init_last_layer(); oracle.init_last_layer()
+            eng.eval_accumulate(X, y)
+            assert abs(eng.eval_finish() - np.log(16)) < 1e-5  # zero output layer again: ln O exactly
+    eng.close()
