@@ -63,10 +63,11 @@ struct LayerLayout {
 };
 
 enum KernelFamily {
-  KF_GEMM_NN = 0, KF_GEMM_NT, KF_GEMM_TN, KF_BN_STATS, KF_ACT_FWD, KF_HIDDEN_BWD, KF_COLSUM, KF_SOFTMAX_XENT,
+  KF_GEMM_NN = 0, KF_GEMM_NT, KF_GEMM_TN, KF_GEMM_DUAL, KF_BN_STATS, KF_ACT_FWD, KF_HIDDEN_BWD, KF_COLSUM, KF_SOFTMAX_XENT,
   KF_LOSS_REDUCE, KF_SOFTMAX, KF_ADAM, KF_EMA, KF_MISC, KF_COUNT
 };
-const char* kFamilyName[KF_COUNT] = {"gemm_f32_nn(fwd affine)", "gemm_f32_nt(dA)",  "gemm_f32_tn(dW)", "bn_stats",
+const char* kFamilyName[KF_COUNT] = {"gemm_f32_nn(fwd affine)", "gemm_f32_nt(dA)",  "gemm_f32_tn(dW)",
+                                     "gemm_f32_dual(dA+dW)",    "bn_stats",
                                      "act_forward",             "hidden_backward",  "colsum",          "softmax_xent",
                                      "loss_reduce",             "softmax_rows",     "adam_apply",      "bn_ema_apply",
                                      "misc"};
@@ -142,6 +143,7 @@ struct tfk_engine {
   float cur_lr_t = 0.f;
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
+  bool dual_gemm = true;         // env TFK_DUAL_GEMM=0: dA and dW of a layer as two launches
 
   // CTC loss (tfk_accumulate_ctc): device copies of the utterance / label offsets and the state workspaces,
   // grown on demand
@@ -382,6 +384,42 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   ProfScope ps(e, fam, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1)), st);
   const int rc = gemm_f32(layout, g, cfg, st);
   if (rc != 0) return fail(rc, "gemm_f32 launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+// dA = dZ . W^T (optionally with the EPI_DACT epilogue) and dW (+)= in^T . dZ -- independent, both reading dZ -- in
+// ONE launch (gemm_f32_dual).  Returns 1 when the pair is not eligible (the caller launches them separately).
+int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int ldw, float* da_out, int ld_da, int T,
+                  int N_da, int K_da, const ActEpi* act, float* stats, const float* in, int ld_in, float* Gw, int ld_g,
+                  int d_in, int d_out, int epi_w) {
+  if (e->bf16 || !e->dual_gemm) return 1;
+  GemmArgs a, w;
+  a.A = dz; a.B = W; a.C = da_out; a.bias = nullptr; a.stats = stats;
+  a.act_a = act ? act->a : nullptr; a.act_z = act ? act->z : nullptr;
+  a.act_mean = act ? act->mean : nullptr; a.act_rstd = act ? act->rstd : nullptr;
+  a.act_nonlin = act ? act->nonlin : 0;
+  a.stats_stride = kMaxRowSplits;
+  a.M = T; a.N = N_da; a.K = K_da; a.lda = ld_dz; a.ldb = ldw; a.ldc = ld_da; a.epi = act ? EPI_DACT : 0;
+  w.A = in; w.B = dz; w.C = Gw; w.bias = nullptr; w.stats = nullptr;
+  w.act_a = w.act_z = w.act_mean = w.act_rstd = nullptr; w.act_nonlin = 0; w.stats_stride = 0;
+  w.M = d_in; w.N = d_out; w.K = T; w.lda = ld_in; w.ldb = ld_dz; w.ldc = ld_g; w.epi = epi_w;
+  const double flops = 2.0 * T * N_da * K_da + 2.0 * d_in * d_out * T;
+  const double bytes = 4.0 * ((double)T * K_da + (double)K_da * N_da + (double)T * N_da) +
+                       4.0 * ((double)T * d_in + (double)T * d_out + (double)d_in * d_out * ((epi_w & EPI_ACCUM) ? 2 : 1));
+  hipEvent_t pa = nullptr, pb = nullptr;
+  if (e->profiling) {
+    pa = get_event(e); pb = get_event(e);
+    hipEventRecord(pa, e->stream);
+  }
+  const int rc = gemm_f32_dual(a, w, e->stream);
+  if (rc == -1) return 1;  // (an unused event pair stays in the pool)
+  if (rc != 0) return fail(rc, "gemm_f32_dual launch failed: %s", hipGetErrorString((hipError_t)rc));
+  if (e->profiling) {
+    hipEventRecord(pb, e->stream);
+    ProfRec r;
+    r.family = KF_GEMM_DUAL; r.flops = flops; r.bytes = bytes; r.a = pa; r.b = pb;
+    e->prof.push_back(r);
+  }
   return 0;
 }
 
@@ -694,9 +732,8 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     HIPCHK(hipEventRecord(e->ev_dz[L], e->stream));
     HIPCHK(hipStreamWaitEvent(sw, e->ev_dz[L], 0));
   }
-  CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
-               epi_w, sw));
-  if (two) HIPCHK(hipEventRecord(e->ev_dw[L], sw));
+  // (when eligible the output layer's dW runs in one launch with the dA that follows: see below)
+  bool out_dw_done = false;
   FinalBatch fin;
   fin.n = 0;
   fin.accumulate = acc;
@@ -707,7 +744,6 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));
     fin.it[fin.n++] = {ws_of(L), G + o.b_off, 0, rs, e->O, e->ldO};
   }
-  if (fire && e->cb) e->cb(e->cb_user, 0);
   int pp = 0;
   // BN chains without L2Norm / dropout: the GEMM that produces a layer's output gradient also applies f' and
   // reduces the two column sums of batch-norm's backward in its epilogue (EPI_DACT), which removes one pass
@@ -723,7 +759,21 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, EPI_DACT, nullptr, ws_of(target), cfg,
                     &act);
   };
-  CHK(dact_gemm(e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], e->O, nact - 1, cfg_o));
+  if (!two) {
+    const ActEpi act = {e->a[nact - 1], e->z[nact - 1], e->mean[nact - 1], e->rstd[nact - 1], e->cfg.nonlin};
+    const int rc = run_gemm_dual(e, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O,
+                                 fuse_hb ? &act : nullptr, fuse_hb ? ws_of(nact - 1) : nullptr, e->a[nact - 1], ldH,
+                                 G + o.w_off, o.ld_out, H, e->O, epi_w);
+    if (rc < 0) return rc;
+    out_dw_done = rc == 0;
+  }
+  if (!out_dw_done) {
+    CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
+                 epi_w, sw));
+    if (two) HIPCHK(hipEventRecord(e->ev_dw[L], sw));
+    CHK(dact_gemm(e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], e->O, nact - 1, cfg_o));
+  }
+  if (fire && e->cb) e->cb(e->cb_user, 0);  // the output layer's weight gradient is enqueued
   int chunks_in = chunks_o;
   for (int l = nact - 1; l >= 0; --l) {
     const LayerLayout& y = e->lay[l];
@@ -754,14 +804,25 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
       HIPCHK(hipEventRecord(e->ev_dz[l], e->stream));
       HIPCHK(hipStreamWaitEvent(sw, e->ev_dz[l], 0));
     }
-    CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w, sw));
-    if (two) HIPCHK(hipEventRecord(e->ev_dw[l], sw));
-    if (l > 0) {
-      // the dA GEMM overwrites dA[pp ^ 1] = dz of layer l + 1, which dW_{l+1} may still be reading
-      if (two && l + 1 <= nact - 1) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l + 1], 0));
-      CHK(dact_gemm(da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], H, l - 1, cfg_h));
-      chunks_in = chunks_h;
+    bool fused = false;
+    if (l > 0 && !two) {  // dW_l and the dA that feeds layer l - 1 both read dz_l: one launch when eligible
+      const ActEpi act = {e->a[l - 1], e->z[l - 1], e->mean[l - 1], e->rstd[l - 1], e->cfg.nonlin};
+      const int rc = run_gemm_dual(e, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H,
+                                   fuse_hb ? &act : nullptr, fuse_hb ? ws_of(l - 1) : nullptr, in, ld_in, G + y.w_off,
+                                   y.ld_out, y.d_in, H, epi_w);
+      if (rc < 0) return rc;
+      fused = rc == 0;
     }
+    if (!fused) {
+      CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w, sw));
+      if (two) HIPCHK(hipEventRecord(e->ev_dw[l], sw));
+      if (l > 0) {
+        // the dA GEMM overwrites dA[pp ^ 1] = dz of layer l + 1, which dW_{l+1} may still be reading
+        if (two && l + 1 <= nact - 1) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l + 1], 0));
+        CHK(dact_gemm(da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], H, l - 1, cfg_h));
+      }
+    }
+    if (l > 0) chunks_in = chunks_h;
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
   }
@@ -880,6 +941,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_OVERLAP_ADAM"))) e->overlap = atoi(v) != 0;
     if ((v = getenv("TFK_OVERLAP_DW"))) e->overlap_dw = atoi(v) != 0;
     if ((v = getenv("TFK_FUSE_HB"))) e->fuse_hb_enabled = atoi(v) != 0;
+    if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
     // few, fat blocks: the optimiser only has to finish within the next forward pass and must leave the
     // CUs' wave slots to the GEMM blocks it runs beside
     e->adam_blocks = (v = getenv("TFK_ADAM_BLOCKS")) ? atoi(v) : 512;

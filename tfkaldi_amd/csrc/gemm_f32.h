@@ -72,6 +72,11 @@ constexpr int kNumGemmConfigs = 9;
 // cfg < 0 => heuristic choice. Returns hipError_t as int.
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream);
 
+// An NT contraction (epi 0 / EPI_DACT) and a TN contraction (epi 0 / EPI_ACCUM) that do not depend on each other,
+// in ONE launch (see gemm_f32_dual_kernel).  Returns -1 when the pair is not eligible (other tile configuration,
+// split-K): the caller then launches them one after the other.
+int gemm_f32_dual(const GemmArgs& nt, const GemmArgs& tn, hipStream_t stream);
+
 // Heuristic used when cfg < 0 (exposed for tests / the sweep tool).
 int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K);
 

@@ -152,18 +152,9 @@ __device__ __forceinline__ void read_frags(float (&f)[NF][4], const float* __res
   }
 }
 
+// One output tile: `bid` is the block's index among the tiles_m * tiles_n tiles of THIS contraction.
 template <class T, int EPI>
-__global__ void __launch_bounds__(T::NT)
-gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (p.nsplit > 1) {  // split-K: this block contracts k in [k0, k0 + ksplit) into its own partial result
-    const int k0 = blockIdx.y * p.ksplit;
-    p.A += T::A_KC ? (size_t)k0 : (size_t)k0 * p.lda;
-    p.B += T::B_KC ? (size_t)k0 : (size_t)k0 * p.ldb;
-    p.K = min(p.ksplit, p.K - k0);
-    p.C += (size_t)blockIdx.y * p.split_stride;
-  }
-
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int tiles_n, int bid, float* smem) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int i = lane & 31;
@@ -176,7 +167,6 @@ gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
   int tm, tn;
   {
     const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
     const int xcd = bid % NUM_XCD, loc = bid / NUM_XCD;
     const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
     const int seq = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -529,6 +519,33 @@ gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
   }
 }
 
+template <class T, int EPI>
+__global__ void __launch_bounds__(T::NT)
+gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (p.nsplit > 1) {  // split-K: this block contracts k in [k0, k0 + ksplit) into its own partial result
+    const int k0 = blockIdx.y * p.ksplit;
+    p.A += T::A_KC ? (size_t)k0 : (size_t)k0 * p.lda;
+    p.B += T::B_KC ? (size_t)k0 : (size_t)k0 * p.ldb;
+    p.K = min(p.ksplit, p.K - k0);
+    p.C += (size_t)blockIdx.y * p.split_stride;
+  }
+  gemm_tile<T, EPI>(p, tiles_m, tiles_n, blockIdx.x, smem);
+}
+
+// Two INDEPENDENT contractions in one launch (backward: dA of a layer and the dW that consumes the same dZ): the
+// blocks of the second start on a CU the moment a block of the first retires, so one kernel's drain (epilogue
+// stores, straggling CUs) overlaps the other's ramp-up instead of idling the matrix pipes.
+template <class T1, int EPI1, class T2, int EPI2>
+__global__ void __launch_bounds__(T1::NT)
+gemm_f32_dual_kernel(GemmArgs p1, GemmArgs p2, int tiles_m1, int tiles_n1, int tiles_m2, int tiles_n2) {
+  static_assert(T1::NT == T2::NT, "both halves use the same block size");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n1 = tiles_m1 * tiles_n1;
+  if ((int)blockIdx.x < n1) gemm_tile<T1, EPI1>(p1, tiles_m1, tiles_n1, blockIdx.x, smem);
+  else gemm_tile<T2, EPI2>(p2, tiles_m2, tiles_n2, blockIdx.x - n1, smem);
+}
+
 int g_min_lds = 0;        // env TFK_GEMM_MIN_LDS (experiments): lower bound of the LDS request
 int g_even_spread = 1;    // env TFK_GEMM_EVEN_SPREAD=0 disables the residency cap below
 
@@ -612,6 +629,27 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
   return (int)hipErrorInvalidValue;
 }
 
+template <int EPI_NT, int EPI_TN>
+int launch_dual(const GemmArgs& a, const GemmArgs& w, hipStream_t stream) {
+  typedef Tile<64, 64, 32, 32, 3, 4, true, true> TA;    // config 3, NT
+  typedef Tile<64, 64, 32, 32, 3, 2, false, false> TW;  // config 3, TN
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dual_kernel<TA, EPI_NT, TW, EPI_TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int tma = (a.M + 63) / 64, tna = (a.N + 63) / 64, tmw = (w.M + 63) / 64, tnw = (w.N + 63) / 64;
+  int lds = TA::LDS_BYTES > TW::LDS_BYTES ? TA::LDS_BYTES : TW::LDS_BYTES;
+  const int floor3 = (160 * 1024 / 3 / 1024 + 1) * 1024;  // two blocks per CU, as the single launches run
+  if (g_even_spread && lds < floor3) lds = floor3;
+  if (g_min_lds > lds) lds = g_min_lds;
+  hipLaunchKernelGGL((gemm_f32_dual_kernel<TA, EPI_NT, TW, EPI_TN>), dim3(tma * tna + tmw * tnw), dim3(TA::NT), lds,
+                     stream, a, w, tma, tna, tmw, tnw);
+  return (int)hipGetLastError();
+}
+
 // C (+)= sum over the split-K partials, in chunk order
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t stride, float* __restrict__ C, size_t n4,
@@ -692,6 +730,21 @@ int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t strea
     }
   }
   return dispatch_epi(layout, args, cfg, stream);
+}
+
+int gemm_f32_dual(const GemmArgs& nt, const GemmArgs& tn, hipStream_t stream) {
+  // only the shapes the heuristic gives the 64x64 configuration to, and no split-K
+  if (gemm_f32_pick_config(GEMM_NT, nt.M, nt.N, nt.K) != 3 || gemm_f32_pick_config(GEMM_TN, tn.M, tn.N, tn.K) != 3)
+    return -1;
+  if ((nt.lda & 3) || (nt.ldb & 3) || (tn.lda & 3) || (tn.ldb & 3)) return (int)hipErrorInvalidValue;
+  const int key = (nt.epi == EPI_DACT ? 2 : nt.epi == 0 ? 0 : -8) + (tn.epi == EPI_ACCUM ? 1 : tn.epi == 0 ? 0 : -8);
+  switch (key) {
+    case 0: return launch_dual<0, 0>(nt, tn, stream);
+    case 1: return launch_dual<0, EPI_ACCUM>(nt, tn, stream);
+    case 2: return launch_dual<EPI_DACT, 0>(nt, tn, stream);
+    case 3: return launch_dual<EPI_DACT, EPI_ACCUM>(nt, tn, stream);
+  }
+  return -1;
 }
 
 }  // namespace tfk

@@ -19,6 +19,8 @@ LAYOUT = {("true", "false"): "gemm_f32_nn(fwd affine)", ("true", "true"): "gemm_
 
 
 def scope(kernel):
+    if "gemm_f32_dual_kernel" in kernel:
+        return "gemm_f32_dual(dA+dW)"
     m = re.search(r"gemm_f32_kernel<.*?Tile<[^>]*?(true|false), (true|false)>", kernel)
     if m:
         return LAYOUT.get((m.group(1), m.group(2)))
