@@ -166,6 +166,14 @@ int tfk_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, co
                        const int32_t* labels, const int32_t* label_len, int flags);
 int tfk_eval_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,
                             const int32_t* labels, const int32_t* label_len, int flags);
+/* The same on UNSPLICED frames (device-side CMVN + splice as tfk_accumulate_raw; the utterance boundaries are
+ * shared): 11x less PCIe traffic, which is what bounds a host-fed CTC step on long utterances. */
+int tfk_accumulate_ctc_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t T, const int32_t* utt_len, int32_t U,
+                           int32_t context_width, const float* cmvn, const int32_t* labels, const int32_t* label_len,
+                           int flags);
+int tfk_eval_accumulate_ctc_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t T, const int32_t* utt_len,
+                                int32_t U, int32_t context_width, const float* cmvn, const int32_t* labels,
+                                const int32_t* label_len, int flags);
 
 /* Replaces `[average_loss, apply_gradients_op]` + the three re-initialisations (trainer.py:336-352):
  * g = clip(G / num_frames, -1, 1); Adam; global_step += 1; returns batch_loss / num_frames (the

@@ -118,6 +118,8 @@ def test_ctc_trainer_end_to_end(gpu, tmp_path):
     paths = synthetic.write_corpus(str(tmp_path), len(lengths), 10, feat_dim=D, lengths=lengths, num_speakers=2)
     text = synthetic.write_text_targets(str(tmp_path), len(lengths))
     reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], C, max(lengths))
+    deferred = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], C, max(lengths),
+                                            cmvn_on_device=True)
     coder = target_coder.TextCoder(target_normalizers.aurora4_normalizer)
     disp = batchdispenser.TextBatchDispenser(reader, coder, U, text)
     O = coder.num_labels + 1  # + the blank, last class
@@ -143,3 +145,12 @@ def test_ctc_trainer_end_to_end(gpu, tmp_path):
     assert losses[-1] < 0.6 * losses[0]
     assert np.isfinite(tr.evaluate(xs, ys))
     tr.close()
+    # the same batch with CMVN + splice deferred to the device (tfk_accumulate_ctc_raw): bit-identical losses
+    disp2 = batchdispenser.TextBatchDispenser(deferred, coder, U, text)
+    xs2, ys2 = disp2.get_batch()
+    assert type(xs2[0]).__name__ == "Unspliced" and xs2[0].cmvn is not None
+    tr2 = CTCTrainer(dnn, F, max(lengths), disp2.max_target_length, 3e-3, 1.0, 100, 2, seed=11)
+    tr2.initialize()
+    assert [tr2.update(xs2, ys2) for _ in range(3)] == losses[:3]
+    tr2.evaluate(xs2, ys2)
+    tr2.close()

@@ -66,6 +66,10 @@ SYMBOLS = {
     "tfk_accumulate_ctc": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int]),
     "tfk_eval_accumulate_ctc": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_int]),
+    "tfk_accumulate_ctc_raw": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                       c_void_p, c_int]),
+    "tfk_eval_accumulate_ctc_raw": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                            c_void_p, c_void_p, c_int]),
     "tfk_posteriors_raw": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                    c_int64, c_int]),
     "tfk_apply": (c_int, [_E, POINTER(c_float)]),

@@ -1300,6 +1300,22 @@ int tfk_eval_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t 
   const CtcSpec c = {utt_len, U, labels, label_len};
   return train_or_eval(e, X, ldx, nullptr, T, flags & ~TFK_LAST_MICROBATCH, 0, nullptr, &c);
 }
+int tfk_accumulate_ctc_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t T, const int32_t* utt_len, int32_t U,
+                           int32_t context_width, const float* cmvn, const int32_t* labels, const int32_t* label_len,
+                           int flags) {
+  if (!utt_len) return fail(-1, "utt_len is NULL");
+  const RawSpec r = {utt_len, U, context_width, cmvn};
+  const CtcSpec c = {utt_len, U, labels, label_len};
+  return train_or_eval(e, raw, ldraw, nullptr, T, flags, 1, &r, &c);
+}
+int tfk_eval_accumulate_ctc_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t T, const int32_t* utt_len,
+                                int32_t U, int32_t context_width, const float* cmvn, const int32_t* labels,
+                                const int32_t* label_len, int flags) {
+  if (!utt_len) return fail(-1, "utt_len is NULL");
+  const RawSpec r = {utt_len, U, context_width, cmvn};
+  const CtcSpec c = {utt_len, U, labels, label_len};
+  return train_or_eval(e, raw, ldraw, nullptr, T, flags & ~TFK_LAST_MICROBATCH, 0, &r, &c);
+}
 
 // The optimiser step in three parts, so that a data-parallel host can run Adam on each span of parameters as soon
 // as ITS gradients are reduced while later collectives are still in flight:

@@ -64,13 +64,18 @@ class CtcMicroBatch(object):
     """A micro-batch for the CTC loss: spliced frames [T, F] of U utterances, their frame counts, their label
     sequences back to back and the label counts (tfk_accumulate_ctc)."""
 
-    def __init__(self, X, utt_lens, labels, label_lens):
+    def __init__(self, X, utt_lens, labels, label_lens, context_width=None, cmvn=None):
         self.X, self.utt_lens, self.labels, self.label_lens = X, utt_lens, labels, label_lens
+        self.context_width, self.cmvn = context_width, cmvn  # context_width set: X holds UNSPLICED frames
 
 
 def _accumulate(engine, mb, last):
     if isinstance(mb, CtcMicroBatch):
-        engine.accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens, last=last)
+        if mb.context_width is not None:
+            engine.accumulate_ctc_raw(mb.X, mb.utt_lens, mb.context_width, mb.labels, mb.label_lens, last=last,
+                                      cmvn=mb.cmvn)
+        else:
+            engine.accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens, last=last)
     elif isinstance(mb, RawMicroBatch):
         engine.accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, last=last, cmvn=mb.cmvn)
     else:
@@ -79,7 +84,11 @@ def _accumulate(engine, mb, last):
 
 def _eval_accumulate(engine, mb):
     if isinstance(mb, CtcMicroBatch):
-        engine.eval_accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens)
+        if mb.context_width is not None:
+            engine.accumulate_ctc_raw(mb.X, mb.utt_lens, mb.context_width, mb.labels, mb.label_lens, cmvn=mb.cmvn,
+                                      train=False)
+        else:
+            engine.eval_accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens)
     elif isinstance(mb, RawMicroBatch):
         engine.eval_accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, cmvn=mb.cmvn)
     else:

@@ -204,6 +204,15 @@ class Engine(object):
             raise ValueError("CTC micro-batch: frames %s / utterance lengths / labels do not match" % (X.shape,))
         return X, utt_lens, labels, label_lens
 
+    def accumulate_ctc_raw(self, raw, utt_lens, context_width, labels, label_lens, last=False, cmvn=None, train=True):
+        """CTC micro-batch from UNSPLICED frames: CMVN + splice on the device (as accumulate_raw)"""
+        raw, utt_lens, labels, label_lens = self._ctc_args(raw, utt_lens, labels, label_lens)
+        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, utt_lens)
+        fn = self.lib.tfk_accumulate_ctc_raw if train else self.lib.tfk_eval_accumulate_ctc_raw
+        check(fn(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0], utt_lens.ctypes.data_as(c_void_p),
+                 utt_lens.size, int(context_width), cmvn_ptr, labels.ctypes.data_as(c_void_p),
+                 label_lens.ctypes.data_as(c_void_p), _lib.LAST_MICROBATCH if (last and train) else 0))
+
     def accumulate_ctc(self, X, utt_lens, labels, label_lens, last=False):
         X, utt_lens, labels, label_lens = self._ctc_args(X, utt_lens, labels, label_lens)
         check(self.lib.tfk_accumulate_ctc(self._h, X.ctypes.data_as(c_void_p), X.shape[1], X.shape[0],

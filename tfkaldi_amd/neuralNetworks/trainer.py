@@ -139,14 +139,18 @@ class Trainer(object, metaclass=ABCMeta):
         for idx in microbatch_indices(len(inputs), self.numutterances_per_minibatch):
             if not idx:
                 continue
-            if self.loss_kind == "ctc":  # label sequences of their own length; frames spliced on the host
-                X = np.concatenate([_spliced(inputs[i]) for i in idx], axis=0)
+            if self.loss_kind == "ctc":  # label sequences of their own length
+                deferred = all(isinstance(inputs[i], Unspliced) for i in idx)  # CMVN / splice on the device
+                frames = [np.asarray(inputs[i]) if deferred else _spliced(inputs[i]) for i in idx]
+                X = np.concatenate(frames, axis=0)
                 if X.shape[0] == 0:
                     continue
                 out.append(CtcMicroBatch(
-                    X, np.array([inputs[i].shape[0] for i in idx], dtype=np.int32),
+                    X, np.array([f.shape[0] for f in frames], dtype=np.int32),
                     np.concatenate([np.asarray(targets[i]).astype(np.int32).reshape(-1) for i in idx]),
-                    np.array([np.asarray(targets[i]).size for i in idx], dtype=np.int32)))
+                    np.array([np.asarray(targets[i]).size for i in idx], dtype=np.int32),
+                    context_width=inputs[idx[0]].context_width if deferred else None,
+                    cmvn=cmvn_table([inputs[i] for i in idx]) if deferred else None))
                 continue
             for i in idx:
                 if inputs[i].shape[0] != targets[i].shape[0]:
