@@ -736,6 +736,7 @@ int gemm_f32_dual(const GemmArgs& nt, const GemmArgs& tn, hipStream_t stream) {
   // only the shapes the heuristic gives the 64x64 configuration to, and no split-K
   if (gemm_f32_pick_config(GEMM_NT, nt.M, nt.N, nt.K) != 3 || gemm_f32_pick_config(GEMM_TN, tn.M, tn.N, tn.K) != 3)
     return -1;
+  if (((tn.M + 63) / 64) * ((tn.N + 63) / 64) < 256 && tn.K >= 2048) return -1;  // that one wants split-K
   if ((nt.lda & 3) || (nt.ldb & 3) || (tn.lda & 3) || (tn.ldb & 3)) return (int)hipErrorInvalidValue;
   const int key = (nt.epi == EPI_DACT ? 2 : nt.epi == 0 ? 0 : -8) + (tn.epi == EPI_ACCUM ? 1 : tn.epi == 0 ? 0 : -8);
   switch (key) {
