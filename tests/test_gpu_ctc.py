@@ -35,7 +35,8 @@ def _oracle_step(oracle, X, utt_lens, labels, label_lens):
     dict(utt=[25, 40], lab=[12, 19], repeat=True),                      # repeated labels: blanks are mandatory
     dict(utt=[7, 60], lab=[7, 2], repeat=False),                        # T == S: every frame emits a label
     dict(utt=[300], lab=[140]),                                         # 281 states: 8 states per lane
-], ids=["mixed", "repeats", "tight", "long"])
+    dict(utt=[210, 150], lab=[70, 66]),                                 # 141 states: 4 states per lane
+], ids=["mixed", "repeats", "tight", "long", "medium"])
 def test_ctc_accumulate_matches_oracle(gpu, case):
     from tfkaldi_amd import _lib
     rng = np.random.default_rng(41)
@@ -154,3 +155,21 @@ def test_ctc_trainer_end_to_end(gpu, tmp_path):
     assert [tr2.update(xs2, ys2) for _ in range(3)] == losses[:3]
     tr2.evaluate(xs2, ys2)
     tr2.close()
+
+
+@pytest.mark.parametrize("T,S", [(800, 100), (1600, 100), (800, 30)])
+def test_ctc_long_utterances_stay_accurate(gpu, T, S):
+    """log p runs into the thousands here; the recursion keeps its state relative to a double-precision offset
+    (re-centred on the maximum every 8 frames), so loss and posteriors stay at fp32 round-off of the INPUTS instead of
+    at the 1e-4 resolution of an fp32 number of that magnitude (which gave 3e-3 errors at T = 1600)"""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(T + S)
+    kw = dict(KW, output_dim=36)
+    eng, oracle = make_pair(rng, max_frames=T, **kw)
+    X = (rng.standard_normal((T, kw["input_dim"])) * 1.5).astype(np.float32)
+    labels = rng.integers(0, 35, size=S).astype(np.int32)
+    eng.accumulate_ctc(X, [T], labels, [S])
+    loss, dlog, _ = ctc_batch(oracle.forward_logits(X), [T], labels, [S])
+    assert_close("loss", eng.scalar(_lib.BATCH_LOSS), loss, 1e-6, 0)
+    assert np.abs(eng.debug_fetch(_lib.DBG_LOGITS, 0, T) - dlog).max() < 5e-4
+    eng.close()

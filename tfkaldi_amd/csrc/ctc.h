@@ -23,6 +23,7 @@ struct CtcBatch {
   int sext;                // row stride of lp / ab: >= 2 * (longest label sequence) + 1, a multiple of 64 * R
   float* lp;               // [T, sext] scratch: log p_t(state s), states = blank, l_0, blank, l_1, ..., blank
   float* ab;               // [T, sext] scratch: alpha, then the state posteriors
+  double* off;             // [T]     scratch: per-frame offset of the re-centred forward variables
   float* utt_loss;         // [U] out: -log p, +inf for an utterance too short for its labels
 };
 

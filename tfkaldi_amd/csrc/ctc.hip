@@ -35,6 +35,22 @@ __device__ __forceinline__ float lane_next(float v, float fill, int lane) {
   const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   return lane == 63 ? fill : __builtin_bit_cast(float, r);
 }
+// maximum over the wave, identical in every lane: quad swaps and row rotations as DPP modifiers, then the four
+// 16-lane rows through v_readlane
+__device__ __forceinline__ float wave_max(float x) {
+#define TFK_DPP(v, ctrl) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
+  x = fmaxf(x, TFK_DPP(x, 0xB1));   // quad_perm [1,0,3,2]
+  x = fmaxf(x, TFK_DPP(x, 0x4E));   // quad_perm [2,3,0,1]
+  x = fmaxf(x, TFK_DPP(x, 0x124));  // row_ror:4
+  x = fmaxf(x, TFK_DPP(x, 0x128));  // row_ror:8
+#undef TFK_DPP
+  const int xi = __builtin_bit_cast(int, x);
+  return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16))),
+               fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)),
+                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48))));
+}
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 
 // utterance of frame t: largest u with seg[u] <= t
@@ -112,14 +128,20 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
   // arrive: PFD rows are kept in flight in a register ring.  The ring is advanced with clamped row indices instead
   // of guards (a surplus step re-does the last row with the state held), so the unrolled body has no branches and
   // the compiler's wait counts stay exact.
+  // Precision: log p of a long utterance runs into the thousands, where fp32 resolves only ~1e-4.  The state
+  // vector is therefore kept RELATIVE to an offset: once per PFD steps its maximum is moved into `off` (double,
+  // wave-uniform; stored per frame), so the per-state values stay small and exact to ~1e-6 whatever Tn is.
   constexpr int PFD = 8;
   float a[R], pre[PFD][R];
+  double off = 0.0;
+  double* offs = b.off + r0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const float v = lp[r];
     a[r] = (s0 + r < 2 && s0 + r < n) ? v : NEG;
     ab[r] = a[r];
   }
+  if (lane == 0) offs[0] = 0.0;
 #pragma unroll
   for (int j = 0; j < PFD; ++j)
 #pragma unroll
@@ -145,11 +167,23 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
         const float v = (s0 + r < n) ? lse3(a[r], p1, skip_in[r] ? p2 : NEG) + cur[r] : NEG;
         na[r] = live ? v : a[r];
       }
+      if (j == PFD - 1) {  // compile-time: re-centre the state vector on its maximum
+        float m = NEG;
+#pragma unroll
+        for (int r = 0; r < R; ++r) m = fmaxf(m, na[r]);
+        m = wave_max(m);
+        if (live && m > -1e29f) {
+          off += (double)m;
+#pragma unroll
+          for (int r = 0; r < R; ++r) na[r] = fmaxf(na[r] - m, NEG);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         a[r] = na[r];
         ab[(size_t)row * b.sext + r] = a[r];
       }
+      if (lane == 0 && live) offs[t] = off;
     }
   }
   // log p(labels) = alpha_T(n-1) (+) alpha_T(n-2)
@@ -163,47 +197,57 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
   for (int r = 0; r < R; ++r)
     if (s0 + r == n - 1 || s0 + r == n - 2) se += expf(a[r] - m);
   for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
-  const float log_z = m + logf(se);
-  const bool feasible = log_z > -1e29f;
-  if (lane == 0) b.utt_loss[u] = feasible ? -log_z : INFINITY;
+  const float log_z_rel = m + logf(se);  // relative to the final offset
+  const bool feasible = log_z_rel > -1e29f;
+  const double log_z = off + (double)log_z_rel;
+  if (lane == 0) b.utt_loss[u] = feasible ? (float)-log_z : INFINITY;
   if (!with_grad) return;
-  // backward sweep: beta in registers, alpha row t read back and replaced by the state posterior; the same ring
+  // backward sweep: beta (relative to its own offset `offb`) in registers, alpha row t read back and replaced by the
+  // state posterior exp((alpha~ + beta~ - lp) + (off_alpha(t) + off_beta(t) - log Z)); the same ring
   float bt[R];
+  double offb = 0.0;
   {
-    float cur[R];
+    const float shift = (float)(offs[Tn - 1] - log_z);  // offsets cancel to a small number: exact enough in fp32
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int s = s0 + r;
-      cur[r] = lp[(size_t)(Tn - 1) * b.sext + r];
-      bt[r] = (s == n - 1 || s == n - 2) ? cur[r] : NEG;
+      const float cur = lp[(size_t)(Tn - 1) * b.sext + r];
+      bt[r] = (s == n - 1 || s == n - 2) ? cur : NEG;
       const float al = ab[(size_t)(Tn - 1) * b.sext + r];
-      ab[(size_t)(Tn - 1) * b.sext + r] = (feasible && s < n) ? expf(al + bt[r] - cur[r] - log_z) : 0.f;
+      ab[(size_t)(Tn - 1) * b.sext + r] = (feasible && s < n) ? __expf(al + bt[r] - cur + shift) : 0.f;
     }
   }
   float prel[PFD][R], prea[PFD][R];
+  double preo[PFD];
 #pragma unroll
-  for (int j = 0; j < PFD; ++j)
+  for (int j = 0; j < PFD; ++j) {
+    const int row = max(Tn - 2 - j, 0);
+    preo[j] = offs[row];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const size_t row = (size_t)max(Tn - 2 - j, 0) * b.sext + r;
-      prel[j][r] = lp[row];
-      prea[j][r] = ab[row];
+      prel[j][r] = lp[(size_t)row * b.sext + r];
+      prea[j][r] = ab[(size_t)row * b.sext + r];
     }
+  }
   for (int t0 = Tn - 2; t0 >= 0; t0 -= PFD) {
 #pragma unroll
     for (int j = 0; j < PFD; ++j) {
       const int t = t0 - j;
       const bool live = t >= 0;
       float cur[R], al[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        cur[r] = prel[j][r];
-        al[r] = prea[j][r];
+      const double offa = preo[j];
+      {
         // rows below 0 are clamped to row 0, which a surplus step must not read after it was rewritten: the ring
         // slot of a dead step is never consumed again, so the clamped value is simply unused
-        const size_t row = (size_t)max(t - PFD, 0) * b.sext + r;
-        prel[j][r] = lp[row];
-        prea[j][r] = ab[row];
+        const int row = max(t - PFD, 0);
+        preo[j] = offs[row];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          cur[r] = prel[j][r];
+          al[r] = prea[j][r];
+          prel[j][r] = lp[(size_t)row * b.sext + r];
+          prea[j][r] = ab[(size_t)row * b.sext + r];
+        }
       }
       const float dn1 = lane_next(bt[0], NEG, lane), dn2 = lane_next(bt[1], NEG, lane);
       float nb[R];
@@ -214,11 +258,23 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
         const float v = (s0 + r < n) ? lse3(bt[r], q1, skip_out[r] ? q2 : NEG) + cur[r] : NEG;
         nb[r] = live ? v : bt[r];
       }
+      if (j == PFD - 1) {  // re-centre beta
+        float m = NEG;
+#pragma unroll
+        for (int r = 0; r < R; ++r) m = fmaxf(m, nb[r]);
+        m = wave_max(m);
+        if (live && m > -1e29f) {
+          offb += (double)m;
+#pragma unroll
+          for (int r = 0; r < R; ++r) nb[r] = fmaxf(nb[r] - m, NEG);
+        }
+      }
       if (live) {
+        const float shift = (float)(offa + offb - log_z);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           bt[r] = nb[r];
-          ab[(size_t)t * b.sext + r] = (feasible && s0 + r < n) ? expf(al[r] + bt[r] - cur[r] - log_z) : 0.f;
+          ab[(size_t)t * b.sext + r] = (feasible && s0 + r < n) ? __expf(al[r] + bt[r] - cur[r] + shift) : 0.f;
         }
       }
     }

@@ -149,6 +149,8 @@ struct tfk_engine {
   // grown on demand
   int32_t *ctc_seg = nullptr, *ctc_lab_off = nullptr, *ctc_lab = nullptr;
   float *ctc_lp = nullptr, *ctc_ab = nullptr, *ctc_utt_loss = nullptr, *ctc_lse = nullptr;
+  double* ctc_off = nullptr;
+  size_t ctc_cap_offrows = 0;
   size_t ctc_cap_seg = 0, ctc_cap_off = 0, ctc_cap_loss = 0, ctc_cap_lab = 0, ctc_cap_lp = 0, ctc_cap_ab = 0,
          ctc_cap_rows = 0;
 
@@ -1049,6 +1051,7 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   CHK(grow(&e->ctc_lp, &e->ctc_cap_lp, (size_t)T * sext));
   CHK(grow(&e->ctc_ab, &e->ctc_cap_ab, (size_t)T * sext));
   CHK(grow(&e->ctc_lse, &e->ctc_cap_rows, (size_t)T));
+  CHK(grow(&e->ctc_off, &e->ctc_cap_offrows, (size_t)T));
   HIPCHK(hipMemcpyAsync(e->ctc_seg, seg.data(), (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(e->ctc_lab_off, off.data(), (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
   if (total > 0)
@@ -1058,7 +1061,7 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   b.logits = e->logits; b.ld = e->ldO; b.post = e->post; b.lse = e->ctc_lse;
   b.seg = e->ctc_seg; b.labels = e->ctc_lab; b.lab_off = e->ctc_lab_off;
   b.U = c.U; b.T = T; b.O = e->O; b.sext = sext;
-  b.lp = e->ctc_lp; b.ab = e->ctc_ab; b.utt_loss = e->ctc_utt_loss;
+  b.lp = e->ctc_lp; b.ab = e->ctc_ab; b.utt_loss = e->ctc_utt_loss; b.off = e->ctc_off;
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * T * e->O + 16.0 * T * sext);
     Twin tw;
@@ -1176,7 +1179,7 @@ int tfk_destroy(tfk_engine* e) {
   if (e->Wb) hipFree(e->Wb);
   if (e->ws_splitk) hipFree(e->ws_splitk);
   for (void* p : {(void*)e->ctc_seg, (void*)e->ctc_lab_off, (void*)e->ctc_lab, (void*)e->ctc_lp, (void*)e->ctc_ab,
-                  (void*)e->ctc_utt_loss, (void*)e->ctc_lse})
+                  (void*)e->ctc_utt_loss, (void*)e->ctc_lse, (void*)e->ctc_off})
     if (p) hipFree(p);
   if (e->h_scalars) hipHostFree(e->h_scalars);
   if (e->h_post) hipHostFree(e->h_post);
