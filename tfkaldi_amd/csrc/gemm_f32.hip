@@ -584,9 +584,14 @@ struct CfgDesc {
 };
 const CfgDesc kCfg[kNumGemmConfigs] = {
     {128, 128, "128x128/4w64x64/s2"},   {128, 64, "128x64/4w64x32/s3p2"},   {64, 128, "64x128/4w32x64/s3p2"},
-    {64, 64, "64x64/4w32x32/s3p4|2"},     {128, 128, "128x128/8w64x32/s3p1"}, {256, 128, "256x128/8w64x64/s2"},
+    {64, 64, "64x64/4w32x32/s3p6|4|3"},     {128, 128, "128x128/8w64x32/s3p1"}, {256, 128, "256x128/8w64x64/s2"},
     {64, 128, "64x128/8w32x32/s3p2"},   {128, 64, "128x64/8w32x32/s3p2"},   {64, 64, "64x64/4w32x32/s3p1"},
 };
+
+// Prefetch distance of the 64x64 configuration per layout (stand-alone 1024x2048x2048 / 2048x2048x1024, same box):
+// NN 4 -> 6: 125.1 -> 128.2 TF;  NT 4 (6: 131.9 -> 131.1);  TN 2 -> 3: 121.9 -> 126.4 TF
+template <bool A_KC, bool B_KC>
+constexpr int kPf3 = A_KC ? (B_KC ? 4 : 6) : 3;
 
 template <bool A_KC, bool B_KC, int EPI>
 int dispatch_cfg(const GemmArgs& p, int cfg, hipStream_t s) {
@@ -596,7 +601,7 @@ int dispatch_cfg(const GemmArgs& p, int cfg, hipStream_t s) {
     case 2: return launch<Tile<64, 128, 32, 64, 3, 2, A_KC, B_KC>, EPI>(p, s);
     // k-contiguous operands (NN / NT) arrive later than m/n-contiguous ones: 4 tiles of prefetch vs 2
     // (measured +3..5 %, profiles/r01_gemm_ablation.txt)
-    case 3: return launch<Tile<64, 64, 32, 32, 3, (A_KC ? 4 : 2), A_KC, B_KC>, EPI>(p, s);
+    case 3: return launch<Tile<64, 64, 32, 32, 3, kPf3<A_KC, B_KC>, A_KC, B_KC>, EPI>(p, s);
     case 4: return launch<Tile<128, 128, 64, 32, 3, 1, A_KC, B_KC>, EPI>(p, s);
     case 5: return launch<Tile<256, 128, 64, 64, 2, 1, A_KC, B_KC>, EPI>(p, s);
     case 6: return launch<Tile<64, 128, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
@@ -631,8 +636,8 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
 
 template <int EPI_NT, int EPI_TN>
 int launch_dual(const GemmArgs& a, const GemmArgs& w, hipStream_t stream) {
-  typedef Tile<64, 64, 32, 32, 3, 4, true, true> TA;    // config 3, NT
-  typedef Tile<64, 64, 32, 32, 3, 2, false, false> TW;  // config 3, TN
+  typedef Tile<64, 64, 32, 32, 3, kPf3<true, true>, true, true> TA;      // config 3, NT
+  typedef Tile<64, 64, 32, 32, 3, kPf3<false, false>, false, false> TW;  // config 3, TN
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dual_kernel<TA, EPI_NT, TW, EPI_TN>),
