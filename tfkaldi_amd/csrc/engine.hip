@@ -88,18 +88,11 @@ struct tfk_engine {
 
   hipStream_t stream = nullptr, copy_stream = nullptr;
   bool own_stream = false;
-  // Side stream, OFF by default (measured slower on MI355X, profiles/r01_overlap_experiment.txt): (1) the
-  // dW GEMMs of backward only feed Adam, so they can run concurrently with the main chain dA -> BN/activation
-  // backward -> dA; (2) Adam (HBM-bound) can overlap the NEXT step's forward, which then waits per layer on
-  // ev_adam_w[l].  Both lose to plain stream order here: every GEMM already fills all 256 CUs, so concurrent
-  // kernels only evict each other's L2 working set and steal wave slots.
-  hipStream_t side = nullptr;
-  bool overlap = false;     // async Adam on the side stream   (TFK_OVERLAP_ADAM=1)
-  bool overlap_dw = false;  // dW GEMMs on the side stream      (TFK_OVERLAP_DW=1)
-  int adam_blocks = 0;      // grid cap of the async Adam launches (0 = kernel default)
-  std::vector<hipEvent_t> ev_dz, ev_dw, ev_adam_w;
-  hipEvent_t ev_adam_vec = nullptr, ev_adam_done = nullptr, ev_fork = nullptr, ev_loss = nullptr;
-  bool adam_pending = false;  // Adam of the last apply may still be running on the side stream
+  // Everything runs in order on ONE stream (plus the copy stream of the host-fed inputs).  Running the weight-
+  // gradient GEMMs or the optimiser on a side stream was measured slower (profiles/r01_overlap_experiment.txt:
+  // every GEMM already fills all 256 CUs, a concurrent kernel only evicts its L2 working set) and was removed;
+  // the independent dA / dW pair of a layer shares one LAUNCH instead (gemm_f32_dual).
+  hipEvent_t ev_loss = nullptr;
 
   // persistent state
   float* state = nullptr;
@@ -291,16 +284,10 @@ struct ProfScope {
   }
 };
 
-// everything this engine has in flight (main, side and copy streams)
+// everything this engine has in flight (main and copy streams)
 int sync_streams(tfk_engine* e) {
   HIPCHK(hipStreamSynchronize(e->copy_stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipStreamSynchronize(e->side));
-  return 0;
-}
-// main stream: do not run ahead of the Adam update still executing on the side stream
-int wait_adam_done(tfk_engine* e) {
-  if (e->adam_pending) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_done, 0));
   return 0;
 }
 
@@ -652,16 +639,10 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   const float* in = Xd;
   int ld_in = ldx;
   const int H = e->H, ldH = e->ldH;
-  const bool gate = e->adam_pending;  // parameters of layer l are ready once ev_adam_w[l] has fired
-  if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_vec, 0));
-  if (e->bf16 && e->shadow_dirty) {
-    CHK(wait_adam_done(e));
-    CHK(refresh_shadow(e));
-  }
+  if (e->bf16 && e->shadow_dirty) CHK(refresh_shadow(e));
   auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; } return t; };
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
-    if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_w[l], 0));
     if (train && e->cfg.batch_norm && !e->cfg.l2_norm) {
       // fused path: the GEMM epilogue emits the per-tile column statistics, ONE column-tiled kernel merges them
       // and applies BN + nonlinearity + dropout (4 kernels per layer -> 2)
@@ -701,13 +682,8 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
     ld_in = ldH;
   }
   const LayerLayout& o = e->lay[e->L];
-  if (gate) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_w[e->L], 0));
   CHK(run_gemm(e, GEMM_NN, e->a[nact - 1], ldH, e->p_param() + o.w_off, o.ld_out, e->logits, e->ldO, T, e->O, H,
                e->p_param() + o.b_off, EPI_BIAS));
-  if (gate) {  // the loss accumulators are re-initialised at the very end of the side-stream work
-    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam_done, 0));
-    e->adam_pending = false;  // everything enqueued on the main stream from here on is ordered behind it
-  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -718,10 +694,6 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   float* G = e->p_grad();
   const int acc = e->grads_fresh ? 0 : 1;
   const int epi_w = acc ? EPI_ACCUM : 0;
-  // With a bucket callback the host launches collectives behind the MAIN stream, so every gradient must be
-  // produced there; otherwise the weight-gradient GEMMs go to the side stream.
-  const bool two = e->overlap_dw && !(fire && e->cb);
-  hipStream_t sw = two ? e->side : e->stream;
   if (!acc)  // layers above the active depth are not visited below: their (logically zero) G must be zero
     for (int l = nact; l < L; ++l) {
       const LayerLayout& q = e->lay[l];
@@ -730,10 +702,6 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
       if (q.beta_sz) HIPCHK(hipMemsetAsync(G + q.beta_off, 0, q.beta_sz * sizeof(float), e->stream));
     }
   // output layer: dZ = softmax - onehot sits in `logits`
-  if (two) {
-    HIPCHK(hipEventRecord(e->ev_dz[L], e->stream));
-    HIPCHK(hipStreamWaitEvent(sw, e->ev_dz[L], 0));
-  }
   // (when eligible the output layer's dW runs in one launch with the dA that follows: see below)
   bool out_dw_done = false;
   FinalBatch fin;
@@ -761,7 +729,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, EPI_DACT, nullptr, ws_of(target), cfg,
                     &act);
   };
-  if (!two) {
+  {
     const ActEpi act = {e->a[nact - 1], e->z[nact - 1], e->mean[nact - 1], e->rstd[nact - 1], e->cfg.nonlin};
     const int rc = run_gemm_dual(e, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O,
                                  fuse_hb ? &act : nullptr, fuse_hb ? ws_of(nact - 1) : nullptr, e->a[nact - 1], ldH,
@@ -771,8 +739,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   }
   if (!out_dw_done) {
     CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
-                 epi_w, sw));
-    if (two) HIPCHK(hipEventRecord(e->ev_dw[L], sw));
+                 epi_w));
     CHK(dact_gemm(e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], e->O, nact - 1, cfg_o));
   }
   if (fire && e->cb) e->cb(e->cb_user, 0);  // the output layer's weight gradient is enqueued
@@ -802,12 +769,8 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     }
     const float* in = l == 0 ? Xd : e->a[l - 1];
     const int ld_in = l == 0 ? ldx : ldH;
-    if (two) {  // dz_l (in `da`) is complete on the main stream -> side stream may read it
-      HIPCHK(hipEventRecord(e->ev_dz[l], e->stream));
-      HIPCHK(hipStreamWaitEvent(sw, e->ev_dz[l], 0));
-    }
     bool fused = false;
-    if (l > 0 && !two) {  // dW_l and the dA that feeds layer l - 1 both read dz_l: one launch when eligible
+    if (l > 0) {  // dW_l and the dA that feeds layer l - 1 both read dz_l: one launch when eligible
       const ActEpi act = {e->a[l - 1], e->z[l - 1], e->mean[l - 1], e->rstd[l - 1], e->cfg.nonlin};
       const int rc = run_gemm_dual(e, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H,
                                    fuse_hb ? &act : nullptr, fuse_hb ? ws_of(l - 1) : nullptr, in, ld_in, G + y.w_off,
@@ -816,21 +779,12 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
       fused = rc == 0;
     }
     if (!fused) {
-      CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w, sw));
-      if (two) HIPCHK(hipEventRecord(e->ev_dw[l], sw));
-      if (l > 0) {
-        // the dA GEMM overwrites dA[pp ^ 1] = dz of layer l + 1, which dW_{l+1} may still be reading
-        if (two && l + 1 <= nact - 1) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l + 1], 0));
-        CHK(dact_gemm(da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], H, l - 1, cfg_h));
-      }
+      CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w));
+      if (l > 0) CHK(dact_gemm(da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], H, l - 1, cfg_h));
     }
     if (l > 0) chunks_in = chunks_h;
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
-  }
-  if (two) {  // join: every weight gradient is complete (and X / a_l / logits are free again) behind this point
-    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[L], 0));
-    for (int l = nact - 1; l >= 0; --l) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_dw[l], 0));
   }
   {  // one kernel turns every layer's partial column sums into the bias / beta gradient sums
     ProfScope ps(e, KF_COLSUM, 0, 0);
@@ -937,26 +891,11 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     e->own_stream = true;
   }
   HIPB(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  HIPB(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   {
     const char* v;
-    if ((v = getenv("TFK_OVERLAP_ADAM"))) e->overlap = atoi(v) != 0;
-    if ((v = getenv("TFK_OVERLAP_DW"))) e->overlap_dw = atoi(v) != 0;
     if ((v = getenv("TFK_FUSE_HB"))) e->fuse_hb_enabled = atoi(v) != 0;
     if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
-    // few, fat blocks: the optimiser only has to finish within the next forward pass and must leave the
-    // CUs' wave slots to the GEMM blocks it runs beside
-    e->adam_blocks = (v = getenv("TFK_ADAM_BLOCKS")) ? atoi(v) : 512;
   }
-  e->ev_dz.assign(e->L + 1, nullptr); e->ev_dw.assign(e->L + 1, nullptr); e->ev_adam_w.assign(e->L + 1, nullptr);
-  for (int l = 0; l <= e->L; ++l) {
-    HIPB(hipEventCreateWithFlags(&e->ev_dz[l], hipEventDisableTiming));
-    HIPB(hipEventCreateWithFlags(&e->ev_dw[l], hipEventDisableTiming));
-    HIPB(hipEventCreateWithFlags(&e->ev_adam_w[l], hipEventDisableTiming));
-  }
-  HIPB(hipEventCreateWithFlags(&e->ev_adam_vec, hipEventDisableTiming));
-  HIPB(hipEventCreateWithFlags(&e->ev_adam_done, hipEventDisableTiming));
-  HIPB(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
   for (int s = 0; s < 2; ++s) {
     HIPB(hipEventCreateWithFlags(&e->copy_done[s], hipEventDisableTiming));
@@ -1118,7 +1057,6 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   }
   if (train) {
     const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
-    CHK(wait_adam_done(e));  // (forward already waited; kept for call orders that skip it)
     if (fire) {
       // loss, frame count and the BN moving-average increments of the step are final once the last micro-batch's
       // forward + loss have run: their (tiny) bucket is announced FIRST, so that its all-reduce is long done when
@@ -1165,14 +1103,9 @@ int tfk_destroy(tfk_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  if (e->side) hipStreamSynchronize(e->side);
   if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
   free_activations(e);
-  for (auto ev : e->ev_dz) if (ev) hipEventDestroy(ev);
-  for (auto ev : e->ev_dw) if (ev) hipEventDestroy(ev);
-  for (auto ev : e->ev_adam_w) if (ev) hipEventDestroy(ev);
-  for (hipEvent_t ev : {e->ev_adam_vec, e->ev_adam_done, e->ev_fork, e->ev_loss}) if (ev) hipEventDestroy(ev);
-  if (e->side) hipStreamDestroy(e->side);
+  if (e->ev_loss) hipEventDestroy(e->ev_loss);
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
@@ -1363,7 +1296,6 @@ int apply_end(tfk_engine* e, float* average_loss) {
   if (!e->apply_direct) e->shadow_dirty = true;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventSynchronize(e->ev_loss));
-  e->adam_pending = false;
   e->grads_fresh = true;
   e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
   e->global_step += 1;
@@ -1373,7 +1305,6 @@ int apply_end(tfk_engine* e, float* average_loss) {
 
 int tfk_apply_begin(tfk_engine* e) {
   if (!e) return fail(-1, "engine is NULL");
-  if (e->overlap) return fail(-1, "the split optimiser step is not available with TFK_OVERLAP_ADAM");
   HIPCHK(hipSetDevice(e->cfg.device));
   return apply_begin(e);
 }
@@ -1391,63 +1322,14 @@ int tfk_apply_end(tfk_engine* e, float* average_loss) {
 int tfk_apply(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
-  if (!e->overlap) {  // one Adam launch over the whole parameter arena, in stream order
-    CHK(apply_begin(e));
-    CHK(apply_span(e, 0, e->P));
-    return apply_end(e, average_loss);
-  }
-  if (e->apply_open) return fail(-1, "tfk_apply inside tfk_apply_begin / tfk_apply_end");
-  const double lr = current_lr(e);
-  e->adam_t += 1;
-  const double t = (double)e->adam_t;
-  const float lr_t = (float)(lr * sqrt(1.0 - pow((double)e->b2, t)) / (1.0 - pow((double)e->b1, t)));
-  if (e->grads_fresh)
-    HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
-  CHK(settle_scalars(e));
-  {
-    ProfScope ps(e, KF_EMA, 0, 16.0 * e->E);
-    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev);
-  }
-  HIPCHK(hipEventRecord(e->ev_loss, e->stream));
-  // Adam: vectors first, then one launch per weight matrix in FORWARD order, each followed by an event the
-  // next step's forward waits on -- on the side stream, so that the forward GEMMs (matrix-bound) and the
-  // optimiser (HBM-bound) overlap.
-  hipStream_t sa = e->side;
-  const int grid_cap = e->adam_blocks;
-  e->shadow_dirty = true;  // the side-stream optimiser does not maintain the bf16 shadow
-  HIPCHK(hipEventRecord(e->ev_fork, e->stream));
-  HIPCHK(hipStreamWaitEvent(sa, e->ev_fork, 0));
-  {
-    const size_t v0 = e->lay[0].b_off;
-    ProfScope ps(e, KF_ADAM, 0, 28.0 * (e->P - v0), sa);
-    adam_apply(sa, e->p_param() + v0, e->p_grad() + v0, e->p_m() + v0, e->p_v() + v0, e->P - v0, e->p_scalars(), lr_t,
-               e->b1, e->b2, e->adam_eps, grid_cap);
-  }
-  HIPCHK(hipEventRecord(e->ev_adam_vec, sa));
-  for (int l = 0; l <= e->L; ++l) {
-    const LayerLayout& y = e->lay[l];
-    {
-      ProfScope ps(e, KF_ADAM, 0, 28.0 * y.w_sz, sa);
-      adam_apply(sa, e->p_param() + y.w_off, e->p_grad() + y.w_off, e->p_m() + y.w_off, e->p_v() + y.w_off, y.w_sz,
-                 e->p_scalars(), lr_t, e->b1, e->b2, e->adam_eps, grid_cap);
-    }
-    HIPCHK(hipEventRecord(e->ev_adam_w[l], sa));
-  }
-  HIPCHK(hipEventRecord(e->ev_adam_done, sa));
-  HIPCHK(hipGetLastError());
-  e->adam_pending = true;
-  HIPCHK(hipEventSynchronize(e->ev_loss));  // the host only waits for the loss, not for the optimiser
-  e->grads_fresh = true;
-  e->scalars_fresh = true;  // (the side stream still reads num_frames: wait_adam_done precedes the next overwrite)
-  e->global_step += 1;
-  if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
-  return 0;
+  CHK(apply_begin(e));
+  CHK(apply_span(e, 0, e->P));  // one Adam launch over the whole parameter arena
+  return apply_end(e, average_loss);
 }
 
 int tfk_eval_finish(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
-  CHK(wait_adam_done(e));
   CHK(read_scalars(e));
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
   return 0;
@@ -1470,7 +1352,6 @@ int tfk_init_last_layer(tfk_engine* e) {
   // re-run the initialisers of layer L: weights ~ N(0, stddev 0) = 0, biases = 0 (dnn.py:67-68, 114-120)
   const LayerLayout& o = e->lay[e->L];
   HIPCHK(hipSetDevice(e->cfg.device));
-  CHK(wait_adam_done(e));
   HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
   e->shadow_dirty = true;
@@ -1579,7 +1460,6 @@ int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* 
 int tfk_zero_accumulators(tfk_engine* e) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
-  CHK(wait_adam_done(e));
   HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->reduce_floats * sizeof(float), e->stream));
   e->grads_fresh = false;  // physically zero now
   e->scalars_fresh = false;
