@@ -1402,6 +1402,19 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
       softmax_rows(e->stream, e->logits, N, e->O, e->ldO, e->post, e->ldO, prior);
     }
     CHK(finish_slot(e, flags, slot_before));
+    const float* src = want_logits ? e->logits : e->post;
+    // a caller that hands over PINNED host memory gets the result by one DMA, without the staging copy
+    hipPointerAttribute_t attr;
+    const bool pinned_out = hipPointerGetAttributes(&attr, out) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned_out) (void)hipGetLastError();  // (an unregistered pointer reports an error: not one of ours)
+    if (pinned_out) {
+      HIPCHK(hipMemcpy2DAsync(out, (size_t)ldo * 4, src, (size_t)e->ldO * 4, (size_t)e->O * 4, N, hipMemcpyDeviceToHost,
+                              e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipGetLastError());
+      e->last_T = N; e->last_nfw = nact; e->last_call = call; e->last_in = Xd;
+      return 0;
+    }
     const size_t need = (size_t)N * e->O;
     if (need > e->h_post_floats) {
       HIPCHK(hipStreamSynchronize(e->stream));
@@ -1410,7 +1423,7 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
       HIPCHK(hipHostMalloc((void**)&e->h_post, need * sizeof(float), hipHostMallocDefault));
       e->h_post_floats = need;
     }
-    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, want_logits ? e->logits : e->post, (size_t)e->ldO * 4,
+    HIPCHK(hipMemcpy2DAsync(e->h_post, (size_t)e->O * 4, src, (size_t)e->ldO * 4,
                             (size_t)e->O * 4, N, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int t = 0; t < N; ++t) memcpy(out + (size_t)t * ldo, e->h_post + (size_t)t * e->O, (size_t)e->O * sizeof(float));

@@ -184,9 +184,20 @@ class Engine(object):
                                                lens.ctypes.data_as(c_void_p), lens.size, int(context_width),
                                                cmvn_ptr, 0))
 
+    def _out_buffer(self, rows):
+        """[rows, O] result array; in pinned host memory (torch's caching pinned allocator) so that the engine can
+        DMA straight into it -- the decode path moves 8 KB per frame back to the host"""
+        if rows * self.O >= 1 << 16:
+            try:
+                import torch
+                return torch.empty((rows, self.O), dtype=torch.float32, pin_memory=True).numpy()
+            except Exception:  # noqa: BLE001  (no torch / no pinned memory: plain pageable memory works as well)
+                pass
+        return np.empty((rows, self.O), dtype=np.float32)
+
     def posteriors_raw(self, raw, lens, context_width, log_div_prior=False, raw_logits=False, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
-        out = np.empty((raw.shape[0], self.O), dtype=np.float32)
+        out = self._out_buffer(raw.shape[0])
         flags = (_lib.LOG_DIV_PRIOR if log_div_prior else 0) | (_lib.RAW_LOGITS if raw_logits else 0)
         cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
         check(self.lib.tfk_posteriors_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0],
@@ -270,7 +281,7 @@ class Engine(object):
 
     def posteriors(self, X, log_div_prior=False, raw_logits=False):
         X = _f32(X)
-        out = np.empty((X.shape[0], self.O), dtype=np.float32)
+        out = self._out_buffer(X.shape[0])
         flags = (_lib.LOG_DIV_PRIOR if log_div_prior else 0) | (_lib.RAW_LOGITS if raw_logits else 0)
         check(self.lib.tfk_posteriors(self._h, X.ctypes.data_as(c_void_p), X.shape[1], X.shape[0],
                                       out.ctypes.data_as(c_void_p), self.O, flags))
