@@ -4,7 +4,7 @@ exactly that everything downstream is BIT-identical to feeding the host-spliced 
 import numpy as np
 import pytest
 
-from util import batch, make_pair
+from util import make_pair
 
 pytestmark = pytest.mark.gpu
 

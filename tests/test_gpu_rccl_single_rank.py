@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 
-from test_gpu_dp_two_ranks import KW, _collect, _data, _engine
+from test_gpu_dp_two_ranks import _collect, _data, _engine
 
 pytestmark = pytest.mark.gpu
 

@@ -3,7 +3,6 @@
 This is plumbing only -- every FLOP of the hot path runs in libtfkaldi_hip.so.  The classes of
 tfkaldi_amd.neuralNetworks (Trainer / Decoder / DNN) are built on it.
 """
-import ctypes
 from ctypes import byref, c_double, c_float, c_int, c_size_t, c_void_p
 
 import numpy as np
