@@ -74,7 +74,7 @@ def _run(lib, torch, layout, M, N, K, cfg, epi=0, seed=0):
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("cfg", list(range(9)))
+@pytest.mark.parametrize("cfg", list(range(10)))
 def test_gemm_ragged_shapes(gpu, layout, cfg):
     import torch
     # nothing a multiple of the tile: exercises every edge predicate and the zero-padded float4 tails
@@ -85,7 +85,7 @@ def test_gemm_ragged_shapes(gpu, layout, cfg):
 @pytest.mark.parametrize("layout,epi", [(0, 0), (0, 1), (0, 5), (2, 0), (2, 2), (1, 0)])
 def test_gemm_epilogues(gpu, layout, epi):
     import torch
-    for cfg in (-1, 0, 3, 6):
+    for cfg in (-1, 0, 3, 6, 9):
         _run(gpu, torch, layout, 130, 100, 64, cfg, epi=epi)      # ragged: predicated epilogue
         _run(gpu, torch, layout, 256, 256, 96, cfg, epi=epi)      # full tiles: straight-line epilogue
 
@@ -114,7 +114,7 @@ def test_gemm_transpose_detecting(gpu):
     dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
     dC = torch.zeros((n, n), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    for cfg in range(9):
+    for cfg in range(10):
         dC.zero_()
         rc = gpu.tfk_gemm_f32(ctypes.c_void_p(st), _lib.GEMM_NN, ctypes.c_void_p(dA.data_ptr()), n,
                               ctypes.c_void_p(dB.data_ptr()), n, ctypes.c_void_p(dC.data_ptr()), n, n, n, n, None, 0, cfg)

@@ -64,10 +64,11 @@ struct GemmArgs {
 //   1: 128x64  block, 4 waves of 64x32, s3 p2     6:  64x128 block, 8 waves of 32x32, s3 p2
 //   2:  64x128 block, 4 waves of 32x64, s3 p2     7: 128x64  block, 8 waves of 32x32, s3 p2
 //   3:  64x64  block, 4 waves of 32x32, s3 p2     8:  64x64  block, 4 waves of 32x32, s3 p1
-//   4: 128x128 block, 8 waves of 64x32, s3 p1
-// The heuristic uses 0 (>= 512 tiles of 128x128) and 3 (everything smaller); the rest are kept for the sweep
-// tool (tools/gemm_sweep.py) that produced profiles/r01_gemm_sweep_*.txt.
-constexpr int kNumGemmConfigs = 9;
+//   4: 128x128 block, 8 waves of 64x32, s3 p1     9:  64x64  block, 4 waves of 32x32, 4-slot ring filled by LDS-DMA
+// The heuristic uses 0 (>= 512 tiles of 128x128) and 9 (everything smaller; 3, its register-staged twin, with
+// TFK_GEMM_DMA=0); the rest are kept for the sweep tool (tools/gemm_sweep.py) that produced
+// profiles/r01_gemm_sweep_*.txt.
+constexpr int kNumGemmConfigs = 10;
 
 // cfg < 0 => heuristic choice. Returns hipError_t as int.
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream);

@@ -1,4 +1,5 @@
-// fp32 MFMA GEMM for gfx950 (CDNA4): LDS-tiled, register-staged, software-pipelined.
+// fp32 MFMA GEMM for gfx950 (CDNA4): LDS-tiled and software-pipelined; tiles reach LDS by LDS-DMA (the 64x64
+// configuration of the hot path) or through registers (the larger tiles).
 //
 // Replaces the TensorFlow matmul kernels behind neuralNetworks/classifiers/layer.py:52 and the
 // tf.gradients of it (neuralNetworks/trainer.py:155) -- see gemm_f32.h for the three layouts.
@@ -13,7 +14,8 @@
 //     an operand contiguous along m/n ("MC") uses one conflict-free ds_read_b32 per step.
 //   * LDS rows of KC tiles are padded by 4 floats (row stride 36 floats = 9 x 16 B, odd in 16-B slots)
 //     so the 16-lane service groups of ds_read_b128 hit 16 distinct slots.
-//   * Pipeline (NSTAGE = 3): iteration t writes the register-staged tile t+2 into ring slot (t+2)%3,
+//   * LDS-DMA pipeline (Tile<..., DMA>): see DmaLoader and the K loop under `if constexpr (T::DMA)`.
+//   * Register pipeline (NSTAGE = 3): iteration t writes the register-staged tile t+2 into ring slot (t+2)%3,
 //     issues the global loads of tile t+3, and computes tile t.  Tile t+1 has been visible in LDS since
 //     the previous barrier, so the fragments of its first k-group are fetched BEFORE this iteration's
 //     barrier, under the last MFMAs of tile t: the matrix pipe never waits for an LDS round trip after a
@@ -27,6 +29,10 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+
+#ifndef TFK_ABL
+#define TFK_ABL 0  // tools/gemm_ablate.hip only: timing variants with pieces of the K loop removed
+#endif
 
 namespace tfk {
 
@@ -42,10 +48,13 @@ constexpr int NUM_XCD = 8;
 
 // NSTAGE_: LDS ring slots (2 or 3); PF_: global-load prefetch distance in tiles beyond the ring (1 or 2
 // register sets in flight; 2 only with the 3-slot ring).
-template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int PF_, bool A_KC_, bool B_KC_>
+// DMA_: the tiles go from memory to the LDS ring by LDS-DMA (buffer_load ... lds) instead of through registers;
+// NSTAGE_ is then the ring depth (4 or 5 slots) and PF_ is unused.
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int PF_, bool A_KC_, bool B_KC_, bool DMA_ = false>
 struct Tile {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, PF = PF_;
-  static_assert(PF_ == 1 || (PF_ >= 2 && PF_ <= 8 && NSTAGE_ == 3), "prefetch distance");
+  static constexpr bool DMA = DMA_;
+  static_assert(DMA_ || PF_ == 1 || (PF_ >= 2 && PF_ <= 8 && NSTAGE_ == 3), "prefetch distance");
   static constexpr bool A_KC = A_KC_, B_KC = B_KC_;
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
   static constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -58,9 +67,10 @@ struct Tile {
   // (summed in the epilogue) such that every wave owns >= 4 chains and consecutive MFMAs never depend.
   static constexpr int KS = (FM * FN >= 4) ? 1 : (FM * FN == 2 ? 2 : 4);
   // LDS images
-  static constexpr int A_LD = A_KC ? (BK + KC_PAD) : BM;
+  // (a DMA image is lane-linear, so its k-contiguous rows are unpadded and XOR-swizzled instead)
+  static constexpr int A_LD = A_KC ? (BK + (DMA ? 0 : KC_PAD)) : BM;
   static constexpr int A_SZ = (A_KC ? BM : BK) * A_LD;
-  static constexpr int B_LD = B_KC ? (BK + KC_PAD) : BN;
+  static constexpr int B_LD = B_KC ? (BK + (DMA ? 0 : KC_PAD)) : BN;
   static constexpr int B_SZ = (B_KC ? BN : BK) * B_LD;
   static constexpr int STAGE = A_SZ + B_SZ;
   static constexpr int LDS_BYTES = NSTAGE * STAGE * 4;
@@ -69,7 +79,7 @@ struct Tile {
   static constexpr int B_F4 = BN * BK / 4 / NT;
   static_assert(BM % WM == 0 && BN % WN == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "staging divisibility");
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+  static_assert(DMA ? (NSTAGE >= 3 && NSTAGE <= 5) : (NSTAGE == 2 || NSTAGE == 3), "ring depth");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -136,13 +146,73 @@ __device__ __forceinline__ void store_tile(const float4 (&r)[NF4], float* __rest
   }
 }
 
+// LDS-DMA staging.  One `buffer_load_dwordx4 ... lds` moves 64 x 16 B per wave from per-lane global addresses to
+// ONE contiguous KiB of LDS (M0 + lane * 16): no staging registers, no ds_write pass.  The LDS image is therefore
+// lane-linear: 16-B chunk q of an operand tile sits at byte q * 16, and any permutation has to be applied on the
+// SOURCE side.  k-contiguous tiles ([ext][32 k], 8 chunks per row) store k-chunk c of row r at chunk position
+// c ^ ((r >> 1) & 7): the four 16-lane service groups of the fragments' ds_read_b128 ({0-3,12-15,20-27}, ...) then
+// touch 16 distinct 16-B slots of the 256-B bank row.  m/n-contiguous tiles ([32 k][ext]) stay linear.
+// hipcc does not count these loads (inline asm): completion is the loop's own s_waitcnt vmcnt(N) + barrier.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int EXT, int NT, int NF4, bool KC>
+struct DmaLoader {
+  i32x4 rsrc;
+  int voff[NF4];
+  int kidx[NF4];
+  int kstride;
+  int k_lim;
+
+  __device__ __forceinline__ void init(const float* base, int ld, int rows, int ext0, int ext_lim, int k_lim_,
+                                       int tid) {
+    const unsigned long long a = (unsigned long long)base;
+    rsrc[0] = (int)(unsigned)a;
+    rsrc[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+    rsrc[2] = rows * ld * 4;
+    rsrc[3] = 0x00020000;
+    k_lim = k_lim_;
+    kstride = KC ? 4 : ld * 4;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int idx = tid + i * NT;  // chunk index inside the tile image
+      int e, k;
+      if (KC) {
+        const int r = idx >> 3;
+        k = ((idx & 7) ^ ((r >> 1) & 7)) << 2;
+        e = ext0 + r;
+        voff[i] = e < ext_lim ? (e * ld + k) * 4 : kOOB;
+      } else {
+        constexpr int C4 = EXT / 4;
+        k = idx / C4;
+        e = ext0 + ((idx % C4) << 2);
+        voff[i] = e < ext_lim ? (k * ld + e) * 4 : kOOB;
+      }
+      kidx[i] = k;
+    }
+  }
+  // piece i of the tile at k0 -> image at LDS byte address `image`
+  __device__ __forceinline__ void issue(int i, unsigned image, int k0, int wave) const {
+    const int off = (k0 + kidx[i] < k_lim) ? voff[i] : kOOB;
+    const unsigned dst = image + (unsigned)(wave * 64 + i * NT) * 16u;
+    const int soff = k0 * kstride;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(dst), "v"(off), "s"(rsrc), "s"(soff)
+                 : "memory");
+  }
+};
+
 // Fragment fetch for one 8-k group g: f[frag][t] is the operand of MFMA step t.
-template <int NF, bool KC, int LD>
+template <int NF, bool KC, int LD, bool SWZ = false>
 __device__ __forceinline__ void read_frags(float (&f)[NF][4], const float* __restrict__ s, int ext_base,
                                            int g, int i, int h) {
 #pragma unroll
   for (int q = 0; q < NF; ++q) {
-    if (KC) {
+    if (KC && SWZ) {
+      const int r = ext_base + q * 32 + i;
+      const float4 v = *reinterpret_cast<const float4*>(s + r * LD + (((g * 2 + h) ^ ((r >> 1) & 7)) << 2));
+      f[q][0] = v.x; f[q][1] = v.y; f[q][2] = v.z; f[q][3] = v.w;
+    } else if (KC) {
       const float4 v = *reinterpret_cast<const float4*>(s + (ext_base + q * 32 + i) * LD + g * 8 + h * 4);
       f[q][0] = v.x; f[q][1] = v.y; f[q][2] = v.z; f[q][3] = v.w;
     } else {
@@ -217,8 +287,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
   } while (0)
 #define TFK_FRAGS(buf, slot, g)                                                            \
   do {                                                                                     \
-    read_frags<T::FM, T::A_KC, T::A_LD>(fa[buf], (slot), wm * T::WM, (g), i, h);           \
-    read_frags<T::FN, T::B_KC, T::B_LD>(fb[buf], (slot) + T::A_SZ, wn * T::WN, (g), i, h); \
+    read_frags<T::FM, T::A_KC, T::A_LD, T::DMA>(fa[buf], (slot), wm * T::WM, (g), i, h);           \
+    read_frags<T::FN, T::B_KC, T::B_LD, T::DMA>(fb[buf], (slot) + T::A_SZ, wn * T::WN, (g), i, h); \
   } while (0)
 #define TFK_MFMA(buf)                                                                                       \
   _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                             \
@@ -227,7 +297,86 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
     acc[t % T::KS][a][b] =                                                                                  \
         __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][a][t], fb[buf][b][t], acc[t % T::KS][a][b], 0, 0, 0)
 
-  if (T::NSTAGE == 3) {
+  if constexpr (T::DMA) {
+    // LDS-DMA ring of NS slots.  Iteration kt computes tile kt from slot kt % NS; tile kt+1 has been visible since
+    // the previous barrier (its first fragments are fetched before this iteration's barrier, as in the register
+    // ring below); tiles kt+2 .. kt+NS-2 are in flight; the pieces of tile kt+NS-1 are issued, one per MFMA gap of
+    // the first k-group, into the slot tile kt-1 left at that barrier.  The iteration ends by waiting for this
+    // wave's pieces of tile kt+2 (vmcnt: the NS-3 younger tiles may stay in flight) and the barrier that makes
+    // every wave's pieces of it visible.
+    constexpr int NS = T::NSTAGE;
+    constexpr int NPA = T::A_F4, NPT = T::A_F4 + T::B_F4;  // pieces per thread per tile
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
+    DmaLoader<T::BM, T::NT, T::A_F4, T::A_KC> da;
+    DmaLoader<T::BN, T::NT, T::B_F4, T::B_KC> db;
+    da.init(p.A, p.lda, T::A_KC ? p.M : p.K, m0, a_ext_lim, a_k_lim, tid);
+    db.init(p.B, p.ldb, T::B_KC ? p.N : p.K, n0, b_ext_lim, b_k_lim, tid);
+#define TFK_PIECE(j, slotidx, kt)                                                                  \
+  do {                                                                                             \
+    if ((j) < NPA) da.issue((j), lds0 + (unsigned)((slotidx) * T::STAGE * 4), (kt) * BK, wave);    \
+    else db.issue((j) - NPA, lds0 + (unsigned)(((slotidx) * T::STAGE + T::A_SZ) * 4), (kt) * BK, wave); \
+  } while (0)
+#define TFK_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n) : "memory")
+#define TFK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory")
+#define TFK_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef TFK_DMA_PLACE
+#define TFK_DMA_PLACE 2  // 0: every piece in k-group 0; 1: spread over the 4 groups; 2: over groups 0 and 1
+#endif
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) TFK_PIECE(j, t, t);
+    TFK_VMCNT((NS - 3) * NPT);
+    TFK_LDS_BARRIER();
+    TFK_FRAGS(0, smem, 0);
+#define TFK_DITER(R, KT)                                                                        \
+  do {                                                                                          \
+    const float* cur = smem + (R) * T::STAGE;                                                   \
+    const float* nxt = smem + (((R) + 1) % NS) * T::STAGE;                                      \
+    constexpr int WR = ((R) + NS - 1) % NS;                                                     \
+    _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                            \
+      if (g + 1 < NG) {                                                                         \
+        TFK_FRAGS((g + 1) & 1, cur, g + 1);                                                     \
+      } else {                                                                                  \
+        TFK_FRAGS(0, nxt, 0);                                                                   \
+      }                                                                                         \
+      TFK_SB();                                                                                 \
+      /* pieces [p0, p1) of tile KT+NS-1 ride behind the first MFMAs of this k-group */         \
+      const int p0 = TFK_DMA_PLACE == 0 ? (g == 0 ? 0 : NPT) : g * NPT / (NG / TFK_DMA_PLACE);  \
+      const int p1 = TFK_DMA_PLACE == 0 ? NPT : min(NPT, (g + 1) * NPT / (NG / TFK_DMA_PLACE)); \
+      int pc = p0;                                                                              \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                             \
+      _Pragma("unroll") for (int a = 0; a < T::FM; ++a)                                         \
+      _Pragma("unroll") for (int b = 0; b < T::FN; ++b) {                                       \
+        acc[t % T::KS][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(                            \
+            fa[g & 1][a][t], fb[g & 1][b][t], acc[t % T::KS][a][b], 0, 0, 0);                   \
+        if (pc < p1 && !(TFK_ABL & 1)) {                                                        \
+          TFK_SB();                                                                             \
+          TFK_PIECE(pc, WR, (KT) + NS - 1);                                                     \
+          TFK_SB();                                                                             \
+        }                                                                                       \
+        ++pc;                                                                                   \
+      }                                                                                         \
+      _Pragma("unroll") for (; pc < p1; ++pc) TFK_PIECE(pc, WR, (KT) + NS - 1);                 \
+      TFK_SB();                                                                                 \
+    }                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (!(TFK_ABL & 16)) TFK_VMCNT((NS - 3) * NPT);                                             \
+    if (!(TFK_ABL & 8)) TFK_LDS_BARRIER();                                                      \
+  } while (0)
+    for (int kt = 0; kt < nk; kt += NS) {
+      TFK_DITER(0, kt);
+      TFK_DITER(1, kt + 1);
+      TFK_DITER(2, kt + 2);
+      if (NS >= 4) TFK_DITER(3 % NS, kt + 3);
+      if (NS >= 5) TFK_DITER(4 % NS, kt + 4);
+    }
+    // the epilogues reuse the ring as scratch: nothing may still be landing in it
+    TFK_VMCNT(0);
+    TFK_LDS_BARRIER();
+#undef TFK_DITER
+#undef TFK_PIECE
+  } else if (T::NSTAGE == 3) {
     // ring slots as rotating pointers: s0 = tile t, s1 = tile t+1, s2 = tile t+2
     float* s0 = smem;
     float* s1 = smem + T::STAGE;
@@ -262,9 +411,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
     // the loads return zeros (kOOB) and the MFMAs of a rounded-up trip count add zeros.
 // TFK_ABL (tools/gemm_ablate.sh only): timing-only variants with pieces of the loop removed --
 // 1 global loads, 2 ring-slot writes, 4 fragment reads, 8 barrier.  Results are then meaningless.
-#ifndef TFK_ABL
-#define TFK_ABL 0
-#endif
 // Instruction placement inside one iteration (sched_group_barrier = "emit N instructions of this class
 // here"): an MFMA occupies the SIMD's matrix pipe for 64 cycles, and whatever the wave issues before its
 // next MFMA must fit in that gap or the pipe idles.  Measured (tools/gemm_ablate.sh): four back-to-back
@@ -586,6 +732,7 @@ const CfgDesc kCfg[kNumGemmConfigs] = {
     {128, 128, "128x128/4w64x64/s2"},   {128, 64, "128x64/4w64x32/s3p2"},   {64, 128, "64x128/4w32x64/s3p2"},
     {64, 64, "64x64/4w32x32/s3p6|4|3"},     {128, 128, "128x128/8w64x32/s3p1"}, {256, 128, "256x128/8w64x64/s2"},
     {64, 128, "64x128/8w32x32/s3p2"},   {128, 64, "128x64/8w32x32/s3p2"},   {64, 64, "64x64/4w32x32/s3p1"},
+    {64, 64, "64x64/4w32x32/dma4"},
 };
 
 // Prefetch distance of the 64x64 configuration per layout (stand-alone 1024x2048x2048 / 2048x2048x1024, same box):
@@ -607,6 +754,7 @@ int dispatch_cfg(const GemmArgs& p, int cfg, hipStream_t s) {
     case 6: return launch<Tile<64, 128, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
     case 7: return launch<Tile<128, 64, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
     case 8: return launch<Tile<64, 64, 32, 32, 3, 1, A_KC, B_KC>, EPI>(p, s);
+    case 9: return launch<Tile<64, 64, 32, 32, 4, 1, A_KC, B_KC, true>, EPI>(p, s);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -634,10 +782,11 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
   return (int)hipErrorInvalidValue;
 }
 
-template <int EPI_NT, int EPI_TN>
+template <int EPI_NT, int EPI_TN, bool DMA>
 int launch_dual(const GemmArgs& a, const GemmArgs& w, hipStream_t stream) {
-  typedef Tile<64, 64, 32, 32, 3, kPf3<true, true>, true, true> TA;      // config 3, NT
-  typedef Tile<64, 64, 32, 32, 3, kPf3<false, false>, false, false> TW;  // config 3, TN
+  // config 3 (register-staged ring) or config 9 (LDS-DMA ring) for both halves
+  typedef Tile<64, 64, 32, 32, DMA ? 4 : 3, DMA ? 1 : kPf3<true, true>, true, true, DMA> TA;      // NT
+  typedef Tile<64, 64, 32, 32, DMA ? 4 : 3, DMA ? 1 : kPf3<false, false>, false, false, DMA> TW;  // TN
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dual_kernel<TA, EPI_NT, TW, EPI_TN>),
@@ -674,6 +823,7 @@ splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t stride, 
 }
 
 int g_forced_cfg = -2;  // -2: env not read yet; -1: heuristic
+int g_dma = 1;          // env TFK_GEMM_DMA=0: the 64x64 tile stages through registers (config 3), not LDS-DMA (9)
 
 }  // namespace
 
@@ -691,6 +841,7 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
     g_forced_cfg = e ? atoi(e) : -1;
     if ((e = getenv("TFK_GEMM_MIN_LDS"))) g_min_lds = atoi(e);
     if ((e = getenv("TFK_GEMM_EVEN_SPREAD"))) g_even_spread = atoi(e);
+    if ((e = getenv("TFK_GEMM_DMA"))) g_dma = atoi(e);
   }
   if (g_forced_cfg >= 0) return g_forced_cfg;
   (void)K;
@@ -699,7 +850,9 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
   // staging per MFMA of a 64x64 tile) wins once it yields two blocks per CU; below that the 64x64 tile with
   // its 3-slot ring and 2-tile prefetch (two or more independent blocks per CU) is fastest for all layouts.
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  return tiles128 >= 512 ? 0 : 3;
+  // The 64x64 tile stages through LDS-DMA (config 9) unless TFK_GEMM_DMA=0 asks for the register ring (config 3):
+  // stand-alone +0.5..1.5 %, BASELINE cfg2 step +1.4 % (profiles/r01_gemm_dma.txt).
+  return tiles128 >= 512 ? 0 : (g_dma ? 9 : 3);
 }
 
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream) {
@@ -739,16 +892,20 @@ int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t strea
 
 int gemm_f32_dual(const GemmArgs& nt, const GemmArgs& tn, hipStream_t stream) {
   // only the shapes the heuristic gives the 64x64 configuration to, and no split-K
-  if (gemm_f32_pick_config(GEMM_NT, nt.M, nt.N, nt.K) != 3 || gemm_f32_pick_config(GEMM_TN, tn.M, tn.N, tn.K) != 3)
-    return -1;
+  const int small = gemm_f32_pick_config(GEMM_NT, nt.M, nt.N, nt.K);
+  if ((small != 3 && small != 9) || gemm_f32_pick_config(GEMM_TN, tn.M, tn.N, tn.K) != small) return -1;
   if (((tn.M + 63) / 64) * ((tn.N + 63) / 64) < 256 && tn.K >= 2048) return -1;  // that one wants split-K
   if ((nt.lda & 3) || (nt.ldb & 3) || (tn.lda & 3) || (tn.ldb & 3)) return (int)hipErrorInvalidValue;
   const int key = (nt.epi == EPI_DACT ? 2 : nt.epi == 0 ? 0 : -8) + (tn.epi == EPI_ACCUM ? 1 : tn.epi == 0 ? 0 : -8);
-  switch (key) {
-    case 0: return launch_dual<0, 0>(nt, tn, stream);
-    case 1: return launch_dual<0, EPI_ACCUM>(nt, tn, stream);
-    case 2: return launch_dual<EPI_DACT, 0>(nt, tn, stream);
-    case 3: return launch_dual<EPI_DACT, EPI_ACCUM>(nt, tn, stream);
+  switch (key + (small == 9 ? 4 : 0)) {
+    case 0: return launch_dual<0, 0, false>(nt, tn, stream);
+    case 1: return launch_dual<0, EPI_ACCUM, false>(nt, tn, stream);
+    case 2: return launch_dual<EPI_DACT, 0, false>(nt, tn, stream);
+    case 3: return launch_dual<EPI_DACT, EPI_ACCUM, false>(nt, tn, stream);
+    case 4: return launch_dual<0, 0, true>(nt, tn, stream);
+    case 5: return launch_dual<0, EPI_ACCUM, true>(nt, tn, stream);
+    case 6: return launch_dual<EPI_DACT, 0, true>(nt, tn, stream);
+    case 7: return launch_dual<EPI_DACT, EPI_ACCUM, true>(nt, tn, stream);
   }
   return -1;
 }

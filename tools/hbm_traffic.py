@@ -21,7 +21,7 @@ LAYOUT = {("true", "false"): "gemm_f32_nn(fwd affine)", ("true", "true"): "gemm_
 def scope(kernel):
     if "gemm_f32_dual_kernel" in kernel:
         return "gemm_f32_dual(dA+dW)"
-    m = re.search(r"gemm_f32_kernel<.*?Tile<[^>]*?(true|false), (true|false)>", kernel)
+    m = re.search(r"gemm_f32_kernel<.*?Tile<(?:\d+, ){6}(true|false), (true|false)[,>]", kernel)
     if m:
         return LAYOUT.get((m.group(1), m.group(2)))
     for key, name in (("adam_kernel", "adam_apply"), ("bn_act_forward", "act_forward"), ("hb_stats", "hb_stats"),
