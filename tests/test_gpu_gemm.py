@@ -121,3 +121,17 @@ def test_gemm_transpose_detecting(gpu):
         assert rc == 0
         torch.cuda.synchronize()
         assert (dC.cpu().numpy() == B).all(), "cfg %d" % cfg
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_random_shapes_lds_dma_tile(gpu, layout):
+    """Random shapes through the LDS-DMA 64x64 tile (config 9, the hot path's tile) and the heuristic: extents of 1,
+    K shorter than one 32-k tile, K not a multiple of 4, ragged last tiles in both directions, K long enough for
+    every ring slot to be recycled many times."""
+    import torch
+    rng = np.random.default_rng(100 + layout)
+    shapes = [(1, 1, 1), (1, 70, 5), (65, 1, 31), (64, 64, 32), (63, 65, 33), (2, 3, 700), (130, 190, 1027)]
+    shapes += [tuple(int(x) for x in rng.integers(1, 260, size=3)) for _ in range(10)]
+    for n, (M, N, K) in enumerate(shapes):
+        _run(gpu, torch, layout, M, N, K, 9 if n % 3 else -1, seed=n)
+    _run(gpu, torch, layout, 96, 80, 1500, 9, epi=(2 if layout == 2 else 0), seed=77)
