@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#ifndef DEPTH
+#define DEPTH 8  // pieces a wave keeps in flight beyond the 4 it just issued
+#endif
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -22,7 +25,7 @@ __global__ void __launch_bounds__(256) dma_fill(const float* src, int iters, flo
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                    : : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH) : "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   if (sink) sink[blockIdx.x * 256 + threadIdx.x] = smem[threadIdx.x];
