@@ -22,8 +22,11 @@ struct CtcBatch {
   int U, T, O;
   int sext;                // row stride of lp / ab: >= 2 * (longest label sequence) + 1, a multiple of 64 * R
   float* lp;               // [T, sext] scratch: log p_t(state s), states = blank, l_0, blank, l_1, ..., blank
-  float* ab;               // [T, sext] scratch: alpha, then the state posteriors
+  float* ab;               // [T, sext] scratch: forward variables alpha~ (relative to off)
+  float* bb;               // [T, sext] scratch: backward variables beta~ (relative to offb); gradient only
   double* off;             // [T]     scratch: per-frame offset of the re-centred forward variables
+  double* offb;            // [T]     scratch: the same for the backward variables
+  double* logz;            // [U]     scratch: log p(labels) in double
   float* utt_loss;         // [U] out: -log p, +inf for an utterance too short for its labels
 };
 

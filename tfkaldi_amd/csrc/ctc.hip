@@ -4,9 +4,10 @@
 //   ctc_gather       log p_t(state) for the 2S+1 states of the frame's utterance, contiguous per frame
 //   ctc_alpha_beta   ONE WAVE PER UTTERANCE: every lane owns R consecutive states in registers, the s-1 / s-2
 //                    neighbours of a lane's first states come from the previous lane by DPP wave shifts -- the time
-//                    recursion runs without LDS and without barriers; alpha rows go to HBM, the backward sweep
-//                    turns them into state posteriors in place
-//   ctc_grad         one wave per frame: folds the state posteriors onto the classes in LABEL ORDER (repeated labels
+//                    recursion runs without LDS and without barriers.  The forward sweep (alpha, loss) and the
+//                    backward sweep (beta) of an utterance are two independent waves of one launch
+//   ctc_grad         one wave per frame: state posteriors from alpha, beta and log Z, folded onto the classes in
+//                    LABEL ORDER (repeated labels
 //                    and the S+1 blanks are summed in a fixed order, so the result is bitwise reproducible)
 // Log space, fp32, with a large finite "minus infinity" so that no inf - inf can arise.
 #include "ctc.h"
@@ -103,12 +104,19 @@ ctc_gather_kernel(CtcBatch b) {
 
 template <int R>
 __global__ void __launch_bounds__(64)
-ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
+ctc_alpha_beta_kernel(CtcBatch b) {
+  // blockIdx.y = 0: the forward variables and the loss; 1 (gradient only): the backward variables.  The two sweeps
+  // need nothing from each other -- only the state posteriors do, and ctc_grad forms those -- so they run as two
+  // independent waves and the chain of Tn dependent steps is paid once, not twice.
   const int u = blockIdx.x, lane = threadIdx.x;
+  const bool backward_sweep = blockIdx.y != 0;
   const int r0 = b.seg[u], Tn = b.seg[u + 1] - r0;
   const int l0 = b.lab_off[u], S = b.lab_off[u + 1] - l0, n = 2 * S + 1;
   if (Tn <= 0) {  // an utterance without frames: only the empty labelling is possible
-    if (lane == 0) b.utt_loss[u] = S == 0 ? 0.f : INFINITY;
+    if (lane == 0 && !backward_sweep) {
+      b.utt_loss[u] = S == 0 ? 0.f : INFINITY;
+      b.logz[u] = 0.0;
+    }
     return;
   }
   const int s0 = lane * R;
@@ -123,7 +131,6 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
     skip_out[r] = lab && j + 1 < S && b.labels[l0 + j + 1] != b.labels[l0 + j];
   }
   const float* lp = b.lp + (size_t)r0 * b.sext + s0;
-  float* ab = b.ab + (size_t)r0 * b.sext + s0;
   // The recursion is a chain of Tn dependent steps of ~100 cycles each, while a row of lp takes ~1000 cycles to
   // arrive: PFD rows are kept in flight in a register ring.  The ring is advanced with clamped row indices instead
   // of guards (a surplus step re-does the last row with the state held), so the unrolled body has no branches and
@@ -132,122 +139,109 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
   // vector is therefore kept RELATIVE to an offset: once per PFD steps its maximum is moved into `off` (double,
   // wave-uniform; stored per frame), so the per-state values stay small and exact to ~1e-6 whatever Tn is.
   constexpr int PFD = 8;
-  float a[R], pre[PFD][R];
+  float pre[PFD][R];
   double off = 0.0;
-  double* offs = b.off + r0;
+  if (!backward_sweep) {
+    float* al = b.ab + (size_t)r0 * b.sext + s0;
+    double* offs = b.off + r0;
+    float a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float v = lp[r];
+      a[r] = (s0 + r < 2 && s0 + r < n) ? v : NEG;
+      al[r] = a[r];
+    }
+    if (lane == 0) offs[0] = 0.0;
+#pragma unroll
+    for (int j = 0; j < PFD; ++j)
+#pragma unroll
+      for (int r = 0; r < R; ++r) pre[j][r] = lp[(size_t)min(1 + j, Tn - 1) * b.sext + r];
+    for (int t0 = 1; t0 < Tn; t0 += PFD) {
+#pragma unroll
+      for (int j = 0; j < PFD; ++j) {
+        const int t = t0 + j;
+        const bool live = t < Tn;
+        const int row = min(t, Tn - 1);
+        float cur[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          cur[r] = pre[j][r];
+          pre[j][r] = lp[(size_t)min(t + PFD, Tn - 1) * b.sext + r];
+        }
+        const float up1 = lane_prev(a[R - 1], NEG, lane), up2 = lane_prev(a[R - 2], NEG, lane);
+        float na[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float p1 = r >= 1 ? a[r - 1] : up1;
+          const float p2 = r >= 2 ? a[r - 2] : (r == 1 ? up1 : up2);
+          const float v = (s0 + r < n) ? lse3(a[r], p1, skip_in[r] ? p2 : NEG) + cur[r] : NEG;
+          na[r] = live ? v : a[r];
+        }
+        if (j == PFD - 1) {  // compile-time: re-centre the state vector on its maximum
+          float m = NEG;
+#pragma unroll
+          for (int r = 0; r < R; ++r) m = fmaxf(m, na[r]);
+          m = wave_max(m);
+          if (live && m > -1e29f) {
+            off += (double)m;
+#pragma unroll
+            for (int r = 0; r < R; ++r) na[r] = fmaxf(na[r] - m, NEG);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          a[r] = na[r];
+          al[(size_t)row * b.sext + r] = a[r];
+        }
+        if (lane == 0 && live) offs[t] = off;
+      }
+    }
+    // log p(labels) = alpha_T(n-1) (+) alpha_T(n-2)
+    float m = NEG;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (s0 + r == n - 1 || s0 + r == n - 2) m = fmaxf(m, a[r]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float se = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (s0 + r == n - 1 || s0 + r == n - 2) se += expf(a[r] - m);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const float log_z_rel = m + logf(se);  // relative to the final offset
+    const bool feasible = log_z_rel > -1e29f;
+    const double log_z = off + (double)log_z_rel;
+    if (lane == 0) {
+      b.utt_loss[u] = feasible ? (float)-log_z : INFINITY;
+      b.logz[u] = log_z;
+    }
+    return;
+  }
+  // backward variables beta~_t(s) (emission of frame t included), relative to their own offsets
+  float* be = b.bb + (size_t)r0 * b.sext + s0;
+  double* offs = b.offb + r0;
+  float bt[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const float v = lp[r];
-    a[r] = (s0 + r < 2 && s0 + r < n) ? v : NEG;
-    ab[r] = a[r];
+    const int s = s0 + r;
+    bt[r] = (s == n - 1 || s == n - 2) ? lp[(size_t)(Tn - 1) * b.sext + r] : NEG;
+    be[(size_t)(Tn - 1) * b.sext + r] = bt[r];
   }
-  if (lane == 0) offs[0] = 0.0;
+  if (lane == 0) offs[Tn - 1] = 0.0;
 #pragma unroll
   for (int j = 0; j < PFD; ++j)
 #pragma unroll
-    for (int r = 0; r < R; ++r) pre[j][r] = lp[(size_t)min(1 + j, Tn - 1) * b.sext + r];
-  for (int t0 = 1; t0 < Tn; t0 += PFD) {
-#pragma unroll
-    for (int j = 0; j < PFD; ++j) {
-      const int t = t0 + j;
-      const bool live = t < Tn;
-      const int row = min(t, Tn - 1);
-      float cur[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        cur[r] = pre[j][r];
-        pre[j][r] = lp[(size_t)min(t + PFD, Tn - 1) * b.sext + r];
-      }
-      const float up1 = lane_prev(a[R - 1], NEG, lane), up2 = lane_prev(a[R - 2], NEG, lane);
-      float na[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float p1 = r >= 1 ? a[r - 1] : up1;
-        const float p2 = r >= 2 ? a[r - 2] : (r == 1 ? up1 : up2);
-        const float v = (s0 + r < n) ? lse3(a[r], p1, skip_in[r] ? p2 : NEG) + cur[r] : NEG;
-        na[r] = live ? v : a[r];
-      }
-      if (j == PFD - 1) {  // compile-time: re-centre the state vector on its maximum
-        float m = NEG;
-#pragma unroll
-        for (int r = 0; r < R; ++r) m = fmaxf(m, na[r]);
-        m = wave_max(m);
-        if (live && m > -1e29f) {
-          off += (double)m;
-#pragma unroll
-          for (int r = 0; r < R; ++r) na[r] = fmaxf(na[r] - m, NEG);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        a[r] = na[r];
-        ab[(size_t)row * b.sext + r] = a[r];
-      }
-      if (lane == 0 && live) offs[t] = off;
-    }
-  }
-  // log p(labels) = alpha_T(n-1) (+) alpha_T(n-2)
-  float m = NEG;
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-    if (s0 + r == n - 1 || s0 + r == n - 2) m = fmaxf(m, a[r]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  float se = 0.f;
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-    if (s0 + r == n - 1 || s0 + r == n - 2) se += expf(a[r] - m);
-  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
-  const float log_z_rel = m + logf(se);  // relative to the final offset
-  const bool feasible = log_z_rel > -1e29f;
-  const double log_z = off + (double)log_z_rel;
-  if (lane == 0) b.utt_loss[u] = feasible ? (float)-log_z : INFINITY;
-  if (!with_grad) return;
-  // backward sweep: beta (relative to its own offset `offb`) in registers, alpha row t read back and replaced by the
-  // state posterior exp((alpha~ + beta~ - lp) + (off_alpha(t) + off_beta(t) - log Z)); the same ring
-  float bt[R];
-  double offb = 0.0;
-  {
-    const float shift = (float)(offs[Tn - 1] - log_z);  // offsets cancel to a small number: exact enough in fp32
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int s = s0 + r;
-      const float cur = lp[(size_t)(Tn - 1) * b.sext + r];
-      bt[r] = (s == n - 1 || s == n - 2) ? cur : NEG;
-      const float al = ab[(size_t)(Tn - 1) * b.sext + r];
-      ab[(size_t)(Tn - 1) * b.sext + r] = (feasible && s < n) ? __expf(al + bt[r] - cur + shift) : 0.f;
-    }
-  }
-  float prel[PFD][R], prea[PFD][R];
-  double preo[PFD];
-#pragma unroll
-  for (int j = 0; j < PFD; ++j) {
-    const int row = max(Tn - 2 - j, 0);
-    preo[j] = offs[row];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      prel[j][r] = lp[(size_t)row * b.sext + r];
-      prea[j][r] = ab[(size_t)row * b.sext + r];
-    }
-  }
+    for (int r = 0; r < R; ++r) pre[j][r] = lp[(size_t)max(Tn - 2 - j, 0) * b.sext + r];
   for (int t0 = Tn - 2; t0 >= 0; t0 -= PFD) {
 #pragma unroll
     for (int j = 0; j < PFD; ++j) {
       const int t = t0 - j;
       const bool live = t >= 0;
-      float cur[R], al[R];
-      const double offa = preo[j];
-      {
-        // rows below 0 are clamped to row 0, which a surplus step must not read after it was rewritten: the ring
-        // slot of a dead step is never consumed again, so the clamped value is simply unused
-        const int row = max(t - PFD, 0);
-        preo[j] = offs[row];
+      const int row = max(t, 0);
+      float cur[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          cur[r] = prel[j][r];
-          al[r] = prea[j][r];
-          prel[j][r] = lp[(size_t)row * b.sext + r];
-          prea[j][r] = ab[(size_t)row * b.sext + r];
-        }
+      for (int r = 0; r < R; ++r) {
+        cur[r] = pre[j][r];
+        pre[j][r] = lp[(size_t)max(t - PFD, 0) * b.sext + r];
       }
       const float dn1 = lane_next(bt[0], NEG, lane), dn2 = lane_next(bt[1], NEG, lane);
       float nb[R];
@@ -264,38 +258,46 @@ ctc_alpha_beta_kernel(CtcBatch b, int with_grad) {
         for (int r = 0; r < R; ++r) m = fmaxf(m, nb[r]);
         m = wave_max(m);
         if (live && m > -1e29f) {
-          offb += (double)m;
+          off += (double)m;
 #pragma unroll
           for (int r = 0; r < R; ++r) nb[r] = fmaxf(nb[r] - m, NEG);
         }
       }
-      if (live) {
-        const float shift = (float)(offa + offb - log_z);
+      // (a surplus step holds the state and rewrites row 0 with the value it already has)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          bt[r] = nb[r];
-          ab[(size_t)t * b.sext + r] = (feasible && s0 + r < n) ? __expf(al[r] + bt[r] - cur[r] + shift) : 0.f;
-        }
+      for (int r = 0; r < R; ++r) {
+        bt[r] = nb[r];
+        be[(size_t)row * b.sext + r] = bt[r];
       }
+      if (lane == 0 && live) offs[t] = off;
     }
   }
 }
 
-// one wave per frame; dynamic LDS: the class row
+// one wave per frame; dynamic LDS: the class row, then the frame's state posteriors
+//   gamma_t(s) = exp((alpha~ + beta~ - lp) + (off_alpha(t) + off_beta(t) - log Z))
+// (the offsets cancel to a small number, which is exact enough in fp32)
 __global__ void __launch_bounds__(64)
 ctc_grad_kernel(CtcBatch b, float* __restrict__ dlogits, Twin tw) {
   extern __shared__ float row[];
+  float* g = row + b.ld;
   const int t = blockIdx.x, lane = threadIdx.x;
   const int u = utt_of(b.seg, b.U, t);
   const int l0 = b.lab_off[u], S = b.lab_off[u + 1] - l0, n = 2 * S + 1;
   const bool live = b.utt_loss[u] < INFINITY;
   const float* pr = b.post + (size_t)t * b.ld;
   for (int c = lane; c < b.ld; c += 64) row[c] = live ? pr[c] : 0.f;
-  const float* g = b.ab + (size_t)t * b.sext;
+  {
+    const float shift = live ? (float)(b.off[t] + b.offb[t] - b.logz[u]) : 0.f;
+    const float* al = b.ab + (size_t)t * b.sext;
+    const float* be = b.bb + (size_t)t * b.sext;
+    const float* lp = b.lp + (size_t)t * b.sext;
+    for (int s = lane; s < n; s += 64) g[s] = live ? __expf(al[s] + be[s] - lp[s] + shift) : 0.f;
+  }
+  __syncthreads();
   float blank = 0.f;
   for (int s = 2 * lane; s < n; s += 128) blank += g[s];
   for (int o = 32; o > 0; o >>= 1) blank += __shfl_xor(blank, o);
-  __syncthreads();
   if (lane == 0 && live) {
     row[b.O - 1] -= blank;
     for (int j = 0; j < S; ++j) row[b.labels[l0 + j]] -= g[2 * j + 1];  // label order: deterministic for repeats
@@ -341,14 +343,15 @@ void ctc_loss_grad(hipStream_t s, const CtcBatch& b, float* dlogits, int with_gr
   hipLaunchKernelGGL(ctc_softmax_kernel, dim3(b.T), dim3(256), 0, s, b.logits, b.O, b.ld, b.post, b.lse);
   const size_t n = (size_t)b.T * b.sext;
   hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, b);
+  const dim3 grid(b.U, with_grad ? 2 : 1);
   switch (b.sext / 64) {
-    case 2: hipLaunchKernelGGL(ctc_alpha_beta_kernel<2>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
-    case 4: hipLaunchKernelGGL(ctc_alpha_beta_kernel<4>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
-    case 8: hipLaunchKernelGGL(ctc_alpha_beta_kernel<8>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
-    default: hipLaunchKernelGGL(ctc_alpha_beta_kernel<16>, dim3(b.U), dim3(64), 0, s, b, with_grad); break;
+    case 2: hipLaunchKernelGGL(ctc_alpha_beta_kernel<2>, grid, dim3(64), 0, s, b); break;
+    case 4: hipLaunchKernelGGL(ctc_alpha_beta_kernel<4>, grid, dim3(64), 0, s, b); break;
+    case 8: hipLaunchKernelGGL(ctc_alpha_beta_kernel<8>, grid, dim3(64), 0, s, b); break;
+    default: hipLaunchKernelGGL(ctc_alpha_beta_kernel<16>, grid, dim3(64), 0, s, b); break;
   }
   if (with_grad)
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3(b.T), dim3(64), (size_t)b.ld * sizeof(float), s, b, dlogits, tw);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(b.T), dim3(64), (size_t)(b.ld + b.sext) * sizeof(float), s, b, dlogits, tw);
 }
 
 void ctc_loss_reduce(hipStream_t s, const float* utt_loss, const int32_t* lab_off, int U, float* scalars,

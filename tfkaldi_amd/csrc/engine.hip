@@ -141,8 +141,13 @@ struct tfk_engine {
   // CTC loss (tfk_accumulate_ctc): device copies of the utterance / label offsets and the state workspaces,
   // grown on demand
   int32_t *ctc_seg = nullptr, *ctc_lab_off = nullptr, *ctc_lab = nullptr;
-  float *ctc_lp = nullptr, *ctc_ab = nullptr, *ctc_utt_loss = nullptr, *ctc_lse = nullptr;
-  double* ctc_off = nullptr;
+  float *ctc_lp = nullptr, *ctc_ab = nullptr, *ctc_bb = nullptr, *ctc_utt_loss = nullptr, *ctc_lse = nullptr;
+  double *ctc_off = nullptr, *ctc_offb = nullptr, *ctc_logz = nullptr;
+  size_t ctc_cap_bb = 0, ctc_cap_offb = 0, ctc_cap_logz = 0;
+  int32_t* h_ctc[2] = {nullptr, nullptr};  // pinned staging of (seg, lab_off, labels)
+  size_t h_ctc_cap[2] = {0, 0};
+  hipEvent_t ctc_staged[2] = {nullptr, nullptr};
+  int ctc_stage_slot = 0;
   size_t ctc_cap_offrows = 0;
   size_t ctc_cap_seg = 0, ctc_cap_off = 0, ctc_cap_loss = 0, ctc_cap_lab = 0, ctc_cap_lp = 0, ctc_cap_ab = 0,
          ctc_cap_rows = 0;
@@ -956,7 +961,10 @@ struct CtcSpec {  // CTC loss instead of the frame-level cross-entropy
 template <class Tp>
 int grow(Tp** p, size_t* cap, size_t need) {
   if (need <= *cap) return 0;
-  if (*p) HIPCHK(hipFree(*p));
+  if (*p) {  // kernels of the previous micro-batch may still read it
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(*p));
+  }
   *p = nullptr;
   const size_t n = need + need / 2;
   HIPCHK(hipMalloc((void**)p, n * sizeof(Tp)));
@@ -982,7 +990,6 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   for (int i = 0; i < total; ++i)  // the blank is the LAST class (tf.nn.ctc_loss): labels live in [0, O - 1)
     if (c.labels[i] < 0 || c.labels[i] >= e->O - 1) return fail(-1, "CTC: label %d outside [0, %d)", c.labels[i], e->O - 1);
   const int sext = ctc_state_stride(max_labels);
-  HIPCHK(hipStreamSynchronize(e->stream));  // the workspaces below may still be read by the previous micro-batch
   CHK(grow(&e->ctc_seg, &e->ctc_cap_seg, (size_t)c.U + 1));
   CHK(grow(&e->ctc_lab_off, &e->ctc_cap_off, (size_t)c.U + 1));
   CHK(grow(&e->ctc_utt_loss, &e->ctc_cap_loss, (size_t)c.U));
@@ -991,16 +998,42 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   CHK(grow(&e->ctc_ab, &e->ctc_cap_ab, (size_t)T * sext));
   CHK(grow(&e->ctc_lse, &e->ctc_cap_rows, (size_t)T));
   CHK(grow(&e->ctc_off, &e->ctc_cap_offrows, (size_t)T));
-  HIPCHK(hipMemcpyAsync(e->ctc_seg, seg.data(), (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemcpyAsync(e->ctc_lab_off, off.data(), (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-  if (total > 0)
-    HIPCHK(hipMemcpyAsync(e->ctc_lab, c.labels, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));  // seg / off are stack-lifetime host buffers
+  CHK(grow(&e->ctc_logz, &e->ctc_cap_logz, (size_t)c.U));
+  if (train) {
+    CHK(grow(&e->ctc_bb, &e->ctc_cap_bb, (size_t)T * sext));
+    CHK(grow(&e->ctc_offb, &e->ctc_cap_offb, (size_t)T));
+  }
+  {
+    // The three small tables go through pinned staging, two buffers used in turn: the host never waits for the
+    // stream here (the event guards the buffer's use two micro-batches ago).
+    const int k = e->ctc_stage_slot ^= 1;
+    const size_t need = 2 * ((size_t)c.U + 1) + (size_t)total;
+    if (!e->ctc_staged[k]) HIPCHK(hipEventCreateWithFlags(&e->ctc_staged[k], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(e->ctc_staged[k]));
+    if (need > e->h_ctc_cap[k]) {
+      if (e->h_ctc[k]) HIPCHK(hipHostFree(e->h_ctc[k]));
+      e->h_ctc[k] = nullptr;
+      e->h_ctc_cap[k] = need + need / 2;
+      HIPCHK(hipHostMalloc((void**)&e->h_ctc[k], e->h_ctc_cap[k] * sizeof(int32_t), hipHostMallocDefault));
+    }
+    int32_t* h = e->h_ctc[k];
+    memcpy(h, seg.data(), ((size_t)c.U + 1) * sizeof(int32_t));
+    memcpy(h + c.U + 1, off.data(), ((size_t)c.U + 1) * sizeof(int32_t));
+    if (total > 0) memcpy(h + 2 * (c.U + 1), c.labels, (size_t)total * sizeof(int32_t));
+    HIPCHK(hipMemcpyAsync(e->ctc_seg, h, (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->ctc_lab_off, h + c.U + 1, (size_t)(c.U + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
+                          e->stream));
+    if (total > 0)
+      HIPCHK(hipMemcpyAsync(e->ctc_lab, h + 2 * (c.U + 1), (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice,
+                            e->stream));
+    HIPCHK(hipEventRecord(e->ctc_staged[k], e->stream));
+  }
   CtcBatch b;
   b.logits = e->logits; b.ld = e->ldO; b.post = e->post; b.lse = e->ctc_lse;
   b.seg = e->ctc_seg; b.labels = e->ctc_lab; b.lab_off = e->ctc_lab_off;
   b.U = c.U; b.T = T; b.O = e->O; b.sext = sext;
-  b.lp = e->ctc_lp; b.ab = e->ctc_ab; b.utt_loss = e->ctc_utt_loss; b.off = e->ctc_off;
+  b.lp = e->ctc_lp; b.ab = e->ctc_ab; b.bb = e->ctc_bb; b.utt_loss = e->ctc_utt_loss;
+  b.off = e->ctc_off; b.offb = e->ctc_offb; b.logz = e->ctc_logz;
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * T * e->O + 16.0 * T * sext);
     Twin tw;
@@ -1112,8 +1145,13 @@ int tfk_destroy(tfk_engine* e) {
   if (e->Wb) hipFree(e->Wb);
   if (e->ws_splitk) hipFree(e->ws_splitk);
   for (void* p : {(void*)e->ctc_seg, (void*)e->ctc_lab_off, (void*)e->ctc_lab, (void*)e->ctc_lp, (void*)e->ctc_ab,
-                  (void*)e->ctc_utt_loss, (void*)e->ctc_lse, (void*)e->ctc_off})
+                  (void*)e->ctc_utt_loss, (void*)e->ctc_lse, (void*)e->ctc_off, (void*)e->ctc_bb, (void*)e->ctc_offb,
+                  (void*)e->ctc_logz})
     if (p) hipFree(p);
+  for (int k = 0; k < 2; ++k) {
+    if (e->h_ctc[k]) hipHostFree(e->h_ctc[k]);
+    if (e->ctc_staged[k]) hipEventDestroy(e->ctc_staged[k]);
+  }
   if (e->h_scalars) hipHostFree(e->h_scalars);
   if (e->h_post) hipHostFree(e->h_post);
   if (e->own_state && e->state) hipFree(e->state);

@@ -19,7 +19,7 @@ struct ActDesc {
   int train;       // dropout only in training mode
 };
 
-constexpr int kMaxRowSplits = 64;
+constexpr int kMaxRowSplits = 256;
 
 // Mixed-precision mode: kernels that produce a GEMM operand also store its bf16 twin (p == nullptr: fp32 mode).
 // ld in bf16 elements, a multiple of 8; padding columns of the twin stay zero from its allocation.

@@ -204,14 +204,14 @@ bn_stats_partial_kernel(const float* __restrict__ z, int T, int ld, int rows_per
 }
 
 // geometry of the "final" kernels that combine the per-chunk partials of a column
-constexpr int FIN_COLS = 64, FIN_KL = 4, FIN_PER = kMaxRowSplits / FIN_KL;
+constexpr int FIN_COLS = 64, FIN_KL = 16, FIN_PER = kMaxRowSplits / FIN_KL;
 
 __global__ void __launch_bounds__(FIN_COLS * FIN_KL)
 bn_stats_final_kernel(const float* __restrict__ ws, int T, int H, int ld, int rows_per, int rs,
                                       float eps, float decay, float* __restrict__ mean, float* __restrict__ rstd,
                                       float* __restrict__ e_mean, float* __restrict__ e_var) {
-  // block = 64 columns x 4 chunk lanes: every thread issues its <= 16 chunk loads back to back (one
-  // memory round trip), then the four lanes of a column combine through LDS in a fixed order.
+  // block = 64 columns x 16 chunk lanes: every thread issues its <= 16 chunk loads back to back (one
+  // memory round trip), then the sixteen lanes of a column combine through LDS in a fixed order.
   __shared__ float sm[FIN_KL][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x;
   const int ky = threadIdx.y;
@@ -231,7 +231,10 @@ bn_stats_final_kernel(const float* __restrict__ ws, int T, int H, int ld, int ro
   for (int j = 0; j < FIN_PER; ++j) tot += nk[j] * mk[j];
   sm[ky][threadIdx.x] = tot;
   __syncthreads();
-  const float mu = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)T;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_KL; ++k) acc += sm[k][threadIdx.x];
+  const float mu = acc / (float)T;
   __syncthreads();
   float m2 = 0.f;
 #pragma unroll
@@ -246,7 +249,10 @@ bn_stats_final_kernel(const float* __restrict__ ws, int T, int H, int ld, int ro
     mean[c] = 0.f; rstd[c] = 0.f;
     return;
   }
-  const float var = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)T;
+  acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_KL; ++k) acc += sm[k][threadIdx.x];
+  const float var = acc / (float)T;
   mean[c] = mu;              // var is biased, as tf.nn.moments
   rstd[c] = rsqrtf(var + eps);
   e_mean[c] = decay * e_mean[c] + (1.f - decay) * mu;
@@ -665,7 +671,9 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_KL) grad_final_kernel(FinalBatc
   sm[ky][threadIdx.x] = s;
   __syncthreads();
   if (ky != 0 || c >= it.N) return;
-  s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_KL; ++k) s += sm[k][threadIdx.x];
   it.g[c] = b.accumulate ? it.g[c] + s : s;
 }
 
