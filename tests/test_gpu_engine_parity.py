@@ -283,3 +283,28 @@ def test_narrow_net_many_frames_split_k(gpu):
     assert all((a[k] == b[k]).all() for k in a)
     assert_close("avg loss", eng.apply(), oracle.apply(), 2e-5, 0)
     eng.close(); twin.close()
+
+
+@pytest.mark.parametrize("keep_prob", [1.0, 0.8])
+def test_tall_microbatch_merges_statistics_once(gpu, keep_prob):
+    """More than 32 GEMM row tiles per micro-batch (here 2200 frames = 35 tiles): the per-tile batch-norm statistics
+    and the EPI_DACT partial sums are merged by one small kernel instead of inside every block of the column-tiled
+    kernels (kMergeOnceChunks, csrc/kernels.h).  Same numbers as ever: hidden outputs, loss, every gradient, moving
+    averages -- with and without dropout (the row-wise kernel applies the same masks)."""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(41)
+    kw = dict(input_dim=33, num_layers=3, num_units=200, output_dim=45, nonlin="tanh", batch_norm=True,
+              keep_prob=keep_prob, init_learning_rate=1e-3, num_steps=100, max_frames=2200)
+    eng, oracle = make_pair(rng, **kw)
+    for T in (2200, 2113):
+        X, y = batch(rng, T, kw["input_dim"], kw["output_dim"])
+        eng.accumulate(X, y)
+        oracle.accumulate(X, y, _masks(eng, T))
+        for l in range(eng.L):
+            assert_close("hidden%d" % l, eng.debug_fetch(_lib.DBG_HIDDEN, l, T), oracle.last_cache[l]["a"], 1e-4, 2e-5)
+        _check_grads(eng, oracle)
+    assert_close("avg loss", eng.apply(), oracle.apply(), 2e-5, 0)
+    for l in range(eng.L):
+        assert_close("mov_mean", eng.get(_lib.BN_MOVING_MEAN, l), oracle.mov_mean[l], 1e-5, 1e-6)
+        assert_close("mov_var", eng.get(_lib.BN_MOVING_VAR, l), oracle.mov_var[l], 1e-5, 1e-6)
+    eng.close()

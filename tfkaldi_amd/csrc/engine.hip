@@ -658,9 +658,18 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
       {
         ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * T * H);
         const ActDesc d = act_desc(e, l, train, call);
-        bn_act_forward(e->stream, d, e->z[l], e->a[l], e->ws_stats, chunk, T, H, ldH, e->bn_eps,
-                       e->bn_decay, e->mean[l], e->rstd[l], e->ema_mean(l), e->ema_var(l),
-                       e->p_param() + y.beta_off, twin_a(l));
+        const int nchunk = (T + chunk - 1) / chunk;
+        if (nchunk > kMergeOnceChunks && nchunk <= kMaxRowSplits) {
+          // tall micro-batch: the statistics are merged once, the row-wise kernel applies them
+          bn_stats_from_chunks(e->stream, e->ws_stats, chunk, T, H, ldH, e->bn_eps, e->bn_decay, e->mean[l], e->rstd[l],
+                               e->ema_mean(l), e->ema_var(l));
+          act_forward(e->stream, d, e->z[l], e->a[l], nullptr, nullptr, e->mean[l], e->rstd[l],
+                      e->p_param() + y.beta_off, T, H, ldH, twin_a(l));
+        } else {
+          bn_act_forward(e->stream, d, e->z[l], e->a[l], e->ws_stats, chunk, T, H, ldH, e->bn_eps,
+                         e->bn_decay, e->mean[l], e->rstd[l], e->ema_mean(l), e->ema_var(l),
+                         e->p_param() + y.beta_off, twin_a(l));
+        }
       }
       in = e->a[l];
       ld_in = ldH;
@@ -763,9 +772,14 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
       Twin tw;
       if (e->bf16) { tw.p = e->dAb[pp]; tw.ld = e->ldHb; }
+      int chunks_eff = fuse_hb ? chunks_in : 0;
+      if (chunks_eff > kMergeOnceChunks) {  // tall micro-batch: reduce the EPI_DACT partial sums once
+        chunk_totals(e->stream, ws_of(l), chunks_eff, ldH);
+        chunks_eff = 1;
+      }
       hidden_backward(e->stream, d, pre_du, da, e->a[l], e->z[l], e->mean[l], e->rstd[l], T, H, ldH, ws_of(l),
-                      fuse_hb ? chunks_in : 0, tw);
-      if (e->cfg.batch_norm) fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, fuse_hb ? chunks_in : rs, H, ldH};
+                      chunks_eff, tw);
+      if (e->cfg.batch_norm) fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, fuse_hb ? chunks_eff : rs, H, ldH};
       fin.it[fin.n++] = {ws_of(l), G + y.b_off, 2, rs, H, ldH};
       if (fin.n + 2 > kMaxFinalItems) {  // very deep nets: flush
         grad_final(e->stream, fin);

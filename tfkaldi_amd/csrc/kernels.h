@@ -64,6 +64,14 @@ void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, con
                      const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks = 0,
                      Twin tw = Twin());
 // per-chunk partial column sums of x[T, ld] into slab 0 of ws (bias gradient of the output layer)
+// Tall micro-batches (more than kMergeOnceChunks GEMM row tiles): merge the per-tile statistics / partial sums ONCE
+// instead of in every block of the column-tiled kernels.
+constexpr int kMergeOnceChunks = 32;
+// stats = the EPI_COLSTATS output [2, ceil(T / chunk_rows), ld] -> mean, rstd and the moving-average increments
+void bn_stats_from_chunks(hipStream_t s, const float* stats, int chunk_rows, int T, int H, int ld, float eps, float decay,
+                          float* mean, float* rstd, float* e_mean, float* e_var);
+// ws slabs 0 and 1 (EPI_DACT output): entry 0 <- sum of the first `chunks` entries
+void chunk_totals(hipStream_t s, float* ws, int chunks, int ld);
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws);
 int row_splits(int T);  // chunks the column-tiled kernels cut T rows into
 

@@ -677,6 +677,32 @@ __global__ void __launch_bounds__(FIN_COLS * FIN_KL) grad_final_kernel(FinalBatc
   it.g[c] = b.accumulate ? it.g[c] + s : s;
 }
 
+// Tall micro-batches: the two per-chunk partial sums of batch-norm's backward (slabs 0 and 1, `chunks` entries each)
+// are reduced ONCE into entry 0 of their slab, so that the column-tiled apply kernel's blocks need not each re-read
+// every chunk.  blockIdx.y = slab.
+__global__ void __launch_bounds__(FIN_COLS * FIN_KL) chunk_totals_kernel(float* __restrict__ ws, int chunks, int ld) {
+  __shared__ float sm[FIN_KL][FIN_COLS];
+  const int c = blockIdx.x * FIN_COLS + threadIdx.x;
+  const int ky = threadIdx.y;
+  float* slab = ws + (size_t)blockIdx.y * kMaxRowSplits * ld;
+  float v[FIN_PER];
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) {
+    const int k = ky + j * FIN_KL;
+    v[j] = (c < ld && k < chunks) ? slab[(size_t)k * ld + c] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < FIN_PER; ++j) s += v[j];
+  sm[ky][threadIdx.x] = s;
+  __syncthreads();
+  if (ky != 0 || c >= ld) return;
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_KL; ++k) s += sm[k][threadIdx.x];
+  slab[c] = s;
+}
+
 __global__ void __launch_bounds__(CT_X * CT_Y)
 colsum_partial_kernel(const float* __restrict__ x, int T, int ld, int rows_per, int rs, float* __restrict__ ws) {
   __shared__ float4 sm[CT_Y][CT_X];
@@ -1011,6 +1037,18 @@ void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, con
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
                      rows_per, stats_chunks > 0 ? stats_chunks : rs, ws, tw);
+}
+
+void bn_stats_from_chunks(hipStream_t s, const float* stats, int chunk_rows, int T, int H, int ld, float eps, float decay,
+                          float* mean, float* rstd, float* e_mean, float* e_var) {
+  const int nchunk = (T + chunk_rows - 1) / chunk_rows;
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((ld + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS, FIN_KL), 0, s, stats, T, H,
+                     ld, chunk_rows, nchunk, eps, decay, mean, rstd, e_mean, e_var);
+}
+
+void chunk_totals(hipStream_t s, float* ws, int chunks, int ld) {
+  hipLaunchKernelGGL(chunk_totals_kernel, dim3((ld + FIN_COLS - 1) / FIN_COLS, 2), dim3(FIN_COLS, FIN_KL), 0, s, ws, chunks,
+                     ld);
 }
 
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws) {
