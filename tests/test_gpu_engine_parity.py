@@ -308,3 +308,35 @@ def test_tall_microbatch_merges_statistics_once(gpu, keep_prob):
         assert_close("mov_mean", eng.get(_lib.BN_MOVING_MEAN, l), oracle.mov_mean[l], 1e-5, 1e-6)
         assert_close("mov_var", eng.get(_lib.BN_MOVING_VAR, l), oracle.mov_var[l], 1e-5, 1e-6)
     eng.close()
+
+
+def test_long_posteriors_pass_is_pipelined_and_equal(gpu, monkeypatch):
+    """tfk_posteriors on a long pass (>= 2 chunks of TFK_POST_CHUNK rows, pinned output) computes chunk c + 1 while
+    chunk c travels back over PCIe.  Rows are independent in evaluation mode: same numbers as the one-shot pass and as
+    the oracle, for spliced and for device-spliced input."""
+    rng = np.random.default_rng(53)
+    kw = dict(input_dim=44, num_layers=2, num_units=96, output_dim=70, nonlin="relu", batch_norm=True, max_frames=5000)
+    T = 4600
+    monkeypatch.setenv("TFK_POST_CHUNK", "2048")
+    piped, oracle = make_pair(rng, **kw)
+    monkeypatch.setenv("TFK_POST_CHUNK", "0")
+    whole, _ = make_pair(np.random.default_rng(53), **kw)
+    X, _ = batch(rng, T, kw["input_dim"], kw["output_dim"])
+    prior = rng.random(kw["output_dim"]).astype(np.float32) + 0.1
+    prior /= prior.sum()
+    for e in (piped, whole):
+        e.set_prior(prior)
+    want = oracle.posteriors(X)
+    for log_div in (False, True):
+        a, b = piped.posteriors(X, log_div_prior=log_div), whole.posteriors(X, log_div_prior=log_div)
+        assert a.shape == b.shape == (T, kw["output_dim"])
+        assert_close("piped vs whole", a, b, 1e-5, 1e-6)
+        ref = np.log(want / prior) if log_div else want
+        assert_close("piped vs oracle", a, ref, 2e-4, 2e-6)
+    # unspliced frames, splice on the device (4 utterances)
+    raw = rng.standard_normal((T, 4)).astype(np.float32)
+    lens = [1000, 1500, 1100, 1000]
+    a = piped.posteriors_raw(raw, lens, 5)
+    b = whole.posteriors_raw(raw, lens, 5)
+    assert_close("raw piped vs whole", a, b, 1e-5, 1e-6)
+    piped.close(); whole.close()

@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -137,6 +138,8 @@ struct tfk_engine {
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
   bool dual_gemm = true;         // env TFK_DUAL_GEMM=0: dA and dW of a layer as two launches
+  int post_chunk = 2048;         // env TFK_POST_CHUNK: rows per chunk of a pipelined tfk_posteriors pass (0: off)
+  std::vector<hipEvent_t> post_ev;
 
   // CTC loss (tfk_accumulate_ctc): device copies of the utterance / label offsets and the state workspaces,
   // grown on demand
@@ -913,6 +916,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   {
     const char* v;
     if ((v = getenv("TFK_FUSE_HB"))) e->fuse_hb_enabled = atoi(v) != 0;
+    if ((v = getenv("TFK_POST_CHUNK"))) e->post_chunk = atoi(v) > 0 ? (int)up((size_t)atoi(v), 64) : 0;
     if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
   }
   HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
@@ -1162,6 +1166,7 @@ int tfk_destroy(tfk_engine* e) {
                   (void*)e->ctc_utt_loss, (void*)e->ctc_lse, (void*)e->ctc_off, (void*)e->ctc_bb, (void*)e->ctc_offb,
                   (void*)e->ctc_logz})
     if (p) hipFree(p);
+  for (hipEvent_t ev : e->post_ev) hipEventDestroy(ev);
   for (int k = 0; k < 2; ++k) {
     if (e->h_ctc[k]) hipHostFree(e->h_ctc[k]);
     if (e->ctc_staged[k]) hipEventDestroy(e->ctc_staged[k]);
@@ -1437,9 +1442,47 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
   if (e->bf16) CHK(twin_input(e, &Xd, &ld, N));
   const int nact = e->nact();
   const uint32_t call = e->call_counter++;
-  CHK(forward(e, Xd, ld, N, 0, nact, nact, call));
   const float* prior = (flags & TFK_LOG_DIV_PRIOR) ? e->prior : nullptr;
   const bool want_logits = (flags & TFK_RAW_LOGITS) != 0;
+  // a caller that hands over PINNED host memory gets the result by DMA, without a staging copy
+  bool pinned_out = false;
+  if (!(flags & TFK_DEVICE_PTRS)) {
+    hipPointerAttribute_t attr;
+    pinned_out = hipPointerGetAttributes(&attr, out) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned_out) (void)hipGetLastError();  // (an unregistered pointer reports an error: not one of ours)
+  }
+  if (pinned_out && !want_logits && !e->bf16 && e->post_chunk > 0 && N >= 2 * e->post_chunk) {
+    // Long passes (batched decode): rows are independent in evaluation mode, so the pass runs in chunks and the
+    // results of chunk c travel to the host on the copy stream while chunk c + 1 is being computed -- the 8 KB per
+    // frame going back over PCIe would otherwise cost as much time as the forward pass itself.
+    const int nchunks = (N + e->post_chunk - 1) / e->post_chunk;
+    while ((int)e->post_ev.size() < nchunks) {
+      hipEvent_t ev;
+      HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e->post_ev.push_back(ev);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+      const int r0 = c * e->post_chunk, n = std::min(e->post_chunk, N - r0);
+      CHK(forward(e, Xd + (size_t)r0 * ld, ld, n, 0, nact, nact, call));
+      {
+        ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * n * e->O);
+        softmax_rows(e->stream, e->logits, n, e->O, e->ldO, e->post + (size_t)r0 * e->ldO, e->ldO, prior);
+      }
+      if (c == nchunks - 1) CHK(finish_slot(e, flags, slot_before));  // the input slot has been read for the last time
+      HIPCHK(hipEventRecord(e->post_ev[c], e->stream));
+      HIPCHK(hipStreamWaitEvent(e->copy_stream, e->post_ev[c], 0));
+      HIPCHK(hipMemcpy2DAsync(out + (size_t)r0 * ldo, (size_t)ldo * 4, e->post + (size_t)r0 * e->ldO, (size_t)e->ldO * 4,
+                              (size_t)e->O * 4, n, hipMemcpyDeviceToHost, e->copy_stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->copy_stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    const int n_last = N - (nchunks - 1) * e->post_chunk;
+    e->last_T = n_last; e->last_nfw = nact; e->last_call = call;
+    e->last_in = Xd + (size_t)(nchunks - 1) * e->post_chunk * ld;
+    return 0;
+  }
+  CHK(forward(e, Xd, ld, N, 0, nact, nact, call));
   if (flags & TFK_DEVICE_PTRS) {
     if (want_logits) {
       HIPCHK(hipMemcpy2DAsync(out, (size_t)ldo * 4, e->logits, (size_t)e->ldO * 4, (size_t)e->O * 4, N,
@@ -1455,10 +1498,6 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
     }
     CHK(finish_slot(e, flags, slot_before));
     const float* src = want_logits ? e->logits : e->post;
-    // a caller that hands over PINNED host memory gets the result by one DMA, without the staging copy
-    hipPointerAttribute_t attr;
-    const bool pinned_out = hipPointerGetAttributes(&attr, out) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (!pinned_out) (void)hipGetLastError();  // (an unregistered pointer reports an error: not one of ours)
     if (pinned_out) {
       HIPCHK(hipMemcpy2DAsync(out, (size_t)ldo * 4, src, (size_t)e->ldO * 4, (size_t)e->O * 4, N, hipMemcpyDeviceToHost,
                               e->stream));
