@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 2
+#define TFK_ABI_VERSION 3
 
 typedef struct tfk_engine tfk_engine;
 
@@ -268,6 +268,11 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
  * leading dimensions (in elements) that are multiples of 8 and zero padding (gemm_bf16.h). */
 int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   int M, int N, int K, const float* bias, int epi);
+/* Tile configuration of the bf16 GEMM (gemm_bf16.h: 0-2 register-staged, 3-6 LDS-DMA staged): force one for every
+ * later call (cfg < 0 restores the heuristic) / ask which one the heuristic gives an [M, N] result.  Tools and
+ * tests only. */
+int tfk_gemm_bf16_force_config(int cfg);
+int tfk_gemm_bf16_config(int M, int N);
 
 #ifdef __cplusplus
 }

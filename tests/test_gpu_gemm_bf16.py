@@ -26,7 +26,8 @@ def _bf16_dev(torch, a):
     return buf.cuda(), ld, rounded
 
 
-def _run(lib, torch, layout, M, N, K, epi=0, seed=0):
+def _run(lib, torch, layout, M, N, K, epi=0, seed=0, cfg=-1):
+    lib.tfk_gemm_bf16_force_config(cfg)
     rng = np.random.default_rng(seed)
     shapes = {0: ((M, K), (K, N)), 1: ((M, K), (N, K)), 2: ((K, M), (K, N))}[layout]
     A = rng.standard_normal(shapes[0]); B = rng.standard_normal(shapes[1])
@@ -49,6 +50,7 @@ def _run(lib, torch, layout, M, N, K, epi=0, seed=0):
     rc = lib.tfk_gemm_bf16(ctypes.c_void_p(st), layout, ctypes.c_void_p(dA.data_ptr()), lda,
                            ctypes.c_void_p(dB.data_ptr()), ldb, ctypes.c_void_p(dC.data_ptr()), ldc, M, N, K,
                            ctypes.c_void_p(dbias.data_ptr()), epi)
+    lib.tfk_gemm_bf16_force_config(-1)
     assert rc == 0, lib.tfk_last_error()
     torch.cuda.synchronize()
     out = dC.cpu().numpy()
@@ -78,6 +80,22 @@ def test_gemm_bf16(gpu, layout, shape):
     if layout == 2:
         M, K = K, M  # TN: the long dimension is the contraction (frames)
     _run(_lib.load(), torch, layout, M, N, K, seed=layout * 100 + M)
+
+
+# every tile configuration (0-2 register-staged, 3-6 LDS-DMA staged: gemm_bf16.h) on ragged shapes that exercise
+# edge tiles in m, n and k, a K shorter than the ring is deep, and one full-size problem per layout
+CFG_SHAPES = [(37, 29, 13), (130, 70, 200), (300, 200, 136), (257, 129, 520), (512, 512, 1088)]
+
+
+@pytest.mark.parametrize("cfg", range(7))
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_bf16_every_config(gpu, layout, cfg):
+    import torch
+    from tfkaldi_amd import _lib
+    for M, N, K in CFG_SHAPES:
+        _run(_lib.load(), torch, layout, M, N, K, seed=cfg * 31 + layout, cfg=cfg)
+    for epi in ((EPI_BIAS,) if layout == 0 else (EPI_ACCUM,) if layout == 2 else ()):
+        _run(_lib.load(), torch, layout, 200, 136, 72, epi=epi, seed=5, cfg=cfg)
 
 
 @pytest.mark.parametrize("layout,epi", [(0, EPI_BIAS), (2, EPI_ACCUM)])

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_flo
 
 from .build import lib_path
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
@@ -98,6 +98,8 @@ SYMBOLS = {
                              c_int, c_void_p, c_int, c_int]),
     "tfk_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int]),
+    "tfk_gemm_bf16_force_config": (c_int, [c_int]),
+    "tfk_gemm_bf16_config": (c_int, [c_int, c_int]),
 }
 
 _lib = None

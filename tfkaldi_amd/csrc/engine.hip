@@ -1684,4 +1684,10 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
   return 0;
 }
 
+int tfk_gemm_bf16_force_config(int cfg) {
+  gemm_bf16_force_config(cfg);
+  return 0;
+}
+int tfk_gemm_bf16_config(int M, int N) { return gemm_bf16_pick_config(M, N); }
+
 }  // extern "C"

@@ -25,19 +25,35 @@ struct GemmArgsB {
   float* stats;           // EPI_COLSTATS: [2, tiles_m, ldc];  EPI_DACT: [2, stats_stride, ldc]
   const float* act_a;     // EPI_DACT operands (see gemm_f32.h)
   const float* act_z;
-  const float* act_mean;
-  const float* act_rstd;
+  const float* act_mean;  // EPI_DACT: batch mean;  EPI_EVAL_ACT: moving mean (nullptr: no batch norm)
+  const float* act_rstd;  // EPI_DACT: batch rstd;  EPI_EVAL_ACT: moving VARIANCE
   int act_nonlin;
   int stats_stride;
   int M, N, K;
   int lda, ldb, ldc;      // lda / ldb in bf16 elements, ldc in floats
-  int epi;                // EPI_* of gemm_f32.h: 0, BIAS, BIAS|COLSTATS (NN); 0, DACT (NT); 0, ACCUM (TN)
+  int epi;                // EPI_* of gemm_f32.h: 0, BIAS, BIAS|COLSTATS, BIAS|EVAL_ACT (NN); 0, DACT (NT); 0, ACCUM (TN)
+  const float* act_beta;  // EPI_EVAL_ACT
+  float bn_eps;
+  bf16_t* C_twin;         // EPI_EVAL_ACT: bf16 copy of the result (the next layer's operand); nullable
+  int ldct;               // its leading dimension in elements (multiple of 8)
 };
+
+// Tile configurations.  0-2: register-staged ring of round 1 (64x64 / 128x64 / 128x128 per 4-wave block).
+// 3-6: LDS-DMA staged, 64x64 (or 64x32) wave tiles:
+//   3: 128x64  block, 4 waves (64x32 each), 5-slot ring  (one block per CU: the 1024-frame shapes)
+//   4: 128x128 block, 4 waves (64x64 each), 4-slot ring
+//   5: 256x128 block, 8 waves (64x64 each), 3-slot ring
+//   6: 128x64  block, 4 waves (64x32 each), 3-slot ring  (two blocks per CU)
+constexpr int kNumGemmBf16Configs = 7;
 
 // Returns hipError_t as int.
 int gemm_bf16(GemmLayout layout, const GemmArgsB& args, hipStream_t stream);
 
 // rows of the block tile gemm_bf16 uses for an [M, N] result (= rows per EPI_COLSTATS / EPI_DACT chunk)
 int gemm_bf16_tile_rows(int M, int N);
+
+// Override the tile heuristic (tools / tests; env TFK_BF16_CFG does the same); -1 restores it.
+void gemm_bf16_force_config(int cfg);
+int gemm_bf16_pick_config(int M, int N);
 
 }  // namespace tfk

@@ -1,19 +1,30 @@
 // bf16 MFMA GEMM for gfx950 (CDNA4): v_mfma_f32_32x32x16_bf16, fp32 accumulate.
 //
 // Replaces the same reference lines as gemm_f32.hip (neuralNetworks/classifiers/layer.py:52 and its tf.gradients,
-// neuralNetworks/trainer.py:155) when the engine runs in mixed precision.
+// neuralNetworks/trainer.py:155) when the engine runs in mixed precision (BASELINE cfg3 / cfg4 arithmetic).
 //
-// One 64x64, 128x64 or 128x128 output tile per 256-thread block (4 waves as 2 x 2), K in steps of 64:
-//   * global -> registers -> LDS through buffer resources (out-of-range chunks come back as zeros, no branches);
-//     three LDS stages fed from a register ring that keeps PF tiles of loads in flight;
-//   * a k-contiguous operand ([ext][k] in memory) is kept as rows of 64 + 8 bf16 (144 B: conflict-free
-//     ds_read_b128) and a lane's MFMA operand -- 8 consecutive k of one row -- is ONE ds_read_b128;
-//   * a k-strided operand ([k][ext] in memory: the weight matrix in the forward GEMM, BOTH operands of the
-//     weight-gradient GEMM) is kept as it lies, rows of 64 + 32 bf16 (192 B), and transposed on the way out of LDS by
-//     ds_read_b64_tr_b16: each 16-lane group reads a [4 k][16 ext] block and every lane receives the 4 k-values of
-//     its own column, two reads per operand.  No transposed copy of weights or activations exists anywhere.
-// At the sizes of this path (1024 rows per GPU) the bf16 contractions are not matrix-bound (8.6 GFLOP = 3.4 us at
-// peak against ~20 MB of operands and a launch): what matters is load latency, hence the deep register ring.
+// Two kernel families share one epilogue:
+//
+// (1) LDS-DMA staged (configs 3-6, the default).  A bf16 contraction does 16x the flops of the fp32 one per byte
+//     of operand, so what bounds it at the sizes of this path is how fast operand tiles reach LDS (~38 B/clk/CU
+//     from L2, profiles/r01_gemm_dma.txt), i.e. the BLOCK tile: bytes per flop fall as 1/BM + 1/BN.  Blocks are
+//     128x64 (the 1024-frame shapes: 256 tiles = one per CU), 128x128 or 256x128 (4 / 8 waves, each wave a
+//     64x64 -- or 64x32 -- patch = 4 (2) accumulator fragments of 32x32), K in steps of 64:
+//       * `buffer_load_dwordx4 ... lds` moves 64 x 16 B per wave-instruction from per-lane global addresses into one
+//         contiguous KiB of LDS: no staging registers, no ds_write pass.  The LDS image is lane-linear, so the
+//         bank-conflict permutation is applied on the SOURCE side and undone by the reader:
+//           - k-contiguous operand ([ext][64 k], 128-byte rows): k-chunk c of row r sits at chunk c ^ ((r >> 1) & 7);
+//             a lane's MFMA operand (8 consecutive k of one row) is ONE ds_read_b128, and the 16-lane service groups
+//             of ds_read_b128 touch 16 distinct 16-byte slots;
+//           - k-strided operand ([64 k][ext]: the weight matrix in forward, BOTH operands of the weight gradient)
+//             stays in memory order and is transposed on the way out of LDS by ds_read_b64_tr_b16 (a 16-lane group
+//             reads a [4 k][16 ext] block); ext-chunk c of k-row r sits at chunk c ^ ((r & 3) << 2) (rows of >= 256 B)
+//             or c ^ (((r >> 1) & 1) << 2) (128-byte rows), which spreads the four rows of a group over all 64 banks.
+//       * ring of NS stages; iteration t issues the pieces of tile t+NS-1 (spread behind the MFMAs of the four
+//         16-k steps) into the slot tile t-1 left, multiplies tile t, then waits with a COUNTED s_waitcnt vmcnt for
+//         its own pieces of tile t+1 only -- the younger tiles stay in flight across the barrier, so the fill path
+//         never drains.  hipcc does not model these loads (inline asm): completion is that wait + s_barrier.
+// (2) register-staged ring of round 1 (configs 0-2; kept for A/B runs: tools/gemm_bf16_sweep.py).
 #include "gemm_bf16.h"
 
 #include <stdlib.h>
@@ -25,13 +36,367 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 64, NT = 256, PF = 4;  // PF: tiles of global loads in flight per block (even)
-constexpr int KC_LD = BK + 8;  // elements per LDS row of a k-contiguous operand (144 B)
+constexpr int BK = 64;
 constexpr int kOOB = (int)0x80000000;
 constexpr int NUM_XCD = 8;
 
-// EXT = tile extent along m (64 or 128) or n (64)
+// XCD-aware order: block b runs on XCD b % 8; each XCD takes a contiguous run of the column-major tile
+// sequence, so the tiles sharing a B panel (and neighbouring A panels) meet in one L2.
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid % NUM_XCD, loc = bid / NUM_XCD;
+  const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
+  const int seq = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  tm = seq % tiles_m;
+  tn = seq / tiles_m;
+}
+
+__device__ __forceinline__ uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+
+// ---- epilogue shared by both families --------------------------------------------------------------------------
+// Wave (wm, wn) of a WAVES_M x WAVES_N arrangement owns the 32x32 fragments acc[a][b] at rows
+// m0 + (wm * FM + a) * 32, columns n0 + (wn * FN + b) * 32.  D reg r of lane (i, h) is row (r&3) + 8*(r>>2) + 4*h,
+// column i of its fragment.  `red` = LDS scratch (the K loop ended behind a barrier), >= 2 * WAVES_M * BN floats.
+template <int EPI, int WAVES_M, int WAVES_N, int FM, int FN>
+__device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][FN], int tiles_m, int tm, int m0, int n0,
+                                         int wm, int wn, int i, int h, float* red) {
+  constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
+  auto row_of = [&](int a, int r) { return m0 + (wm * FM + a) * 32 + 4 * h + (r & 3) + 8 * (r >> 2); };
+#pragma unroll
+  for (int b = 0; b < FN; ++b) {
+    const int cidx = (wn * FN + b) * 32 + i;
+    const int col = n0 + cidx;
+    const bool col_ok = col < p.N;
+    const int colc = col_ok ? col : p.N - 1;
+    if constexpr ((EPI & EPI_BIAS) != 0) {
+      const float bv = p.bias[colc];
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += bv;
+    }
+    if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
+      // evaluation-mode batch norm + nonlinearity: the operations of bn_stats_eval + act_forward (kernels.hip),
+      // in their order
+      const bool bn = p.act_mean != nullptr;
+      const float mu = bn ? p.act_mean[colc] : 0.f;
+      const float rs = bn ? rsqrtf(p.act_rstd[colc] + p.bn_eps) : 1.f;
+      const float be = bn ? p.act_beta[colc] : 0.f;
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float u = acc[a][b][r];
+          if (bn) u = (u - mu) * rs + be;
+          switch (p.act_nonlin) {
+            case 0: u = fmaxf(u, 0.f); break;
+            case 1: u = 1.f / (1.f + expf(-u)); break;
+            case 2: u = tanhf(u); break;
+            default: break;
+          }
+          acc[a][b][r] = u;
+        }
+    }
+    if constexpr ((EPI & EPI_COLSTATS) != 0) {
+      // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
+      const int n_tile = min(BM, p.M - m0);
+      float cmean = 0.f;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[a][b][r];
+            if (row_of(a, r) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
+          }
+        s += __shfl_xor(s, 32);
+        if (h == 0) red[wm * BN + cidx] = s;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) t += red[w * BN + cidx];
+        if (pass == 0) {
+          cmean = t / (float)n_tile;
+        } else if (wm == 0 && h == 0 && col_ok) {
+          p.stats[((size_t)0 * tiles_m + tm) * p.ldc + col] = cmean;
+          p.stats[((size_t)1 * tiles_m + tm) * p.ldc + col] = t;
+        }
+        __syncthreads();
+      }
+    }
+    if constexpr ((EPI & EPI_DACT) != 0) {
+      // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
+      const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < FM; ++a) {
+        float av[16], zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row_of(a, r), p.M - 1);
+          av[r] = p.act_a[(size_t)row * p.ldc + colc];
+          zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float d1;
+          switch (p.act_nonlin) {
+            case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+            case 1: d1 = av[r] * (1.f - av[r]); break;
+            case 2: d1 = 1.f - av[r] * av[r]; break;
+            default: d1 = 1.f;
+          }
+          const float du = acc[a][b][r] * d1;
+          acc[a][b][r] = du;
+          if (row_of(a, r) < p.M) {
+            s1 += du;
+            s2 += du * (zv[r] - mu) * rsd;
+          }
+        }
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        red[(0 * WAVES_M + wm) * BN + cidx] = s1;
+        red[(1 * WAVES_M + wm) * BN + cidx] = s2;
+      }
+      __syncthreads();
+      if (wm == 0 && h == 0 && col_ok) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) {
+          t1 += red[(0 * WAVES_M + w) * BN + cidx];
+          t2 += red[(1 * WAVES_M + w) * BN + cidx];
+        }
+        p.stats[((size_t)0 * p.stats_stride + tm) * p.ldc + col] = t1;
+        p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = t2;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+      float old[16];
+      if constexpr ((EPI & EPI_ACCUM) != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = p.C[(size_t)min(row_of(a, r), p.M - 1) * p.ldc + colc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_of(a, r);
+        float v = acc[a][b][r];
+        if (EPI & EPI_ACCUM) v += old[r];
+        if (col_ok && row < p.M) {
+          p.C[(size_t)row * p.ldc + col] = v;
+          if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
+            if (p.C_twin) p.C_twin[(size_t)row * p.ldct + col] = f2bf(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================================
+// (1) LDS-DMA staged kernel
+// ================================================================================================================
+
+// ext-chunk permutation of a k-strided tile row (see the header comment)
+template <int EXT>
+__device__ __forceinline__ int ks_swz(int r) {
+  return EXT == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2);
+}
+
+// One operand's share of a stage: EXT rows (k-contiguous) or 64 k-rows of EXT elements; EXT * 128 bytes either way.
+template <bool KC, int EXT, int NTH>
+struct DmaOperand {
+  static constexpr int NP = EXT * 8 / NTH;  // 16-byte pieces per thread per tile
+  static_assert((EXT * 8) % NTH == 0 && NP >= 1, "pieces per thread");
+  i32x4 rsrc;
+  int voff[NP];  // byte offset of the piece's source inside the matrix, k-tile term excluded; kOOB outside along ext
+  int kidx[NP];  // its first k inside a tile
+  int kstride;   // bytes per unit of k
+  int k_lim;
+
+  __device__ __forceinline__ void init(const bf16_t* base, int ld, int rows, int ext0, int ext_lim, int k_lim_,
+                                       int tid) {
+    const unsigned long long a = (unsigned long long)base;
+    rsrc[0] = (int)(unsigned)a;
+    rsrc[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+    rsrc[2] = rows * ld * 2;
+    rsrc[3] = 0x00020000;
+    k_lim = k_lim_;
+    kstride = KC ? 2 : ld * 2;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int idx = tid + j * NTH;  // chunk position inside the LDS image
+      if (KC) {
+        const int r = idx >> 3;
+        const int k = ((idx & 7) ^ ((r >> 1) & 7)) << 3;
+        const int e = ext0 + r;
+        voff[j] = e < ext_lim ? (e * ld + k) * 2 : kOOB;
+        kidx[j] = k;
+      } else {
+        constexpr int CH = EXT / 8;
+        const int r = idx / CH;
+        const int c = (idx % CH) ^ ks_swz<EXT>(r);
+        const int e = ext0 + (c << 3);
+        voff[j] = e < ext_lim ? (r * ld + e) * 2 : kOOB;
+        kidx[j] = r;
+      }
+    }
+  }
+  // piece j of the tile at k0 -> image at LDS byte address `image` (out-of-range pieces land as zeros)
+  __device__ __forceinline__ void issue(int j, unsigned image, int k0, int wave) const {
+    const int off = (k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
+    const unsigned dst = image + (unsigned)(wave * 64 + j * NTH) * 16u;
+    const int soff = k0 * kstride;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(dst), "v"(off), "s"(rsrc), "s"(soff)
+                 : "memory");
+  }
+};
+
+// MFMA operand fetch from the DMA image.  NF fragments of 32 rows (columns) starting at fragment index frag0.
+template <bool KC, int EXT, int NF>
+struct Frag {
+  int off[KC ? 4 : NF];
+  __device__ __forceinline__ void init(int lane, int frag0) {
+    if constexpr (KC) {
+      const int i = lane & 31, kb = lane >> 5, sw = (i >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) off[ks] = (frag0 * 32 + i) * 128 + ((((2 * ks + kb) ^ sw)) << 4);
+    } else {
+      constexpr int ROWB = EXT * 2;
+      const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
+      const int jj = EXT == 64 ? (j >> 1) : j;
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+        off[f] = (8 * kb + j) * ROWB + ((4 * ((frag0 + f) ^ jj) + 2 * half + (q >> 1)) << 4) + ((q & 1) << 3);
+    }
+  }
+  // fragment f, 16-k step ks of the operand image at `img`
+  __device__ __forceinline__ bf16x8 read(const char* img, int f, int ks) const {
+    if constexpr (KC) {
+      return *reinterpret_cast<const bf16x8*>(img + off[ks] + f * 32 * 128);
+    } else {
+      constexpr int ROWB = EXT * 2;
+      typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+      const char* q = img + off[f] + ks * 16 * ROWB;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * ROWB));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+};
+
+#define TFKB_WAIT_BARRIER(n) \
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "n"(n) : "memory")
+
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
+gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTH = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
+  typedef DmaOperand<A_KC, BM, NTH> OA;
+  typedef DmaOperand<B_KC, BN, NTH> OB;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int NPA = OA::NP, NP = OA::NP + OB::NP;
+  static_assert(NS >= 3 && (NS - 2) * NP <= 63, "ring depth / vmcnt range");
+  static_assert(FM * FN >= 2, "two independent accumulator chains per wave");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int tm, tn;
+  tile_of_block(tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int K8 = (p.K + 7) & ~7;
+  OA la;
+  OB lb;
+  // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
+  // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
+  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid);
+  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid);
+  Frag<A_KC, BM, FM> qa;
+  Frag<B_KC, BN, FN> qb;
+  qa.init(lane, wm * FM);
+  qb.init(lane, wn * FN);
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int a = 0; a < FM; ++a)
+#pragma unroll
+    for (int b = 0; b < FN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
+  auto piece = [&](int j, int slot, int kt) {
+    if (j < NPA) la.issue(j, lds0 + (unsigned)(slot * STAGE), kt * BK, wave);
+    else lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + A_BYTES), kt * BK, wave);
+  };
+  const int nk = (p.K + BK - 1) / BK;
+  // prologue: tiles 0 .. NS-2 (tiles beyond K land as zeros without touching memory)
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) piece(j, t, t);
+  TFKB_WAIT_BARRIER((NS - 2) * NP);
+
+  bf16x8 fa[2][FM], fb[2][FN];
+  auto read_frags = [&](int buf, const char* st, int ks) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a) fa[buf][a] = qa.read(st, a, ks);
+#pragma unroll
+    for (int b = 0; b < FN; ++b) fb[buf][b] = qb.read(st + A_BYTES, b, ks);
+  };
+  int rs = 0, ws = NS - 1;
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* st = smem + rs * STAGE;
+    read_frags(0, st, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < 4) read_frags(cur ^ 1, st, ks + 1);
+      // this 16-k step's share of the pieces of tile kt+NS-1 (into the slot tile kt-1 left at the last barrier)
+#pragma unroll
+      for (int j = ks * NP / 4; j < (ks + 1) * NP / 4; ++j) piece(j, ws, kt + NS - 1);
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // this wave's pieces of tile kt+1 have landed (the NS-2 younger tiles stay in flight); the barrier makes every
+    // wave's pieces visible and retires all reads of tile kt
+    TFKB_WAIT_BARRIER((NS - 2) * NP);
+    rs = rs + 1 == NS ? 0 : rs + 1;
+    ws = ws + 1 == NS ? 0 : ws + 1;
+  }
+  TFKB_WAIT_BARRIER(0);  // the epilogue reuses the ring as scratch: nothing may still be landing in it
+  epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
+}
+
+// ================================================================================================================
+// (2) register-staged ring (round 1): one 64x64, 128x64 or 128x128 tile per 4-wave block, three LDS stages fed from
+//     a register ring that keeps PF tiles of loads in flight; k-contiguous rows padded to 144 B, k-strided rows to
+//     EXT * 2 + 64 B (both conflict-free).
+// ================================================================================================================
+constexpr int NT = 256, PF = 4;  // PF: tiles of global loads in flight per block (even)
+constexpr int KC_LD = BK + 8;    // elements per LDS row of a k-contiguous operand (144 B)
+
 template <bool KC, int EXT>
 struct Operand {
   static constexpr int LD = KC ? KC_LD : EXT + 32;   // k-strided: one k per row of EXT + 32 elements (192 / 320 B)
@@ -48,7 +413,6 @@ struct Loader {
   int kstride;    // bytes per unit of k
   int k_lim;
 
-  // chunk c of the tile: (row, 8-element column) in the memory order of the operand
   static __device__ __forceinline__ void coords(int c, int& r, int& q) {
     if (KC) { r = c >> 3; q = (c & 7) << 3; }                       // [ext][k]: 8 chunks per 64-k row
     else { r = c / (EXT / 8); q = (c % (EXT / 8)) << 3; }           // [k][ext]: EXT / 8 chunks per k row
@@ -104,19 +468,12 @@ __device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks
   }
 }
 
-// TFK_ABLB (tools/gemm_bf16_ablate.hip only): timing-only variants with pieces of the K loop removed --
-// 1 global loads, 2 LDS writes, 4 fragment reads, 8 barrier.  Results are wrong by construction.
-#ifndef TFK_ABLB
-#define TFK_ABLB 0
-#endif
-
-// FM / FN: 32-row / 32-column MFMA fragments per wave.  Block tile = (64 * FM) x (64 * FN), four waves as 2 x 2, wave
-// tile (32 * FM) x (32 * FN).  Larger wave tiles stage fewer bytes AND fewer staging instructions per MFMA (a
-// ds_write_b128 holds its wave ~13 cycles, an MFMA lasts 32): 64x64 -> 128x64 -> 128x128 as the problem allows.
+// FM / FN: 32-row / 32-column MFMA fragments per wave.  Block tile = (64 * FM) x (64 * FN), four waves as 2 x 2.
 template <bool A_KC, bool B_KC, int EPI, int FM, int FN>
 __global__ void __launch_bounds__(NT)
 gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_e[];
+  bf16_t* smem = smem_e;
   constexpr int BM = 64 * FM, BN = 64 * FN;
   typedef Operand<A_KC, BM> OA;
   typedef Operand<B_KC, BN> OB;
@@ -128,48 +485,29 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   const int i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware order: block b runs on XCD b % 8; each XCD takes a contiguous run of the column-major tile
-  // sequence, so the tiles sharing a B panel (and neighbouring A panels) meet in one L2.
   int tm, tn;
-  {
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid % NUM_XCD, loc = bid / NUM_XCD;
-    const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
-    const int seq = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    tm = seq % tiles_m;
-    tn = seq / tiles_m;
-  }
+  tile_of_block(tiles_m, tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
   Loader<A_KC, BM> la;
   Loader<B_KC, BN> lb;
-  // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
-  // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
   la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid);
   lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid);
 
-  // a wave owns FM * FN accumulator fragments; with a single fragment the k-steps alternate between two
-  // accumulators so that consecutive MFMAs never depend on each other
-  constexpr int KS = (FM * FN == 1) ? 2 : 1;
-  f32x16 acc[FM][FN][KS];
+  // with a single fragment per wave the k-steps alternate between two accumulators so that consecutive MFMAs never
+  // depend on each other
+  constexpr bool ALT = FM * FN == 1;
+  f32x16 acc[FM][FN], acc_alt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_alt[r] = 0.f;
 #pragma unroll
   for (int a = 0; a < FM; ++a)
 #pragma unroll
     for (int b = 0; b < FN; ++b)
 #pragma unroll
-      for (int q = 0; q < KS; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][q][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // Pipeline (one barrier per K step of 64, nothing on the critical path but the MFMAs):
-  //   registers: a ring of PF tiles of global loads in flight (a K step computes for a few hundred cycles per
-  //              wave, a load takes over a thousand);
-  //   LDS:       three stages -- while tile t is multiplied, tile t+1 (made visible by the previous barrier) is
-  //              already readable and tile t+2 is written;
-  //   fragments: double-buffered per 16-k step; the last step of a tile prefetches the first of the next.
   const int nk = (p.K + BK - 1) / BK;
   u32x4 ra[PF][OA::NCH], rb[PF][OB::NCH];
 #pragma unroll
@@ -206,189 +544,122 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
       // their loads, and it then waits for (nearly) ALL outstanding loads before each LDS write.
       const int kt = kt0 + j;
       const int s2 = (j + 2) % PF;  // register set holding tile kt + 2
-      if (!(TFK_ABLB & 2)) {
-        la.store(ra[s2], st2, tid);
-        lb.store(rb[s2], st2 + A_SZ, tid);
-      }
-      if (!(TFK_ABLB & 1)) {
-        la.load(ra[s2], (kt + 2 + PF) * BK);
-        lb.load(rb[s2], (kt + 2 + PF) * BK);
-      }
+      la.store(ra[s2], st2, tid);
+      lb.store(rb[s2], st2 + A_SZ, tid);
+      la.load(ra[s2], (kt + 2 + PF) * BK);
+      lb.load(rb[s2], (kt + 2 + PF) * BK);
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const int cur = ks & 1;  // KSTEPS is even: every tile starts in buffer 0
-        if (!(TFK_ABLB & 4)) {
-          if (ks + 1 < KSTEPS) read_frags(cur ^ 1, st0, ks + 1);
-          else read_frags(cur ^ 1, st1, 0);
+        if (ks + 1 < KSTEPS) read_frags(cur ^ 1, st0, ks + 1);
+        else read_frags(cur ^ 1, st1, 0);
+        if (ALT && (ks & 1)) {
+          acc_alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0], fb[cur][0], acc_alt, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b)
-            acc[a][b][ks % KS] =
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b][ks % KS], 0, 0, 0);
       }
-      if (!(TFK_ABLB & 8)) __syncthreads();
+      __syncthreads();
       bf16_t* t = st0; st0 = st1; st1 = st2; st2 = t;
     }
   }
-  if constexpr (KS == 2) {
+  if constexpr (ALT) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[0][0][1][r];
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_alt[r];
   }
-
-  // ---- epilogue: D reg r of lane (i, h) is row (r&3) + 8*(r>>2) + 4*h, column i of a 32x32 fragment ----
-  float* red = reinterpret_cast<float*>(smem);  // [2][2 waves along m][BN]; the K loop ended behind a barrier
-  auto row_of = [&](int a, int r) { return m0 + wm * 32 * FM + a * 32 + 4 * h + (r & 3) + 8 * (r >> 2); };
-#pragma unroll
-  for (int b = 0; b < FN; ++b) {
-    const int col = n0 + wn * 32 * FN + b * 32 + i;
-    const bool col_ok = col < p.N;
-    const int colc = col_ok ? col : p.N - 1;
-    const int cidx = wn * 32 * FN + b * 32 + i;
-    if constexpr ((EPI & EPI_BIAS) != 0) {
-      const float bv = p.bias[colc];
-#pragma unroll
-      for (int a = 0; a < FM; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][0][r] += bv;
-    }
-    if constexpr ((EPI & EPI_COLSTATS) != 0) {
-      // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
-      const int n_tile = min(BM, p.M - m0);
-      float cmean = 0.f;
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        float s = 0.f;
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[a][b][0][r];
-            if (row_of(a, r) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
-          }
-        s += __shfl_xor(s, 32);
-        if (h == 0) red[wm * BN + cidx] = s;
-        __syncthreads();
-        const float t = red[cidx] + red[BN + cidx];
-        if (pass == 0) {
-          cmean = t / (float)n_tile;
-        } else if (wm == 0 && h == 0 && col_ok) {
-          p.stats[((size_t)0 * tiles_m + tm) * p.ldc + col] = cmean;
-          p.stats[((size_t)1 * tiles_m + tm) * p.ldc + col] = t;
-        }
-        __syncthreads();
-      }
-    }
-    if constexpr ((EPI & EPI_DACT) != 0) {
-      // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
-      const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int a = 0; a < FM; ++a) {
-        float av[16], zv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(row_of(a, r), p.M - 1);
-          av[r] = p.act_a[(size_t)row * p.ldc + colc];
-          zv[r] = p.act_z[(size_t)row * p.ldc + colc];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float d1;
-          switch (p.act_nonlin) {
-            case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
-            case 1: d1 = av[r] * (1.f - av[r]); break;
-            case 2: d1 = 1.f - av[r] * av[r]; break;
-            default: d1 = 1.f;
-          }
-          const float du = acc[a][b][0][r] * d1;
-          acc[a][b][0][r] = du;
-          if (row_of(a, r) < p.M) {
-            s1 += du;
-            s2 += du * (zv[r] - mu) * rsd;
-          }
-        }
-      }
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (h == 0) {
-        red[(0 * 2 + wm) * BN + cidx] = s1;
-        red[(1 * 2 + wm) * BN + cidx] = s2;
-      }
-      __syncthreads();
-      if (wm == 0 && h == 0 && col_ok) {
-        p.stats[((size_t)0 * p.stats_stride + tm) * p.ldc + col] = red[(0 * 2 + 0) * BN + cidx] + red[(0 * 2 + 1) * BN + cidx];
-        p.stats[((size_t)1 * p.stats_stride + tm) * p.ldc + col] = red[(1 * 2 + 0) * BN + cidx] + red[(1 * 2 + 1) * BN + cidx];
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < FM; ++a) {
-      float old[16];
-      if constexpr ((EPI & EPI_ACCUM) != 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = p.C[(size_t)min(row_of(a, r), p.M - 1) * p.ldc + colc];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row_of(a, r);
-        float v = acc[a][b][0][r];
-        if (EPI & EPI_ACCUM) v += old[r];
-        if (col_ok && row < p.M) p.C[(size_t)row * p.ldc + col] = v;
-      }
-    }
-  }
+  epilogue<EPI, 2, 2, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 
-// tile shape: the largest of 128x128 / 128x64 / 64x64 that still gives (nearly) every CU a block
-int pick_tile(int M, int N) {  // returns 10 * FM + FN
-  static const int forced = [] { const char* q = getenv("TFK_BF16_TILE"); return q ? atoi(q) : 0; }();
-  if (forced == 11 || forced == 21 || forced == 22) return forced;
-  const int m128 = (M + 127) / 128;
-  if (m128 * ((N + 127) / 128) >= 192) return 22;
-  if (m128 * ((N + 63) / 64) >= 192) return 21;
-  return 11;
+// ---- host side ---------------------------------------------------------------------------------------------------
+struct CfgB {
+  int bm, bn;
+};
+const CfgB kCfgB[kNumGemmBf16Configs] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}, {128, 128}, {256, 128}, {128, 64}};
+int g_forced_b = -2;  // -2: env not read yet; -1: heuristic
+
+template <class Kern>
+int launch_grid(Kern kern, const GemmArgsB& p, int bm, int bn, int threads, size_t lds, hipStream_t stream, bool* attr_done) {
+  const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;
+  if (!*attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    *attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(threads), lds, stream, p, tiles_m, tiles_n);
+  return (int)hipGetLastError();
 }
 
 template <bool A_KC, bool B_KC, int EPI, int FM, int FN>
-int launch_tile(const GemmArgsB& p, hipStream_t stream) {
+int launch_reg(const GemmArgsB& p, hipStream_t stream) {
   constexpr int BM = 64 * FM, BN = 64 * FN;
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)3 * (Operand<A_KC, BM>::SZ + Operand<B_KC, BN>::SZ) * sizeof(bf16_t);
   static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>), dim3(tiles_m * tiles_n), dim3(NT), lds, stream, p,
-                     tiles_m, tiles_n);
-  return (int)hipGetLastError();
+  return launch_grid(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>, p, BM, BN, NT, lds, stream, &attr_done);
 }
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+int launch_dma(const GemmArgsB& p, hipStream_t stream) {
+  constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
+  const size_t lds = (size_t)NS * (BM + BN) * 128;
+  static_assert((size_t)NS * (BM + BN) * 128 <= 160 * 1024, "LDS");
+  static bool attr_done = false;
+  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS>, p, BM, BN,
+                     WAVES_M * WAVES_N * 64, lds, stream, &attr_done);
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgsB& p, hipStream_t stream) {
-  switch (pick_tile(p.M, p.N)) {
-    case 22: return launch_tile<A_KC, B_KC, EPI, 2, 2>(p, stream);
-    case 21: return launch_tile<A_KC, B_KC, EPI, 2, 1>(p, stream);
-    default: return launch_tile<A_KC, B_KC, EPI, 1, 1>(p, stream);
+  switch (gemm_bf16_pick_config(p.M, p.N)) {
+    case 0: return launch_reg<A_KC, B_KC, EPI, 1, 1>(p, stream);
+    case 1: return launch_reg<A_KC, B_KC, EPI, 2, 1>(p, stream);
+    case 2: return launch_reg<A_KC, B_KC, EPI, 2, 2>(p, stream);
+    case 3: return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 5>(p, stream);
+    case 4: return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 4>(p, stream);
+    case 5: return launch_dma<A_KC, B_KC, EPI, 4, 2, 2, 2, 3>(p, stream);
+    case 6: return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 3>(p, stream);
   }
+  return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
 
-int gemm_bf16_tile_rows(int M, int N) { return 64 * (pick_tile(M, N) / 10); }
+void gemm_bf16_force_config(int cfg) { g_forced_b = (cfg >= 0 && cfg < kNumGemmBf16Configs) ? cfg : -1; }
+
+// The largest block tile that still gives (nearly) every CU a block: bytes staged per flop fall as 1/BM + 1/BN.
+int gemm_bf16_pick_config(int M, int N) {
+  if (g_forced_b == -2) {
+    const char* q = getenv("TFK_BF16_CFG");
+    const int v = q ? atoi(q) : -1;
+    g_forced_b = (v >= 0 && v < kNumGemmBf16Configs) ? v : -1;
+  }
+  if (g_forced_b >= 0) return g_forced_b;
+  const long m256 = (M + 255) / 256, m128 = (M + 127) / 128, n128 = (N + 127) / 128, n64 = (N + 63) / 64;
+  if (m256 * n128 >= 200) return 5;
+  if (m128 * n128 >= 200) return 4;
+  return m128 * n64 > 256 ? 6 : 3;
+}
+
+int gemm_bf16_tile_rows(int M, int N) { return kCfgB[gemm_bf16_pick_config(M, N)].bm; }
 
 int gemm_bf16(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
   if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 3)) return (int)hipErrorInvalidValue;
+  {  // operands are addressed with 32-bit byte offsets through buffer resources
+    const long a_rows = layout == GEMM_TN ? p.K : p.M;
+    const long b_rows = layout == GEMM_NT ? p.N : p.K;
+    if (a_rows * p.lda * 2 >= (1L << 31) || b_rows * p.ldb * 2 >= (1L << 31)) return (int)hipErrorInvalidValue;
+  }
   switch (layout) {
     case GEMM_NN:
       switch (p.epi) {
         case 0: return launch<true, false, 0>(p, stream);
         case EPI_BIAS: return launch<true, false, EPI_BIAS>(p, stream);
         case EPI_BIAS | EPI_COLSTATS: return launch<true, false, EPI_BIAS | EPI_COLSTATS>(p, stream);
+        case EPI_BIAS | EPI_EVAL_ACT: return launch<true, false, EPI_BIAS | EPI_EVAL_ACT>(p, stream);
       }
       break;
     case GEMM_NT:

@@ -26,6 +26,11 @@ enum : int {
   EPI_COLSTATS = 8,    // also emit, per BM-row tile, each column's mean and sum of squared deviations of the
                        // stored values (the batch-norm statistics of the layer, Chan-mergeable):
                        // stats[(0 * tiles_m + tile_m) * ldc + col] = mean, stats[(1 * tiles_m + tile_m) * ldc + col] = M2
+  EPI_EVAL_ACT = 32,   // evaluation-mode hidden layer in ONE launch (decoder.py:36-44, trainer.py:77-79 with
+                       // is_training=False): C = f(((result + bias) - moving_mean) * rsqrt(moving_var + eps) + beta)
+                       // -- the same operations, in the same order, as EPI_BIAS followed by bn_stats_eval and
+                       // act_forward.  act_mean = moving mean (nullptr: no batch norm), act_rstd = moving VARIANCE,
+                       // act_beta = beta, bn_eps, act_nonlin.  Requires EPI_BIAS.
   EPI_DACT = 16,       // C = du = result * f'(act_a) (derivative through the layer output act_a = f(u)), and per
                        // BM-row tile the column sums batch-norm's backward needs:
                        // stats[(0 * stats_stride + tile_m) * ldc + col] = sum du,
@@ -48,6 +53,8 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldb, ldc;
   int epi;
+  const float* act_beta = nullptr;  // EPI_EVAL_ACT
+  float bn_eps = 0.f;
   // Split-K (optional; epi 0 / EPI_ACCUM only): when the output has too few tiles to fill the chip and K is long
   // -- the weight gradient of a narrow layer over many frames -- the contraction is cut into chunks that run as
   // extra blocks into partial results in `splitk_ws`, summed in chunk order by a second kernel (deterministic).
