@@ -3,15 +3,27 @@
 Workload = BASELINE.json configs[1] ("cfg2"): 6x2048 ReLU + batch-norm DNN, 40-dim fbank +-5 splice = 440
 inputs, 2000 pdf-ids, 1024 frames (16 utterances x 64 frames) per GPU per optimiser step, fp32 (exact-fp32 MFMA).
 One "step" = one full optimiser step of the reference's Trainer.update: forward + softmax-CE + backward on the
-micro-batch, gradient all-reduce when N > 1, mean -> clip -> Adam, BN moving averages, loss returned to the host.
+micro-batch, gradient exchange when N > 1, mean -> clip -> Adam, BN moving averages, loss returned to the host.
 Weak scaling: every rank owns its own 1024-frame micro-batch (one micro-batch per GPU, as the reference's
 128-utterance batch in 16-utterance micro-batches maps onto 8 GPUs); `value` = all ranks' frames / max-rank time.
-Inputs come from synthetic ark/scp/alignment files through the product's feature reader + batch dispenser and
-are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+Inputs come from synthetic ark/scp/alignment files through the product's feature reader + batch dispenser; a ring
+of DISTINCT micro-batches (a different one every step) is resident in HBM before the timed region.
+
+`--gpus N` with N > 1 from a bare shell launches N ranks itself (torch.distributed.run, one rank per GPU over RCCL);
+under torchrun / the driver's own launcher (WORLD_SIZE set) it joins that group.  Prints ONE JSON line on rank 0.
+
+Besides the contract's fields the line carries: `roofline` (dominant kernel, live HIP-event timing),
+`host_fed_value` (the same step fed from HOST numpy through tfk_accumulate: PCIe inclusive, never `value`),
+`loss_trace_gpu` / `loss_trace_cpu` (per-step average_loss of the first 20 steps from the engine and from the CPU
+stand-in on the same micro-batch sequence) with their largest relative difference, `posterior_max_err` (decoder
+posteriors of one utterance vs the float64 oracle holding the engine's parameters), and `cpu_baseline`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -29,40 +41,103 @@ M_MACS = F * H + (L - 1) * H * H + H * O
 FLOP_PER_FRAME = 6 * M_MACS - 2 * F * H  # fwd 2M, dW 2M, dA 2M minus the unneeded layer-0 dA
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # v_mfma_f32_32x32x16_bf16, dense (--dtype bfloat16 only)
+TRACE_STEPS = 20                         # per-step average_loss of the first 20 steps
+MAX_RING = 16                            # distinct micro-batches resident per rank
 
 
-def make_batch(rank, world, workdir):
-    """this rank's micro-batch through the product I/O path: ark -> CMVN -> splice -> dispenser"""
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: re-execute under torch.distributed.run, one rank per GPU."""
+    import torch
+    share = os.environ.get("TFK_SHARE_DEVICE") == "1"  # tests only: several ranks on one GPU (gloo)
+    have = torch.cuda.device_count()
+    if not share and have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def make_batches(rank, world, count, workdir):
+    """`count` micro-batches of this rank through the product I/O path (ark -> CMVN -> splice -> dispenser): step i
+    of the job is the reference's batch i (world * 16 utterances in dispenser order), of which rank r takes the
+    r-th 16-utterance micro-batch."""
     from tfkaldi_amd import synthetic
     from tfkaldi_amd.processing import batchdispenser, feature_reader, target_coder
-    paths = synthetic.write_corpus(workdir, UTT_PER_GPU * world, O, feat_dim=F_RAW, utt_len=UTT_LEN)
+    paths = synthetic.write_corpus(workdir, UTT_PER_GPU * world * count, O, feat_dim=F_RAW, utt_len=UTT_LEN)
     reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, UTT_LEN)
     coder = target_coder.AlignmentCoder(lambda x, y: x, O)
     disp = batchdispenser.AlignmentBatchDispenser(reader, coder, UTT_PER_GPU, paths["alignments"])
-    for _ in range(rank + 1):
+    out = []
+    for g in range(world * count):
         xs, ys = disp.get_batch()
-    return np.concatenate(xs, 0), np.concatenate(ys, 0).astype(np.int32)
+        if g % world == rank:
+            out.append((np.ascontiguousarray(np.concatenate(xs, 0)), np.concatenate(ys, 0).astype(np.int32)))
+    return out
 
 
-def cpu_baseline(X, y, hidden_weights, budget_s=20.0):
-    """the same optimiser step on the host cores (PyTorch CPU restatement; TensorFlow is not available)"""
+def cpu_baseline(batches, hidden_weights, budget_s=20.0):
+    """the same optimiser steps on the host cores (PyTorch-CPU restatement; TensorFlow is not installable here)"""
     import torch
     from oracle.torch_cpu_step import TorchCpuTrainer
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 64)  # beyond ~64 threads the 1024-row GEMMs of this step stop scaling on the host
     t = TorchCpuTrainer(F, L, H, O, nonlin="relu", batch_norm=True, threads=cores)
     t.set_hidden_weights(hidden_weights)
-    t.accumulate(X, y); t.apply()  # warm-up
-    steps, t0 = 0, time.perf_counter()
+    trace, steps, t0 = [], 0, time.perf_counter()
     while True:
-        t.accumulate(X, y); t.apply()
+        X, y = batches[steps % len(batches)]
+        t.accumulate(X, y)
+        trace.append(t.apply())
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or steps >= 50:
+        if (dt > budget_s and steps >= TRACE_STEPS) or steps >= 60 or dt > 3 * budget_s:
             break
     return {"value": steps * T / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d optimiser steps of the same cfg2 micro-batch (%d frames each) after 1 warm-up, "
-                      "PyTorch-CPU fp32 restatement of CrossEnthropyTrainer.update (TensorFlow absent)" % (steps, T)}
+            "sample": "%d optimiser steps from the same initial weights over the same micro-batch sequence (%d frames "
+                      "each), no warm-up, PyTorch-CPU fp32 restatement of CrossEnthropyTrainer.update (a stand-in: "
+                      "TensorFlow, the reference's CPU path, is absent)" % (steps, T)}, trace[:TRACE_STEPS]
+
+
+def posterior_error(eng, X):
+    """max |engine posterior - float64 oracle posterior| on one utterance, the oracle holding the engine's parameters"""
+    from oracle.dnn_oracle import OracleDNN
+    from tfkaldi_amd import _lib
+    orc = OracleDNN(F, L, H, O, nonlin="relu", batch_norm=True)
+    for l in range(L + 1):
+        orc.W[l] = eng.get(_lib.WEIGHTS, l).astype(np.float64)
+        orc.b[l] = eng.get(_lib.BIASES, l).astype(np.float64)
+    for l in range(L):
+        orc.beta[l] = eng.get(_lib.BN_BETA, l).astype(np.float64)
+        orc.mov_mean[l] = eng.get(_lib.BN_MOVING_MEAN, l).astype(np.float64)
+        orc.mov_var[l] = eng.get(_lib.BN_MOVING_VAR, l).astype(np.float64)
+    return float(np.abs(eng.posteriors(X).astype(np.float64) - orc.posteriors(X)).max())
+
+
+def measured_traffic(kernel_name):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (tools/profile_step.sh +
+    tools/hbm_traffic.py), valid only for the kernel sources it was measured on."""
+    from tfkaldi_amd.build import csrc_hash
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/hbm_traffic.json"
+    rec = json.load(open(path))
+    meta = rec.get("_meta", {})
+    if meta.get("csrc_sha16") != csrc_hash():
+        return None, "profiles/hbm_traffic.json is stale (measured on csrc %s, this build is %s): dropped" % (
+            meta.get("csrc_sha16"), csrc_hash())
+    if kernel_name not in rec:
+        return None, "kernel not in profiles/hbm_traffic.json"
+    return rec[kernel_name]["bytes_per_launch"], (
+        "profiles/hbm_traffic.json (csrc %s, %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this "
+        "command, (2*FETCH+WRITE)*1024 per MI355X_MICROARCH.md; L2<->fabric side, Infinity-Cache hits included"
+        % (meta.get("csrc_sha16"), meta.get("measured", "?")))
 
 
 def main():
@@ -74,7 +149,11 @@ def main():
     ap.add_argument("--dtype", choices=["float32", "bfloat16"], default="float32",
                     help="float32 (default) is BASELINE cfg2's arithmetic and the only valid headline; bfloat16 runs "
                          "the same workload in the engine's mixed-precision mode (cfg3/cfg4 arithmetic) for reference")
+    ap.add_argument("--exchange", choices=["sharded", "allreduce"], default=None,
+                    help="N > 1: reduce-scatter + sharded Adam + all-gather (default) or all-reduce + full Adam")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     # stdout carries exactly ONE line, the JSON record: libraries that chat on stdout (RCCL prints its library
     # path from C stdio at teardown) are diverted to stderr until the record is written
@@ -89,17 +168,18 @@ def main():
 
     rank, world, local_rank = init_from_env()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)  # (init_from_env folds local_rank onto one device under TFK_SHARE_DEVICE)
     dp = DataParallel()
 
+    total_steps = args.steps + args.warmup
+    ring = max(1, min(total_steps, MAX_RING))
     with tempfile.TemporaryDirectory(prefix="tfkaldi_bench_") as workdir:
-        X, y = make_batch(rank, world, os.path.join(workdir, "rank%d" % rank))
-    assert X.shape == (T, F) and X.dtype == np.float32 and y.shape == (T,)
+        batches = make_batches(rank, world, ring, os.path.join(workdir, "rank%d" % rank))
+    assert all(X.shape == (T, F) and X.dtype == np.float32 and y.shape == (T,) for X, y in batches)
 
     cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, init_learning_rate=1e-3,
-                           num_steps=args.steps + args.warmup, max_frames=T, device=local_rank,
-                           compute_dtype=args.dtype)
+                           num_steps=3 * total_steps, max_frames=T, device=local_rank, compute_dtype=args.dtype)
     eng = Engine(cfg, torch_state=dp.enabled)
     rng = np.random.default_rng(7)
     hidden = [(rng.standard_normal((F if l == 0 else H, H)) / np.sqrt(F if l == 0 else H)).astype(np.float32)
@@ -107,23 +187,37 @@ def main():
     for l, w in enumerate(hidden):
         eng.set(_lib.WEIGHTS, l, w)
 
-    dX = torch.from_numpy(X).cuda()
-    dy = torch.from_numpy(y).cuda()
+    dev = [(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()) for X, y in batches]
     torch.cuda.synchronize()
 
+    exchange = None
     if dp.enabled:
         import torch.distributed as dist
-        # the product's exchange step: per-layer bucket announcements from backward, coalesced into a few large
-        # asynchronous all-reduces (tfkaldi_amd/dataparallel.py)
-        reducer = BucketReducer(eng, stream_ctx=lambda: torch.cuda.stream(eng.torch_stream))
+        # the product's exchange step (tfkaldi_amd/dataparallel.py): per-layer bucket announcements from backward,
+        # coalesced into a few large asynchronous collectives launched while backward is still being enqueued
+        reducer = BucketReducer(eng, stream_ctx=lambda: torch.cuda.stream(eng.torch_stream), mode=args.exchange)
+        exchange = reducer.mode
         eng.set_bucket_callback(reducer.on_bucket)
         eng.set_later_microbatches(world - 1 - rank)
 
-    def step():
-        eng.accumulate_device(dX.data_ptr(), F, dy.data_ptr(), T, last=True)
+    counter = [0]
+
+    def finish():
         if dp.enabled:
-            return reducer.finish_and_apply(eng)  # Adam per reduced span, behind the collectives still in flight
+            return reducer.finish_and_apply(eng)  # optimiser per reduced span, behind the collectives still in flight
         return eng.apply()
+
+    def step():
+        dX, dy = dev[counter[0] % ring]
+        counter[0] += 1
+        eng.accumulate_device(dX.data_ptr(), F, dy.data_ptr(), T, last=True)
+        return finish()
+
+    def step_host():
+        X, y = batches[counter[0] % ring]
+        counter[0] += 1
+        eng.accumulate(X, y, last=True)  # pinned double-buffered staging + H2D on the copy stream (tfk_accumulate)
+        return finish()
 
     def fence():
         eng.synchronize()
@@ -139,8 +233,18 @@ def main():
         losses.append(step())
     fence()
     elapsed = time.perf_counter() - t0
+    my_ms = 1e3 * elapsed / args.steps
+    # the same step fed from host memory (SURVEY 8d / the reference's feed_dict), a different micro-batch per step
+    for _ in range(min(3, args.steps)):
+        step_host()
+    fence()
+    th = time.perf_counter()
+    for _ in range(args.steps):
+        step_host()
+    fence()
+    elapsed_host = time.perf_counter() - th
     # Per-kernel HIP-event timing on the engine stream, over the same K steps repeated right after the timed
-    # region: bracketing every launch with two events costs ~10 % of wall time, so it is kept out of `value`.
+    # regions: bracketing every launch with two events costs ~10 % of wall time, so it is kept out of `value`.
     eng.profile_begin()
     t1 = time.perf_counter()
     for _ in range(args.steps):
@@ -148,10 +252,16 @@ def main():
     fence()
     elapsed_profiled = time.perf_counter() - t1
     stats = eng.profile_end()
+    per_rank_ms = [my_ms]
+    backend = None
     if dp.enabled:
-        t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        elapsed = float(t_max.item())
+        t_all = torch.tensor([elapsed, elapsed_host], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(t_all) for _ in range(world)]
+        dist.all_gather(gathered, t_all)
+        per_rank_ms = [1e3 * float(g[0].item()) / args.steps for g in gathered]
+        elapsed = max(float(g[0].item()) for g in gathered)
+        elapsed_host = max(float(g[1].item()) for g in gathered)
+        backend = dist.get_backend()
 
     if rank == 0:
         gemms = [s for s in stats if s["name"].startswith("gemm_f32")]
@@ -160,38 +270,45 @@ def main():
         all_gemm_tf = sum(s["flops"] for s in gemms) / sum(s["total_ms"] for s in gemms) / 1e9
         value = world * T * args.steps / elapsed
         peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "float32" else PEAK_BF16_MFMA_TFLOPS
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tfile) and args.dtype == "float32":  # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command
-            rec = json.load(open(tfile)).get(dom["name"])
-            if rec:
-                traffic = rec["bytes_per_launch"]
-                traffic_src = ("profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
-                               "(2*FETCH+WRITE)*1024 per MI355X_MICROARCH; L2<->fabric side, Infinity-Cache hits included")
+        traffic, traffic_src = (None, "fp32 only") if args.dtype != "float32" else measured_traffic(dom["name"])
         out = {
             "metric": "acoustic frames/sec (train step)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_with_event_profiling": 1e3 * elapsed_profiled / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "float32" else "bf16 operands, f32 accumulate / master / optimiser",
-            "data": "synthetic ark/scp/alignment files (SURVEY 8d) read through the feature reader + dispenser; "
-                    "random-init weights N(0,1/sqrt(d_in)), zero output layer",
+            "data": "synthetic ark/scp/alignment files (SURVEY 8d) read through the feature reader + dispenser, %d "
+                    "distinct micro-batches per rank cycled (a different one every step); random-init weights "
+                    "N(0,1/sqrt(d_in)), zero output layer" % ring,
             "config": {"workload": "cfg2: 6x2048 ReLU+BN DNN, 440-in (40 fbank +-5), 2000 pdf, %d frames/GPU/step, "
                                    "%s, Adam" % (T, "fp32 MFMA" if args.dtype == "float32" else "bf16 MFMA (mixed precision)"),
                        "frames_per_gpu": T, "global_frames": world * T,
                        "parallelism": "dp%d" % world, "flop_per_frame": FLOP_PER_FRAME},
+            "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend, "exchange": exchange,
+            "per_rank_ms_per_step": per_rank_ms,
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                          "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
                          "all_gemm_tflops": all_gemm_tf,
-                         "step_tflops": value / world * FLOP_PER_FRAME / 1e12},
+                         "step_tflops": value / world * FLOP_PER_FRAME / 1e12,
+                         "step_frac": value / world * FLOP_PER_FRAME / 1e12 / peak},
+            "host_fed_value": world * T * args.steps / elapsed_host,
+            "host_fed_note": "same step, micro-batch handed over as HOST numpy [1024, 440] + targets through "
+                             "tfk_accumulate (PCIe inclusive; never `value`)",
             "loss_first_last": [losses[0], losses[-1]],
+            "loss_trace_gpu": losses[:TRACE_STEPS],
             "kernel_ms_per_step": {s["name"]: s["total_ms"] / args.steps for s in stats},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, y, hidden)
+            out["cpu_baseline"], trace_cpu = cpu_baseline(batches, hidden)
+            out["loss_trace_cpu"] = trace_cpu
+            n = min(len(trace_cpu), len(out["loss_trace_gpu"]))
+            if n:
+                out["loss_trace_max_rel_diff"] = max(abs(a - b) / max(abs(b), 1e-30)
+                                                     for a, b in zip(out["loss_trace_gpu"][:n], trace_cpu[:n]))
+            out["posterior_max_err"] = posterior_error(eng, batches[0][0][:UTT_LEN])
     eng.close()
     if dp.enabled:
         dist.destroy_process_group()
