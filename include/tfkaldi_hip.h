@@ -209,7 +209,8 @@ int tfk_posteriors_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t N
  * one micro-batch on each of B/U GPUs the same computation.  Buckets: b in [0, L] is the weight-gradient span of
  * layer L - b (the order backward produces them), L + 1 every bias / beta gradient, L + 2 the scalars + the BN
  * increments.  With TFK_LAST_MICROBATCH they are announced in the order L + 2 (right after the loss, before
- * backward), 0 .. L, L + 1. */
+ * backward), 0 .. L, L + 1 -- also during layer-wise growth, when the layers above the active depth have a zero
+ * gradient (they are announced right after bucket 0). */
 int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
 /* `init_grads` / `init_loss` / `init_num_frames` (trainer.py:350-352) done eagerly: writes zeros over the whole
  * reduce region.  tfk_apply re-initialises lazily (the next step's first micro-batch overwrites G), so a rank
@@ -232,6 +233,12 @@ int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user);
 int tfk_apply_begin(tfk_engine* e);
 int tfk_apply_span(tfk_engine* e, size_t offset_floats, size_t num_floats);
 int tfk_apply_end(tfk_engine* e, float* average_loss);
+
+/* Sharded exchange step (reduce-scatter -> tfk_apply_span on this rank's share -> all-gather of the updated
+ * parameters written straight into the arena by the collective): tells the engine that parameters changed behind
+ * the optimiser's back, so the bf16 weight shadow of the mixed-precision mode is rebuilt before its next use.
+ * Call between the last tfk_apply_span and tfk_apply_end (or at any other time). */
+int tfk_params_touched(tfk_engine* e);
 
 /* Number of micro-batches of this optimiser step that ranks AFTER this one process: weights this
  * rank's BN moving-average increment by bn_decay^later so the all-reduced result equals the

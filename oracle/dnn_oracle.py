@@ -147,9 +147,15 @@ class OracleDNN(object):
         return self.init_lr * self.decay ** (float(self.global_step) / self.num_steps) * self.lr_fact
 
     # ---- forward ----
-    def _forward(self, X, train, masks=None, nfw=None):
+    def _forward(self, X, train, masks=None, nfw=None, relu_active=None):
         """dnn.py:73-108 on flat frames X[T, F] (seq2nonseq, seq_convertors.py:12-39, is the caller's
-        utterance-major concatenation).  Returns logits and the per-layer cache for backward."""
+        utterance-major concatenation).  Returns logits and the per-layer cache for backward.
+
+        relu_active (test hook, ReLU nets only): per hidden layer a boolean [T, H] on/off pattern that REPLACES the
+        oracle's own `u > 0` in the forward pass and in the derivative.  A unit whose pre-activation lies within
+        fp32 round-off of the kink can come out on the other side in an fp32 implementation; pinning the pattern to
+        the one the implementation chose lets every gradient be compared element-wise, while the caller asserts
+        how rare (and how close to the kink) the disagreements are."""
         nact = self.num_active()
         if nfw is None:
             nfw = nact
@@ -172,6 +178,11 @@ class OracleDNN(object):
                 u = xhat + self.beta[l]
                 c["xhat"], c["rstd"] = xhat, rstd
             v = _nonlin(u, self.nonlin)                               # activation.py:84
+            if relu_active is not None:
+                assert self.nonlin == "relu"
+                c["own_active"], c["u"] = u > 0, u
+                c["dact"] = np.asarray(relu_active[l], dtype=np.float64)
+                v = u * c["dact"]
             c["v"] = v
             w = v
             if self.l2:                                               # activation.py:101-111
@@ -200,23 +211,23 @@ class OracleDNN(object):
         return loss, ex / se
 
     # ---- update_gradients_op: one micro-batch (trainer.py:160-169) ----
-    def accumulate(self, X, y, masks=None):
+    def accumulate(self, X, y, masks=None, relu_active=None):
         """Forward (train) + loss + backward; G += g, batch_loss += loss, num_frames += T, BN EMA.
-        masks: per hidden layer 0/1 keep masks [T, H] when dropout is on.  Returns the dict of this
-        micro-batch's gradients (tf.gradients, trainer.py:155) for inspection."""
+        masks: per hidden layer 0/1 keep masks [T, H] when dropout is on.  relu_active: see _forward.  Returns the
+        dict of this micro-batch's gradients (tf.gradients, trainer.py:155) for inspection."""
         y = np.asarray(y).astype(np.int64)
         T = len(y)
-        logits, cache, nact = self._train_forward(X, masks)
+        logits, cache, nact = self._train_forward(X, masks, relu_active)
         loss, prob = self._xent(logits, y)
         dz = prob.copy()
         dz[np.arange(T), y] -= 1.0                                    # d(sum CE)/dlogits
         return self._backward_and_accumulate(dz, loss, T, logits, cache, nact)
 
-    def _train_forward(self, X, masks=None):
+    def _train_forward(self, X, masks=None, relu_active=None):
         # All BN layers' UPDATE_OPS are fetched (trainer.py:164-169), so with layer-wise growth the
         # hidden layers above the active depth are still evaluated in training mode.
         nfw = self.L if (self.layerwise and self.bn) else None
-        return self._forward(X, True, masks, nfw)
+        return self._forward(X, True, masks, nfw, relu_active)
 
     # Loss-agnostic entry points (used with the CTC oracle, oracle/ctc_oracle.py): the training-mode logits of a
     # micro-batch, then the rest of update_gradients_op from a given d loss / d logits.
@@ -245,7 +256,7 @@ class OracleDNN(object):
                 s, v = c["s"], c["v"]
                 dot = (dw * v).sum(axis=1, keepdims=True)
                 dv = np.where(s > 1, dw / s - v * (2.0 * dot / (self.H * s * s)), dw)
-            du = dv * _nonlin_grad(c["v"], self.nonlin)
+            du = dv * (c["dact"] if "dact" in c else _nonlin_grad(c["v"], self.nonlin))
             if self.bn:
                 g["beta%d" % l] = du.sum(axis=0)
                 xhat, rstd = c["xhat"], c["rstd"]

@@ -1,6 +1,7 @@
 """Test double: the float64 oracle behind the Engine methods that tfkaldi_amd.dataparallel uses, with the
-same reduce-region layout idea ([G | loss, frames, #micro-batches, pad | BN moving-average increments]).
-Lets the world_size-2 gloo tests drive the PRODUCT's DataParallel class on CPU."""
+same reduce-region layout idea ([G | loss, frames, #micro-batches, pad | BN moving-average increments]) and the
+same optimiser protocol (apply_begin / apply_span on a span of the flat parameter arena / apply_end, param_view).
+Lets the world_size-2 gloo tests drive the PRODUCT's DataParallel class -- both exchange steps -- on CPU."""
 import numpy as np
 import torch
 
@@ -17,6 +18,7 @@ class OracleEngine(object):
         self._buckets, off = [], 0
         for ks in self.keys:
             n = sum(oracle.params()[k].size for k in ks)
+            n = (n + 15) // 16 * 16  # spans are padded like the engine's (there to 64 floats): they divide by 4 * world
             self._buckets.append((off, n))
             off += n
         self.P = off
@@ -97,6 +99,71 @@ class OracleEngine(object):
         self._mov0, self._nmb = None, 0
         r[:] = 0
         return o.apply()
+
+    # ---- the optimiser in parts, on spans of the flat arena (include/tfkaldi_hip.h: tfk_apply_begin / _span / _end) ----
+    def _flat(self, d):
+        out = np.zeros(self.P)
+        for (off, _), ks in zip(self._buckets, self.keys):
+            for k in ks:
+                out[off:off + d[k].size] = d[k].ravel()
+                off += d[k].size
+        return out
+
+    def _unflat(self, flat, d):
+        for (off, _), ks in zip(self._buckets, self.keys):
+            for k in ks:
+                d[k][...] = flat[off:off + d[k].size].reshape(d[k].shape)
+                off += d[k].size
+
+    def param_view(self):
+        if not hasattr(self, "params_flat"):
+            self.params_flat = torch.from_numpy(self._flat(self.o.params()))
+        return self.params_flat
+
+    def apply_begin(self):
+        o = self.o
+        r = self.region.numpy()
+        if self._nmb == 0:
+            self._snapshot()
+        self._frames = float(r[self.P + 1])
+        self._loss = float(r[self.P])
+        total_mb = int(round(r[self.P + 2]))
+        if o.bn:
+            d = o.bn_decay
+            e = r[self.P + 4:].reshape(2 * o.L, o.H)
+            for l in range(o.L):
+                o.mov_mean[l] = d ** total_mb * self._mov0[0][l] + e[2 * l]
+                o.mov_var[l] = d ** total_mb * self._mov0[1][l] + e[2 * l + 1]
+        lr = o.learning_rate()
+        o.adam_t += 1
+        self._lr_t = lr * np.sqrt(1.0 - o.b2 ** o.adam_t) / (1.0 - o.b1 ** o.adam_t)
+        self.param_view().numpy()[:] = self._flat(o.params())
+        self._m, self._v = self._flat(o.m), self._flat(o.v)
+
+    def apply_span(self, off, n):
+        o = self.o
+        n = min(n, self.P - off)
+        if n <= 0:
+            return
+        sl = slice(off, off + n)
+        g = np.clip(self.region.numpy()[sl] / self._frames, -1.0, 1.0)
+        self._m[sl] = o.b1 * self._m[sl] + (1 - o.b1) * g
+        self._v[sl] = o.b2 * self._v[sl] + (1 - o.b2) * g * g
+        self.params_flat.numpy()[sl] -= self._lr_t * self._m[sl] / (np.sqrt(self._v[sl]) + o.eps)
+
+    def apply_end(self):
+        o = self.o
+        # Adam moments of spans this rank did not update stay at their old values in a sharded step: a real rank
+        # never reads them again for those spans either (it always updates the same sub-spans), but the test double
+        # shares one oracle state, so only the parameters are compared across ranks
+        self._unflat(self.params_flat.numpy(), o.params())
+        self._unflat(self._m, o.m)
+        self._unflat(self._v, o.v)
+        o.global_step += 1
+        o._zero_accumulators()
+        self._mov0, self._nmb = None, 0
+        self.region.numpy()[:] = 0
+        return self._loss / self._frames
 
     def eval_accumulate(self, X, y):
         self.o.eval_accumulate(X, y)

@@ -32,19 +32,23 @@ def _oracle():
     return o
 
 
-def _worker(rank, world, port, num_mb, out_dir):
+def _worker(rank, world, port, num_mb, out_dir, mode="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_engine import OracleEngine
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
     assert init_from_env() == (rank, world, 0)
-    dp = DataParallel()
+    import tfkaldi_amd.dataparallel as dpmod
+    dpmod.BucketReducer.MIN_SHARD_FLOATS = 8  # the test net is tiny: shard every span that divides
+    dp = DataParallel(mode=mode)
     assert dp.enabled and dp.world == world and dp.rank == rank
     eng = OracleEngine(_oracle())
     losses = []
     for step in range(2):
         losses.append(dp.train_step(eng, _data(num_mb, seed=step)))
+        if mode == "sharded" and num_mb >= world:
+            assert "rs" in dp.last_kinds, dp.last_kinds  # the sharded exchange really ran
     losses.append(dp.eval_step(eng, _data(num_mb, seed=7)))
     o = eng.o
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses),
@@ -60,10 +64,13 @@ def _free_port():
     return port
 
 
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
 @pytest.mark.parametrize("num_mb", [4, 3, 1])  # even shards, uneven shards, one idle rank
-def test_two_ranks_equal_serial(tmp_path, num_mb):
+def test_two_ranks_equal_serial(tmp_path, num_mb, mode):
+    """both exchange steps of BucketReducer: reduce-scatter -> Adam on the rank's share -> all-gather of the
+    parameters ("sharded") and all-reduce -> full Adam on every rank ("allreduce")"""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), num_mb, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), num_mb, str(tmp_path), mode), nprocs=world, join=True)
     serial = _oracle()
     want = []
     for step in range(2):

@@ -173,3 +173,32 @@ def test_ctc_long_utterances_stay_accurate(gpu, T, S):
     assert_close("loss", eng.scalar(_lib.BATCH_LOSS), loss, 1e-6, 0)
     assert np.abs(eng.debug_fetch(_lib.DBG_LOGITS, 0, T) - dlog).max() < 5e-4
     eng.close()
+
+
+def test_ctc_cfg5_size_against_oracle(gpu):
+    """BASELINE configs[4] at its stated size: 4x512 stacked DNN over 16 utterances of ~800 frames (12.8 k frames per
+    micro-batch), ~100 character labels each, 35 characters + blank -- loss, dLogits and every gradient against the
+    float64 CTC + DNN oracles.  (tanh: keeps the ReLU-kink sign question out of a test about the CTC recursion;
+    800-frame utterances have log p ~ -2500, which the kernel's re-centred fp32 state vector has to carry.)"""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(47)
+    kw = dict(input_dim=440, num_layers=4, num_units=512, output_dim=36, nonlin="tanh", batch_norm=True,
+              init_learning_rate=1e-3, num_steps=50)
+    utt = [800, 760, 800, 640, 800, 800, 712, 800, 800, 555, 800, 800, 800, 790, 800, 800]
+    lab = [100, 96, 100, 80, 100, 110, 90, 100, 100, 70, 100, 104, 100, 99, 100, 100]
+    T = int(np.sum(utt))
+    eng, oracle = make_pair(rng, max_frames=T, **kw)
+    X, labels = _batch(rng, utt, lab, kw["input_dim"], kw["output_dim"])
+    eng.accumulate_ctc(X, utt, labels, lab)
+    loss, dlog = _oracle_step(oracle, X, utt, labels, lab)
+    assert np.isfinite(loss) and loss / sum(lab) > 1.0
+    assert_close("batch_loss", eng.scalar(_lib.BATCH_LOSS), loss, 5e-5, 0)
+    assert eng.scalar(_lib.NUM_FRAMES) == sum(lab)
+    assert_close("dlogits", eng.debug_fetch(_lib.DBG_LOGITS, 0, T), dlog, rtol=1e-4, atol=5e-4)
+    got = engine_grads(eng)
+    for k, want in oracle.G.items():
+        if k.startswith("b") and not k.startswith("beta") and k != "b%d" % oracle.L:
+            continue  # bias under batch norm: true gradient 0
+        assert_close("G[%s]" % k, got[k], want, rtol=1e-3, atol=5e-4 * max(np.abs(want).max(), 1e-3))
+    assert_close("avg loss", eng.apply(), oracle.apply(), 5e-5, 0)
+    eng.close()

@@ -22,11 +22,11 @@ def _data(num_mb, seed):
              rng.integers(0, KW["output_dim"], size=50 + 9 * i).astype(np.int32)) for i in range(num_mb)]
 
 
-def _engine(torch_state, dtype="float32"):
+def _engine(torch_state, dtype="float32", kw=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import make_pair
-    eng, _ = make_pair(np.random.default_rng(3), torch_state=torch_state, compute_dtype=dtype, **KW)
+    eng, _ = make_pair(np.random.default_rng(3), torch_state=torch_state, compute_dtype=dtype, **(kw or KW))
     return eng
 
 
@@ -42,16 +42,16 @@ def _collect(eng, losses):
     return out
 
 
-def _worker(rank, world, port, num_mb, out_dir, dtype="float32"):
+def _worker(rank, world, port, num_mb, out_dir, dtype="float32", mode="sharded", kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo", TFK_DP_MIN_SHARD="64")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
     init_from_env()
-    dp = DataParallel()
+    dp = DataParallel(mode=mode)
     assert dp.enabled
-    eng = _engine(torch_state=True, dtype=dtype)
+    eng = _engine(torch_state=True, dtype=dtype, kw=kw)
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **_collect(eng, losses))
@@ -59,12 +59,20 @@ def _worker(rank, world, port, num_mb, out_dir, dtype="float32"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_mb,dtype", [(4, "float32"), (3, "float32"), (1, "float32"), (3, "bfloat16")])
-def test_two_ranks_match_serial(gpu, tmp_path, num_mb, dtype):
+LAYERWISE = dict(KW, num_layers=3, layerwise_init=True)  # one active hidden layer of three at initialisedlayers = 0
+
+
+@pytest.mark.parametrize("num_mb,dtype,mode,kw", [
+    (4, "float32", "sharded", None), (3, "float32", "sharded", None), (1, "float32", "sharded", None),
+    (3, "bfloat16", "sharded", None), (3, "float32", "allreduce", None), (3, "bfloat16", "allreduce", None),
+    # layer-wise growth below full depth with an idle rank: every rank must announce -- and launch -- the same
+    # collectives in the same order whatever the active depth is (round-1 advisor finding)
+    (1, "float32", "sharded", LAYERWISE), (1, "float32", "allreduce", LAYERWISE), (3, "float32", "sharded", LAYERWISE)])
+def test_two_ranks_match_serial(gpu, tmp_path, num_mb, dtype, mode, kw):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, num_mb, str(tmp_path), dtype), nprocs=2, join=True)
-    eng = _engine(torch_state=False, dtype=dtype)
+    mp.spawn(_worker, args=(2, port, num_mb, str(tmp_path), dtype, mode, kw), nprocs=2, join=True)
+    eng = _engine(torch_state=False, dtype=dtype, kw=kw)
     want = []
     for step in range(3):
         mbs = _data(num_mb, step)

@@ -340,3 +340,24 @@ def test_long_posteriors_pass_is_pipelined_and_equal(gpu, monkeypatch):
     b = whole.posteriors_raw(raw, lens, 5)
     assert_close("raw piped vs whole", a, b, 1e-5, 1e-6)
     piped.close(); whole.close()
+
+
+def test_apply_without_frames_fails_loudly(gpu):
+    """an optimiser step with num_frames = 0 is G / 0 (trainer.py:174-175): the reference would write NaN into every
+    parameter; the engine leaves the parameters alone and tfk_apply reports the error (round-1 advisor finding)"""
+    from tfkaldi_amd import _lib
+    rng = np.random.default_rng(77)
+    kw = dict(SMALL, nonlin="relu", batch_norm=True)
+    eng, oracle = make_pair(rng, **kw)
+    before = engine_params(eng)
+    with pytest.raises(_lib.EngineError, match="without frames"):
+        eng.apply()
+    after = engine_params(eng)
+    assert all((after[k] == before[k]).all() for k in before)
+    assert eng.global_step == 0 and eng.scalar(_lib.ADAM_STEPS) == 0
+    X, y = batch(rng, 40, kw["input_dim"], kw["output_dim"])  # the engine is still usable, and still in step with the oracle
+    eng.accumulate(X, y)
+    oracle.accumulate(X, y)
+    assert_close("loss", eng.apply(), oracle.apply(), 2e-5, 0)
+    assert eng.global_step == 1
+    eng.close()

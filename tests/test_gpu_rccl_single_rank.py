@@ -24,18 +24,20 @@ def _free_port():
     return port
 
 
-def _worker(rank, port, num_mb, out_dir):
+def _worker(rank, port, num_mb, out_dir, mode="sharded"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
     init_from_env()
     assert dist.get_backend() == "nccl"
-    dp = DataParallel()
+    dp = DataParallel(mode=mode)
     assert dp.enabled
     eng = _engine(torch_state=True)
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
+    if mode == "sharded":  # RCCL's reduce-scatter / all-gather really carried the step
+        assert "rs" in dp.last_kinds, dp.last_kinds
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
     np.savez(os.path.join(out_dir, "rccl.npz"), **_collect(eng, losses))
     eng.close()
@@ -43,10 +45,11 @@ def _worker(rank, port, num_mb, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_single_rank_rccl_is_identity(gpu, tmp_path):
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_single_rank_rccl_is_identity(gpu, tmp_path, mode):
     import torch.multiprocessing as mp
     num_mb = 3
-    mp.spawn(_worker, args=(_free_port(), num_mb, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_worker, args=(_free_port(), num_mb, str(tmp_path), mode), nprocs=1, join=True)
     eng = _engine(torch_state=False)
     want = []
     for step in range(3):
@@ -75,3 +78,82 @@ def test_bench_dp_branch_over_rccl(gpu):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
+    assert line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl" and line["exchange"] == "sharded"
+    assert line["host_fed_value"] > 0 and len(line["loss_trace_gpu"]) == 7
+
+
+@pytest.mark.timeout(600)
+def test_bench_self_launches_its_ranks(gpu):
+    """`python bench.py --gpus 2` from a bare environment (no WORLD_SIZE): bench.py starts its own ranks through
+    torch.distributed.run.  On the 1-GPU test box the two ranks share the device and talk over gloo (RCCL refuses
+    two ranks per GPU); with >= 2 GPUs this is the driver's RCCL command as it stands."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    real = torch.cuda.device_count() >= 2
+    if not real:
+        env.update(TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup",
+                          "2"], env=env, capture_output=True, text=True, timeout=550)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 2
+    assert line["config"]["global_frames"] == 2048 and line["scaling"] == "weak"
+    assert line["rccl_ranks"] == (2 if real else 0) and line["dist_backend"] == ("nccl" if real else "gloo")
+    assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
+
+
+def _rccl_worker(rank, world, port, num_mb, out_dir, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tfkaldi_amd.dataparallel import DataParallel, init_from_env
+    _, _, local = init_from_env()
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    dp = DataParallel(mode=mode)
+    from tfkaldi_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_pair
+    from test_gpu_dp_two_ranks import KW
+    eng, _ = make_pair(np.random.default_rng(3), torch_state=True, device=local, **KW)
+    losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
+    losses.append(dp.eval_step(eng, _data(num_mb, 9)))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **_collect(eng, losses))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_two_real_rccl_ranks_match_serial(gpu, tmp_path, mode):
+    """two ranks on two GPUs over RCCL (skipped on a 1-GPU box): the data-parallel step == the serial step"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    num_mb = 4
+    mp.spawn(_rccl_worker, args=(2, _free_port(), num_mb, str(tmp_path), mode), nprocs=2, join=True)
+    eng = _engine(torch_state=False)
+    want = []
+    for step in range(3):
+        mbs = _data(num_mb, step)
+        for i, (X, y) in enumerate(mbs):
+            eng.accumulate(X, y, last=(i == len(mbs) - 1))
+        want.append(eng.apply())
+    for X, y in _data(num_mb, 9):
+        eng.eval_accumulate(X, y)
+    want.append(eng.eval_finish())
+    ref = _collect(eng, want)
+    eng.close()
+    lr = 1e-3
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert np.allclose(got["losses"], ref["losses"], rtol=2e-6, atol=0), (got["losses"], ref["losses"])
+        for k in ref:
+            if k == "losses":
+                continue
+            if k.startswith("m"):
+                assert np.allclose(got[k], ref[k], rtol=1e-5, atol=1e-7), k
+            else:
+                err = np.abs(got[k] - ref[k])
+                assert np.mean(err > 0.02 * lr * 3) < 0.01 and err.max() <= 2 * lr * 3, k

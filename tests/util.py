@@ -47,7 +47,7 @@ def make_pair(rng, output_too=True, **kw):
     oracle = OracleDNN(gemm_dtype=dtype, **oracle_kwargs(kw))
     randomize(oracle, rng, output_too)
     cfg = _lib.make_config(max_frames=kw.get("max_frames", 256), seed=kw.get("seed", 1234), compute_dtype=dtype,
-                           **oracle_kwargs(kw))
+                           device=kw.get("device", 0), **oracle_kwargs(kw))
     eng = Engine(cfg, torch_state=kw.get("torch_state", False))
     copy_oracle_to_engine(oracle, eng)
     return eng, oracle

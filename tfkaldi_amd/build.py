@@ -22,6 +22,17 @@ def lib_path():
     return os.path.join(LIBDIR, LIBNAME)
 
 
+def csrc_hash():
+    """sha256 (first 16 hex digits) over the kernel sources: stamps measurements that are only valid for the kernels
+    they were taken on (profiles/hbm_traffic.json, read by bench.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as fid:
+            h.update(name.encode() + b"\0" + fid.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

@@ -138,6 +138,7 @@ struct tfk_engine {
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
   bool dual_gemm = true;         // env TFK_DUAL_GEMM=0: dA and dW of a layer as two launches
+  bool fuse_eval = true;         // env TFK_FUSE_EVAL=0: evaluation-mode layers as GEMM + bn_stats_eval + act_forward
   int post_chunk = 2048;         // env TFK_POST_CHUNK: rows per chunk of a pipelined tfk_posteriors pass (0: off)
   std::vector<hipEvent_t> post_ev;
 
@@ -333,6 +334,11 @@ int refresh_shadow(tfk_engine* e) {
 struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient the GEMM produces
   const float *a, *z, *mean, *rstd;
   int nonlin;
+  // EPI_EVAL_ACT (a == z == nullptr): mean / rstd = moving mean / moving VARIANCE (nullptr without batch norm)
+  const float* beta = nullptr;
+  float eps = 0.f;
+  bf16_t* twin = nullptr;  // mixed precision: bf16 copy of the result
+  int ld_twin = 0;
 };
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr, float* stats = nullptr,
@@ -349,6 +355,8 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.act_mean = act ? act->mean : nullptr; b.act_rstd = act ? act->rstd : nullptr;
     b.act_nonlin = act ? act->nonlin : 0;
     b.stats_stride = kMaxRowSplits;
+    b.act_beta = act ? act->beta : nullptr; b.bn_eps = act ? act->eps : 0.f;
+    b.C_twin = act ? act->twin : nullptr; b.ldct = act ? act->ld_twin : 0;
     b.M = M; b.N = N; b.K = K; b.lda = lda8; b.ldb = ldb8; b.ldc = ldc; b.epi = epi;
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
@@ -363,6 +371,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   g.act_mean = act ? act->mean : nullptr; g.act_rstd = act ? act->rstd : nullptr;
   g.act_nonlin = act ? act->nonlin : 0;
   g.stats_stride = kMaxRowSplits;
+  g.act_beta = act ? act->beta : nullptr; g.bn_eps = act ? act->eps : 0.f;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   if (layout == GEMM_TN && K >= 2048 && (size_t)M * N < ((size_t)1 << 20)) {
     // narrow layer, many frames: the weight gradient may run split-K (gemm_f32.h) -- partials of up to 32 chunks
@@ -678,6 +687,20 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
       ld_in = ldH;
       continue;
     }
+    if (!train && !e->cfg.l2_norm && e->fuse_eval) {
+      // evaluation mode (decoder.py:36-44, trainer.py:77-79): affine, moving-statistics batch norm and the
+      // nonlinearity in ONE launch -- the GEMM epilogue writes the layer output (dropout is the identity here)
+      ActEpi ev = {nullptr, nullptr, e->cfg.batch_norm ? e->mov_mean(l) : nullptr,
+                   e->cfg.batch_norm ? e->mov_var(l) : nullptr, e->cfg.nonlin};
+      ev.beta = e->cfg.batch_norm ? e->p_param() + y.beta_off : nullptr;
+      ev.eps = e->bn_eps;
+      if (e->bf16) { ev.twin = e->ab[l]; ev.ld_twin = e->ldHb; }
+      CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->a[l], ldH, T, H, y.d_in,
+                   e->p_param() + y.b_off, EPI_BIAS | EPI_EVAL_ACT, nullptr, nullptr, -1, &ev));
+      in = e->a[l];
+      ld_in = ldH;
+      continue;
+    }
     CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
                  e->p_param() + y.b_off, EPI_BIAS));
     if (e->cfg.batch_norm) {
@@ -759,7 +782,13 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
                  epi_w));
     CHK(dact_gemm(e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], e->O, nact - 1, cfg_o));
   }
-  if (fire && e->cb) e->cb(e->cb_user, 0);  // the output layer's weight gradient is enqueued
+  if (fire && e->cb) {
+    e->cb(e->cb_user, 0);  // the output layer's weight gradient is enqueued
+    // Layers above the active depth (layer-wise growth) receive no gradient -- the zero branch of the tf.case,
+    // dnn.py:97-104; their G is zero already.  Their buckets are announced HERE, so that the order is 0, 1, .. L
+    // whatever the active depth is: a rank without micro-batches replays exactly that order (dataparallel.py).
+    for (int l = L - 1; l >= nact; --l) e->cb(e->cb_user, L - l);
+  }
   int chunks_in = chunks_o;
   for (int l = nact - 1; l >= 0; --l) {
     const LayerLayout& y = e->lay[l];
@@ -812,10 +841,6 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     ProfScope ps(e, KF_COLSUM, 0, 0);
     grad_final(e->stream, fin);
   }
-  // layers above the active depth receive no gradient (zero branch of the tf.case); their buckets are
-  // still announced so that every rank reduces the same spans.
-  if (fire && e->cb)
-    for (int l = L - 1; l >= nact; --l) e->cb(e->cb_user, L - l);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -918,6 +943,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_FUSE_HB"))) e->fuse_hb_enabled = atoi(v) != 0;
     if ((v = getenv("TFK_POST_CHUNK"))) e->post_chunk = atoi(v) > 0 ? (int)up((size_t)atoi(v), 64) : 0;
     if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
+    if ((v = getenv("TFK_FUSE_EVAL"))) e->fuse_eval = atoi(v) != 0;
   }
   HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
   for (int s = 0; s < 2; ++s) {
@@ -1355,6 +1381,14 @@ int apply_end(tfk_engine* e, float* average_loss) {
   HIPCHK(hipEventSynchronize(e->ev_loss));
   e->grads_fresh = true;
   e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
+  if (!(e->h_scalars[1] > 0.f)) {
+    // no frame reached this step (on any rank): G / num_frames is 0/0.  The optimiser kernel left the parameters
+    // alone (adam_kernel); undo the step bookkeeping and say so instead of returning a NaN loss.
+    e->adam_t -= 1;
+    if (average_loss) *average_loss = NAN;
+    return fail(-1, "optimiser step without frames: num_frames = %g (no micro-batch was accumulated)",
+                (double)e->h_scalars[1]);
+  }
   e->global_step += 1;
   if (average_loss) *average_loss = e->h_scalars[0] / e->h_scalars[1];
   return 0;
@@ -1461,19 +1495,38 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
       HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       e->post_ev.push_back(ev);
     }
+    // on an error inside the loop: nothing may still be writing the caller's buffer or reading the input slot
+    auto bail = [&](int rc) {
+      (void)hipStreamSynchronize(e->copy_stream);
+      (void)hipStreamSynchronize(e->stream);
+      (void)finish_slot(e, flags, slot_before);
+      return rc;
+    };
+#define CHKB(expr)                         \
+  do {                                     \
+    int rc_ = (expr);                      \
+    if (rc_ != 0) return bail(rc_);        \
+  } while (0)
+#define HIPB2(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) return bail(fail((int)e_, "%s failed: %s", #expr, hipGetErrorString(e_)));  \
+  } while (0)
     for (int c = 0; c < nchunks; ++c) {
       const int r0 = c * e->post_chunk, n = std::min(e->post_chunk, N - r0);
-      CHK(forward(e, Xd + (size_t)r0 * ld, ld, n, 0, nact, nact, call));
+      CHKB(forward(e, Xd + (size_t)r0 * ld, ld, n, 0, nact, nact, call));
       {
         ProfScope ps(e, KF_SOFTMAX, 0, 8.0 * n * e->O);
         softmax_rows(e->stream, e->logits, n, e->O, e->ldO, e->post + (size_t)r0 * e->ldO, e->ldO, prior);
       }
-      if (c == nchunks - 1) CHK(finish_slot(e, flags, slot_before));  // the input slot has been read for the last time
-      HIPCHK(hipEventRecord(e->post_ev[c], e->stream));
-      HIPCHK(hipStreamWaitEvent(e->copy_stream, e->post_ev[c], 0));
-      HIPCHK(hipMemcpy2DAsync(out + (size_t)r0 * ldo, (size_t)ldo * 4, e->post + (size_t)r0 * e->ldO, (size_t)e->ldO * 4,
-                              (size_t)e->O * 4, n, hipMemcpyDeviceToHost, e->copy_stream));
+      if (c == nchunks - 1) CHKB(finish_slot(e, flags, slot_before));  // the input slot has been read for the last time
+      HIPB2(hipEventRecord(e->post_ev[c], e->stream));
+      HIPB2(hipStreamWaitEvent(e->copy_stream, e->post_ev[c], 0));
+      HIPB2(hipMemcpy2DAsync(out + (size_t)r0 * ldo, (size_t)ldo * 4, e->post + (size_t)r0 * e->ldO, (size_t)e->ldO * 4,
+                             (size_t)e->O * 4, n, hipMemcpyDeviceToHost, e->copy_stream));
     }
+#undef CHKB
+#undef HIPB2
     HIPCHK(hipStreamSynchronize(e->copy_stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
@@ -1573,6 +1626,12 @@ int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user) {
   if (!e) return fail(-1, "engine is NULL");
   e->cb = fn;
   e->cb_user = user;
+  return 0;
+}
+int tfk_params_touched(tfk_engine* e) {
+  if (!e) return fail(-1, "engine is NULL");
+  e->shadow_dirty = true;
+  if (e->apply_open) e->apply_direct = false;  // tfk_apply_end must not declare the shadow current
   return 0;
 }
 int tfk_set_later_microbatches(tfk_engine* e, int32_t later) {

@@ -627,6 +627,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
     const int colc = col_ok ? col : p.N - 1;
     float bv = 0.f;
     if (EPI & EPI_BIAS) bv = p.bias[colc];
+    // EPI_EVAL_ACT: evaluation-mode batch norm + nonlinearity of the layer, the operations of bn_stats_eval +
+    // act_forward (kernels.hip) in their order, so the result is what the three-launch path stores
+    bool ev_bn = false;
+    float ev_mu = 0.f, ev_rs = 1.f, ev_be = 0.f;
+    if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
+      ev_bn = p.act_mean != nullptr;
+      if (ev_bn) {
+        ev_mu = p.act_mean[colc];
+        ev_rs = rsqrtf(p.act_rstd[colc] + p.bn_eps);
+        ev_be = p.act_beta[colc];
+      }
+    }
 #pragma unroll
     for (int a = 0; a < T::FM; ++a) {
       const int rbase = m0 + wm * T::WM + a * 32 + 4 * h;
@@ -648,6 +660,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
         v += bv;
         if (EPI & EPI_ACCUM) v += old[r];
         if (EPI & EPI_RELU) v = fmaxf(v, 0.f);
+        if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
+          if (ev_bn) v = (v - ev_mu) * ev_rs + ev_be;
+          switch (p.act_nonlin) {
+            case 0: v = fmaxf(v, 0.f); break;
+            case 1: v = 1.f / (1.f + expf(-v)); break;
+            case 2: v = tanhf(v); break;
+            default: break;
+          }
+        }
         outv[r] = v;
       }
       if (full_tile) {  // block-uniform: straight-line stores, no per-element exec masking
@@ -768,6 +789,7 @@ int dispatch_epi(GemmLayout layout, const GemmArgs& p, int cfg, hipStream_t s) {
         case EPI_BIAS: return dispatch_cfg<true, false, EPI_BIAS>(p, cfg, s);
         case EPI_BIAS | EPI_RELU: return dispatch_cfg<true, false, EPI_BIAS | EPI_RELU>(p, cfg, s);
         case EPI_BIAS | EPI_COLSTATS: return dispatch_cfg<true, false, EPI_BIAS | EPI_COLSTATS>(p, cfg, s);
+        case EPI_BIAS | EPI_EVAL_ACT: return dispatch_cfg<true, false, EPI_BIAS | EPI_EVAL_ACT>(p, cfg, s);
       }
       break;
     case GEMM_NT:

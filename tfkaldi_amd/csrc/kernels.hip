@@ -805,25 +805,80 @@ __global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restri
   }
 }
 
+// decoder.py:44 softmax (prior == nullptr) or nnet.py:280-286 log(softmax / prior), one 256-thread block per frame;
+// like softmax_xent_kernel the row is read ONCE (16-byte loads) and stays in registers for the three passes.
+template <int NV>  // float4 per thread; NV == 0: generic (re-reads global)
 __global__ void __launch_bounds__(256)
 softmax_rows_kernel(const float* __restrict__ logits, int O, int ld, float* __restrict__ out, int64_t ldo,
-                    const float* __restrict__ prior) {
+                    const float* __restrict__ prior, int vec_out) {
   __shared__ float sm[4];
   const int row = blockIdx.x;
   const float* zr = logits + (size_t)row * ld;
   float* orow = out + (size_t)row * ldo;
+  const int nc4 = ld >> 2;
+  constexpr int NVR = NV > 0 ? NV : 1;
+  float4 v[NVR];
   float mx = -INFINITY;
-  for (int c = threadIdx.x; c < O; c += 256) mx = fmaxf(mx, zr[c]);
+  if (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NVR; ++j) {
+      const int c4 = threadIdx.x + j * 256;
+      v[j] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (c4 < nc4) {
+        const float4 t = ld4(zr + (c4 << 2));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((c4 << 2) + k < O) el(v[j], k) = el(t, k);
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+    }
+  } else {
+    for (int c = threadIdx.x; c < O; c += 256) mx = fmaxf(mx, zr[c]);
+  }
   mx = block_max(mx, sm);
   float se = 0.f;
-  for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
-  se = block_sum(se, sm);
-  if (prior) {
-    const float lse = mx + logf(se);
-    for (int c = threadIdx.x; c < O; c += 256) orow[c] = (zr[c] - lse) - logf(prior[c]);
+  float4 ex[NVR];
+  if (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NVR; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = expf(el(v[j], k) - mx);  // exp(-inf) = 0 for the masked tail
+        el(ex[j], k) = e;
+        se += e;
+      }
+    }
   } else {
-    const float inv = 1.f / se;
-    for (int c = threadIdx.x; c < O; c += 256) orow[c] = expf(zr[c] - mx) * inv;
+    for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
+  }
+  se = block_sum(se, sm);
+  const float lse = mx + logf(se), inv = 1.f / se;
+  if (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NVR; ++j) {
+      const int c4 = threadIdx.x + j * 256, c = c4 << 2;
+      if (c >= O) continue;
+      float4 r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // z - lse - log prior instead of log(softmax / prior): finite where the posterior underflows
+        if (prior) el(r, k) = c + k < O ? (el(v[j], k) - lse) - logf(prior[c + k]) : 0.f;
+        else el(r, k) = el(ex[j], k) * inv;
+      }
+      if (vec_out && c + 3 < O) {
+        st4(orow + c, r);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (c + k < O) orow[c + k] = el(r, k);
+      }
+    }
+  } else {
+    if (prior) {
+      for (int c = threadIdx.x; c < O; c += 256) orow[c] = (zr[c] - lse) - logf(prior[c]);
+    } else {
+      for (int c = threadIdx.x; c < O; c += 256) orow[c] = expf(zr[c] - mx) * inv;
+    }
   }
 }
 
@@ -854,6 +909,9 @@ __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
             const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps, uint16_t* __restrict__ wb,
             size_t n4_wb) {
+  // a step without frames (G / 0): the reference would write NaN into every parameter; here the parameters are
+  // left alone and tfk_apply_end reports the error
+  if (!(scalars[1] > 0.f)) return;
   const float inv_n = 1.f / scalars[1];  // G / float(num_frames): trainer.py:174-175
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * UN) {
@@ -1080,7 +1138,14 @@ void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bo
 
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
                   const float* prior) {
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(T), dim3(256), 0, s, logits, O, ld, out, ldo, prior);
+  const int nc4 = ld / 4;
+  const int vec = ((ldo & 3) == 0 && (((uintptr_t)out) & 15) == 0) ? 1 : 0;  // 16-byte stores when the rows allow them
+  const dim3 g(T), b(256);
+  if (nc4 <= 256) hipLaunchKernelGGL(softmax_rows_kernel<1>, g, b, 0, s, logits, O, ld, out, ldo, prior, vec);
+  else if (nc4 <= 512) hipLaunchKernelGGL(softmax_rows_kernel<2>, g, b, 0, s, logits, O, ld, out, ldo, prior, vec);
+  else if (nc4 <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<4>, g, b, 0, s, logits, O, ld, out, ldo, prior, vec);
+  else if (nc4 <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<8>, g, b, 0, s, logits, O, ld, out, ldo, prior, vec);
+  else hipLaunchKernelGGL(softmax_rows_kernel<0>, g, b, 0, s, logits, O, ld, out, ldo, prior, vec);
 }
 
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,

@@ -51,6 +51,15 @@ def init_from_env():
     return rank, world, local_rank
 
 
+def rank_seed(seed, rank):
+    """The dropout RNG key of data-parallel rank `rank`.  The engine draws the keep mask of element (row, column) of
+    layer l in its k-th accumulate call from Philox(key = seed, counter = (column / 4, row, l, k)); ranks run the same
+    call indices on DIFFERENT micro-batches, so with one shared key the micro-batches of a step would all be dropped
+    with the same pattern (the reference draws a fresh mask in every session.run, activation.py:140-141).  Rank 0
+    keeps `seed`, so a single-process run is unchanged."""
+    return (int(seed) ^ ((int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+
+
 class RawMicroBatch(object):
     """A micro-batch whose +-context splice (and optionally CMVN) happens on the device: unspliced frames
     [T, D], targets [T], utterance lengths [U], the context width and the optional [U, 2, D] (mean, std) table
@@ -108,14 +117,27 @@ def partition(num_items, world):
 
 class BucketReducer(object):
     """Turns the engine's bucket announcements (one per weight matrix, in backward order, then the vector / scalar
-    tail) into asynchronous SUM all-reduces launched while backward is still being enqueued.
+    tail) into asynchronous collectives launched while backward is still being enqueued.
 
     Consecutive announcements are adjacent in the reduce region (the arena is W_0 .. W_L and they arrive as
     W_L .. W_0), so they are COALESCED until a collective carries at least `min_bytes`: xGMI is point-to-point and a
     ring / tree step is bound by one link, so a few large collectives reach a much higher bus bandwidth than one
-    per 16 MB layer, at the price of starting a little later.  TFK_DP_BUCKET_MB (default 48) sets the size."""
+    per 16 MB layer, at the price of starting a little later.  TFK_DP_BUCKET_MB (default 48) sets the size.
 
-    def __init__(self, engine, group=None, min_bytes=None, stream_ctx=None):
+    Two exchange steps (`mode`, env TFK_DP_EXCHANGE):
+      "sharded" (default)  every coalesced gradient span is REDUCE-SCATTERED in place (rank r receives the sum of
+                 sub-span r), the optimiser (mean -> clip -> Adam, tfk_apply_span) runs on that 1/world of the
+                 span only, and the updated parameters are ALL-GATHERED in place.  Same bytes on the wire as an
+                 all-reduce, 1/world of the optimiser's HBM traffic per GPU (28 B per parameter: the step is
+                 optimiser-bound at BASELINE cfg3 / cfg4 sizes).  Adam is element-wise, so the result is
+                 identical to the replicated update.  Spans that do not divide (or are tiny: the bias / beta
+                 vectors, the scalar + BN tail) are all-reduced and updated on every rank.
+      "allreduce"  SUM all-reduce of every span, full optimiser on every rank (round 1)."""
+
+    MIN_SHARD_FLOATS = int(os.environ.get("TFK_DP_MIN_SHARD", str(1 << 14)))  # smaller spans are all-reduced
+    _rs_supported = True
+
+    def __init__(self, engine, group=None, min_bytes=None, stream_ctx=None, mode=None):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -124,17 +146,57 @@ class BucketReducer(object):
             min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", "48")) * (1 << 20))
         self.min_floats = max(1, min_bytes // 4)
         self._stream_ctx = stream_ctx or contextlib.nullcontext
+        mode = mode or os.environ.get("TFK_DP_EXCHANGE", "sharded")
+        if mode not in ("sharded", "allreduce"):
+            raise ValueError("exchange mode %r" % (mode,))
+        if mode == "sharded" and not (hasattr(engine, "param_view") and hasattr(engine, "apply_span")):
+            mode = "allreduce"
+        self.mode = mode
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        self.rank = dist.get_rank(group) if ready else 0
+        self.num_params = self.buckets[-1][0]  # the scalar + BN tail starts where the gradient arena ends
         self.handles, self.errors = [], []
         self._lo = self._hi = None
         self.launched = []  # (offset, floats) of every collective of the current step (tests / diagnostics)
+        self.kinds = []     # "rs" (reduce-scatter: only sub-span `rank` is valid afterwards) or "ar" per collective
+
+    def _shardable(self, lo, hi):
+        n = hi - lo
+        return (self.mode == "sharded" and hi <= self.num_params and n % (4 * self.world) == 0
+                and n >= self.MIN_SHARD_FLOATS)
 
     def _launch(self):
         if self._lo is None:
             return
         lo, hi, self._lo, self._hi = self._lo, self._hi, None, None
+        if self.mode == "sharded" and lo < self.num_params < hi:
+            # a coalesced span that runs from the gradient arena into the scalar + BN tail: two collectives
+            self._lo, self._hi = lo, self.num_params
+            self._launch()
+            self._lo, self._hi = self.num_params, hi
+            self._launch()
+            return
+        d = self._dist
         with self._stream_ctx():
-            self.handles.append(self._dist.all_reduce(self.view[lo:hi], op=self._dist.ReduceOp.SUM, group=self.group,
-                                                      async_op=True))
+            h = None
+            if self._shardable(lo, hi) and BucketReducer._rs_supported:
+                c = (hi - lo) // self.world
+                own = self.view[lo + self.rank * c:lo + (self.rank + 1) * c]
+                try:
+                    h = d.reduce_scatter_tensor(own, self.view[lo:hi], op=d.ReduceOp.SUM, group=self.group,
+                                                async_op=True)
+                except (RuntimeError, NotImplementedError):
+                    # the backend has no reduce-scatter for this tensor type (gloo on device memory: tests only);
+                    # every rank takes the same branch, so the collectives still match
+                    BucketReducer._rs_supported = False
+            if h is not None:
+                self.handles.append(h)
+                self.kinds.append("rs")
+            else:
+                self.handles.append(d.all_reduce(self.view[lo:hi], op=d.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+                self.kinds.append("ar")
         self.launched.append((lo, hi - lo))
 
     def on_bucket(self, b):
@@ -153,7 +215,10 @@ class BucketReducer(object):
             self.errors.append(exc)
 
     def finish(self):
-        """launch what is still pending, make the engine's stream wait for every collective of the step"""
+        """launch what is still pending, make the engine's stream wait for every collective of the step (all-reduce
+        mode only: after a reduce-scatter the gradient arena is not whole)"""
+        if self.mode != "allreduce":
+            raise RuntimeError("BucketReducer.finish() needs mode='allreduce'; use finish_and_apply()")
         self._launch()
         if self.errors:
             raise self.errors[0]
@@ -161,20 +226,23 @@ class BucketReducer(object):
             for h in self.handles:
                 h.wait()
         del self.handles[:]
+        del self.kinds[:]
         launched, self.launched = self.launched, []
         return launched
 
     def finish_and_apply(self, engine):
         """The optimiser step pipelined behind the collectives: the engine's stream waits for the (small, early)
         collective that carries the scalars, starts the step (tfk_apply_begin), then waits for each remaining
-        collective in launch order and runs Adam on exactly that span of parameters (tfk_apply_span) while the later
-        collectives are still in flight.  Returns the average loss (tfk_apply_end)."""
+        collective in launch order and runs Adam on exactly the span of parameters whose gradient sum this rank now
+        holds (tfk_apply_span) while the later collectives are still in flight; a reduce-scattered span's updated
+        parameters are all-gathered behind its Adam.  Returns the average loss (tfk_apply_end)."""
         if not hasattr(engine, "apply_span"):
             self.finish()
             return engine.apply()
         self._launch()
         if self.errors:
             raise self.errors[0]
+        d = self._dist
         head_off, head_n = self.buckets[-1]
         waited = set()
 
@@ -188,19 +256,37 @@ class BucketReducer(object):
             if off < head_off + head_n and off + n > head_off:
                 wait(i)
         engine.apply_begin()
+        gathers = []
+        params = engine.param_view() if "rs" in self.kinds else None
         for i, (off, n) in enumerate(self.launched):
             wait(i)
-            engine.apply_span(off, n)  # (spans beyond the parameter arena are clipped by the engine)
+            if self.kinds[i] == "rs":
+                c = n // self.world
+                lo = off + self.rank * c
+                engine.apply_span(lo, c)
+                with self._stream_ctx():  # behind this span's Adam on the engine stream
+                    gathers.append(d.all_gather_into_tensor(params[off:off + n], params[lo:lo + c], group=self.group,
+                                                            async_op=True))
+            else:
+                engine.apply_span(off, n)  # (spans beyond the parameter arena are clipped by the engine)
+        if gathers:
+            with self._stream_ctx():
+                for g in gathers:
+                    g.wait()
+            if hasattr(engine, "params_touched"):
+                engine.params_touched()  # parameters outside this rank's spans changed behind the optimiser's back
         del self.handles[:]
         self.last_launched, self.launched = self.launched, []
+        self.last_kinds, self.kinds = self.kinds, []
         return engine.apply_end()
 
 
 class DataParallel(object):
     """Shards the micro-batches of one optimiser step over the ranks of a process group."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, mode=None):
         self.group = group
+        self.mode = mode  # exchange step of BucketReducer (None: TFK_DP_EXCHANGE or "sharded")
         self.rank, self.world = 0, 1
         self._forced = False
         try:
@@ -234,7 +320,7 @@ class DataParallel(object):
         start, end = partition(len(microbatches), self.world)[self.rank]
         mine = microbatches[start:end]
         engine.set_later_microbatches(len(microbatches) - end)
-        reducer = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(engine))
+        reducer = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(engine), mode=self.mode)
         engine.set_bucket_callback(reducer.on_bucket)
         try:
             for i, mb in enumerate(mine):
@@ -248,6 +334,7 @@ class DataParallel(object):
             engine.set_bucket_callback(None)
         loss = reducer.finish_and_apply(engine)
         self.last_collectives = getattr(reducer, "last_launched", None)
+        self.last_kinds = getattr(reducer, "last_kinds", None)
         return loss
 
     def eval_step(self, engine, microbatches):

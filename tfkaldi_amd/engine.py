@@ -316,6 +316,17 @@ class Engine(object):
         off = (ptr - self._state.data_ptr()) // 4
         return self._state[off:off + n]
 
+    def param_view(self):
+        """torch view of the parameter arena [P] (same offsets as the gradient part of the reduce region); the
+        sharded exchange step all-gathers the updated parameters straight into it (requires torch_state=True)"""
+        if self._state is None:
+            raise RuntimeError("param_view needs Engine(..., torch_state=True)")
+        ptr, _ = self.reduce_region()
+        return self._state[0:(ptr - self._state.data_ptr()) // 4]
+
+    def params_touched(self):
+        check(self.lib.tfk_params_touched(self._h))
+
     def set_bucket_callback(self, fn):
         """fn(bucket) is called from accumulate(last=True) once the bucket's kernels are enqueued."""
         if fn is None:

@@ -1,5 +1,7 @@
 """The DNN classifier (reference neuralNetworks/classifiers/dnn.py): `num_layers` hidden FFLayers sharing
 one activation chain plus a linear output layer, executed by the HIP engine."""
+import os
+
 import numpy as np
 
 from ... import _lib
@@ -20,8 +22,12 @@ class ModelSaver(object):
         self.engine = engine
 
     def save(self, sess, filename):
-        with open(filename, "wb") as fid:
+        # written next to the target and renamed: a crash while saving cannot damage the previous checkpoint
+        # (nnet.py's `validated` fallback model lives at a fixed path)
+        tmp = "%s.tmp%d" % (filename, os.getpid())
+        with open(tmp, "wb") as fid:
             np.savez(fid, **self.engine.model_tensors())
+        os.replace(tmp, filename)
 
     def restore(self, sess, filename):
         with np.load(filename) as data:

@@ -20,7 +20,7 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .. import _lib
-from ..dataparallel import CtcMicroBatch, DataParallel, RawMicroBatch
+from ..dataparallel import CtcMicroBatch, DataParallel, RawMicroBatch, rank_seed
 from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
 
@@ -94,7 +94,7 @@ class Trainer(object, metaclass=ABCMeta):
         self.engine = classifier.create_engine(
             input_dim, torch_state=self.dp.enabled, init_learning_rate=init_learning_rate,
             learning_rate_decay=learning_rate_decay, num_steps=num_steps, max_frames=min(max_frames, 1 << 16),
-            seed=self._seed, device=device)
+            seed=rank_seed(self._seed, self.dp.rank), device=device)  # per-rank dropout stream
         self.modelsaver = ModelSaver(self.engine)
         self.control_ops = classifier.control_ops(self.engine)
         self.global_step = _StepVariable(self.engine)
@@ -134,9 +134,20 @@ class Trainer(object, metaclass=ABCMeta):
         self.summarywriter = open(os.path.join(logdir, "summaries.jsonl"), "a")
 
     # ---- batching ----
+    _warned_truncation = False
+
     def _microbatches(self, inputs, targets):
         out = []
-        for idx in microbatch_indices(len(inputs), self.numutterances_per_minibatch):
+        plan = microbatch_indices(len(inputs), self.numutterances_per_minibatch)
+        used = sum(len(idx) for idx in plan)
+        if used < len(inputs) and not Trainer._warned_truncation:
+            # the reference's padding arithmetic (trainer.py:280-294) silently drops the tail of a batch whose size
+            # is not a multiple of numutterances_per_minibatch; kept for parity, but said once
+            print("WARNING batch of %d utterances with numutterances_per_minibatch = %d: the last %d utterance(s) of "
+                  "every such batch are not used (reference behaviour: trainer.py:280-294)"
+                  % (len(inputs), self.numutterances_per_minibatch, len(inputs) - used))
+            Trainer._warned_truncation = True
+        for idx in plan:
             if not idx:
                 continue
             if self.loss_kind == "ctc":  # label sequences of their own length
@@ -180,7 +191,11 @@ class Trainer(object, metaclass=ABCMeta):
         Returns:
             the loss at this step (batch_loss / num_frames, evaluated before the parameter update)
         """
-        loss = self.dp.train_step(self.engine, self._microbatches(inputs, targets))
+        microbatches = self._microbatches(inputs, targets)
+        if not microbatches:
+            raise ValueError("Trainer.update: the batch holds no frames (no micro-batch could be built from %d "
+                             "utterance(s))" % len(inputs))
+        loss = self.dp.train_step(self.engine, microbatches)
         if self.summarywriter is not None:
             self.summarywriter.write(json.dumps({"step": self.engine.global_step, "loss": loss,
                                                  "learning_rate": self.engine.scalar(_lib.LEARNING_RATE)}) + "\n")
@@ -207,9 +222,11 @@ class Trainer(object, metaclass=ABCMeta):
         """model + the `train_variables` scope: global_step and learning_rate_fact.  As in the reference
         (trainer.py:204-205) the Adam moments and beta powers are NOT part of a checkpoint."""
         self.modelsaver.save(None, filename)
-        with open(filename + "_trainvars", "wb") as fid:
+        tmp = filename + "_trainvars.tmp%d" % os.getpid()
+        with open(tmp, "wb") as fid:
             np.savez(fid, global_step=np.array(self.engine.global_step, dtype=np.int64),
                      learning_rate_fact=np.array(self.engine.scalar(_lib.LEARNING_RATE_FACT), dtype=np.float64))
+        os.replace(tmp, filename + "_trainvars")
 
     def restore_trainer(self, filename):
         self.modelsaver.restore(None, filename)

@@ -1,7 +1,10 @@
 """Summarise the two rocprofv3 --pmc passes of tools/profile_step.sh (FETCH_SIZE, WRITE_SIZE: separate runs, as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_hbm_traffic.{json,txt}.
 
-    python tools/hbm_traffic.py gpurun_out/<tag> profiles/r01
+    python tools/hbm_traffic.py gpurun_out/<tag> profiles/r02
+
+Also writes profiles/hbm_traffic.json (the copy bench.py reads), stamped with the hash of the kernel sources it was
+measured on: bench.py drops the figure when the sources have changed since.
 
 Bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports exactly half the bytes of
 wide (16 B/lane) coalesced reads (guide, "HBM" section); both counters are in KiB.  This is the L2 <-> fabric
@@ -10,8 +13,13 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tfkaldi_amd.build import csrc_hash  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
 LAYOUT = {("true", "false"): "gemm_f32_nn(fwd affine)", ("true", "true"): "gemm_f32_nt(dA)",
@@ -54,7 +62,10 @@ for s in fetch:
     w = sum(write[s]) / len(write[s])
     out[s] = {"fetch_size_kb": f, "write_size_kb": w, "bytes_per_launch": (2 * f + w) * 1024,
               "launches_sampled": len(fetch[s]), "kernels": sorted(names[s])}
+out["_meta"] = {"csrc_sha16": csrc_hash(), "measured": time.strftime("%Y-%m-%d"), "source": os.path.basename(dst)}
 json.dump(out, open(dst + "_hbm_traffic.json", "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
+del out["_meta"]
 with open(dst + "_hbm_traffic.txt", "w") as fid:
     fid.write("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 10 --warmup 3`\n")
     fid.write("bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950 correction, MI355X_MICROARCH.md)\n\n")
