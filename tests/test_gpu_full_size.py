@@ -190,20 +190,35 @@ def test_cfg4_per_gpu_size_bf16_against_oracle(gpu):
     assert worst < 5e-3, worst
     rel = lambda got, want: float(np.linalg.norm(got - want) / np.linalg.norm(want))
     np.testing.assert_allclose(eng.scalar(_lib.BATCH_LOSS), oracle.batch_loss, rtol=1e-3)
+    # Tolerances: operand values within fp32 round-off of a bf16 rounding boundary round to different neighbours on
+    # the two sides (1 bf16 ulp = 0.4 % of that operand); the flips of every contraction compound through the eight
+    # layers forwards and backwards, so the bound grows with the distance from the data / from the loss.
+    report = {"relu_disagreement": worst}
+    bad = []
     for l in (0, 3, 7):
-        assert rel(hidden[l], oracle.last_cache[l]["a"]) < 3e-3, (l, rel(hidden[l], oracle.last_cache[l]["a"]))
+        r = rel(hidden[l], oracle.last_cache[l]["a"])
+        report["hidden%d" % l] = r
+        if r > 2e-3 + 5e-4 * l:
+            bad.append("hidden%d" % l)
     got = engine_grads(eng)
     for k in ("W8", "b8", "W7", "beta7", "W5", "W4", "beta3", "W1", "W0", "beta0"):
         want = oracle.G[k]
         assert np.abs(want).max() > 0, k  # non-trivial data in every contraction
         r = rel(got[k], want)
-        assert r < (5e-3 if k in ("W8", "b8") else 3e-2), (k, r)
+        report["G[%s]" % k] = r
+        depth = 8 - int(k.lstrip("Wbeta"))  # layers between this gradient and the loss
+        if r > 6e-3 + 4e-3 * depth:
+            bad.append("G[%s]" % k)
         # and element-wise on a sample of rows / columns: no isolated wrong tile can hide in a norm
         if got[k].ndim == 2:
             rows = rng.choice(got[k].shape[0], size=8, replace=False)
             cols = rng.choice(got[k].shape[1], size=8, replace=False)
             scale = np.abs(want).max()
-            assert np.abs(got[k][rows] - want[rows]).max() < 0.05 * scale, k
-            assert np.abs(got[k][:, cols] - want[:, cols]).max() < 0.05 * scale, k
+            e = max(np.abs(got[k][rows] - want[rows]).max(), np.abs(got[k][:, cols] - want[:, cols]).max()) / scale
+            report["G[%s] sampled max err / max" % k] = e
+            if e > 0.05:
+                bad.append("G[%s] sampled" % k)
+    print("cfg4 bf16 parity report:", {k: float("%.3g" % v) for k, v in report.items()})
+    assert not bad, (bad, report)
     np.testing.assert_allclose(eng.apply(), oracle.apply(), rtol=1e-3)
     eng.close()

@@ -178,3 +178,49 @@ def test_dnn_call_signature(gpu):
     assert (np.stack(again) == np.stack(logits)).all()
     with pytest.raises(ValueError):
         dnn(inputs, lens, reuse=True, scope="Other")
+
+
+def test_minimal_classifier_subclass_trains(gpu, tmp_path):
+    """The extension contract of neuralNetworks/classifiers/classifier.py: a user classifier that defines ONLY
+    engine_config() (a 3 x 20 sigmoid net without batch norm -- not something DNN's constructor arguments of this
+    test would give) is trainable through CrossEnthropyTrainer, evaluable through the reference's call signature and
+    decodable through Decoder, and matches the float64 oracle of that network."""
+    from tfkaldi_amd import _lib
+    from tfkaldi_amd.neuralNetworks.classifiers.classifier import Classifier
+    from tfkaldi_amd.neuralNetworks.decoder import Decoder
+    from tfkaldi_amd.neuralNetworks.trainer import CrossEnthropyTrainer
+
+    class Sigmoid3(Classifier):
+        def engine_config(self, input_dim, **trainer_options):
+            return _lib.make_config(input_dim, 3, 20, self.output_dim, nonlin="sigmoid", **trainer_options)
+
+    paths, _ = _corpus(tmp_path)
+    disp = _dispenser(paths, 4)
+    F = F_RAW * (2 * CONTEXT + 1)
+    net = Sigmoid3(O)
+    trainer = CrossEnthropyTrainer(net, F, disp.max_input_length, disp.max_target_length, 1e-2, 1.0, 20, 2, seed=11)
+    trainer.initialize()
+    assert trainer.control_ops is None
+    oracle = _oracle_like(trainer, net, 11, input_dim=F, num_layers=3, num_units=20, output_dim=O, nonlin="sigmoid",
+                          batch_norm=False, init_learning_rate=1e-2, learning_rate_decay=1.0, num_steps=20)
+    for step in range(3):
+        xs, ys = disp.get_batch()
+        got = trainer.update(xs, ys)
+        for idx in reference_microbatches(len(xs), 2):
+            oracle.accumulate(np.concatenate([xs[i] for i in idx]), np.concatenate([ys[i] for i in idx]))
+        assert_close("loss %d" % step, got, oracle.apply(), 1e-4 * (step + 1), 0)
+    prefix = str(tmp_path / "sigmoid3")
+    trainer.save_model(prefix)
+    xs, _ = disp.get_batch()
+    dec = Decoder(net, F, 64)
+    dec.restore(prefix)
+    assert_close("posteriors", dec(xs[0]), oracle.posteriors(xs[0]), 5e-3, 1e-6)
+    dec.close()
+    trainer.close()
+    # the reference's call signature (classifier.py:16-37), inference mode, fresh variables in their own scope
+    seq = [np.random.default_rng(1).standard_normal((2, F)).astype(np.float32) for _ in range(5)]
+    logits, lens, saver, ops = net(seq, [5, 3], scope="probe")
+    assert len(logits) == 5 and logits[0].shape == (2, O) and ops is None and list(lens) == [5, 3]
+    assert not np.any(logits[0])  # zero output layer: dnn.py:67-68
+    with pytest.raises(NotImplementedError):
+        net(seq, [5, 3], is_training=True, reuse=True, scope="probe")

@@ -94,6 +94,9 @@ struct tfk_engine {
   // every GEMM already fills all 256 CUs, a concurrent kernel only evicts its L2 working set) and was removed;
   // the independent dA / dW pair of a layer shares one LAUNCH instead (gemm_f32_dual).
   hipEvent_t ev_loss = nullptr;
+  hipEvent_t ev_grow = nullptr;          // orders the copy stream behind a stream-ordered (re)allocation
+  std::vector<void*> host_garbage;       // outgrown pinned staging buffers: released at tfk_destroy (hipHostFree
+                                         // synchronises the device, which growth must not do)
 
   // persistent state
   float* state = nullptr;
@@ -300,6 +303,25 @@ int sync_streams(tfk_engine* e) {
   return 0;
 }
 
+// Device buffers that grow on demand are allocated and released in STREAM ORDER on the engine stream
+// (hipMallocAsync / hipFreeAsync): growing for an unusually long micro-batch neither waits for the work already
+// enqueued nor stalls the host -- the old buffers are released behind the kernels that still read them.
+void dev_free(tfk_engine* e, void* p, bool async) {
+  if (!p) return;
+  if (async) (void)hipFreeAsync(p, e->stream);
+  else (void)hipFree(p);
+}
+int dev_alloc(tfk_engine* e, void** p, size_t bytes, bool zero) {
+  HIPCHK(hipMallocAsync(p, bytes, e->stream));
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
+  return 0;
+}
+void host_retire(tfk_engine* e, void* p, bool async) {
+  if (!p) return;
+  if (async) e->host_garbage.push_back(p);
+  else (void)hipHostFree(p);
+}
+
 // bf16 twin of an fp32 GEMM operand buffer (mixed-precision mode)
 const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
   for (int s = 0; s < 2; ++s) {
@@ -376,11 +398,11 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   if (layout == GEMM_TN && K >= 2048 && (size_t)M * N < ((size_t)1 << 20)) {
     // narrow layer, many frames: the weight gradient may run split-K (gemm_f32.h) -- partials of up to 32 chunks
     const size_t need = (size_t)32 * M * ldc;
-    if (need > e->ws_splitk_floats) {
-      HIPCHK(hipStreamSynchronize(e->stream));
-      if (e->ws_splitk) HIPCHK(hipFree(e->ws_splitk));
+    if (need > e->ws_splitk_floats) {  // stream-ordered: behind the GEMMs that still read the old workspace
+      dev_free(e, e->ws_splitk, true);
       e->ws_splitk = nullptr;
-      HIPCHK(hipMalloc((void**)&e->ws_splitk, need * sizeof(float)));
+      e->ws_splitk_floats = 0;
+      CHK(dev_alloc(e, (void**)&e->ws_splitk, need * sizeof(float), false));
       e->ws_splitk_floats = need;
     }
     g.splitk_ws = e->ws_splitk;
@@ -429,23 +451,23 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
   return 0;
 }
 
-void free_activations(tfk_engine* e) {
-  auto fr = [](float*& p) { if (p) { hipFree(p); p = nullptr; } };
+void free_activations(tfk_engine* e, bool async = false) {
+  auto fr = [&](float*& p) { dev_free(e, p, async); p = nullptr; };
   for (int s = 0; s < 2; ++s) {
     fr(e->dX[s]);
-    if (e->dY[s]) { hipFree(e->dY[s]); e->dY[s] = nullptr; }
+    dev_free(e, e->dY[s], async); e->dY[s] = nullptr;
     fr(e->dA[s]);
-    if (e->hX[s]) { hipHostFree(e->hX[s]); e->hX[s] = nullptr; }
-    if (e->hY[s]) { hipHostFree(e->hY[s]); e->hY[s] = nullptr; }
+    host_retire(e, e->hX[s], async); e->hX[s] = nullptr;
+    host_retire(e, e->hY[s], async); e->hY[s] = nullptr;
     fr(e->dRaw[s]);
-    if (e->dSeg[s]) { hipFree(e->dSeg[s]); e->dSeg[s] = nullptr; }
-    if (e->hRaw[s]) { hipHostFree(e->hRaw[s]); e->hRaw[s] = nullptr; }
-    if (e->hSeg[s]) { hipHostFree(e->hSeg[s]); e->hSeg[s] = nullptr; }
+    dev_free(e, e->dSeg[s], async); e->dSeg[s] = nullptr;
+    host_retire(e, e->hRaw[s], async); e->hRaw[s] = nullptr;
+    host_retire(e, e->hSeg[s], async); e->hSeg[s] = nullptr;
     fr(e->dCmvn[s]);
-    if (e->hCmvn[s]) { hipHostFree(e->hCmvn[s]); e->hCmvn[s] = nullptr; }
+    host_retire(e, e->hCmvn[s], async); e->hCmvn[s] = nullptr;
   }
   e->cmvn_cap = 0;
-  auto frb = [](bf16_t*& p) { if (p) { hipFree(p); p = nullptr; } };
+  auto frb = [&](bf16_t*& p) { dev_free(e, p, async); p = nullptr; };
   for (int s = 0; s < 2; ++s) { frb(e->Xb[s]); frb(e->dAb[s]); }
   for (auto& p : e->ab) frb(p);
   frb(e->logb);
@@ -457,6 +479,7 @@ void free_activations(tfk_engine* e) {
   e->cap = 0;
 }
 
+// synchronous allocations of create (small, once)
 int alloc_zero(float** p, size_t floats) {
   HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
   HIPCHK(hipMemset(*p, 0, floats * sizeof(float)));
@@ -467,55 +490,64 @@ int alloc_zero_b(bf16_t** p, size_t elems) {
   HIPCHK(hipMemset(*p, 0, elems * sizeof(bf16_t)));
   return 0;
 }
+// stream-ordered, zero-filled
+int grow_zero(tfk_engine* e, float** p, size_t floats) { return dev_alloc(e, (void**)p, floats * sizeof(float), true); }
+int grow_zero_b(tfk_engine* e, bf16_t** p, size_t elems) { return dev_alloc(e, (void**)p, elems * sizeof(bf16_t), true); }
 
 int reserve(tfk_engine* e, int T) {
   if (T <= e->cap) return 0;
-  HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipStreamSynchronize(e->copy_stream));
   int cap = e->cap + e->cap / 2;
   if (cap < T) cap = T;
   cap = (int)up(cap, 64);
-  free_activations(e);
+  // The pinned staging buffers of the last two micro-batches may still be the source of their H2D copies: wait for
+  // those copies (the copy stream only -- compute keeps running); everything on the device is released and
+  // re-allocated in stream order behind the kernels already enqueued, without a host or device synchronisation.
+  for (int s = 0; s < 2; ++s)
+    if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
+  free_activations(e, /*async=*/true);
   const int L = e->L;
   for (int s = 0; s < 2; ++s) {
-    CHK(alloc_zero(&e->dX[s], (size_t)cap * e->ldF));
-    HIPCHK(hipMalloc((void**)&e->dY[s], (size_t)cap * sizeof(int32_t)));
-    CHK(alloc_zero(&e->dA[s], (size_t)cap * e->ldH));
+    CHK(grow_zero(e, &e->dX[s], (size_t)cap * e->ldF));
+    CHK(dev_alloc(e, (void**)&e->dY[s], (size_t)cap * sizeof(int32_t), false));
+    CHK(grow_zero(e, &e->dA[s], (size_t)cap * e->ldH));
     HIPCHK(hipHostMalloc((void**)&e->hX[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&e->hY[s], (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
     // raw frames: at most F columns (context 0); one utterance per frame at worst
-    CHK(alloc_zero(&e->dRaw[s], (size_t)cap * e->ldF));
-    HIPCHK(hipMalloc((void**)&e->dSeg[s], (size_t)(cap + 1) * sizeof(int32_t)));
+    CHK(grow_zero(e, &e->dRaw[s], (size_t)cap * e->ldF));
+    CHK(dev_alloc(e, (void**)&e->dSeg[s], (size_t)(cap + 1) * sizeof(int32_t), false));
     HIPCHK(hipHostMalloc((void**)&e->hRaw[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&e->hSeg[s], (size_t)(cap + 1) * sizeof(int32_t), hipHostMallocDefault));
     e->slot_used[s] = false;
   }
   e->z.assign(L, nullptr); e->a.assign(L, nullptr); e->v.assign(L, nullptr); e->rowscale.assign(L, nullptr);
   for (int l = 0; l < L; ++l) {
-    CHK(alloc_zero(&e->z[l], (size_t)cap * e->ldH));
-    CHK(alloc_zero(&e->a[l], (size_t)cap * e->ldH));
+    CHK(grow_zero(e, &e->z[l], (size_t)cap * e->ldH));
+    CHK(grow_zero(e, &e->a[l], (size_t)cap * e->ldH));
     if (e->cfg.l2_norm) {
-      CHK(alloc_zero(&e->v[l], (size_t)cap * e->ldH));
-      CHK(alloc_zero(&e->rowscale[l], (size_t)cap));
+      CHK(grow_zero(e, &e->v[l], (size_t)cap * e->ldH));
+      CHK(grow_zero(e, &e->rowscale[l], (size_t)cap));
     }
   }
   if (e->bf16) {
     for (int s = 0; s < 2; ++s) {
-      CHK(alloc_zero_b(&e->Xb[s], (size_t)cap * e->ldFb));
-      CHK(alloc_zero_b(&e->dAb[s], (size_t)cap * e->ldHb));
+      CHK(grow_zero_b(e, &e->Xb[s], (size_t)cap * e->ldFb));
+      CHK(grow_zero_b(e, &e->dAb[s], (size_t)cap * e->ldHb));
     }
     e->ab.assign(L, nullptr);
-    for (int l = 0; l < L; ++l) CHK(alloc_zero_b(&e->ab[l], (size_t)cap * e->ldHb));
-    CHK(alloc_zero_b(&e->logb, (size_t)cap * e->ldOb));
+    for (int l = 0; l < L; ++l) CHK(grow_zero_b(e, &e->ab[l], (size_t)cap * e->ldHb));
+    CHK(grow_zero_b(e, &e->logb, (size_t)cap * e->ldOb));
   }
-  CHK(alloc_zero(&e->logits, (size_t)cap * e->ldO));
-  CHK(alloc_zero(&e->post, (size_t)cap * e->ldO));
-  CHK(alloc_zero(&e->row_loss, (size_t)cap));
+  CHK(grow_zero(e, &e->logits, (size_t)cap * e->ldO));
+  CHK(grow_zero(e, &e->post, (size_t)cap * e->ldO));
+  CHK(grow_zero(e, &e->row_loss, (size_t)cap));
   const int ldmax = e->ldH > e->ldO ? e->ldH : e->ldO;
-  CHK(alloc_zero(&e->ws, (size_t)3 * kMaxRowSplits * ldmax));
-  CHK(alloc_zero(&e->ws_stats, (size_t)2 * ((cap + 63) / 64) * e->ldH));
+  CHK(grow_zero(e, &e->ws, (size_t)3 * kMaxRowSplits * ldmax));
+  CHK(grow_zero(e, &e->ws_stats, (size_t)2 * ((cap + 63) / 64) * e->ldH));
   e->ws_bwd_stride = (size_t)3 * kMaxRowSplits * ldmax;
-  CHK(alloc_zero(&e->ws_bwd, e->ws_bwd_stride * (L + 1)));
+  CHK(grow_zero(e, &e->ws_bwd, e->ws_bwd_stride * (L + 1)));
+  // the copy stream writes the new input slots: not before their allocation + zero fill in engine-stream order
+  HIPCHK(hipEventRecord(e->ev_grow, e->stream));
+  HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_grow, 0));
   e->cap = cap;
   return 0;
 }
@@ -581,14 +613,19 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
   const int s = e->slot;
   const size_t cmvn_floats = cmvn ? (size_t)2 * U * D : 0;
   if (cmvn_floats > e->cmvn_cap) {
-    HIPCHK(hipStreamSynchronize(e->copy_stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    // the tables of the last two micro-batches: their H2D copies (copy stream) must be over before the pinned side
+    // is retired; the device side is released / re-allocated in engine-stream order (the splice kernels that read it
+    // are on that stream, and the copies were awaited by it)
+    for (int k = 0; k < 2; ++k)
+      if (e->slot_used[k]) HIPCHK(hipEventSynchronize(e->copy_done[k]));
     for (int k = 0; k < 2; ++k) {
-      if (e->dCmvn[k]) { hipFree(e->dCmvn[k]); e->dCmvn[k] = nullptr; }
-      if (e->hCmvn[k]) { hipHostFree(e->hCmvn[k]); e->hCmvn[k] = nullptr; }
-      HIPCHK(hipMalloc((void**)&e->dCmvn[k], 2 * cmvn_floats * sizeof(float)));
+      dev_free(e, e->dCmvn[k], true); e->dCmvn[k] = nullptr;
+      host_retire(e, e->hCmvn[k], true); e->hCmvn[k] = nullptr;
+      CHK(dev_alloc(e, (void**)&e->dCmvn[k], 2 * cmvn_floats * sizeof(float), false));
       HIPCHK(hipHostMalloc((void**)&e->hCmvn[k], 2 * cmvn_floats * sizeof(float), hipHostMallocDefault));
     }
+    HIPCHK(hipEventRecord(e->ev_grow, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->copy_stream, e->ev_grow, 0));
     e->cmvn_cap = 2 * cmvn_floats;
   }
   if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
@@ -946,6 +983,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_FUSE_EVAL"))) e->fuse_eval = atoi(v) != 0;
   }
   HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
+  HIPB(hipEventCreateWithFlags(&e->ev_grow, hipEventDisableTiming));
   for (int s = 0; s < 2; ++s) {
     HIPB(hipEventCreateWithFlags(&e->copy_done[s], hipEventDisableTiming));
     HIPB(hipEventCreateWithFlags(&e->compute_done[s], hipEventDisableTiming));
@@ -1003,15 +1041,13 @@ struct CtcSpec {  // CTC loss instead of the frame-level cross-entropy
   const int32_t* label_len;  // [U]
 };
 template <class Tp>
-int grow(Tp** p, size_t* cap, size_t need) {
+int grow(tfk_engine* e, Tp** p, size_t* cap, size_t need) {
   if (need <= *cap) return 0;
-  if (*p) {  // kernels of the previous micro-batch may still read it
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipFree(*p));
-  }
+  dev_free(e, *p, true);  // stream-ordered: kernels of the previous micro-batch may still read it
   *p = nullptr;
+  *cap = 0;
   const size_t n = need + need / 2;
-  HIPCHK(hipMalloc((void**)p, n * sizeof(Tp)));
+  CHK(dev_alloc(e, (void**)p, n * sizeof(Tp), false));
   *cap = n;
   return 0;
 }
@@ -1034,18 +1070,18 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   for (int i = 0; i < total; ++i)  // the blank is the LAST class (tf.nn.ctc_loss): labels live in [0, O - 1)
     if (c.labels[i] < 0 || c.labels[i] >= e->O - 1) return fail(-1, "CTC: label %d outside [0, %d)", c.labels[i], e->O - 1);
   const int sext = ctc_state_stride(max_labels);
-  CHK(grow(&e->ctc_seg, &e->ctc_cap_seg, (size_t)c.U + 1));
-  CHK(grow(&e->ctc_lab_off, &e->ctc_cap_off, (size_t)c.U + 1));
-  CHK(grow(&e->ctc_utt_loss, &e->ctc_cap_loss, (size_t)c.U));
-  CHK(grow(&e->ctc_lab, &e->ctc_cap_lab, (size_t)(total > 0 ? total : 1)));
-  CHK(grow(&e->ctc_lp, &e->ctc_cap_lp, (size_t)T * sext));
-  CHK(grow(&e->ctc_ab, &e->ctc_cap_ab, (size_t)T * sext));
-  CHK(grow(&e->ctc_lse, &e->ctc_cap_rows, (size_t)T));
-  CHK(grow(&e->ctc_off, &e->ctc_cap_offrows, (size_t)T));
-  CHK(grow(&e->ctc_logz, &e->ctc_cap_logz, (size_t)c.U));
+  CHK(grow(e, &e->ctc_seg, &e->ctc_cap_seg, (size_t)c.U + 1));
+  CHK(grow(e, &e->ctc_lab_off, &e->ctc_cap_off, (size_t)c.U + 1));
+  CHK(grow(e, &e->ctc_utt_loss, &e->ctc_cap_loss, (size_t)c.U));
+  CHK(grow(e, &e->ctc_lab, &e->ctc_cap_lab, (size_t)(total > 0 ? total : 1)));
+  CHK(grow(e, &e->ctc_lp, &e->ctc_cap_lp, (size_t)T * sext));
+  CHK(grow(e, &e->ctc_ab, &e->ctc_cap_ab, (size_t)T * sext));
+  CHK(grow(e, &e->ctc_lse, &e->ctc_cap_rows, (size_t)T));
+  CHK(grow(e, &e->ctc_off, &e->ctc_cap_offrows, (size_t)T));
+  CHK(grow(e, &e->ctc_logz, &e->ctc_cap_logz, (size_t)c.U));
   if (train) {
-    CHK(grow(&e->ctc_bb, &e->ctc_cap_bb, (size_t)T * sext));
-    CHK(grow(&e->ctc_offb, &e->ctc_cap_offb, (size_t)T));
+    CHK(grow(e, &e->ctc_bb, &e->ctc_cap_bb, (size_t)T * sext));
+    CHK(grow(e, &e->ctc_offb, &e->ctc_cap_offb, (size_t)T));
   }
   {
     // The three small tables go through pinned staging, two buffers used in turn: the host never waits for the
@@ -1182,7 +1218,10 @@ int tfk_destroy(tfk_engine* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
   free_activations(e);
+  for (void* p : e->host_garbage) (void)hipHostFree(p);
+  e->host_garbage.clear();
   if (e->ev_loss) hipEventDestroy(e->ev_loss);
+  if (e->ev_grow) hipEventDestroy(e->ev_grow);
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);

@@ -75,7 +75,9 @@ struct GemmArgs {
 // The heuristic uses 0 (>= 512 tiles of 128x128) and 9 (everything smaller; 3, its register-staged twin, with
 // TFK_GEMM_DMA=0); the rest are kept for the sweep tool (tools/gemm_sweep.py) that produced
 // profiles/r01_gemm_sweep_*.txt.
-constexpr int kNumGemmConfigs = 10;
+//  10: 128x64 block, 4 waves of 64x32 / 11: 64x128, 4 waves of 32x64 / 12: 128x128, 4 waves of 64x64 -- all with
+//      the 4-slot LDS-DMA ring (round-2 experiment: larger wave tiles on the DMA path)
+constexpr int kNumGemmConfigs = 13;
 
 // cfg < 0 => heuristic choice. Returns hipError_t as int.
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream);

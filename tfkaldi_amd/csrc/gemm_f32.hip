@@ -753,7 +753,8 @@ const CfgDesc kCfg[kNumGemmConfigs] = {
     {128, 128, "128x128/4w64x64/s2"},   {128, 64, "128x64/4w64x32/s3p2"},   {64, 128, "64x128/4w32x64/s3p2"},
     {64, 64, "64x64/4w32x32/s3p6|4|3"},     {128, 128, "128x128/8w64x32/s3p1"}, {256, 128, "256x128/8w64x64/s2"},
     {64, 128, "64x128/8w32x32/s3p2"},   {128, 64, "128x64/8w32x32/s3p2"},   {64, 64, "64x64/4w32x32/s3p1"},
-    {64, 64, "64x64/4w32x32/dma4"},
+    {64, 64, "64x64/4w32x32/dma4"},     {128, 64, "128x64/4w64x32/dma4"},   {64, 128, "64x128/4w32x64/dma4"},
+    {128, 128, "128x128/4w64x64/dma4"},
 };
 
 // Prefetch distance of the 64x64 configuration per layout (stand-alone 1024x2048x2048 / 2048x2048x1024, same box):
@@ -776,6 +777,9 @@ int dispatch_cfg(const GemmArgs& p, int cfg, hipStream_t s) {
     case 7: return launch<Tile<128, 64, 32, 32, 3, 2, A_KC, B_KC>, EPI>(p, s);
     case 8: return launch<Tile<64, 64, 32, 32, 3, 1, A_KC, B_KC>, EPI>(p, s);
     case 9: return launch<Tile<64, 64, 32, 32, 4, 1, A_KC, B_KC, true>, EPI>(p, s);
+    case 10: return launch<Tile<128, 64, 64, 32, 4, 1, A_KC, B_KC, true>, EPI>(p, s);
+    case 11: return launch<Tile<64, 128, 32, 64, 4, 1, A_KC, B_KC, true>, EPI>(p, s);
+    case 12: return launch<Tile<128, 128, 64, 64, 4, 1, A_KC, B_KC, true>, EPI>(p, s);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -874,7 +878,10 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   // The 64x64 tile stages through LDS-DMA (config 9) unless TFK_GEMM_DMA=0 asks for the register ring (config 3):
   // stand-alone +0.5..1.5 %, BASELINE cfg2 step +1.4 % (profiles/r01_gemm_dma.txt).
-  return tiles128 >= 512 ? 0 : (g_dma ? 9 : 3);
+  // Round 2 (profiles/r02_gemm_f32_sweep.txt): the 128x128 tile on the LDS-DMA ring (config 12) matches or beats its
+  // register-staged twin (config 0) on every cfg4-size contraction (NT 140 vs 136 TF); 128x64 / 64x128 DMA tiles
+  // (10, 11) do not beat 64x64 on the 1024-frame shapes.
+  return tiles128 >= 512 ? (g_dma ? 12 : 0) : (g_dma ? 9 : 3);
 }
 
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream) {

@@ -5,10 +5,8 @@ import os
 import numpy as np
 
 from ... import _lib
-from ...engine import Engine
-from . import seq_convertors
 from .activation import TfActivation, engine_options
-from .classifier import Classifier
+from .classifier import Classifier, ControlOp  # noqa: F401  (ControlOp: re-exported)
 from .layer import FFLayer
 
 
@@ -34,16 +32,6 @@ class ModelSaver(object):
             self.engine.load_model_tensors({k: data[k] for k in data.files})
 
 
-class ControlOp(object):
-    """a graph operation with a .run() (the reference's control_ops values are tf Operations)"""
-
-    def __init__(self, fn):
-        self._fn = fn
-
-    def run(self, feed_dict=None, session=None):
-        self._fn()
-
-
 class DNN(Classifier):
     """feed-forward fully connected network"""
 
@@ -57,7 +45,6 @@ class DNN(Classifier):
         self.activation = activation
         self.layerwise_init = layerwise_init
         self.compute_dtype = compute_dtype
-        self._scopes = {}
 
     # ---- structure ----
     def layers(self):
@@ -75,9 +62,6 @@ class DNN(Classifier):
                                 learning_rate_decay=learning_rate_decay, num_steps=num_steps, max_frames=max_frames,
                                 seed=seed, device=device, compute_dtype=self.compute_dtype, **opts)
 
-    def create_engine(self, input_dim, torch_state=False, **options):
-        return Engine(self.engine_config(input_dim, **options), torch_state=torch_state)
-
     def initialize(self, engine, rng):
         """run the variable initialisers: hidden weights N(0, 1/sqrt(d_in)), output weights N(0, 0) = 0,
         biases 0, beta 0, moving mean 0 / variance 1 (layer.py:39-48, dnn.py:67-68)"""
@@ -93,34 +77,3 @@ class DNN(Classifier):
         engine.set(_lib.WEIGHTS, self.num_layers, out.initial_weights(self.num_units, rng))
         engine.set(_lib.BIASES, self.num_layers, np.zeros(self.output_dim, dtype=np.float32))
         engine.set_scalar(_lib.INITIALISED_LAYERS, 0)
-
-    def control_ops(self, engine):
-        """{'add': ..., 'init': ...} with layer-wise initialisation, else None (dnn.py:114-122)"""
-        if not self.layerwise_init:
-            return None
-        return {"add": ControlOp(engine.add_layer), "init": ControlOp(engine.init_last_layer)}
-
-    # ---- the reference's call signature, evaluated eagerly ----
-    def __call__(self, inputs, seq_length, is_training=False, reuse=False, scope=None):
-        """Forward computation on sequential data: `inputs` is a list with a [batch, input_dim] array per
-        time step, `seq_length` the utterance lengths.  Returns (sequential logits, seq_length, saver,
-        control_ops) like reference dnn.py:37-131.  Variables live in `scope`; reuse=False creates them
-        (freshly initialised), reuse=True shares the ones created earlier.  Only inference mode is
-        available through this entry point -- training runs through a Trainer."""
-        if is_training:
-            raise NotImplementedError("training-mode evaluation runs through neuralNetworks.trainer.Trainer")
-        scope = scope or type(self).__name__
-        if reuse:
-            if scope not in self._scopes:
-                raise ValueError("Variable scope %s does not exist, reuse=True" % scope)
-            engine = self._scopes[scope]
-        else:
-            if scope in self._scopes:
-                raise ValueError("Variable scope %s already exists, did you mean to set reuse=True?" % scope)
-            engine = self.create_engine(int(np.asarray(inputs[0]).shape[1]))
-            self.initialize(engine, np.random.default_rng())
-            self._scopes[scope] = engine
-        flat = seq_convertors.seq2nonseq([np.asarray(x, dtype=np.float32) for x in inputs], seq_length)
-        logits = engine.posteriors(flat, raw_logits=True)
-        seq_logits = seq_convertors.nonseq2seq(logits, seq_length, len(inputs))
-        return seq_logits, seq_length, ModelSaver(engine), self.control_ops(engine)

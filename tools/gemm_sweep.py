@@ -12,7 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tfkaldi_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-NAMES = ["128x128/4w2", "128x64/4wp2", "64x128/4wp2", "64x64/4wp2", "128x128/8w3", "256x128/8w2", "64x128/8wp2", "128x64/8wp2", "64x64/4wp1"]
+ALL = ["128x128/4w2", "128x64/4wp2", "64x128/4wp2", "64x64/4wp2", "128x128/8w3", "256x128/8w2", "64x128/8wp2", "128x64/8wp2",
+       "64x64/4wp1", "64x64/dma4", "128x64/dma4", "64x128/dma4", "128x128/dma4"]
+# TFK_SWEEP_CFGS="0,3,9,10,11,12": the configurations to time (default: all), interleaved rounds, median
+CFGS = [int(x) for x in os.environ.get("TFK_SWEEP_CFGS", ",".join(str(i) for i in range(len(ALL)))).split(",")]
+NAMES = [ALL[c] for c in CFGS]
 LAY = ["NN", "NT", "TN"]
 
 
@@ -51,10 +55,14 @@ def main():
         print("== %s  T=%d F=%d H=%d O=%d" % (tag, T, F, H, O))
         print("%-6s %-3s %6s %6s %6s | " % ("op", "lay", "M", "N", "K") + " ".join("%11s" % n for n in NAMES))
         for name, layout, M, N, K in shapes(T, F, H, O):
+            times = {c: [] for c in CFGS}
+            for _ in range(5):
+                for c in CFGS:
+                    times[c].append(bench(layout, M, N, K, c, iters=10)[0])
             row = []
-            for cfg in range(len(NAMES)):
-                ms, tf = bench(layout, M, N, K, cfg)
-                row.append((ms, tf))
+            for c in CFGS:
+                ms = sorted(times[c])[len(times[c]) // 2]
+                row.append((ms, 2.0 * M * N * K / ms / 1e9))
             out["%s/%s" % (tag, name)] = row
             print("%-6s %-3s %6d %6d %6d | " % (name, LAY[layout], M, N, K) +
                   " ".join("%5.1fTF%4.0fus" % (tf, ms * 1e3) for ms, tf in row))
