@@ -361,6 +361,7 @@ struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient th
   float eps = 0.f;
   bf16_t* twin = nullptr;  // mixed precision: bf16 copy of the result
   int ld_twin = 0;
+  float scale = 1.f;       // EPI_DACT: 1 / keep_prob of a ReLU + dropout chain
 };
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr, float* stats = nullptr,
@@ -379,6 +380,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.stats_stride = kMaxRowSplits;
     b.act_beta = act ? act->beta : nullptr; b.bn_eps = act ? act->eps : 0.f;
     b.C_twin = act ? act->twin : nullptr; b.ldct = act ? act->ld_twin : 0;
+    b.act_scale = act ? act->scale : 1.f;
     b.M = M; b.N = N; b.K = K; b.lda = lda8; b.ldb = ldb8; b.ldc = ldc; b.epi = epi;
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
@@ -394,6 +396,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   g.act_nonlin = act ? act->nonlin : 0;
   g.stats_stride = kMaxRowSplits;
   g.act_beta = act ? act->beta : nullptr; g.bn_eps = act ? act->eps : 0.f;
+  g.act_scale = act ? act->scale : 1.f;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   if (layout == GEMM_TN && K >= 2048 && (size_t)M * N < ((size_t)1 << 20)) {
     // narrow layer, many frames: the weight gradient may run split-K (gemm_f32.h) -- partials of up to 32 chunks
@@ -426,6 +429,7 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
   a.act_a = act ? act->a : nullptr; a.act_z = act ? act->z : nullptr;
   a.act_mean = act ? act->mean : nullptr; a.act_rstd = act ? act->rstd : nullptr;
   a.act_nonlin = act ? act->nonlin : 0;
+  a.act_scale = act ? act->scale : 1.f;
   a.stats_stride = kMaxRowSplits;
   a.M = T; a.N = N_da; a.K = K_da; a.lda = ld_dz; a.ldb = ldw; a.ldc = ld_da; a.epi = act ? EPI_DACT : 0;
   w.A = in; w.B = dz; w.C = Gw; w.bias = nullptr; w.stats = nullptr;
@@ -798,16 +802,23 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   int cfg_h, cfg_o;
   const int rows_h = gemm_chunk_rows(e, GEMM_NT, T, H, H, &cfg_h), rows_o = gemm_chunk_rows(e, GEMM_NT, T, H, e->O, &cfg_o);
   const int chunks_h = (T + rows_h - 1) / rows_h, chunks_o = (T + rows_o - 1) / rows_o;
-  const bool fuse_hb = e->cfg.batch_norm && !e->cfg.l2_norm && !(e->cfg.keep_prob < 1.f) && e->fuse_hb_enabled &&
-                       chunks_h <= kMaxRowSplits && chunks_o <= kMaxRowSplits;
+  // Dropout behind a ReLU fuses as well: a = relu(u) * mask / keep, so d a / d u = (a > 0) / keep exactly -- the
+  // epilogue reads it off the stored layer output without regenerating the mask.  (Behind sigmoid / tanh the kept
+  // value would have to be un-scaled first; those chains keep the separate pass.)
+  const bool drop = e->cfg.keep_prob < 1.f;
+  const float dscale = drop ? 1.f / e->cfg.keep_prob : 1.f;
+  const bool fuse_hb = e->cfg.batch_norm && !e->cfg.l2_norm && (!drop || e->cfg.nonlin == TFK_NONLIN_RELU) &&
+                       e->fuse_hb_enabled && chunks_h <= kMaxRowSplits && chunks_o <= kMaxRowSplits;
   auto dact_gemm = [&](const float* dz, int ld_dz, const float* W, int ldw, float* out, int K, int target, int cfg) {
     if (!fuse_hb) return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, 0);
-    const ActEpi act = {e->a[target], e->z[target], e->mean[target], e->rstd[target], e->cfg.nonlin};
+    ActEpi act = {e->a[target], e->z[target], e->mean[target], e->rstd[target], e->cfg.nonlin};
+    act.scale = dscale;
     return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, EPI_DACT, nullptr, ws_of(target), cfg,
                     &act);
   };
   {
-    const ActEpi act = {e->a[nact - 1], e->z[nact - 1], e->mean[nact - 1], e->rstd[nact - 1], e->cfg.nonlin};
+    ActEpi act = {e->a[nact - 1], e->z[nact - 1], e->mean[nact - 1], e->rstd[nact - 1], e->cfg.nonlin};
+    act.scale = dscale;
     const int rc = run_gemm_dual(e, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O,
                                  fuse_hb ? &act : nullptr, fuse_hb ? ws_of(nact - 1) : nullptr, e->a[nact - 1], ldH,
                                  G + o.w_off, o.ld_out, H, e->O, epi_w);
@@ -859,7 +870,8 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     const int ld_in = l == 0 ? ldx : ldH;
     bool fused = false;
     if (l > 0) {  // dW_l and the dA that feeds layer l - 1 both read dz_l: one launch when eligible
-      const ActEpi act = {e->a[l - 1], e->z[l - 1], e->mean[l - 1], e->rstd[l - 1], e->cfg.nonlin};
+      ActEpi act = {e->a[l - 1], e->z[l - 1], e->mean[l - 1], e->rstd[l - 1], e->cfg.nonlin};
+      act.scale = dscale;
       const int rc = run_gemm_dual(e, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H,
                                    fuse_hb ? &act : nullptr, fuse_hb ? ws_of(l - 1) : nullptr, in, ld_in, G + y.w_off,
                                    y.ld_out, y.d_in, H, epi_w);

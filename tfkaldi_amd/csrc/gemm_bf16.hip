@@ -27,6 +27,7 @@
 // (2) register-staged ring of round 1 (configs 0-2; kept for A/B runs: tools/gemm_bf16_sweep.py).
 #include "gemm_bf16.h"
 
+#include <math.h>
 #include <stdlib.h>
 
 namespace tfk {
@@ -42,16 +43,23 @@ constexpr int BK = 64;
 constexpr int kOOB = (int)0x80000000;
 constexpr int NUM_XCD = 8;
 
-// XCD-aware order: block b runs on XCD b % 8; each XCD takes a contiguous run of the column-major tile
-// sequence, so the tiles sharing a B panel (and neighbouring A panels) meet in one L2.
-__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int& tm, int& tn) {
+// XCD-aware order: block b runs on XCD b % 8 and each XCD takes a contiguous run of a GROUPED tile sequence (groups of
+// `group_rows` tile rows, column-major inside a group), i.e. a patch of about group_rows x (run / group_rows) tiles that
+// share A row-panels and B column-panels in that XCD's L2.  The host picks group_rows so that the patch is square in
+// BYTES (group_rows * BM ~ columns * BN), which minimises what the eight private L2s fetch from the fabric.
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int group_rows, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
   const int bid = blockIdx.x;
   const int xcd = bid % NUM_XCD, loc = bid / NUM_XCD;
   const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
   const int seq = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  tm = seq % tiles_m;
-  tn = seq / tiles_m;
+  const int per_group = group_rows * tiles_n;
+  const int grp = seq / per_group;
+  const int first_m = grp * group_rows;
+  const int gsize = min(group_rows, tiles_m - first_m);
+  const int within = seq - grp * per_group;
+  tm = first_m + within % gsize;
+  tn = within / gsize;
 }
 
 __device__ __forceinline__ uint16_t f2bf(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
@@ -132,6 +140,7 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
     if constexpr ((EPI & EPI_DACT) != 0) {
       // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
       const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
+      const float dscale = p.act_scale > 0.f ? p.act_scale : 1.f;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int a = 0; a < FM; ++a) {
@@ -146,7 +155,7 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
         for (int r = 0; r < 16; ++r) {
           float d1;
           switch (p.act_nonlin) {
-            case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+            case 0: d1 = av[r] > 0.f ? dscale : 0.f; break;
             case 1: d1 = av[r] * (1.f - av[r]); break;
             case 2: d1 = 1.f - av[r] * av[r]; break;
             default: d1 = 1.f;
@@ -300,7 +309,7 @@ struct Frag {
 
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
-gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
+gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
@@ -317,7 +326,7 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tm, tn;
-  tile_of_block(tiles_m, tiles_n, tm, tn);
+  tile_of_block(tiles_m, tiles_n, group_rows, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
@@ -471,7 +480,7 @@ __device__ __forceinline__ bf16x8 fragment(const bf16_t* s, int ext_base, int ks
 // FM / FN: 32-row / 32-column MFMA fragments per wave.  Block tile = (64 * FM) x (64 * FN), four waves as 2 x 2.
 template <bool A_KC, bool B_KC, int EPI, int FM, int FN>
 __global__ void __launch_bounds__(NT)
-gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
+gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_e[];
   bf16_t* smem = smem_e;
   constexpr int BM = 64 * FM, BN = 64 * FN;
@@ -486,7 +495,7 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  tile_of_block(tiles_m, tiles_n, tm, tn);
+  tile_of_block(tiles_m, tiles_n, group_rows, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
@@ -580,6 +589,7 @@ struct CfgB {
 };
 const CfgB kCfgB[kNumGemmBf16Configs] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}, {128, 128}, {256, 128}, {128, 64}};
 int g_forced_b = -2;  // -2: env not read yet; -1: heuristic
+int g_group_rows = 0;  // env TFK_BF16_GROUP_ROWS (experiments): tile rows per XCD patch; 0 = balanced, large = column-major
 
 template <class Kern>
 int launch_grid(Kern kern, const GemmArgsB& p, int bm, int bn, int threads, size_t lds, hipStream_t stream, bool* attr_done) {
@@ -590,7 +600,15 @@ int launch_grid(Kern kern, const GemmArgsB& p, int bm, int bn, int threads, size
     if (e != hipSuccess) return (int)e;
     *attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(threads), lds, stream, p, tiles_m, tiles_n);
+  // tile rows per XCD patch: ~sqrt(tiles per XCD * BN / BM) makes the patch square in bytes
+  int group_rows = g_group_rows;
+  if (group_rows <= 0) {
+    const double per_xcd = (double)tiles_m * tiles_n / NUM_XCD;
+    group_rows = (int)(sqrt(per_xcd * bn / bm) + 0.5);
+  }
+  if (group_rows < 1) group_rows = 1;
+  if (group_rows > tiles_m) group_rows = tiles_m;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(threads), lds, stream, p, tiles_m, tiles_n, group_rows);
   return (int)hipGetLastError();
 }
 
@@ -635,6 +653,7 @@ int gemm_bf16_pick_config(int M, int N) {
     const char* q = getenv("TFK_BF16_CFG");
     const int v = q ? atoi(q) : -1;
     g_forced_b = (v >= 0 && v < kNumGemmBf16Configs) ? v : -1;
+    if ((q = getenv("TFK_BF16_GROUP_ROWS"))) g_group_rows = atoi(q);
   }
   if (g_forced_b >= 0) return g_forced_b;
   const long m256 = (M + 255) / 256, m128 = (M + 127) / 128, n128 = (N + 127) / 128, n64 = (N + 63) / 64;

@@ -582,7 +582,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
           }
           float d1;  // f' through the output, as kernels.hip nonlin_bwd
           switch (p.act_nonlin) {
-            case 0: d1 = av[r] > 0.f ? 1.f : 0.f; break;
+            case 0: d1 = av[r] > 0.f ? p.act_scale : 0.f; break;  // (a > 0) / keep behind dropout, else 1
             case 1: d1 = av[r] * (1.f - av[r]); break;
             case 2: d1 = 1.f - av[r] * av[r]; break;
             default: d1 = 1.f;
