@@ -304,6 +304,12 @@ struct Frag {
   }
 };
 
+// TFKB_ABL (tools/gemm_bf16_ablate.hip only): timing-only variants of the DMA kernel with pieces of the K loop removed
+// -- 1 MFMAs, 2 LDS-DMA pieces, 4 fragment reads.  Results are wrong by construction.
+#ifndef TFKB_ABL
+#define TFKB_ABL 0
+#endif
+
 #define TFKB_WAIT_BARRIER(n) \
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "n"(n) : "memory")
 
@@ -351,6 +357,7 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
   auto piece = [&](int j, int slot, int kt) {
+    if (TFKB_ABL & 2) return;
     if (j < NPA) la.issue(j, lds0 + (unsigned)(slot * STAGE), kt * BK, wave);
     else lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + A_BYTES), kt * BK, wave);
   };
@@ -364,11 +371,25 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 
   bf16x8 fa[2][FM], fb[2][FN];
   auto read_frags = [&](int buf, const char* st, int ks) {
+    if (TFKB_ABL & 4) return;
 #pragma unroll
     for (int a = 0; a < FM; ++a) fa[buf][a] = qa.read(st, a, ks);
 #pragma unroll
     for (int b = 0; b < FN; ++b) fb[buf][b] = qb.read(st + A_BYTES, b, ks);
   };
+  if (TFKB_ABL & 4) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[q][a][e] = (__bf16)(float)(lane + e);
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[q][b][e] = (__bf16)(float)(lane - e);
+    }
+  }
   int rs = 0, ws = NS - 1;
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
@@ -381,11 +402,18 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
       // this 16-k step's share of the pieces of tile kt+NS-1 (into the slot tile kt-1 left at the last barrier)
 #pragma unroll
       for (int j = ks * NP / 4; j < (ks + 1) * NP / 4; ++j) piece(j, ws, kt + NS - 1);
+      if (TFKB_ABL & 1) {  // keep the fragment reads alive without the MFMAs
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+        for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][a]));
 #pragma unroll
-        for (int b = 0; b < FN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][b]));
+      } else {
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // this wave's pieces of tile kt+1 have landed (the NS-2 younger tiles stay in flight); the barrier makes every
