@@ -12,8 +12,8 @@ shutil.copy(f, dst + "_bench_kernel_stats.csv")
 with open(dst + "_bench_kernel_stats.txt", "w") as out:
     out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 50 --warmup 5 "
               "--no-cpu-baseline   (MI355X%s)\n" % (", " + note if note else ""))
-    out.write("# 55 warm/timed + 50 event-profiled steps of BASELINE cfg2; avg/min/max in microseconds "
-              "(tfk::(anonymous namespace):: stripped)\n")
+    out.write("# 5 warm-up + 50 timed (HBM-resident input) + 3 + 50 host-fed + 50 event-profiled steps of BASELINE cfg2; avg/min/max in "
+              "microseconds (tfk::(anonymous namespace):: stripped)\n")
     for r in csv.DictReader(open(f)):
         name = r["Name"].replace("tfk::(anonymous namespace)::", "").replace("void tfk::", "")
         out.write("%-120s calls=%6d avg_us=%9.2f min_us=%9.2f max_us=%9.2f pct=%s\n" % (
