@@ -234,6 +234,13 @@ int tfk_apply_begin(tfk_engine* e);
 int tfk_apply_span(tfk_engine* e, size_t offset_floats, size_t num_floats);
 int tfk_apply_end(tfk_engine* e, float* average_loss);
 
+/* Called on the host right before the kernels that READ the parameters of hidden layer `layer` (0 .. L - 1), of the
+ * output layer (L) or of every layer (-1: tensor get / set, the bf16 shadow rebuild) are enqueued.  A host that writes
+ * parameters asynchronously -- the all-gather of the sharded exchange step, still in flight when the next step's
+ * forward pass starts -- makes the engine stream wait for exactly that write here. */
+typedef void (*tfk_layer_fn)(void* user, int layer);
+int tfk_set_layer_callback(tfk_engine* e, tfk_layer_fn fn, void* user);
+
 /* Sharded exchange step (reduce-scatter -> tfk_apply_span on this rank's share -> all-gather of the updated
  * parameters written straight into the arena by the collective): tells the engine that parameters changed behind
  * the optimiser's back, so the bf16 weight shadow of the mixed-precision mode is rebuilt before its next use.

@@ -90,6 +90,7 @@ SYMBOLS = {
     "tfk_set_bucket_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
     "tfk_set_later_microbatches": (c_int, [_E, c_int32]),
     "tfk_params_touched": (c_int, [_E]),
+    "tfk_set_layer_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
     "tfk_synchronize": (c_int, [_E]),
     "tfk_stream": (c_int, [_E, POINTER(c_void_p)]),
     "tfk_profile_begin": (c_int, [_E]),

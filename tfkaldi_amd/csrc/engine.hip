@@ -188,6 +188,8 @@ struct tfk_engine {
 
   tfk_bucket_fn cb = nullptr;
   void* cb_user = nullptr;
+  tfk_layer_fn layer_cb = nullptr;  // "the parameters of this layer are about to be read" (tfk_set_layer_callback)
+  void* layer_user = nullptr;
 
   // last call (debug fetch)
   int last_T = 0, last_nfw = 0;
@@ -320,6 +322,13 @@ void host_retire(tfk_engine* e, void* p, bool async) {
   if (!p) return;
   if (async) e->host_garbage.push_back(p);
   else (void)hipHostFree(p);
+}
+
+// The host may still be writing parameters asynchronously (the sharded exchange step all-gathers the updated
+// parameters while the next step's forward pass is already being enqueued): tell it which layer's parameters the
+// next kernels read (-1: all of them), so that it can make the engine stream wait for exactly that write.
+inline void need_params(tfk_engine* e, int layer) {
+  if (e->layer_cb) e->layer_cb(e->layer_user, layer);
 }
 
 // bf16 twin of an fp32 GEMM operand buffer (mixed-precision mode)
@@ -697,10 +706,14 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   const float* in = Xd;
   int ld_in = ldx;
   const int H = e->H, ldH = e->ldH;
-  if (e->bf16 && e->shadow_dirty) CHK(refresh_shadow(e));
+  if (e->bf16 && e->shadow_dirty) {
+    need_params(e, -1);  // the shadow is rebuilt from every weight matrix
+    CHK(refresh_shadow(e));
+  }
   auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; } return t; };
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
+    need_params(e, l);
     if (train && e->cfg.batch_norm && !e->cfg.l2_norm) {
       // fused path: the GEMM epilogue emits the per-tile column statistics, ONE column-tiled kernel merges them
       // and applies BN + nonlinearity + dropout (4 kernels per layer -> 2)
@@ -763,6 +776,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
     ld_in = ldH;
   }
   const LayerLayout& o = e->lay[e->L];
+  need_params(e, e->L);
   CHK(run_gemm(e, GEMM_NN, e->a[nact - 1], ldH, e->p_param() + o.w_off, o.ld_out, e->logits, e->ldO, T, e->O, H,
                e->p_param() + o.b_off, EPI_BIAS));
   HIPCHK(hipGetLastError());
@@ -1280,6 +1294,7 @@ int tfk_tensor_get(tfk_engine* e, int kind, int slot, int layer, float* host, si
     memset(host, 0, count * sizeof(float));
     return 0;
   }
+  if (slot == TFK_SLOT_PARAM) need_params(e, -1);
   CHK(sync_streams(e));
   HIPCHK(hipMemcpy2D(host, (size_t)t.cols * 4, t.ptr, (size_t)t.ld * 4, (size_t)t.cols * 4, t.rows, hipMemcpyDeviceToHost));
   return 0;
@@ -1291,6 +1306,7 @@ int tfk_tensor_set(tfk_engine* e, int kind, int slot, int layer, const float* ho
   CHK(tensor_ref(e, kind, slot, layer, &t));
   if (count != (size_t)t.rows * t.cols) return fail(-1, "count %zu != %d x %d", count, t.rows, t.cols);
   HIPCHK(hipSetDevice(e->cfg.device));
+  if (slot == TFK_SLOT_PARAM) need_params(e, -1);
   CHK(sync_streams(e));
   if (slot == TFK_SLOT_GRAD && e->grads_fresh) {
     HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->P * sizeof(float), e->stream));
@@ -1494,6 +1510,7 @@ int tfk_init_last_layer(tfk_engine* e) {
   // re-run the initialisers of layer L: weights ~ N(0, stddev 0) = 0, biases = 0 (dnn.py:67-68, 114-120)
   const LayerLayout& o = e->lay[e->L];
   HIPCHK(hipSetDevice(e->cfg.device));
+  need_params(e, -1);
   HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
   e->shadow_dirty = true;
@@ -1677,6 +1694,12 @@ int tfk_set_bucket_callback(tfk_engine* e, tfk_bucket_fn fn, void* user) {
   if (!e) return fail(-1, "engine is NULL");
   e->cb = fn;
   e->cb_user = user;
+  return 0;
+}
+int tfk_set_layer_callback(tfk_engine* e, tfk_layer_fn fn, void* user) {
+  if (!e) return fail(-1, "engine is NULL");
+  e->layer_cb = fn;
+  e->layer_user = user;
   return 0;
 }
 int tfk_params_touched(tfk_engine* e) {

@@ -160,6 +160,14 @@ class BucketReducer(object):
         self._lo = self._hi = None
         self.launched = []  # (offset, floats) of every collective of the current step (tests / diagnostics)
         self.kinds = []     # "rs" (reduce-scatter: only sub-span `rank` is valid afterwards) or "ar" per collective
+        # Parameter all-gathers of the last sharded step that nobody has waited for yet, in launch order (ascending
+        # offsets = forward order).  With an engine that announces parameter reads (tfk_set_layer_callback) they stay
+        # in flight across the step boundary and the NEXT forward pass waits layer by layer: the gather of layer l+1's
+        # weights travels over xGMI while layer l is being multiplied.
+        self.pending = []
+        self.async_gather = mode == "sharded" and hasattr(engine, "set_layer_callback")
+        if self.async_gather:
+            engine.set_layer_callback(self.on_layer)
 
     def _shardable(self, lo, hi):
         n = hi - lo
@@ -214,6 +222,35 @@ class BucketReducer(object):
         except Exception as exc:  # noqa: BLE001
             self.errors.append(exc)
 
+    def drain(self):
+        """make the engine's stream wait for every parameter all-gather still in flight"""
+        if self.pending:
+            with self._stream_ctx():
+                self.pending[-1][2].wait()  # collectives complete in launch order
+            del self.pending[:]
+
+    def on_layer(self, layer):
+        """engine hook (tfk_set_layer_callback): kernels that read the parameters of `layer` (0 .. L, -1 = all) are
+        about to be enqueued -- wait for the gathers that cover them (weights of the layer + the bias / beta vectors)"""
+        if not self.pending:
+            return
+        try:
+            if layer < 0:
+                self.drain()
+                return
+            num_layers = len(self.buckets) - 3
+            spans = [self.buckets[num_layers - layer], self.buckets[num_layers + 1]]
+            last = -1
+            for i, (off, n, _) in enumerate(self.pending):
+                if any(off < so + sn and off + n > so for so, sn in spans):
+                    last = i
+            if last >= 0:
+                with self._stream_ctx():
+                    self.pending[last][2].wait()  # (and, in launch order, everything before it)
+                del self.pending[:last + 1]
+        except Exception as exc:  # noqa: BLE001  (cannot propagate through the C callback)
+            self.errors.append(exc)
+
     def finish(self):
         """launch what is still pending, make the engine's stream wait for every collective of the step (all-reduce
         mode only: after a reduce-scatter the gradient arena is not whole)"""
@@ -255,26 +292,29 @@ class BucketReducer(object):
         for i, (off, n) in enumerate(self.launched):
             if off < head_off + head_n and off + n > head_off:
                 wait(i)
+        self.drain()  # (gathers of the previous step that no forward pass has consumed: none in a training loop)
         engine.apply_begin()
-        gathers = []
-        params = engine.param_view() if "rs" in self.kinds else None
+        sharded = []
         for i, (off, n) in enumerate(self.launched):
             wait(i)
             if self.kinds[i] == "rs":
                 c = n // self.world
-                lo = off + self.rank * c
-                engine.apply_span(lo, c)
-                with self._stream_ctx():  # behind this span's Adam on the engine stream
-                    gathers.append(d.all_gather_into_tensor(params[off:off + n], params[lo:lo + c], group=self.group,
-                                                            async_op=True))
+                engine.apply_span(off + self.rank * c, c)
+                sharded.append((off, n))
             else:
                 engine.apply_span(off, n)  # (spans beyond the parameter arena are clipped by the engine)
-        if gathers:
-            with self._stream_ctx():
-                for g in gathers:
-                    g.wait()
+        if sharded:
+            params = engine.param_view()
+            with self._stream_ctx():  # behind the optimiser kernels on the engine stream, lowest offsets (layer 0) first
+                for off, n in sorted(sharded):
+                    c = n // self.world
+                    lo = off + self.rank * c
+                    h = d.all_gather_into_tensor(params[off:off + n], params[lo:lo + c], group=self.group, async_op=True)
+                    self.pending.append((off, n, h))
             if hasattr(engine, "params_touched"):
-                engine.params_touched()  # parameters outside this rank's spans changed behind the optimiser's back
+                engine.params_touched()  # parameters outside this rank's spans change behind the optimiser's back
+            if not self.async_gather:
+                self.drain()
         del self.handles[:]
         self.last_launched, self.launched = self.launched, []
         self.last_kinds, self.kinds = self.kinds, []
@@ -289,6 +329,7 @@ class DataParallel(object):
         self.mode = mode  # exchange step of BucketReducer (None: TFK_DP_EXCHANGE or "sharded")
         self.rank, self.world = 0, 1
         self._forced = False
+        self._reducers = {}  # one BucketReducer per engine: it carries the in-flight parameter gathers across steps
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -309,6 +350,20 @@ class DataParallel(object):
         import torch
         return torch.cuda.stream(stream)
 
+    def reducer(self, engine):
+        r = self._reducers.get(id(engine))
+        if r is None:
+            r = self._reducers[id(engine)] = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(engine),
+                                                           mode=self.mode)
+        return r
+
+    def drain(self, engine):
+        """wait (on the engine's stream) for parameter all-gathers still in flight: before the engine is closed or its
+        state tensor is read behind the engine's back"""
+        r = self._reducers.get(id(engine))
+        if r is not None:
+            r.drain()
+
     def train_step(self, engine, microbatches):
         """`microbatches`: the (X[T, F], y[T]) micro-batches of the WHOLE step, identical on every rank.
         Returns the average loss over all of them (reference Trainer.update's return value)."""
@@ -320,7 +375,7 @@ class DataParallel(object):
         start, end = partition(len(microbatches), self.world)[self.rank]
         mine = microbatches[start:end]
         engine.set_later_microbatches(len(microbatches) - end)
-        reducer = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(engine), mode=self.mode)
+        reducer = self.reducer(engine)
         engine.set_bucket_callback(reducer.on_bucket)
         try:
             for i, mb in enumerate(mine):

@@ -30,6 +30,7 @@ class Engine(object):
         self._state = None
         self._stream = None
         self._cb = None
+        self._layer_cb = None
         if torch_state:
             import torch
             nbytes = c_size_t()
@@ -335,6 +336,16 @@ class Engine(object):
             return
         self._cb = _lib.BUCKET_FN(lambda user, bucket: fn(bucket))
         check(self.lib.tfk_set_bucket_callback(self._h, self._cb, None))
+
+    def set_layer_callback(self, fn):
+        """fn(layer) is called right before kernels that read the parameters of `layer` (0 .. L; -1 = all) are
+        enqueued (tfk_set_layer_callback): the hook of the asynchronous parameter all-gather."""
+        if fn is None:
+            self._layer_cb = None
+            check(self.lib.tfk_set_layer_callback(self._h, _lib.BUCKET_FN(), None))
+            return
+        self._layer_cb = _lib.BUCKET_FN(lambda user, layer: fn(layer))
+        check(self.lib.tfk_set_layer_callback(self._h, self._layer_cb, None))
 
     def zero_accumulators(self):
         check(self.lib.tfk_zero_accumulators(self._h))

@@ -238,6 +238,8 @@ class Trainer(object, metaclass=ABCMeta):
         if self.summarywriter is not None:
             self.summarywriter.close()
             self.summarywriter = None
+        self.dp.drain(self.engine)
+        self.engine.synchronize()
         self.engine.close()
 
 
