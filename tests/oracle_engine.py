@@ -45,6 +45,17 @@ class OracleEngine(object):
     def set_bucket_callback(self, fn):
         self.cb = fn
 
+    def set_layer_callback(self, fn):
+        """as Engine.set_layer_callback: fn(layer) before parameters are read (the asynchronous all-gather's hook)"""
+        self.layer_cb = fn
+
+    def sync_params(self):
+        """parameters may still be arriving (all-gather in flight): wait, then adopt the flat arena"""
+        if getattr(self, "layer_cb", None):
+            self.layer_cb(-1)
+        if hasattr(self, "params_flat"):
+            self._unflat(self.params_flat.numpy(), self.o.params())
+
     def _snapshot(self):
         if self._mov0 is None and self.o.bn:
             self._mov0 = ([m.copy() for m in self.o.mov_mean], [v.copy() for v in self.o.mov_var])
@@ -70,6 +81,7 @@ class OracleEngine(object):
             r[self.P + 4:] = np.concatenate(e)
 
     def accumulate(self, X, y, last=False):
+        self.sync_params()
         self._snapshot()
         self.o.accumulate(X, y)
         self._nmb += 1
@@ -137,6 +149,7 @@ class OracleEngine(object):
         lr = o.learning_rate()
         o.adam_t += 1
         self._lr_t = lr * np.sqrt(1.0 - o.b2 ** o.adam_t) / (1.0 - o.b1 ** o.adam_t)
+        self.sync_params()
         self.param_view().numpy()[:] = self._flat(o.params())
         self._m, self._v = self._flat(o.m), self._flat(o.v)
 
@@ -166,6 +179,7 @@ class OracleEngine(object):
         return self._loss / self._frames
 
     def eval_accumulate(self, X, y):
+        self.sync_params()
         self.o.eval_accumulate(X, y)
         r = self.region.numpy()
         r[self.P] = self.o.batch_loss

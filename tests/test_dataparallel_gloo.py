@@ -50,6 +50,7 @@ def _worker(rank, world, port, num_mb, out_dir, mode="allreduce"):
         if mode == "sharded" and num_mb >= world:
             assert "rs" in dp.last_kinds, dp.last_kinds  # the sharded exchange really ran
     losses.append(dp.eval_step(eng, _data(num_mb, seed=7)))
+    eng.sync_params()
     o = eng.o
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses),
              mov_mean=np.stack(o.mov_mean), mov_var=np.stack(o.mov_var), **o.params())

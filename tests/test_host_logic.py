@@ -357,3 +357,57 @@ def test_lds_dma_image_layout_is_a_conflict_free_bijection():
             for grp in groups:
                 slots = {(addr[lane] // 16) % 16 for lane in grp}
                 assert len(slots) == 16, (ext_base, g, grp)
+
+
+def test_async_gather_waits_layer_by_layer():
+    """BucketReducer.on_layer (the engine's tfk_set_layer_callback hook): a forward pass waits only for the parameter
+    all-gathers that cover the layer it is about to read -- in launch order, so everything issued before them too --
+    and `-1` (tensor get / set, shadow rebuild) waits for all of them."""
+    from tfkaldi_amd.dataparallel import BucketReducer
+
+    class Handle(object):
+        def __init__(self, log, i):
+            self.log, self.i = log, i
+
+        def wait(self):
+            self.log.append(self.i)
+
+    class FakeEngine(object):
+        # arena: W_0 (2) | W_1 (8) | W_2 (8) | W_3 = output layer (4) | vectors (1) | tail (1), in KiB-floats
+        def buckets(self):
+            k = 1024
+            w = [(0, 2 * k), (2 * k, 8 * k), (10 * k, 8 * k), (18 * k, 4 * k)]
+            return w[::-1] + [(22 * k, k), (23 * k, k)]
+
+        def reduce_view(self):
+            return np.zeros(24 * 1024, dtype=np.float32)
+
+    red = BucketReducer.__new__(BucketReducer)
+    BucketReducer.__init__(red, FakeEngine(), min_bytes=1, mode="allreduce")
+    k = 1024
+
+    def fresh():
+        log = []
+        # gathers in launch (= ascending offset) order: [W_0 + W_1], [W_2], [W_3 + vectors]
+        red.pending = [(0, 10 * k, Handle(log, 0)), (10 * k, 8 * k, Handle(log, 1)), (18 * k, 5 * k, Handle(log, 2))]
+        return log
+
+    log = fresh()
+    red.on_layer(0)          # W_0 is in gather 0, but the bias / beta vectors travel in gather 2: all three are needed
+    assert log == [2] and red.pending == []
+    # with the vectors in a span of their own (an all-reduced tail: nothing pending for them) layers wait one by one
+    log = []
+    red.pending = [(0, 10 * k, Handle(log, 0)), (10 * k, 8 * k, Handle(log, 1)), (18 * k, 4 * k, Handle(log, 2))]
+    red.on_layer(0)
+    assert log == [0] and len(red.pending) == 2
+    red.on_layer(1)          # already there (same gather as W_0): nothing to wait for
+    assert log == [0] and len(red.pending) == 2
+    red.on_layer(2)
+    assert log == [0, 1] and len(red.pending) == 1
+    red.on_layer(3)          # the output layer
+    assert log == [0, 1, 2] and red.pending == []
+    red.on_layer(0)          # nothing pending: no-op
+    assert log == [0, 1, 2]
+    log = fresh()
+    red.on_layer(-1)
+    assert log == [2] and red.pending == [] and not red.errors

@@ -122,7 +122,8 @@ class BucketReducer(object):
     Consecutive announcements are adjacent in the reduce region (the arena is W_0 .. W_L and they arrive as
     W_L .. W_0), so they are COALESCED until a collective carries at least `min_bytes`: xGMI is point-to-point and a
     ring / tree step is bound by one link, so a few large collectives reach a much higher bus bandwidth than one
-    per 16 MB layer, at the price of starting a little later.  TFK_DP_BUCKET_MB (default 48) sets the size.
+    per 16 MB layer, at the price of starting a little later.  TFK_DP_BUCKET_MB sets the size (default 48, 24 for the
+    sharded exchange).
 
     Two exchange steps (`mode`, env TFK_DP_EXCHANGE):
       "sharded" (default)  every coalesced gradient span is REDUCE-SCATTERED in place (rank r receives the sum of
@@ -142,9 +143,6 @@ class BucketReducer(object):
         self._dist = dist
         self.group = group
         self.view, self.buckets = engine.reduce_view(), engine.buckets()
-        if min_bytes is None:
-            min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", "48")) * (1 << 20))
-        self.min_floats = max(1, min_bytes // 4)
         self._stream_ctx = stream_ctx or contextlib.nullcontext
         mode = mode or os.environ.get("TFK_DP_EXCHANGE", "sharded")
         if mode not in ("sharded", "allreduce"):
@@ -152,10 +150,18 @@ class BucketReducer(object):
         if mode == "sharded" and not (hasattr(engine, "param_view") and hasattr(engine, "apply_span")):
             mode = "allreduce"
         self.mode = mode
+        if min_bytes is None:
+            # sharded: the parameter gathers are consumed layer by layer by the next forward pass, so finer spans
+            # overlap better (two 16 MB layers per collective at BASELINE cfg2); both values are untuned guesses --
+            # no multi-GPU node was available to this build
+            default_mb = "24" if mode == "sharded" else "48"
+            min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", default_mb)) * (1 << 20))
+        self.min_floats = max(1, min_bytes // 4)
         ready = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if ready else 1
         self.rank = dist.get_rank(group) if ready else 0
         self.num_params = self.buckets[-1][0]  # the scalar + BN tail starts where the gradient arena ends
+        self.vec_off = self.buckets[-2][0] if len(self.buckets) >= 2 else self.num_params  # bias / beta vectors
         self.handles, self.errors = [], []
         self._lo = self._hi = None
         self.launched = []  # (offset, floats) of every collective of the current step (tests / diagnostics)
@@ -171,20 +177,24 @@ class BucketReducer(object):
 
     def _shardable(self, lo, hi):
         n = hi - lo
-        return (self.mode == "sharded" and hi <= self.num_params and n % (4 * self.world) == 0
+        return (self.mode == "sharded" and hi <= self.vec_off and n % (4 * self.world) == 0
                 and n >= self.MIN_SHARD_FLOATS)
 
     def _launch(self):
         if self._lo is None:
             return
         lo, hi, self._lo, self._hi = self._lo, self._hi, None, None
-        if self.mode == "sharded" and lo < self.num_params < hi:
-            # a coalesced span that runs from the gradient arena into the scalar + BN tail: two collectives
-            self._lo, self._hi = lo, self.num_params
-            self._launch()
-            self._lo, self._hi = self.num_params, hi
-            self._launch()
-            return
+        if self.mode == "sharded":
+            # a coalesced span that runs from the weight matrices into the bias / beta vectors, or from the gradient
+            # arena into the scalar + BN tail, is cut there: only weight matrices are sharded (the vectors are a few
+            # thousand values: all-reduced and updated on every rank, so that no layer ever waits for THEIR gather)
+            for cut in (self.vec_off, self.num_params):
+                if lo < cut < hi:
+                    self._lo, self._hi = lo, cut
+                    self._launch()
+                    self._lo, self._hi = cut, hi
+                    self._launch()
+                    return
         d = self._dist
         with self._stream_ctx():
             h = None
