@@ -1151,8 +1151,12 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
                 float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb) {
   const size_t n4 = n / 4;
-  size_t blocks = (n4 + 255) / 256;
-  static const size_t max_blocks = [] { const char* q = getenv("TFK_ADAM_GRID"); return (size_t)(q ? atoi(q) : 256 * 32); }();  // measured: 2 groups per thread x 8192 blocks, cfg2 111 -> 107 us, cfg4 789 -> 723 us
+  static const int un_div = [] { const char* q = getenv("TFK_ADAM_UNROLL"); const int u = q ? atoi(q) : 2; return u == 4 ? 4 : u == 2 ? 2 : 1; }();
+  size_t blocks = ((n4 + un_div - 1) / un_div + 255) / 256;
+  // One trip per thread (grid = every group of 4 parameters / UN), not a grid-stride loop over a capped grid: round 2 measured,
+  // at BASELINE cfg4's 152 M parameters in mixed precision, 887 us with round 1's cap of 8192 blocks, 851 / 843 / 809 at 16 k / 32 k /
+  // 64 k and 742 us uncapped (5.7 TB/s); cfg2 (26 M parameters) is indifferent (105-109 us).  profiles/r02_adam_experiments.txt
+  static const size_t max_blocks = [] { const char* q = getenv("TFK_ADAM_GRID"); return (size_t)(q ? atoi(q) : (1 << 22)); }();
   if (blocks > max_blocks) blocks = max_blocks;
   if (grid_cap > 0 && blocks > (size_t)grid_cap) blocks = grid_cap;
   if (blocks == 0) return;
