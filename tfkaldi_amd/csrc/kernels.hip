@@ -929,12 +929,15 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
       if (i >= n4) continue;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float gk = fminf(fmaxf(el(gv[u], k) * inv_n, -1.f), 1.f);  // clip_by_value: trainer.py:178-179
-        const float mk = b1 * el(mv[u], k) + (1.f - b1) * gk;
-        const float vk = b2 * el(vv[u], k) + (1.f - b2) * gk * gk;
+        // Every operation is spelled out with its rounding: the result of an element must not depend on which unrolled
+        // body or which launch geometry processed it (the compiler contracted the two bodies differently -- 1-ulp
+        // differences between a span-wise and a whole-arena update, i.e. between the sharded and the serial step).
+        const float gk = fminf(fmaxf(__fmul_rn(el(gv[u], k), inv_n), -1.f), 1.f);  // clip_by_value: trainer.py:178-179
+        const float mk = __fmaf_rn(b1, el(mv[u], k), __fmul_rn(1.f - b1, gk));
+        const float vk = __fmaf_rn(b2, el(vv[u], k), __fmul_rn(1.f - b2, __fmul_rn(gk, gk)));
         el(mv[u], k) = mk;
         el(vv[u], k) = vk;
-        el(wv[u], k) -= lr_t * mk / (sqrtf(vk) + eps);
+        el(wv[u], k) = __fsub_rn(el(wv[u], k), __fdiv_rn(__fmul_rn(lr_t, mk), __fadd_rn(__fsqrt_rn(vk), eps)));
       }
       st4s<NT>(m + 4 * i, mv[u]);
       st4s<NT>(v + 4 * i, vv[u]);
