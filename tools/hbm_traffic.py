@@ -1,4 +1,4 @@
-"""Summarise the two rocprofv3 --pmc passes of tools/profile_step.sh (FETCH_SIZE, WRITE_SIZE: separate runs, as
+"""Summarise the two rocprofv3 --pmc passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE: separate runs, as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_hbm_traffic.{json,txt}.
 
     python tools/hbm_traffic.py gpurun_out/<tag> profiles/r02

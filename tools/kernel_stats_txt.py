@@ -1,4 +1,4 @@
-"""Turn rocprofv3's <pid>_kernel_stats.csv (tools/profile_step.sh, trace pass) into the profiles/<round>_bench_kernel_stats
+"""Turn rocprofv3's <pid>_kernel_stats.csv (tools/profile_round.sh, trace pass) into the profiles/<round>_bench_kernel_stats
 .csv / .txt pair.  usage: kernel_stats_txt.py gpurun_out/<tag> profiles/r01 ["note"]"""
 import csv
 import glob
