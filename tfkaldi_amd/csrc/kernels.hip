@@ -639,8 +639,10 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (t.col + k >= H) el(dz, k) = 0.f;
-        st4(da + (size_t)r * ld + t.col, dz);
-        st4_twin(tw, r, t.col, dz);
+        // mixed precision: both contractions that consume dz read its bf16 twin, nothing reads the fp32 copy again
+        // (the bias gradient is the column sum taken right here): it is not stored -- a third of this kernel's traffic
+        if (tw.p) st4_twin(tw, r, t.col, dz);
+        else st4(da + (size_t)r * ld + t.col, dz);
         sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
       }
 #pragma unroll
