@@ -4,6 +4,8 @@
 # counter passes; the same trace for the mixed-precision bench; then the per-configuration step lines.
 tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+# (the clock pre-warm GEMMs of bench.py are switched off under the profiler: they would fill the kernel statistics)
+export TFK_BENCH_PREWARM_MS=0
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B --steps 50 --warmup 5 > $out.trace.log 2>&1
@@ -15,6 +17,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-for
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_bf16 -- $B --steps 50 --warmup 5 --dtype bfloat16 > $out.trace_bf16.log 2>&1
 cd $GRAFT_REPO_ROOT
 for c in cfg2 cfg3 cfg4; do timeout 200 python tools/step_line.py $c $out.step_$c.json > /dev/null 2>&1; done
+unset TFK_BENCH_PREWARM_MS
 timeout 300 python bench.py --steps 100 --warmup 10 > $out.bench.json 2> $out.bench.err
 timeout 300 python bench.py --steps 100 --warmup 10 --dtype bfloat16 --no-cpu-baseline > $out.bench_bf16.json 2> $out.bench_bf16.err
 ls $out* | head -40
