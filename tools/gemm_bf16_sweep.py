@@ -15,6 +15,8 @@ from tfkaldi_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 NAMES = ["r64x64", "r128x64", "r128x128", "d128x64s5", "d128x128s4", "d256x128s3", "d128x64s3"]
+# TFK_SWEEP_CFGS="3,5": only these configurations
+SEL = [int(x) for x in os.environ["TFK_SWEEP_CFGS"].split(",")] if os.environ.get("TFK_SWEEP_CFGS") else list(range(len(NAMES)))
 LAY = ["NN", "NT", "TN"]
 
 
@@ -81,7 +83,7 @@ def main():
     quick = "--quick" in sys.argv
     outfile = [a for a in sys.argv[1:] if not a.startswith("--")]
     out = {}
-    cfgs = list(range(len(NAMES)))
+    cfgs = SEL
     confs = {"cfg3/gpu": (1024, 440, 2048, 4000), "cfg4/gpu": (2048, 440, 4096, 8000)}
     # small ragged problems: every configuration must be right on edge tiles too
     for layout, M, N, K in [(0, 37, 29, 13), (1, 65, 63, 130), (2, 100, 250, 72), (0, 300, 200, 136), (2, 129, 257, 520)]:
@@ -91,10 +93,10 @@ def main():
         assert max(errs) < 1e-5, "ragged-shape mismatch"
     for tag, (T, F, H, O) in confs.items():
         print("== %s  T=%d F=%d H=%d O=%d   (TFLOP/s, us; heuristic choice marked *)" % (tag, T, F, H, O))
-        print("%-5s %-2s %5s %5s %5s | " % ("op", "ly", "M", "N", "K") + " ".join("%13s" % n for n in NAMES))
+        print("%-5s %-2s %5s %5s %5s | " % ("op", "ly", "M", "N", "K") + " ".join("%13s" % NAMES[c] for c in cfgs))
         for name, layout, M, N, K in shapes(T, F, H, O):
             pr = Problem(layout, M, N, K)
-            errs = [pr.check(c) for c in cfgs]
+            errs = {c: pr.check(c) for c in cfgs}
             bad = [NAMES[c] for c in cfgs if errs[c] > 1e-5]
             lib.tfk_gemm_bf16_force_config(-1)
             pick = lib.tfk_gemm_bf16_config(M, N)
@@ -109,11 +111,11 @@ def main():
                 ms = statistics.median(times[c])
                 row.append((ms, 2.0 * M * N * K / ms / 1e9))
             out["%s/%s" % (tag, name)] = {"shape": [M, N, K], "layout": LAY[layout], "pick": pick,
-                                         "tflops": [r[1] for r in row], "us": [r[0] * 1e3 for r in row],
-                                         "rel_err": errs}
+                                         "configs": cfgs, "tflops": [r[1] for r in row], "us": [r[0] * 1e3 for r in row],
+                                         "rel_err": [errs[c] for c in cfgs]}
             print("%-5s %-2s %5d %5d %5d | " % (name, LAY[layout], M, N, K) +
                   " ".join("%6.0f%s%5.0fus" % (tf, "*" if c == pick else " ", ms * 1e3)
-                           for c, (ms, tf) in enumerate(row)) + ("   WRONG: %s" % bad if bad else ""), flush=True)
+                           for c, (ms, tf) in zip(cfgs, row)) + ("   WRONG: %s" % bad if bad else ""), flush=True)
     lib.tfk_gemm_bf16_force_config(-1)
     if outfile:
         json.dump(out, open(outfile[0], "w"), indent=1)
