@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 3
+#define TFK_ABI_VERSION 4
 
 typedef struct tfk_engine tfk_engine;
 
@@ -287,6 +287,73 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
  * tests only. */
 int tfk_gemm_bf16_force_config(int cfg);
 int tfk_gemm_bf16_config(int M, int N);
+
+/* ---- feature computation: wav samples -> fbank / mfcc / ssc (+ deltas), CMVN statistics ------------ */
+/*
+ * The step in FRONT of the feature reader: processing/feat.py:7-69 (FeatureComputer),
+ * processing/base.py:39-284 (mfcc, fbank, logfbank, ssc, lifter, deriv, delta, ddelta), processing/sigproc.py:33-191
+ * (preemphasis, framesig, magspec, powspec) and processing/prepare_data.py:80-118 (compute_cmvn), computed in
+ * float64 as the reference does (numpy's default), for a whole BATCH of utterances per call.
+ *
+ * All pointers of the compute calls are DEVICE pointers; work is ordered on `stream` (a hipStream_t; NULL = the
+ * default stream).  A plan may be used from one thread at a time.
+ *
+ * Signals of the batch are concatenated: utterance u owns samples [sig_off[u], sig_off[u+1]) and frames
+ * [frame_off[u], frame_off[u+1]) -- the caller counts frames as sigproc.py:49-55 does (1 if len <= frame_len, else
+ * 1 + ceil((len - frame_len) / frame_step)) -- and frame t of an utterance covers its samples
+ * [t*frame_step, t*frame_step + frame_len), zero-padded past the end of the utterance (sigproc.py:57-66), after the
+ * pre-emphasis y[0] = x[0], y[i] = x[i] - preemph * x[i-1] (sigproc.py:180-191).  Frames longer than nfft are
+ * truncated and shorter ones zero-padded by the transform (numpy.fft.rfft(frames, nfft): sigproc.py:138).
+ */
+typedef struct tfk_feat tfk_feat;
+
+enum { TFK_FEAT_FBANK = 0, TFK_FEAT_MFCC = 1, TFK_FEAT_SSC = 2,        /* feat.py:21-28: log-fbank, mfcc, ssc */
+       TFK_FEAT_FBANK_RAW = 3 };  /* base.fbank (base.py:59-98): filterbank energies and frame energy WITHOUT the log */
+enum { TFK_DYN_NODELTA = 0, TFK_DYN_DELTA = 1, TFK_DYN_DDELTA = 2 };   /* feat.py:30-37 */
+enum { TFK_SAMPLE_I16 = 0, TFK_SAMPLE_F64 = 1 };                       /* scipy.io.wavfile's int16 / anything else as float64 */
+enum { TFK_STAGE_FRAMES = 1, TFK_STAGE_MAGSPEC = 2, TFK_STAGE_POWSPEC = 3 };
+
+typedef struct tfk_feat_config {
+  int32_t struct_size;     /* sizeof(tfk_feat_config) */
+  int32_t device;          /* HIP device ordinal */
+  int32_t kind;            /* TFK_FEAT_* */
+  int32_t dynamic;         /* TFK_DYN_* */
+  int32_t frame_len;       /* samples per frame:  round(winlen * rate)  (sigproc.py:50) */
+  int32_t frame_step;      /* samples per step:   round(winstep * rate) (sigproc.py:51) */
+  int32_t nfft;            /* transform length: a power of two in [32, 4096] */
+  int32_t nfilt;           /* mel filters (<= nfft / 2) */
+  int32_t numcep;          /* TFK_FEAT_MFCC: cepstra kept (<= nfilt) */
+  int32_t include_energy;  /* append log(frame energy) as the last static column (feat.py:61-62) */
+  double preemph;          /* pre-emphasis coefficient */
+} tfk_feat_config;
+
+/* Tables are HOST pointers, copied: filterbank[nfilt][nfft/2+1] (base.get_filterbanks), bin_weight[nfft/2+1]
+ * (TFK_FEAT_SSC: numpy.linspace(1, rate/2, nfft/2+1), base.py:151), dct[nfilt][numcep] and lifter[numcep]
+ * (TFK_FEAT_MFCC: the orthonormal DCT-II matrix and the lifter weights, base.py:55-56,226-246). */
+int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const double* bin_weight, const double* dct,
+                    const double* lifter, tfk_feat** out);
+int tfk_feat_destroy(tfk_feat* f);
+/* columns of the feature matrix: (nfilt or numcep, + 1 with the energy) * (1, 2 or 3) */
+int tfk_feat_dim(const tfk_feat* f, int32_t* dim);
+/* FeatureComputer.__call__ (feat.py:42-69) for a batch: out[n_frames][ld_out] as float32 (what ArkWriter stores,
+ * ark.py:202) or float64 (what the reference's functions return). */
+int tfk_feat_compute(tfk_feat* f, void* stream, const void* signal, int sample_type, const int64_t* sig_off,
+                     const int64_t* frame_off, int32_t n_utts, int64_t n_frames, void* out, int64_t ld_out, int out_f64);
+/* Intermediate results of the same pipeline as float64: TFK_STAGE_FRAMES [n_frames][frame_len] (sigproc.framesig of
+ * the pre-emphasised signal), TFK_STAGE_MAGSPEC / TFK_STAGE_POWSPEC [n_frames][nfft/2+1] (sigproc.py:125-153). */
+int tfk_feat_stage(tfk_feat* f, void* stream, int stage, const void* signal, int sample_type, const int64_t* sig_off,
+                   const int64_t* frame_off, int32_t n_utts, int64_t n_frames, double* out, int64_t ld_out);
+/* base.deriv / delta / ddelta (base.py:248-284) on a float64 matrix x[n_rows][ld_x] of `dim` columns whose rows
+ * [row_off[u], row_off[u+1]) are one utterance each (scipy.ndimage.convolve1d's 'reflect' boundary applies per
+ * utterance): out[n_rows][ld_out] = [x | d x | d d x] limited to 1 + dynamic blocks.  deriv_only: out = d x. */
+int tfk_feat_dynamic(void* stream, const double* x, int64_t ld_x, int32_t dim, const int64_t* row_off, int32_t n_utts,
+                     int64_t n_rows, int dynamic, int deriv_only, void* out, int64_t ld_out, int out_f64);
+/* compute_cmvn (prepare_data.py:80-118): speaker s owns the utterances [spk_off[s], spk_off[s+1]) of the list
+ * (utt_row[q], utt_len[q]) = first row and row count in feats[.][ld] (float32, `dim` columns);
+ * stats[s] = [[sum x | count], [sum x^2 | 0]] as [2][dim+1] doubles, the sums accumulated row after row in float32
+ * exactly as numpy reduces the reference's float32 matrix. */
+int tfk_cmvn_stats(void* stream, const float* feats, int64_t ld, int32_t dim, const int64_t* spk_off,
+                   const int64_t* utt_row, const int64_t* utt_len, int32_t n_spk, double* stats);
 
 #ifdef __cplusplus
 }

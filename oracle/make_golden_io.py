@@ -1,9 +1,9 @@
 """Generate tests/golden/io_*.npz|.bin from the REFERENCE's own numpy code (run in the build container only).
 
 The reference's processing/ package is Python 2; it is converted with lib2to3 into a scratch directory under
-/tmp (never into this repository) with two mechanical shims -- numpy-2 rejects
-`np.set_printoptions(threshold=np.nan)` (processing/ark.py:25-26) and struct/bytes comparisons need
-bytes literals under Python 3 (ark.py:73-76, 204-206).  The fixtures are DATA: inputs and the outputs the
+/tmp (never into this repository) with mechanical shims -- numpy-2 rejects
+`np.set_printoptions(threshold=np.nan)` (processing/ark.py:25-26), struct/bytes comparisons need
+bytes literals under Python 3 (ark.py:73-76, 204-206), and Python 2's flooring int `/` in base.py becomes `//`.  The fixtures are DATA: inputs and the outputs the
 reference produced for them.
 
     python oracle/make_golden_io.py          # needs /root/reference; writes tests/golden/
@@ -40,6 +40,11 @@ def import_reference_processing():
     s = open(bd).read()
     s = s.replace("with gzip.open(target_path, 'rb') as fid:", "with gzip.open(target_path, 'rt') as fid:")
     open(bd, "w").write(s)
+    # base.py relies on Python 2's flooring `/` between ints (`nfft/2+1`, `samplerate/2`: base.py:76,134,151,205-217)
+    bp = os.path.join(dst, "base.py")
+    s = open(bp).read()
+    s = s.replace("nfft/2+1", "nfft//2+1").replace("samplerate/2", "samplerate//2")
+    open(bp, "w").write(s)
     sys.path.insert(0, scratch)
     sys.path.insert(0, dst)  # the package uses implicit relative imports (import ark, import readfiles)
     import processing.ark as ark_mod  # noqa

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_flo
 
 from .build import lib_path
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
@@ -41,6 +41,20 @@ class TfkKernelStat(Structure):
     _fields_ = [("name", c_char * 48), ("launches", c_int64), ("total_ms", c_double), ("flops", c_double),
                 ("bytes", c_double)]
 
+
+class TfkFeatConfig(Structure):
+    """tfk_feat_config of include/tfkaldi_hip.h (feature computation plan)"""
+    _fields_ = [
+        ("struct_size", c_int32), ("device", c_int32), ("kind", c_int32), ("dynamic", c_int32),
+        ("frame_len", c_int32), ("frame_step", c_int32), ("nfft", c_int32), ("nfilt", c_int32), ("numcep", c_int32),
+        ("include_energy", c_int32), ("preemph", c_double),
+    ]
+
+
+FEAT_KIND = {"fbank": 0, "mfcc": 1, "ssc": 2, "fbank_raw": 3}   # TFK_FEAT_*
+FEAT_DYNAMIC = {"nodelta": 0, "delta": 1, "ddelta": 2}          # TFK_DYN_*
+SAMPLE_I16, SAMPLE_F64 = 0, 1
+STAGE_FRAMES, STAGE_MAGSPEC, STAGE_POWSPEC = 1, 2, 3
 
 BUCKET_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int)
 
@@ -102,6 +116,16 @@ SYMBOLS = {
                               c_int, c_void_p, c_int]),
     "tfk_gemm_bf16_force_config": (c_int, [c_int]),
     "tfk_gemm_bf16_config": (c_int, [c_int, c_int]),
+    "tfk_feat_create": (c_int, [POINTER(TfkFeatConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(_E)]),
+    "tfk_feat_destroy": (c_int, [_E]),
+    "tfk_feat_dim": (c_int, [_E, POINTER(c_int32)]),
+    "tfk_feat_compute": (c_int, [_E, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64,
+                                 c_int]),
+    "tfk_feat_stage": (c_int, [_E, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int32, c_int64, c_void_p,
+                               c_int64]),
+    "tfk_feat_dynamic": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int64, c_int, c_int, c_void_p,
+                                 c_int64, c_int]),
+    "tfk_cmvn_stats": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
 }
 
 _lib = None

@@ -390,6 +390,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.act_beta = act ? act->beta : nullptr; b.bn_eps = act ? act->eps : 0.f;
     b.C_twin = act ? act->twin : nullptr; b.ldct = act ? act->ld_twin : 0;
     b.act_scale = act ? act->scale : 1.f;
+    b.act_keep = act ? 1.f / act->scale : 1.f;
     b.M = M; b.N = N; b.K = K; b.lda = lda8; b.ldb = ldb8; b.ldc = ldc; b.epi = epi;
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
@@ -406,6 +407,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   g.stats_stride = kMaxRowSplits;
   g.act_beta = act ? act->beta : nullptr; g.bn_eps = act ? act->eps : 0.f;
   g.act_scale = act ? act->scale : 1.f;
+  g.act_keep = act ? 1.f / act->scale : 1.f;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   if (layout == GEMM_TN && K >= 2048 && (size_t)M * N < ((size_t)1 << 20)) {
     // narrow layer, many frames: the weight gradient may run split-K (gemm_f32.h) -- partials of up to 32 chunks
@@ -439,6 +441,8 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
   a.act_mean = act ? act->mean : nullptr; a.act_rstd = act ? act->rstd : nullptr;
   a.act_nonlin = act ? act->nonlin : 0;
   a.act_scale = act ? act->scale : 1.f;
+  a.act_keep = act ? 1.f / act->scale : 1.f;
+  a.act_beta = act ? act->beta : nullptr;
   a.stats_stride = kMaxRowSplits;
   a.M = T; a.N = N_da; a.K = K_da; a.lda = ld_dz; a.ldb = ldw; a.ldc = ld_da; a.epi = act ? EPI_DACT : 0;
   w.A = in; w.B = dz; w.C = Gw; w.bias = nullptr; w.stats = nullptr;
@@ -827,12 +831,14 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     if (!fuse_hb) return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, 0);
     ActEpi act = {e->a[target], e->z[target], e->mean[target], e->rstd[target], e->cfg.nonlin};
     act.scale = dscale;
+    act.beta = e->p_param() + e->lay[target].beta_off;
     return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, EPI_DACT, nullptr, ws_of(target), cfg,
                     &act);
   };
   {
     ActEpi act = {e->a[nact - 1], e->z[nact - 1], e->mean[nact - 1], e->rstd[nact - 1], e->cfg.nonlin};
     act.scale = dscale;
+    act.beta = e->cfg.batch_norm ? e->p_param() + e->lay[nact - 1].beta_off : nullptr;
     const int rc = run_gemm_dual(e, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O,
                                  fuse_hb ? &act : nullptr, fuse_hb ? ws_of(nact - 1) : nullptr, e->a[nact - 1], ldH,
                                  G + o.w_off, o.ld_out, H, e->O, epi_w);
@@ -886,6 +892,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     if (l > 0) {  // dW_l and the dA that feeds layer l - 1 both read dz_l: one launch when eligible
       ActEpi act = {e->a[l - 1], e->z[l - 1], e->mean[l - 1], e->rstd[l - 1], e->cfg.nonlin};
       act.scale = dscale;
+      act.beta = e->cfg.batch_norm ? e->p_param() + e->lay[l - 1].beta_off : nullptr;
       const int rc = run_gemm_dual(e, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H,
                                    fuse_hb ? &act : nullptr, fuse_hb ? ws_of(l - 1) : nullptr, in, ld_in, G + y.w_off,
                                    y.ld_out, y.d_in, H, epi_w);
@@ -1217,6 +1224,11 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
 }
 
 }  // namespace
+
+namespace tfk {
+// the other translation units of the library (features.hip) report through the same thread-local message
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}  // namespace tfk
 
 extern "C" {
 

@@ -1,0 +1,535 @@
+// Feature computation on the device (gfx950): wav samples -> pre-emphasis -> frames -> power spectrum -> mel
+// filterbank -> log / DCT + lifter / spectral centroids -> deltas, and the per-speaker CMVN sums.
+//
+// Reference semantics (vrenkens/tfkaldi, all float64 numpy):
+//   processing/feat.py:42-69        FeatureComputer.__call__: features, optional log-energy column, dynamics
+//   processing/base.py:39-154       mfcc / fbank / logfbank / ssc
+//   processing/base.py:226-284      lifter, deriv (scipy.ndimage.convolve1d [2,1,0,-1,-2], 'reflect'), delta, ddelta
+//   processing/sigproc.py:33-191    framesig (rectangular window, zero padding), magspec, powspec, preemphasis
+//   processing/prepare_data.py:80-118  compute_cmvn (float32 row-after-row sums)
+//
+// Shape of the work: a frame is 400 samples in, 40 numbers out, ~25 kFLOP of float64 in between -- neither an HBM nor an
+// MFMA problem; what bounds it is LDS traffic of the transform.  One WAVEFRONT owns one frame: the 512-point real
+// transform is a 256-point complex radix-2 transform over (even, odd) sample pairs, resident in that wave's 6 KB slice
+// of LDS, untangled into the half spectrum on the way to the power; the mel filterbank is a dense [bins x filters]
+// product with the filter index on the lanes (coalesced table reads, LDS-broadcast spectrum); no intermediate leaves
+// the CU except the static features of utterances that need deltas (float64, read back by the dynamics kernel with
+// the 'reflect' boundary applied per utterance).  Thousands of frames of a whole batch of utterances go in one launch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/tfkaldi_hip.h"
+
+namespace tfk {
+int set_error(int code, const char* msg);  // engine.hip (thread-local message behind tfk_last_error)
+}
+
+namespace {
+
+constexpr double kEps = 2.220446049250313e-16;  // numpy.finfo(float).eps: base.py:84,94
+constexpr int kMaxFft = 4096;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return tfk::set_error(code ? code : -1, buf);
+}
+
+#define HIPCHK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct Batch {
+  const void* sig;
+  const int64_t* sig_off;
+  const int64_t* frame_off;
+  int n_utts;
+  int64_t n_frames;
+};
+
+struct FrameArgs {
+  Batch b;
+  int frame_len, frame_step, nfft, log2_n2, nfilt, ncep, kind, include_energy, stage;
+  double preemph, inv_nfft;
+  const double* fbT;   // [nbins][nfilt]
+  const double* binw;  // [nbins]
+  const double* dct;   // [nfilt][ncep]
+  const double* lift;  // [ncep]
+  const double2* tw;   // e^{-2 pi i k / nfft}, k < nfft/2
+  void* out;
+  int64_t ld_out;
+  int out_f64;
+};
+
+// last utterance whose first frame (row) is <= f
+__device__ __forceinline__ int find_utt(const int64_t* off, int n, int64_t f) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= f) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <int SAMPLE>
+__device__ __forceinline__ double raw_sample(const void* sig, int64_t i) {
+  if (SAMPLE == TFK_SAMPLE_I16) return (double)((const int16_t*)sig)[i];
+  return ((const double*)sig)[i];
+}
+
+// pre-emphasised sample i of the utterance at [base, base + len): sigproc.py:180-191 -- two roundings, as numpy's
+// `signal[1:] - coeff * signal[:-1]` has; zero past the end (the padding of sigproc.py:57-60 follows the filter)
+template <int SAMPLE>
+__device__ __forceinline__ double emph_sample(const void* sig, int64_t base, int64_t len, int64_t i, double coeff) {
+#pragma clang fp contract(off)  // HIP's __dmul_rn / __dsub_rn are plain operators: without this the pair fuses into one FMA
+  if (i >= len) return 0.0;
+  const double x = raw_sample<SAMPLE>(sig, base + i);
+  if (i == 0 || coeff == 0.0) return x;
+  const double scaled = coeff * raw_sample<SAMPLE>(sig, base + i - 1);
+  return x - scaled;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void put(void* out, int64_t idx, double v) { ((T*)out)[idx] = (T)v; }
+
+// LDS of one frame belongs to one wavefront: its DS instructions execute in order, so a wave-level fence (for the
+// compiler) is all that separates a transform stage from the next
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- sigproc.framesig of the pre-emphasised signal: out[f][n], n < frame_len ----
+template <int SAMPLE>
+__global__ __launch_bounds__(256) void frames_kernel(FrameArgs p) {
+  const int64_t f = blockIdx.x;
+  const int u = find_utt(p.b.frame_off, p.b.n_utts, f);
+  const int64_t t = f - p.b.frame_off[u];
+  const int64_t base = p.b.sig_off[u], len = p.b.sig_off[u + 1] - base;
+  double* out = (double*)p.out + f * p.ld_out;
+  for (int n = threadIdx.x; n < p.frame_len; n += blockDim.x)
+    out[n] = emph_sample<SAMPLE>(p.b.sig, base, len, t * p.frame_step + n, p.preemph);
+}
+
+// ---- one wavefront per frame: samples -> spectrum -> features ----
+template <int SAMPLE>
+__global__ __launch_bounds__(256) void feat_frames_kernel(FrameArgs p) {
+  extern __shared__ double lds[];
+  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N2 = p.nfft >> 1;
+  double2* tws = (double2*)lds;                         // twiddles, shared by the block's waves
+  double* zr = lds + 2 * N2 + (size_t)wave * (3 * N2 + 2);
+  double* zi = zr + N2;
+  double* pw = zi + N2;                                 // [N2 + 1] half spectrum (power or magnitude)
+  for (int k = threadIdx.x; k < N2; k += blockDim.x) tws[k] = p.tw[k];
+  __syncthreads();
+  const int64_t f = (int64_t)blockIdx.x * waves + wave;
+  if (f >= p.b.n_frames) return;                         // no block-wide barrier below this line
+
+  const int u = find_utt(p.b.frame_off, p.b.n_utts, f);
+  const int64_t t = f - p.b.frame_off[u];
+  const int64_t base = p.b.sig_off[u], len = p.b.sig_off[u + 1] - base;
+  const int used = min(p.frame_len, p.nfft);             // numpy.fft.rfft(frames, nfft) truncates / zero-pads
+  const int64_t s0 = t * p.frame_step;
+  // (even, odd) sample pairs become the complex points of the half-length transform, stored bit-reversed
+  for (int m = lane; m < N2; m += 64) {
+    const int n0 = 2 * m;
+    const double e = n0 < used ? emph_sample<SAMPLE>(p.b.sig, base, len, s0 + n0, p.preemph) : 0.0;
+    const double o = n0 + 1 < used ? emph_sample<SAMPLE>(p.b.sig, base, len, s0 + n0 + 1, p.preemph) : 0.0;
+    const int r = (int)(__brev((unsigned)m) >> (32 - p.log2_n2));
+    zr[r] = e;
+    zi[r] = o;
+  }
+  wave_sync();
+  for (int s = 0; s < p.log2_n2; ++s) {
+    const int half = 1 << s;
+    for (int b = lane; b < (N2 >> 1); b += 64) {
+      const int j = b & (half - 1);
+      const int i0 = ((b >> s) << (s + 1)) + j, i1 = i0 + half;
+      const double2 w = tws[(size_t)j * (N2 >> s)];
+      const double ar = zr[i0], ai = zi[i0], br = zr[i1], bi = zi[i1];
+      const double tr = w.x * br - w.y * bi, ti = w.x * bi + w.y * br;
+      zr[i0] = ar + tr; zi[i0] = ai + ti;
+      zr[i1] = ar - tr; zi[i1] = ai - ti;
+    }
+    wave_sync();
+  }
+  // untangle: X[k] = E[k] + W^k O[k] with E = (Z[k] + conj Z[N2-k]) / 2, O = -i (Z[k] - conj Z[N2-k]) / 2
+  double esum = 0.0;
+  for (int k = lane; k <= N2; k += 64) {
+    double xr, xi;
+    if (k == 0) { xr = zr[0] + zi[0]; xi = 0.0; }
+    else if (k == N2) { xr = zr[0] - zi[0]; xi = 0.0; }
+    else {
+      const double ar = zr[k], ai = zi[k], br = zr[N2 - k], bi = -zi[N2 - k];
+      const double er = 0.5 * (ar + br), ei = 0.5 * (ai + bi);
+      const double orr = 0.5 * (ai - bi), oi = -0.5 * (ar - br);
+      const double2 w = tws[k];
+      xr = er + (w.x * orr - w.y * oi);
+      xi = ei + (w.x * oi + w.y * orr);
+    }
+    const double h = hypot(xr, xi);                       // numpy.absolute (sigproc.py:139)
+    const double pk = p.inv_nfft * (h * h);                // 1.0/nfft * numpy.square(.) (sigproc.py:153)
+    pw[k] = p.stage == TFK_STAGE_MAGSPEC ? h : pk;
+    esum += pk;
+  }
+  wave_sync();
+  if (p.stage) {
+    double* out = (double*)p.out + f * p.ld_out;
+    for (int k = lane; k <= N2; k += 64) out[k] = pw[k];
+    return;
+  }
+  double energy = wave_sum(esum);                         // base.py:80-84
+  if (energy == 0.0) energy = kEps;
+
+  // mel filterbank: feat[j] = sum_k P[k] fb[j][k] over ALL bins, as numpy.dot does (base.py:90); filters on the lanes
+  double* logf = zr;                                      // the transform is done with its buffers
+  const int nbins = N2 + 1;
+  const int d_static = (p.kind == TFK_FEAT_MFCC ? p.ncep : p.nfilt);
+  const int64_t row = f * p.ld_out;
+  for (int j = lane; j < p.nfilt; j += 64) {
+    double acc = 0.0, num = 0.0;
+    if (p.kind == TFK_FEAT_SSC) {
+      for (int k = 0; k < nbins; ++k) {
+        const double w = p.fbT[(size_t)k * p.nfilt + j], pk = pw[k];
+        acc = fma(pk, w, acc);
+        num = fma(pk * p.binw[k], w, num);               // numpy.dot(pspec * tiles, filterbank.T) (base.py:154)
+      }
+    } else {
+      for (int k = 0; k < nbins; ++k) acc = fma(pw[k], p.fbT[(size_t)k * p.nfilt + j], acc);
+    }
+    double v;
+    if (p.kind == TFK_FEAT_SSC) {
+      v = num / acc;                                       // base.py:154: the denominator is not guarded there
+    } else {
+      if (acc == 0.0) acc = kEps;                          // base.py:93-94
+      v = p.kind == TFK_FEAT_FBANK_RAW ? acc : log(acc);
+    }
+    if (p.kind == TFK_FEAT_MFCC) logf[j] = v;
+    else if (p.out_f64) put<double>(p.out, row + j, v);
+    else put<float>(p.out, row + j, v);
+  }
+  if (p.kind == TFK_FEAT_MFCC) {
+    wave_sync();
+    for (int c = lane; c < p.ncep; c += 64) {
+      double acc = 0.0;
+      for (int j = 0; j < p.nfilt; ++j) acc = fma(logf[j], p.dct[(size_t)j * p.ncep + c], acc);
+      const double v = p.lift[c] * acc;                   // base.py:56,243
+      if (p.out_f64) put<double>(p.out, row + c, v); else put<float>(p.out, row + c, v);
+    }
+  }
+  if (p.include_energy && lane == 0) {                     // feat.py:61-62: log-energy is the last static column
+    const double v = p.kind == TFK_FEAT_FBANK_RAW ? energy : log(energy);
+    if (p.out_f64) put<double>(p.out, row + d_static, v); else put<float>(p.out, row + d_static, v);
+  }
+}
+
+// ---- base.deriv / delta / ddelta with scipy's 'reflect' boundary per utterance ----
+struct DynArgs {
+  const double* x;
+  int64_t ld_x;
+  int dim;
+  const int64_t* row_off;
+  int n_utts;
+  int64_t n_rows;
+  int dynamic, deriv_only;
+  void* out;
+  int64_t ld_out;
+  int out_f64;
+};
+
+__device__ __forceinline__ int64_t reflect(int64_t i, int64_t n) {  // d c b a | a b c d | d c b a
+  const int64_t period = 2 * n;
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - 1 - i : i;
+}
+
+// scipy's correlate1d on the anti-symmetric kernel: tmp = w0 x[t]; tmp += w[-2] (x[t-2] - x[t+2]); tmp += w[-1] (x[t-1] - x[t+1])
+__device__ __forceinline__ double deriv5(double c, double m2, double m1, double p1, double p2) {
+#pragma clang fp contract(off)
+  double acc = 0.0 * c;
+  acc = acc + -2.0 * (m2 - p2);
+  acc = acc + -1.0 * (m1 - p1);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void dynamic_kernel(DynArgs p) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.n_rows * p.dim) return;
+  const int64_t f = idx / p.dim;
+  const int c = (int)(idx - f * p.dim);
+  const int u = find_utt(p.row_off, p.n_utts, f);
+  const int64_t r0 = p.row_off[u], n = p.row_off[u + 1] - r0, t = f - r0;
+  auto X = [&](int64_t tt) { return p.x[(r0 + reflect(tt, n)) * p.ld_x + c]; };
+  auto D1 = [&](int64_t tt) {
+    const int64_t q = reflect(tt, n);                      // the first derivative AT a (reflected) frame
+    return deriv5(X(q), X(q - 2), X(q - 1), X(q + 1), X(q + 2));
+  };
+  const double x0 = X(t), d1 = D1(t);
+  const int64_t row = f * p.ld_out;
+  auto store = [&](int64_t col, double v) {
+    if (p.out_f64) put<double>(p.out, row + col, v); else put<float>(p.out, row + col, v);
+  };
+  if (p.deriv_only) { store(c, d1); return; }
+  store(c, x0);
+  if (p.dynamic >= 1) store(p.dim + c, d1);
+  if (p.dynamic >= 2) store(2 * (int64_t)p.dim + c, deriv5(d1, D1(t - 2), D1(t - 1), D1(t + 1), D1(t + 2)));
+}
+
+// ---- compute_cmvn: float32 sums accumulated row after row (numpy's axis-0 reduction of a C-contiguous matrix) ----
+__global__ __launch_bounds__(64) void cmvn_stats_kernel(const float* __restrict__ feats, int64_t ld, int dim,
+                                                        const int64_t* __restrict__ spk_off,
+                                                        const int64_t* __restrict__ utt_row,
+                                                        const int64_t* __restrict__ utt_len, double* __restrict__ stats) {
+#pragma clang fp contract(off)  // numpy squares in float32 and then adds: two roundings
+  const int s = blockIdx.x;
+  const int c = blockIdx.y * 64 + threadIdx.x;
+  double* out = stats + (size_t)s * 2 * (dim + 1);
+  int64_t count = 0;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t q = spk_off[s]; q < spk_off[s + 1]; ++q) {
+    const int64_t n = utt_len[q];
+    count += n;
+    if (c >= dim) continue;
+    const float* x = feats + utt_row[q] * ld + c;
+    int64_t r = 0;
+    for (; r + 8 <= n; r += 8) {                           // loads are independent of the (serial) adds: batch them
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = x[(r + i) * ld];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float sq = v[i] * v[i];                        // numpy.square in float32, then the float32 sum
+        s1 = s1 + v[i];
+        s2 = s2 + sq;
+      }
+    }
+    for (; r < n; ++r) {
+      const float v = x[r * ld];
+      const float sq = v * v;
+      s1 = s1 + v;
+      s2 = s2 + sq;
+    }
+  }
+  if (c < dim) {
+    out[c] = (double)s1;
+    out[dim + 1 + c] = (double)s2;
+  } else if (c == dim) {
+    out[dim] = (double)count;                              // prepare_data.py:111
+    out[2 * dim + 1] = 0.0;
+  }
+}
+
+int check_batch(const void* signal, const int64_t* sig_off, const int64_t* frame_off, int32_t n_utts, int64_t n_frames,
+                const void* out, int sample_type) {
+  if (n_utts < 0 || n_frames < 0) return fail(-1, "negative batch size");
+  if (n_frames == 0 || n_utts == 0) return 0;
+  if (!signal || !sig_off || !frame_off || !out) return fail(-1, "NULL device pointer");
+  if (sample_type != TFK_SAMPLE_I16 && sample_type != TFK_SAMPLE_F64) return fail(-1, "unknown sample type %d", sample_type);
+  return 0;
+}
+
+}  // namespace
+
+struct tfk_feat {
+  tfk_feat_config cfg;
+  int nbins, d0, dim, log2_n2;
+  double* tables = nullptr;  // one allocation: fbT | binw | dct | lift | twiddles
+  double *fbT = nullptr, *binw = nullptr, *dct = nullptr, *lift = nullptr;
+  double2* tw = nullptr;
+  double* work = nullptr;    // static features of a batch that needs deltas, [frames][d0] float64
+  size_t work_cap = 0;
+};
+
+namespace {
+
+FrameArgs frame_args(const tfk_feat* f, const void* signal, const int64_t* sig_off, const int64_t* frame_off,
+                     int n_utts, int64_t n_frames) {
+  FrameArgs a;
+  memset(&a, 0, sizeof(a));
+  a.b = Batch{signal, sig_off, frame_off, n_utts, n_frames};
+  a.frame_len = f->cfg.frame_len; a.frame_step = f->cfg.frame_step; a.nfft = f->cfg.nfft; a.log2_n2 = f->log2_n2;
+  a.nfilt = f->cfg.nfilt; a.ncep = f->cfg.numcep; a.kind = f->cfg.kind; a.include_energy = f->cfg.include_energy;
+  a.preemph = f->cfg.preemph; a.inv_nfft = 1.0 / f->cfg.nfft;
+  a.fbT = f->fbT; a.binw = f->binw; a.dct = f->dct; a.lift = f->lift; a.tw = f->tw;
+  return a;
+}
+
+int launch_frames(const tfk_feat* f, hipStream_t st, const FrameArgs& a, int sample_type) {
+  const int N2 = f->cfg.nfft / 2;
+  const int waves = f->cfg.nfft <= 1024 ? 4 : 1;          // 160 KB of LDS per CU: 6 KB per frame at nfft 512
+  const size_t lds = ((size_t)2 * N2 + (size_t)waves * (3 * N2 + 2)) * sizeof(double);
+  const unsigned grid = (unsigned)((a.b.n_frames + waves - 1) / waves);
+  if (sample_type == TFK_SAMPLE_I16)
+    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_I16>, dim3(grid), dim3(64 * waves), lds, st, a);
+  else
+    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_F64>, dim3(grid), dim3(64 * waves), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const double* bin_weight, const double* dct,
+                    const double* lifter, tfk_feat** out) {
+  if (!cfg || !out) return fail(-1, "cfg / out is NULL");
+  if (cfg->struct_size != (int32_t)sizeof(tfk_feat_config))
+    return fail(-1, "tfk_feat_config.struct_size %d != %zu", cfg->struct_size, sizeof(tfk_feat_config));
+  if (cfg->kind < TFK_FEAT_FBANK || cfg->kind > TFK_FEAT_FBANK_RAW) return fail(-1, "unknown feature type %d", cfg->kind);
+  if (cfg->dynamic < TFK_DYN_NODELTA || cfg->dynamic > TFK_DYN_DDELTA) return fail(-1, "unknown dynamic type %d", cfg->dynamic);
+  if (cfg->frame_len < 1 || cfg->frame_step < 1) return fail(-1, "frame_len / frame_step must be positive");
+  int lg = 0;
+  while ((1 << lg) < cfg->nfft) ++lg;
+  if (cfg->nfft < 32 || cfg->nfft > kMaxFft || (1 << lg) != cfg->nfft)
+    return fail(-1, "nfft %d: the device transform takes a power of two in [32, %d]", cfg->nfft, kMaxFft);
+  if (cfg->nfilt < 1 || cfg->nfilt > cfg->nfft / 2) return fail(-1, "nfilt %d must be in [1, nfft/2]", cfg->nfilt);
+  if (!filterbank) return fail(-1, "filterbank is NULL");
+  if (cfg->kind == TFK_FEAT_MFCC && (cfg->numcep < 1 || cfg->numcep > cfg->nfilt || !dct || !lifter))
+    return fail(-1, "mfcc needs 1 <= numcep <= nfilt, a DCT matrix and lifter weights");
+  if (cfg->kind == TFK_FEAT_SSC && !bin_weight) return fail(-1, "ssc needs the bin weights");
+  HIPCHK(hipSetDevice(cfg->device));
+  tfk_feat* f = new tfk_feat();
+  f->cfg = *cfg;
+  f->nbins = cfg->nfft / 2 + 1;
+  f->log2_n2 = lg - 1;
+  f->d0 = (cfg->kind == TFK_FEAT_MFCC ? cfg->numcep : cfg->nfilt) + (cfg->include_energy ? 1 : 0);
+  f->dim = f->d0 * (1 + cfg->dynamic);
+  const int ncep = cfg->kind == TFK_FEAT_MFCC ? cfg->numcep : 0;
+  const size_t n_fb = (size_t)f->nbins * cfg->nfilt, n_dct = (size_t)cfg->nfilt * ncep, n_tw = (size_t)cfg->nfft;  // nfft/2 double2
+  std::vector<double> host(n_fb + f->nbins + n_dct + ncep + n_tw, 0.0);
+  double* h = host.data();
+  for (int j = 0; j < cfg->nfilt; ++j)                       // transposed: the filter index runs over the lanes
+    for (int k = 0; k < f->nbins; ++k) h[(size_t)k * cfg->nfilt + j] = filterbank[(size_t)j * f->nbins + k];
+  h += n_fb;
+  if (bin_weight) memcpy(h, bin_weight, f->nbins * sizeof(double));
+  h += f->nbins;
+  if (ncep) { memcpy(h, dct, n_dct * sizeof(double)); memcpy(h + n_dct, lifter, ncep * sizeof(double)); }
+  h += n_dct + ncep;
+  for (int k = 0; k < cfg->nfft / 2; ++k) {
+    const long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / cfg->nfft;
+    h[2 * k] = (double)cosl(ang);
+    h[2 * k + 1] = (double)sinl(ang);
+  }
+  hipError_t e = hipMalloc((void**)&f->tables, host.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(f->tables, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (f->tables) hipFree(f->tables);
+    delete f;
+    return fail((int)e, "feature tables: %s", hipGetErrorString(e));
+  }
+  f->fbT = f->tables;
+  f->binw = f->fbT + n_fb;
+  f->dct = f->binw + f->nbins;
+  f->lift = f->dct + n_dct;
+  f->tw = (double2*)(f->lift + ncep);
+  *out = f;
+  return 0;
+}
+
+int tfk_feat_destroy(tfk_feat* f) {
+  if (!f) return 0;
+  if (f->work) hipFree(f->work);
+  if (f->tables) hipFree(f->tables);
+  delete f;
+  return 0;
+}
+
+int tfk_feat_dim(const tfk_feat* f, int32_t* dim) {
+  if (!f || !dim) return fail(-1, "NULL argument");
+  *dim = f->dim;
+  return 0;
+}
+
+int tfk_feat_compute(tfk_feat* f, void* stream, const void* signal, int sample_type, const int64_t* sig_off,
+                     const int64_t* frame_off, int32_t n_utts, int64_t n_frames, void* out, int64_t ld_out, int out_f64) {
+  if (!f) return fail(-1, "plan is NULL");
+  if (int rc = check_batch(signal, sig_off, frame_off, n_utts, n_frames, out, sample_type)) return rc;
+  if (n_frames == 0 || n_utts == 0) return 0;
+  if (ld_out < f->dim) return fail(-1, "ld_out %lld < feature dimension %d", (long long)ld_out, f->dim);
+  hipStream_t st = (hipStream_t)stream;
+  FrameArgs a = frame_args(f, signal, sig_off, frame_off, n_utts, n_frames);
+  if (f->cfg.dynamic == TFK_DYN_NODELTA) {
+    a.out = out; a.ld_out = ld_out; a.out_f64 = out_f64;
+    return launch_frames(f, st, a, sample_type);
+  }
+  const size_t need = (size_t)n_frames * f->d0;
+  if (need > f->work_cap) {                                 // stream-ordered growth: earlier launches may still read it
+    if (f->work) HIPCHK(hipFreeAsync(f->work, st));
+    f->work = nullptr; f->work_cap = 0;
+    const size_t cap = need + need / 4;
+    HIPCHK(hipMallocAsync((void**)&f->work, cap * sizeof(double), st));
+    f->work_cap = cap;
+  }
+  a.out = f->work; a.ld_out = f->d0; a.out_f64 = 1;
+  if (int rc = launch_frames(f, st, a, sample_type)) return rc;
+  return tfk_feat_dynamic(stream, f->work, f->d0, f->d0, frame_off, n_utts, n_frames, f->cfg.dynamic, 0, out, ld_out, out_f64);
+}
+
+int tfk_feat_stage(tfk_feat* f, void* stream, int stage, const void* signal, int sample_type, const int64_t* sig_off,
+                   const int64_t* frame_off, int32_t n_utts, int64_t n_frames, double* out, int64_t ld_out) {
+  if (!f) return fail(-1, "plan is NULL");
+  if (stage < TFK_STAGE_FRAMES || stage > TFK_STAGE_POWSPEC) return fail(-1, "unknown stage %d", stage);
+  if (int rc = check_batch(signal, sig_off, frame_off, n_utts, n_frames, out, sample_type)) return rc;
+  if (n_frames == 0 || n_utts == 0) return 0;
+  const int cols = stage == TFK_STAGE_FRAMES ? f->cfg.frame_len : f->nbins;
+  if (ld_out < cols) return fail(-1, "ld_out %lld < %d columns of this stage", (long long)ld_out, cols);
+  hipStream_t st = (hipStream_t)stream;
+  FrameArgs a = frame_args(f, signal, sig_off, frame_off, n_utts, n_frames);
+  a.out = out; a.ld_out = ld_out; a.out_f64 = 1; a.stage = stage;
+  if (stage != TFK_STAGE_FRAMES) return launch_frames(f, st, a, sample_type);
+  if (n_frames > 0x7fffffffLL) return fail(-1, "too many frames for one launch");
+  if (sample_type == TFK_SAMPLE_I16)
+    hipLaunchKernelGGL(frames_kernel<TFK_SAMPLE_I16>, dim3((unsigned)n_frames), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(frames_kernel<TFK_SAMPLE_F64>, dim3((unsigned)n_frames), dim3(256), 0, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tfk_feat_dynamic(void* stream, const double* x, int64_t ld_x, int32_t dim, const int64_t* row_off, int32_t n_utts,
+                     int64_t n_rows, int dynamic, int deriv_only, void* out, int64_t ld_out, int out_f64) {
+  if (n_rows == 0 || n_utts == 0 || dim == 0) return 0;
+  if (!x || !row_off || !out || n_rows < 0 || n_utts < 0 || dim < 0) return fail(-1, "bad argument");
+  if (dynamic < TFK_DYN_NODELTA || dynamic > TFK_DYN_DDELTA) return fail(-1, "unknown dynamic type %d", dynamic);
+  const int64_t cols = deriv_only ? dim : (int64_t)dim * (1 + dynamic);
+  if (ld_x < dim || ld_out < cols) return fail(-1, "leading dimension smaller than the row");
+  DynArgs a{x, ld_x, dim, row_off, n_utts, n_rows, dynamic, deriv_only, out, ld_out, out_f64};
+  const int64_t total = n_rows * dim;
+  hipLaunchKernelGGL(dynamic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tfk_cmvn_stats(void* stream, const float* feats, int64_t ld, int32_t dim, const int64_t* spk_off,
+                   const int64_t* utt_row, const int64_t* utt_len, int32_t n_spk, double* stats) {
+  if (n_spk == 0) return 0;
+  if (!feats || !spk_off || !utt_row || !utt_len || !stats || dim < 1 || n_spk < 0 || ld < dim)
+    return fail(-1, "bad argument");
+  hipLaunchKernelGGL(cmvn_stats_kernel, dim3((unsigned)n_spk, (unsigned)(dim / 64 + 1)), dim3(64), 0,
+                     (hipStream_t)stream, feats, ld, dim, spk_off, utt_row, utt_len, stats);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

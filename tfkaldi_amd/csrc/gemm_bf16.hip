@@ -141,6 +141,10 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
       // da -> du = da * f'(a) in the accumulators + the two column sums of batch-norm's backward for this tile
       const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
       const float dscale = p.act_scale > 0.f ? p.act_scale : 1.f;
+      // ReLU chains: the normalised pre-activation where du != 0 is a * keep - beta -- z is not read (gemm_f32.hip)
+      const bool from_a = p.act_nonlin == 0 && p.act_beta != nullptr;
+      const float be = from_a ? p.act_beta[colc] : 0.f;
+      const float keep = p.act_keep > 0.f ? p.act_keep : 1.f;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int a = 0; a < FM; ++a) {
@@ -149,7 +153,13 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
         for (int r = 0; r < 16; ++r) {
           const int row = min(row_of(a, r), p.M - 1);
           av[r] = p.act_a[(size_t)row * p.ldc + colc];
-          zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+        }
+        if (!from_a) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(row_of(a, r), p.M - 1);
+            zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -164,7 +174,7 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
           acc[a][b][r] = du;
           if (row_of(a, r) < p.M) {
             s1 += du;
-            s2 += du * (zv[r] - mu) * rsd;
+            s2 += du * (from_a ? av[r] * keep - be : (zv[r] - mu) * rsd);
           }
         }
       }

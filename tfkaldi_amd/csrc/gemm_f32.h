@@ -58,6 +58,8 @@ struct GemmArgs {
   // EPI_DACT with dropout behind a ReLU: a = relu(u) * keep_mask / keep, so d a / d u = (a > 0) / keep -- the mask
   // need not be regenerated.  act_scale = 1 / keep (1 without dropout); only valid with act_nonlin == relu.
   float act_scale = 1.f;
+  float act_keep = 1.f;   // EPI_DACT: keep_prob (1 without dropout); with act_beta set and a ReLU chain the epilogue takes
+                          // the normalised pre-activation from the layer output (a * keep - beta) and does not read act_z
   // Split-K (optional; epi 0 / EPI_ACCUM only): when the output has too few tiles to fill the chip and K is long
   // -- the weight gradient of a narrow layer over many frames -- the contraction is cut into chunks that run as
   // extra blocks into partial results in `splitk_ws`, summed in chunk order by a second kernel (deterministic).

@@ -561,6 +561,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
       const int col = n0 + wn * T::WN + b * 32 + i;
       const int colc = min(col, p.N - 1);
       const float mu = p.act_mean[colc], rsd = p.act_rstd[colc];
+      // ReLU chains: du is non-zero only where a > 0, and there the normalised pre-activation is a * keep - beta
+      // (a = relu(xhat + beta) * mask / keep): the second statistic needs no read of z at all -- half of this
+      // epilogue's traffic.  Other nonlinearities read z and use (z - mean) * rstd.
+      const bool from_a = p.act_nonlin == 0 && p.act_beta != nullptr;
+      const float be = from_a ? p.act_beta[colc] : 0.f;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int a = 0; a < T::FM; ++a) {
@@ -570,7 +575,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
         for (int r = 0; r < 16; ++r) {
           const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
           av[r] = p.act_a[(size_t)row * p.ldc + colc];
-          zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+        }
+        if (!from_a) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+            zv[r] = p.act_z[(size_t)row * p.ldc + colc];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -591,7 +602,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
           acc[0][a][b][r] = du;
           if (rbase + (r & 3) + 8 * (r >> 2) < p.M) {
             s1 += du;
-            s2 += du * (zv[r] - mu) * rsd;
+            s2 += du * (from_a ? av[r] * p.act_keep - be : (zv[r] - mu) * rsd);
           }
         }
       }

@@ -1,0 +1,42 @@
+"""FeatureComputer with the reference's interface (processing/feat.py), running on the GPU."""
+import numpy as np
+
+from . import base
+
+
+class FeatureComputer(object):
+    """computes one type of features (feat.py:7-69).  `__call__` is the reference's per-utterance entry point;
+    `compute_batch` does a whole list of utterances in one device pass."""
+
+    def __init__(self, featureType, dynamic, conf):
+        if featureType not in ('fbank', 'mfcc', 'ssc'):
+            raise Exception('unknown feature type')
+        if dynamic not in ('nodelta', 'delta', 'ddelta'):
+            raise Exception('unknown dynamic type')
+        self.feature_type, self.dynamic, self.conf = featureType, dynamic, conf
+        self._plans = {}
+
+    def plan(self, rate):
+        if rate not in self._plans:
+            self._plans[rate] = base.make_plan(self.feature_type, self.dynamic, rate, self.conf,
+                                               include_energy=self.conf['include_energy'] == 'True')
+        return self._plans[rate]
+
+    def _prepared(self, sig, rate):
+        if self.conf['snip_edges'] == 'True':
+            sig = snip(sig, rate, float(self.conf['winlen']), float(self.conf['winstep']))
+        return sig
+
+    def __call__(self, sig, rate):
+        """feat.py:42-69: [NUMFRAMES, dim] float64"""
+        return self.plan(rate).compute([self._prepared(np.asarray(sig), rate)])[0]
+
+    def compute_batch(self, sigs, rate, dtype=np.float32):
+        """features of many utterances recorded at one sample rate; float32 is what the ark files store"""
+        return self.plan(rate).compute([self._prepared(np.asarray(s), rate) for s in sigs], dtype=dtype)
+
+
+def snip(sig, rate, winlen, winstep):
+    """feat.py:71-90: cut the tail that does not fill a whole window step"""
+    num_frames = int((len(sig) - winlen * rate) / (winstep * rate))
+    return sig[0:int(num_frames * winstep * rate + winlen * rate)]
