@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/tfkaldi_hip.h"
@@ -58,15 +59,31 @@ struct Batch {
   int64_t n_frames;
 };
 
+// Where a frame starts, resolved once per batch by frame_meta_kernel: the transform kernel then begins with ONE
+// 16-byte load instead of an utterance search and three dependent offset loads.
+struct FrameMeta {
+  int64_t start;   // index of the frame's first sample in the concatenated signal
+  int32_t avail;   // samples of its utterance from there on (<= 0: none), clamped to int32
+  int32_t first;   // the frame starts at sample 0 of its utterance (y[0] = x[0], sigproc.py:191)
+};
+
+// The mel filterbank is triangles: filter j is non-zero on the bins [lo[j], lo[j] + cnt[j]) only, and its weights
+// there sit at val[off[j] ...] -- ~2 values per bin instead of nfilt.
 struct FrameArgs {
   Batch b;
   int frame_len, frame_step, nfft, log2_n2, nfilt, ncep, kind, include_energy, stage;
   double preemph, inv_nfft;
-  const double* fbT;   // [nbins][nfilt]
-  const double* binw;  // [nbins]
-  const double* dct;   // [nfilt][ncep]
-  const double* lift;  // [ncep]
-  const double2* tw;   // e^{-2 pi i k / nfft}, k < nfft/2
+  const int* fb_meta;    // [3][nfilt]: lo | cnt | off, then (n_items > 0) [4][64] items: filter | lo | cnt | off, [nfilt+1] first item
+  const double* fb_val;  // [fb_nnz]
+  int fb_nnz;
+  int n_items;           // > 0: the supports are cut into <= 64 pieces of near-equal length, one per lane (see create)
+  int n_meta;            // ints in fb_meta
+  int dct_lds;           // the DCT matrix is small enough to be staged in LDS
+  const double* binw;    // [nbins]
+  const double* dct;     // [nfilt][ncep]
+  const double* lift;    // [ncep]
+  const double2* tw;     // e^{-2 pi i k / nfft}, k < nfft/2
+  const FrameMeta* fmeta;  // [n_frames]
   void* out;
   int64_t ld_out;
   int out_f64;
@@ -130,66 +147,157 @@ __global__ __launch_bounds__(256) void frames_kernel(FrameArgs p) {
 }
 
 // ---- one wavefront per frame: samples -> spectrum -> features ----
+struct alignas(16) Cplx { double x, y; };  // 16-byte LDS accesses: a wave's 64 points sweep all banks once
+__device__ __forceinline__ Cplx cmul(Cplx a, double2 w) { return Cplx{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+
+// pre-emphasised sample n of the frame described by fm (emph_sample in frame coordinates)
 template <int SAMPLE>
-__global__ __launch_bounds__(256) void feat_frames_kernel(FrameArgs p) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ double emph_at(const void* sig, const FrameMeta& fm, int n, double coeff) {
+#pragma clang fp contract(off)
+  if (n >= fm.avail) return 0.0;
+  const double x = raw_sample<SAMPLE>(sig, fm.start + n);
+  if ((n == 0 && fm.first) || coeff == 0.0) return x;
+  const double scaled = coeff * raw_sample<SAMPLE>(sig, fm.start + n - 1);
+  return x - scaled;
+}
+
+// (even, odd) pre-emphasised sample pair m of a frame: one complex point of the half-length transform
+template <int SAMPLE>
+__device__ __forceinline__ Cplx sample_pair(const FrameArgs& p, const FrameMeta& fm, int used, int m) {
+  const int n0 = 2 * m;
+  Cplx v;
+  v.x = n0 < used ? emph_at<SAMPLE>(p.b.sig, fm, n0, p.preemph) : 0.0;
+  v.y = n0 + 1 < used ? emph_at<SAMPLE>(p.b.sig, fm, n0 + 1, p.preemph) : 0.0;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void frame_meta_kernel(Batch b, int frame_step, FrameMeta* out) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= b.n_frames) return;
+  const int u = find_utt(b.frame_off, b.n_utts, f);
+  const int64_t t = f - b.frame_off[u];
+  const int64_t base = b.sig_off[u], len = b.sig_off[u + 1] - base, s0 = t * frame_step;
+  const int64_t avail = len - s0;
+  out[f] = FrameMeta{base + s0, (int32_t)(avail > 0x7fffffff ? 0x7fffffff : (avail < 0 ? 0 : avail)), t == 0 ? 1 : 0};
+}
+
+// twiddle e^{-2 pi i m / nfft} for m < nfft (the table holds the first half turn)
+__device__ __forceinline__ double2 twiddle(const double2* tws, int N2, int m) {
+  if (m < N2) return tws[m];
+  const double2 w = tws[m - N2];
+  return double2{-w.x, -w.y};
+}
+
+template <int SAMPLE>
+__global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int N2 = p.nfft >> 1;
-  double2* tws = (double2*)lds;                         // twiddles, shared by the block's waves
-  double* zr = lds + 2 * N2 + (size_t)wave * (3 * N2 + 2);
-  double* zi = zr + N2;
-  double* pw = zi + N2;                                 // [N2 + 1] half spectrum (power or magnitude)
+  const int N2 = p.nfft >> 1, nbins = N2 + 1;
+  // block-shared tables, then two [N2] complex buffers per wave
+  double2* tws = (double2*)lds;
+  double* fbv = lds + 2 * N2;
+  double* binw = fbv + p.fb_nnz;
+  double* dcts = binw + (p.kind == TFK_FEAT_SSC ? nbins : 0);
+  int* meta = (int*)(dcts + (p.dct_lds ? p.nfilt * p.ncep : 0));
+  const size_t table_bytes = ((size_t)((double*)meta - lds) * sizeof(double) + (size_t)p.n_meta * sizeof(int) + 15) & ~(size_t)15;
+  double* mine = lds + table_bytes / sizeof(double) + (size_t)wave * 4 * N2;
+  Cplx* bufA = (Cplx*)mine;
+  Cplx* bufB = bufA + N2;
   for (int k = threadIdx.x; k < N2; k += blockDim.x) tws[k] = p.tw[k];
+  for (int k = threadIdx.x; k < p.fb_nnz; k += blockDim.x) fbv[k] = p.fb_val[k];
+  for (int k = threadIdx.x; k < p.n_meta; k += blockDim.x) meta[k] = p.fb_meta[k];
+  if (p.kind == TFK_FEAT_SSC)
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) binw[k] = p.binw[k];
+  if (p.dct_lds)
+    for (int k = threadIdx.x; k < p.nfilt * p.ncep; k += blockDim.x) dcts[k] = p.dct[k];
   __syncthreads();
   const int64_t f = (int64_t)blockIdx.x * waves + wave;
   if (f >= p.b.n_frames) return;                         // no block-wide barrier below this line
 
-  const int u = find_utt(p.b.frame_off, p.b.n_utts, f);
-  const int64_t t = f - p.b.frame_off[u];
-  const int64_t base = p.b.sig_off[u], len = p.b.sig_off[u + 1] - base;
+  const FrameMeta fm = p.fmeta[f];
   const int used = min(p.frame_len, p.nfft);             // numpy.fft.rfft(frames, nfft) truncates / zero-pads
-  const int64_t s0 = t * p.frame_step;
-  // (even, odd) sample pairs become the complex points of the half-length transform, stored bit-reversed
-  for (int m = lane; m < N2; m += 64) {
-    const int n0 = 2 * m;
-    const double e = n0 < used ? emph_sample<SAMPLE>(p.b.sig, base, len, s0 + n0, p.preemph) : 0.0;
-    const double o = n0 + 1 < used ? emph_sample<SAMPLE>(p.b.sig, base, len, s0 + n0 + 1, p.preemph) : 0.0;
-    const int r = (int)(__brev((unsigned)m) >> (32 - p.log2_n2));
-    zr[r] = e;
-    zi[r] = o;
+
+  // Half-length complex transform, Stockham autosort (natural order in and out, ping-pong between the two buffers),
+  // radix 4 with one leading radix-2 pass when log2(N2) is odd.  The first pass has unit twiddles and takes its
+  // points straight from global memory.
+  Cplx* src = bufA;
+  Cplx* dst = bufB;
+  int Ns;
+  if (p.log2_n2 & 1) {
+    for (int j = lane; j < (N2 >> 1); j += 64) {
+      const Cplx a = sample_pair<SAMPLE>(p, fm, used, j);
+      const Cplx b = sample_pair<SAMPLE>(p, fm, used, j + (N2 >> 1));
+      dst[2 * j] = Cplx{a.x + b.x, a.y + b.y};
+      dst[2 * j + 1] = Cplx{a.x - b.x, a.y - b.y};
+    }
+    Ns = 2;
+  } else {
+    const int q = N2 >> 2;
+    for (int j = lane; j < q; j += 64) {
+      const Cplx v0 = sample_pair<SAMPLE>(p, fm, used, j);
+      const Cplx v1 = sample_pair<SAMPLE>(p, fm, used, j + q);
+      const Cplx v2 = sample_pair<SAMPLE>(p, fm, used, j + 2 * q);
+      const Cplx v3 = sample_pair<SAMPLE>(p, fm, used, j + 3 * q);
+      const Cplx a{v0.x + v2.x, v0.y + v2.y}, b{v0.x - v2.x, v0.y - v2.y};
+      const Cplx c{v1.x + v3.x, v1.y + v3.y}, d{v1.y - v3.y, -(v1.x - v3.x)};  // d = -i (v1 - v3)
+      dst[4 * j] = Cplx{a.x + c.x, a.y + c.y};
+      dst[4 * j + 1] = Cplx{b.x + d.x, b.y + d.y};
+      dst[4 * j + 2] = Cplx{a.x - c.x, a.y - c.y};
+      dst[4 * j + 3] = Cplx{b.x - d.x, b.y - d.y};
+    }
+    Ns = 4;
   }
   wave_sync();
-  for (int s = 0; s < p.log2_n2; ++s) {
-    const int half = 1 << s;
-    for (int b = lane; b < (N2 >> 1); b += 64) {
-      const int j = b & (half - 1);
-      const int i0 = ((b >> s) << (s + 1)) + j, i1 = i0 + half;
-      const double2 w = tws[(size_t)j * (N2 >> s)];
-      const double ar = zr[i0], ai = zi[i0], br = zr[i1], bi = zi[i1];
-      const double tr = w.x * br - w.y * bi, ti = w.x * bi + w.y * br;
-      zr[i0] = ar + tr; zi[i0] = ai + ti;
-      zr[i1] = ar - tr; zi[i1] = ai - ti;
+  { Cplx* tmp = src; src = dst; dst = tmp; }
+  for (; Ns < N2; Ns <<= 2) {
+    const int q = N2 >> 2;
+    const int tstep = N2 / (2 * Ns);                      // w = e^{-2 pi i k / (4 Ns)} = table[k * N2 / (2 Ns)]
+    for (int j = lane; j < q; j += 64) {
+      const int k = j & (Ns - 1);
+      const int m1 = k * tstep;
+      // (twiddles of a pass are strided table reads: many lanes on few LDS banks -- they come through the L1 instead,
+      // where the 4 KB table stays resident; the loads do not depend on the data and are issued ahead of it)
+      const double2 w1 = p.tw[m1], w2 = p.tw[2 * m1], w3 = twiddle(p.tw, N2, 3 * m1);
+      const Cplx v0 = src[j];
+      const Cplx v1 = cmul(src[j + q], w1);
+      const Cplx v2 = cmul(src[j + 2 * q], w2);
+      const Cplx v3 = cmul(src[j + 3 * q], w3);
+      const Cplx a{v0.x + v2.x, v0.y + v2.y}, b{v0.x - v2.x, v0.y - v2.y};
+      const Cplx c{v1.x + v3.x, v1.y + v3.y}, d{v1.y - v3.y, -(v1.x - v3.x)};
+      const int o = ((j - k) << 2) + k;
+      dst[o] = Cplx{a.x + c.x, a.y + c.y};
+      dst[o + Ns] = Cplx{b.x + d.x, b.y + d.y};
+      dst[o + 2 * Ns] = Cplx{a.x - c.x, a.y - c.y};
+      dst[o + 3 * Ns] = Cplx{b.x - d.x, b.y - d.y};
     }
     wave_sync();
+    Cplx* tmp = src; src = dst; dst = tmp;
   }
-  // untangle: X[k] = E[k] + W^k O[k] with E = (Z[k] + conj Z[N2-k]) / 2, O = -i (Z[k] - conj Z[N2-k]) / 2
+  // Untangle the real spectrum: with E = (Z[k] + conj Z[N2-k]) / 2, O = -i (Z[k] - conj Z[N2-k]) / 2 and
+  // T = W^k O:  X[k] = E + T,  X[N2-k] = conj(E - T).  One lane owns the pair (k, N2-k); the spectrum goes into the
+  // buffer the transform left free.
+  double* pw = (double*)dst;                              // [N2 + 1]
   double esum = 0.0;
-  for (int k = lane; k <= N2; k += 64) {
-    double xr, xi;
-    if (k == 0) { xr = zr[0] + zi[0]; xi = 0.0; }
-    else if (k == N2) { xr = zr[0] - zi[0]; xi = 0.0; }
-    else {
-      const double ar = zr[k], ai = zi[k], br = zr[N2 - k], bi = -zi[N2 - k];
-      const double er = 0.5 * (ar + br), ei = 0.5 * (ai + bi);
-      const double orr = 0.5 * (ai - bi), oi = -0.5 * (ar - br);
-      const double2 w = tws[k];
-      xr = er + (w.x * orr - w.y * oi);
-      xi = ei + (w.x * oi + w.y * orr);
-    }
-    const double h = hypot(xr, xi);                       // numpy.absolute (sigproc.py:139)
-    const double pk = p.inv_nfft * (h * h);                // 1.0/nfft * numpy.square(.) (sigproc.py:153)
-    pw[k] = p.stage == TFK_STAGE_MAGSPEC ? h : pk;
+  auto emit = [&](int k, double xr, double xi) {
+    const double sq = fma(xr, xr, xi * xi);               // |X|^2 (sigproc.py:139,153 take the square of the modulus)
+    const double pk = p.inv_nfft * sq;
+    pw[k] = p.stage == TFK_STAGE_MAGSPEC ? sqrt(sq) : pk;
     esum += pk;
+  };
+  for (int k = lane; k <= (N2 >> 1); k += 64) {
+    if (k == 0) {
+      const Cplx z = src[0];
+      emit(0, z.x + z.y, 0.0);
+      emit(N2, z.x - z.y, 0.0);
+    } else {
+      const Cplx a = src[k], bq = src[N2 - k];
+      const double br = bq.x, bi = -bq.y;
+      const double er = 0.5 * (a.x + br), ei = 0.5 * (a.y + bi);
+      const Cplx o{0.5 * (a.y - bi), -0.5 * (a.x - br)};
+      const Cplx tt = cmul(o, tws[k]);
+      emit(k, er + tt.x, ei + tt.y);
+      if (2 * k != N2) emit(N2 - k, er - tt.x, ei - tt.y);
+    }
   }
   wave_sync();
   if (p.stage) {
@@ -200,21 +308,53 @@ __global__ __launch_bounds__(256) void feat_frames_kernel(FrameArgs p) {
   double energy = wave_sum(esum);                         // base.py:80-84
   if (energy == 0.0) energy = kEps;
 
-  // mel filterbank: feat[j] = sum_k P[k] fb[j][k] over ALL bins, as numpy.dot does (base.py:90); filters on the lanes
-  double* logf = zr;                                      // the transform is done with its buffers
-  const int nbins = N2 + 1;
+  // mel filterbank (base.py:90).  A filter's support runs from 4 bins (low mels) to ~45 (high mels): with the filters
+  // on the lanes the loop is as long as the widest and most lanes idle.  The supports are therefore cut into <= 64
+  // pieces of near-equal length (create()), one per lane; the pieces of a filter are added up in order afterwards.
+  double* logf = (double*)src;                            // the transform's other buffer is free now
+  double* part = logf + p.nfilt;                          // [2][64] partial sums of the pieces
   const int d_static = (p.kind == TFK_FEAT_MFCC ? p.ncep : p.nfilt);
   const int64_t row = f * p.ld_out;
+  if (p.n_items > 0) {
+    const int* item = meta + 3 * p.nfilt;
+    if (lane < p.n_items) {
+      const int lo = item[64 + lane], cnt = item[128 + lane];
+      const double* w = fbv + item[192 + lane];
+      double acc = 0.0, num = 0.0;
+      if (p.kind == TFK_FEAT_SSC) {
+        for (int i = 0; i < cnt; ++i) {
+          const double pk = pw[lo + i];
+          acc = fma(pk, w[i], acc);
+          num = fma(pk * binw[lo + i], w[i], num);         // numpy.dot(pspec * tiles, filterbank.T) (base.py:154)
+        }
+        part[64 + lane] = num;
+      } else {
+        for (int i = 0; i < cnt; ++i) acc = fma(pw[lo + i], w[i], acc);
+      }
+      part[lane] = acc;
+    }
+    wave_sync();
+  }
   for (int j = lane; j < p.nfilt; j += 64) {
     double acc = 0.0, num = 0.0;
-    if (p.kind == TFK_FEAT_SSC) {
-      for (int k = 0; k < nbins; ++k) {
-        const double w = p.fbT[(size_t)k * p.nfilt + j], pk = pw[k];
-        acc = fma(pk, w, acc);
-        num = fma(pk * p.binw[k], w, num);               // numpy.dot(pspec * tiles, filterbank.T) (base.py:154)
+    if (p.n_items > 0) {
+      const int* first = meta + 3 * p.nfilt + 256;
+      for (int it = first[j]; it < first[j + 1]; ++it) {
+        acc += part[it];
+        if (p.kind == TFK_FEAT_SSC) num += part[64 + it];
       }
     } else {
-      for (int k = 0; k < nbins; ++k) acc = fma(pw[k], p.fbT[(size_t)k * p.nfilt + j], acc);
+      const int lo = meta[j], cnt = meta[p.nfilt + j];
+      const double* w = fbv + meta[2 * p.nfilt + j];
+      if (p.kind == TFK_FEAT_SSC) {
+        for (int i = 0; i < cnt; ++i) {
+          const double pk = pw[lo + i];
+          acc = fma(pk, w[i], acc);
+          num = fma(pk * binw[lo + i], w[i], num);
+        }
+      } else {
+        for (int i = 0; i < cnt; ++i) acc = fma(pw[lo + i], w[i], acc);
+      }
     }
     double v;
     if (p.kind == TFK_FEAT_SSC) {
@@ -229,10 +369,12 @@ __global__ __launch_bounds__(256) void feat_frames_kernel(FrameArgs p) {
   }
   if (p.kind == TFK_FEAT_MFCC) {
     wave_sync();
+    const double* dct = p.dct_lds ? dcts : p.dct;
     for (int c = lane; c < p.ncep; c += 64) {
       double acc = 0.0;
-      for (int j = 0; j < p.nfilt; ++j) acc = fma(logf[j], p.dct[(size_t)j * p.ncep + c], acc);
-      const double v = p.lift[c] * acc;                   // base.py:56,243
+#pragma unroll 8
+      for (int j = 0; j < p.nfilt; ++j) acc = fma(logf[j], dct[(size_t)j * p.ncep + c], acc);
+      const double v = p.lift[c] * acc;                    // base.py:56,243
       if (p.out_f64) put<double>(p.out, row + c, v); else put<float>(p.out, row + c, v);
     }
   }
@@ -352,15 +494,21 @@ int check_batch(const void* signal, const int64_t* sig_off, const int64_t* frame
 
 struct tfk_feat {
   tfk_feat_config cfg;
-  int nbins, d0, dim, log2_n2;
-  double* tables = nullptr;  // one allocation: fbT | binw | dct | lift | twiddles
-  double *fbT = nullptr, *binw = nullptr, *dct = nullptr, *lift = nullptr;
+  int nbins, d0, dim, log2_n2, fb_nnz, dct_lds, waves, n_items, n_meta;
+  size_t lds_bytes;
+  double* tables = nullptr;  // one allocation: filter values | binw | dct | lift | twiddles | filter meta (ints)
+  double *fb_val = nullptr, *binw = nullptr, *dct = nullptr, *lift = nullptr;
   double2* tw = nullptr;
+  int* fb_meta = nullptr;
   double* work = nullptr;    // static features of a batch that needs deltas, [frames][d0] float64
   size_t work_cap = 0;
+  FrameMeta* fmeta = nullptr;  // [frames] of the batch in flight
+  size_t fmeta_cap = 0;
 };
 
 namespace {
+
+constexpr size_t kLdsBudget = 160 * 1024;
 
 FrameArgs frame_args(const tfk_feat* f, const void* signal, const int64_t* sig_off, const int64_t* frame_off,
                      int n_utts, int64_t n_frames) {
@@ -368,21 +516,33 @@ FrameArgs frame_args(const tfk_feat* f, const void* signal, const int64_t* sig_o
   memset(&a, 0, sizeof(a));
   a.b = Batch{signal, sig_off, frame_off, n_utts, n_frames};
   a.frame_len = f->cfg.frame_len; a.frame_step = f->cfg.frame_step; a.nfft = f->cfg.nfft; a.log2_n2 = f->log2_n2;
-  a.nfilt = f->cfg.nfilt; a.ncep = f->cfg.numcep; a.kind = f->cfg.kind; a.include_energy = f->cfg.include_energy;
+  a.nfilt = f->cfg.nfilt; a.ncep = f->cfg.kind == TFK_FEAT_MFCC ? f->cfg.numcep : 0; a.kind = f->cfg.kind;
+  a.include_energy = f->cfg.include_energy;
   a.preemph = f->cfg.preemph; a.inv_nfft = 1.0 / f->cfg.nfft;
-  a.fbT = f->fbT; a.binw = f->binw; a.dct = f->dct; a.lift = f->lift; a.tw = f->tw;
+  a.fb_meta = f->fb_meta; a.fb_val = f->fb_val; a.fb_nnz = f->fb_nnz; a.dct_lds = f->dct_lds;
+  a.n_items = f->n_items; a.n_meta = f->n_meta;
+  a.binw = f->binw; a.dct = f->dct; a.lift = f->lift; a.tw = f->tw;
   return a;
 }
 
-int launch_frames(const tfk_feat* f, hipStream_t st, const FrameArgs& a, int sample_type) {
-  const int N2 = f->cfg.nfft / 2;
-  const int waves = f->cfg.nfft <= 1024 ? 4 : 1;          // 160 KB of LDS per CU: 6 KB per frame at nfft 512
-  const size_t lds = ((size_t)2 * N2 + (size_t)waves * (3 * N2 + 2)) * sizeof(double);
+int launch_frames(tfk_feat* f, hipStream_t st, FrameArgs& a, int sample_type) {
+  const size_t need = (size_t)a.b.n_frames;
+  if (need > f->fmeta_cap) {                                // stream-ordered growth: earlier launches may still read it
+    if (f->fmeta) HIPCHK(hipFreeAsync(f->fmeta, st));
+    f->fmeta = nullptr; f->fmeta_cap = 0;
+    const size_t cap = need + need / 4;
+    HIPCHK(hipMallocAsync((void**)&f->fmeta, cap * sizeof(FrameMeta), st));
+    f->fmeta_cap = cap;
+  }
+  hipLaunchKernelGGL(frame_meta_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, a.b, a.frame_step, f->fmeta);
+  HIPCHK(hipGetLastError());
+  a.fmeta = f->fmeta;
+  const int waves = f->waves;
   const unsigned grid = (unsigned)((a.b.n_frames + waves - 1) / waves);
   if (sample_type == TFK_SAMPLE_I16)
-    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_I16>, dim3(grid), dim3(64 * waves), lds, st, a);
+    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_I16>, dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
   else
-    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_F64>, dim3(grid), dim3(64 * waves), lds, st, a);
+    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_F64>, dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -416,20 +576,82 @@ int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const 
   f->d0 = (cfg->kind == TFK_FEAT_MFCC ? cfg->numcep : cfg->nfilt) + (cfg->include_energy ? 1 : 0);
   f->dim = f->d0 * (1 + cfg->dynamic);
   const int ncep = cfg->kind == TFK_FEAT_MFCC ? cfg->numcep : 0;
-  const size_t n_fb = (size_t)f->nbins * cfg->nfilt, n_dct = (size_t)cfg->nfilt * ncep, n_tw = (size_t)cfg->nfft;  // nfft/2 double2
-  std::vector<double> host(n_fb + f->nbins + n_dct + ncep + n_tw, 0.0);
+  const int nfilt = cfg->nfilt, nbins = f->nbins, N2 = cfg->nfft / 2;
+  // the support of every filter (a triangle of base.get_filterbanks; any matrix works, zeros inside a support are kept)
+  std::vector<int> meta(3 * nfilt + 1, 0);
+  std::vector<double> vals;
+  for (int j = 0; j < nfilt; ++j) {
+    int lo = nbins, hi = 0;
+    for (int k = 0; k < nbins; ++k)
+      if (filterbank[(size_t)j * nbins + k] != 0.0) { lo = k < lo ? k : lo; hi = k + 1; }
+    if (hi <= lo) { lo = 0; hi = 0; }
+    meta[j] = lo; meta[nfilt + j] = hi - lo; meta[2 * nfilt + j] = (int)vals.size();
+    for (int k = lo; k < hi; ++k) vals.push_back(filterbank[(size_t)j * nbins + k]);
+  }
+  f->fb_nnz = (int)vals.size();
+  // pieces for the lanes: the smallest piece length C with sum_j ceil(cnt_j / C) <= 64; needs room for the partial
+  // sums next to the log-energies in one transform buffer (2 N2 doubles)
+  f->n_items = 0;
+  if (nfilt <= 64 && 2 * N2 >= nfilt + 128) {
+    int C = 1;
+    for (;; ++C) {
+      int items = 0;
+      for (int j = 0; j < nfilt; ++j) items += meta[nfilt + j] ? (meta[nfilt + j] + C - 1) / C : 0;
+      if (items <= 64) break;
+    }
+    std::vector<int> it(4 * 64, 0), first(nfilt + 1, 0);
+    int n = 0;
+    for (int j = 0; j < nfilt; ++j) {
+      first[j] = n;
+      for (int s0 = 0; s0 < meta[nfilt + j]; s0 += C, ++n) {
+        it[n] = j; it[64 + n] = meta[j] + s0; it[128 + n] = std::min(C, meta[nfilt + j] - s0); it[192 + n] = meta[2 * nfilt + j] + s0;
+      }
+    }
+    first[nfilt] = n;
+    f->n_items = n;
+    meta.resize(3 * nfilt);
+    meta.insert(meta.end(), it.begin(), it.end());
+    meta.insert(meta.end(), first.begin(), first.end());
+  } else {
+    meta.resize(3 * nfilt);
+  }
+  f->n_meta = (int)meta.size();
+  const size_t n_dct = (size_t)nfilt * ncep, n_tw = (size_t)cfg->nfft /* nfft/2 double2 */, n_meta = (meta.size() + 1) / 2 + 1;
+  std::vector<double> host(vals.size() + nbins + n_dct + ncep + n_tw + n_meta, 0.0);
   double* h = host.data();
-  for (int j = 0; j < cfg->nfilt; ++j)                       // transposed: the filter index runs over the lanes
-    for (int k = 0; k < f->nbins; ++k) h[(size_t)k * cfg->nfilt + j] = filterbank[(size_t)j * f->nbins + k];
-  h += n_fb;
-  if (bin_weight) memcpy(h, bin_weight, f->nbins * sizeof(double));
-  h += f->nbins;
+  memcpy(h, vals.data(), vals.size() * sizeof(double));
+  h += vals.size();
+  if (bin_weight) memcpy(h, bin_weight, nbins * sizeof(double));
+  h += nbins;
   if (ncep) { memcpy(h, dct, n_dct * sizeof(double)); memcpy(h + n_dct, lifter, ncep * sizeof(double)); }
   h += n_dct + ncep;
-  for (int k = 0; k < cfg->nfft / 2; ++k) {
+  for (int k = 0; k < N2; ++k) {
     const long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / cfg->nfft;
     h[2 * k] = (double)cosl(ang);
     h[2 * k + 1] = (double)sinl(ang);
+  }
+  h += n_tw;
+  memcpy(h, meta.data(), meta.size() * sizeof(int));
+  // LDS: twiddles + filter values (+ ssc weights, + the DCT matrix while it is small) + meta, then 4 N2 doubles per
+  // wave; as many waves (frames) per block as fit next to a second block on the CU, eight at most
+  f->dct_lds = n_dct * sizeof(double) <= 16 * 1024;
+  const size_t shared_raw = ((size_t)2 * N2 + vals.size() + (cfg->kind == TFK_FEAT_SSC ? nbins : 0) + (f->dct_lds ? n_dct : 0)) * sizeof(double) +
+                        meta.size() * sizeof(int);
+  const size_t shared = (shared_raw + 15) & ~(size_t)15;
+  const size_t per_wave = (size_t)4 * N2 * sizeof(double);
+  if (shared + per_wave > kLdsBudget) {
+    delete f;
+    return fail(-1, "this configuration needs %zu bytes of LDS for one frame (160 KB per CU)", shared + per_wave);
+  }
+  int waves = 8;
+  while (waves > 1 && 2 * (shared + waves * per_wave) > kLdsBudget) waves >>= 1;
+  f->waves = waves;
+  f->lds_bytes = shared + waves * per_wave;
+  if (f->lds_bytes > 64 * 1024) {
+    hipError_t ea = hipFuncSetAttribute((const void*)feat_frames_kernel<TFK_SAMPLE_I16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
+    if (ea == hipSuccess)
+      ea = hipFuncSetAttribute((const void*)feat_frames_kernel<TFK_SAMPLE_F64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
+    if (ea != hipSuccess) { delete f; return fail((int)ea, "LDS size attribute: %s", hipGetErrorString(ea)); }
   }
   hipError_t e = hipMalloc((void**)&f->tables, host.size() * sizeof(double));
   if (e == hipSuccess) e = hipMemcpy(f->tables, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -438,11 +660,12 @@ int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const 
     delete f;
     return fail((int)e, "feature tables: %s", hipGetErrorString(e));
   }
-  f->fbT = f->tables;
-  f->binw = f->fbT + n_fb;
-  f->dct = f->binw + f->nbins;
+  f->fb_val = f->tables;
+  f->binw = f->fb_val + vals.size();
+  f->dct = f->binw + nbins;
   f->lift = f->dct + n_dct;
   f->tw = (double2*)(f->lift + ncep);
+  f->fb_meta = (int*)(f->lift + ncep + n_tw);
   *out = f;
   return 0;
 }
@@ -450,6 +673,7 @@ int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const 
 int tfk_feat_destroy(tfk_feat* f) {
   if (!f) return 0;
   if (f->work) hipFree(f->work);
+  if (f->fmeta) hipFree(f->fmeta);
   if (f->tables) hipFree(f->tables);
   delete f;
   return 0;
