@@ -141,3 +141,27 @@ def test_feature_computer_rejects_unknown_types():
         feat.FeatureComputer("plp", "nodelta", {})
     with pytest.raises(Exception, match="unknown dynamic type"):
         feat.FeatureComputer("fbank", "dddelta", {})
+
+
+def test_reference_import_line_resolves_to_the_gpu_backed_modules():
+    """main.py:7 `from processing import ark, prepare_data, feature_reader, batchdispenser, target_coder`"""
+    import sys
+    from tfkaldi_amd import compat
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "processing" or k.startswith("processing.")
+             or k == "neuralNetworks" or k.startswith("neuralNetworks.")}
+    try:
+        compat.install()
+        from processing import ark as a, prepare_data as p, feature_reader as fr, batchdispenser as bd, target_coder as tc  # noqa: F401
+        import processing.feat
+        import processing.base
+        import processing.sigproc
+        assert p is prepare_data and processing.feat is feat and processing.base is base
+        assert p.__name__ == "tfkaldi_amd.processing.prepare_data"
+    finally:
+        for k in [k for k in sys.modules if k == "processing" or k.startswith("processing.") or k == "neuralNetworks"
+                  or k.startswith("neuralNetworks.")]:
+            if k not in saved:
+                del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v

@@ -3,9 +3,10 @@
     from neuralNetworks import nnet
     from processing import ark, prepare_data, feature_reader, batchdispenser, target_coder
 
-`install()` registers `neuralNetworks` and `processing` in sys.modules.  Modules this package does not
-provide (the offline feature extraction: processing/prepare_data.py, feat.py, base.py, sigproc.py -- outside
-the training hot path) are still found in the reference checkout when `reference_root` is given.
+`install()` registers `neuralNetworks` and `processing` in sys.modules, including the feature computation
+(processing/prepare_data.py, feat.py, base.py, sigproc.py: GPU-backed here).  Modules this package does not
+provide (`target_normalizers` variants of other corpora, ...) are still found in the reference checkout when
+`reference_root` is given.
 """
 import importlib
 import os
@@ -17,7 +18,8 @@ def install(reference_root=None):
     sys.modules["neuralNetworks"] = neuralNetworks
     sys.modules["processing"] = processing
     for pkg, names in (("neuralNetworks", ("nnet", "trainer", "decoder", "classifiers")),
-                       ("processing", ("ark", "feature_reader", "batchdispenser", "target_coder", "readfiles"))):
+                       ("processing", ("ark", "feature_reader", "batchdispenser", "target_coder", "readfiles", "prepare_data",
+                                      "feat", "base", "sigproc"))):
         for name in names:
             sys.modules["%s.%s" % (pkg, name)] = importlib.import_module("tfkaldi_amd.%s.%s" % (pkg, name))
     if reference_root:
