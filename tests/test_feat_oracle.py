@@ -136,6 +136,15 @@ def test_read_wav_plain_and_piped(tmp_path):
     assert rate2 == 16000 and np.array_equal(piped, samples)
 
 
+def test_empty_signal_raises_like_the_reference():
+    conf = dict(winlen='0.025', winstep='0.01', snip_edges='True', include_energy='False')
+    with pytest.raises(IndexError):
+        feat.FeatureComputer("fbank", "nodelta", conf)(np.zeros(0, dtype=np.int16), 16000)
+    with pytest.raises(IndexError):
+        fo.compute_features(np.zeros(0, dtype=np.int16), 16000, "fbank", "nodelta",
+                            dict(conf, nfilt='40', nfft='512', lowfreq='0', highfreq='-1', preemph='0.97'))
+
+
 def test_feature_computer_rejects_unknown_types():
     with pytest.raises(Exception, match="unknown feature type"):
         feat.FeatureComputer("plp", "nodelta", {})

@@ -25,15 +25,19 @@ class FeatureComputer(object):
     def _prepared(self, sig, rate):
         if self.conf['snip_edges'] == 'True':
             sig = snip(sig, rate, float(self.conf['winlen']), float(self.conf['winstep']))
+        if len(sig) == 0:  # the reference's pre-emphasis reads `signal[0]` (sigproc.py:191)
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")
         return sig
 
     def __call__(self, sig, rate):
         """feat.py:42-69: [NUMFRAMES, dim] float64"""
-        return self.plan(rate).compute([self._prepared(np.asarray(sig), rate)])[0]
+        sig = self._prepared(np.asarray(sig), rate)
+        return self.plan(rate).compute([sig])[0]
 
     def compute_batch(self, sigs, rate, dtype=np.float32):
         """features of many utterances recorded at one sample rate; float32 is what the ark files store"""
-        return self.plan(rate).compute([self._prepared(np.asarray(s), rate) for s in sigs], dtype=dtype)
+        sigs = [self._prepared(np.asarray(s), rate) for s in sigs]
+        return self.plan(rate).compute(sigs, dtype=dtype)
 
 
 def snip(sig, rate, winlen, winstep):
