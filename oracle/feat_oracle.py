@@ -31,7 +31,8 @@ def py2_round(x):
 def preemphasis(signal, coeff=0.95):
     """sigproc.py:180-191: y[0] = x[0], y[n] = x[n] - coeff * x[n-1] (float64 as soon as coeff is a float)"""
     signal = np.asarray(signal)
-    return np.concatenate((signal[:1].astype(np.float64), signal[1:] - coeff * signal[:-1]))
+    head = signal[0]  # an empty signal raises IndexError here, as in the reference
+    return np.concatenate(([head], signal[1:] - coeff * signal[:-1])).astype(np.float64, copy=False)
 
 
 def num_frames(slen, frame_len, frame_step):
