@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -150,25 +151,65 @@ __global__ __launch_bounds__(256) void frames_kernel(FrameArgs p) {
 struct alignas(16) Cplx { double x, y; };  // 16-byte LDS accesses: a wave's 64 points sweep all banks once
 __device__ __forceinline__ Cplx cmul(Cplx a, double2 w) { return Cplx{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
 
-// pre-emphasised sample n of the frame described by fm (emph_sample in frame coordinates)
+// (even, odd) pre-emphasised sample pair m of a frame: one complex point of the half-length transform.
+// Branch-free: the three samples x[2m-1], x[2m], x[2m+1] are loaded unconditionally from clamped (always valid)
+// addresses and the edge rules are applied with selects -- with a branch per rule the compiler waits for every load
+// before it issues the next one, and a frame's 16 loads cost 16 round trips to the L2.
+// Requires fm.avail >= 1 (the caller skips frames of empty utterances: all their points are zero).
+template <int SAMPLE> struct RawOf { typedef int T; };        // int16 samples travel as sign-extended 32-bit registers
+template <> struct RawOf<TFK_SAMPLE_F64> { typedef double T; };
+
 template <int SAMPLE>
-__device__ __forceinline__ double emph_at(const void* sig, const FrameMeta& fm, int n, double coeff) {
-#pragma clang fp contract(off)
-  if (n >= fm.avail) return 0.0;
-  const double x = raw_sample<SAMPLE>(sig, fm.start + n);
-  if ((n == 0 && fm.first) || coeff == 0.0) return x;
-  const double scaled = coeff * raw_sample<SAMPLE>(sig, fm.start + n - 1);
-  return x - scaled;
+__device__ __forceinline__ typename RawOf<SAMPLE>::T raw_load(const void* sig, int64_t i) {
+  if (SAMPLE == TFK_SAMPLE_I16) return (typename RawOf<SAMPLE>::T)((const int16_t*)sig)[i];
+  return (typename RawOf<SAMPLE>::T)((const double*)sig)[i];
 }
 
-// (even, odd) pre-emphasised sample pair m of a frame: one complex point of the half-length transform
+// the three loads of pair m (addresses only -- nothing here waits for memory)
+template <int SAMPLE>
+__device__ __forceinline__ void load_pair(const FrameArgs& p, const FrameMeta& fm, int m, typename RawOf<SAMPLE>::T& xa,
+                                          typename RawOf<SAMPLE>::T& xb, typename RawOf<SAMPLE>::T& xc) {
+  const int n0 = 2 * m, n1 = n0 + 1, last = fm.avail - 1;
+  const bool head = n0 == 0 && fm.first;
+  const int ia = head ? 0 : min(n0 - 1, last);            // (a frame that does not start its utterance has a sample before it)
+  xa = raw_load<SAMPLE>(p.b.sig, fm.start + ia);
+  xb = raw_load<SAMPLE>(p.b.sig, fm.start + min(n0, last));
+  xc = raw_load<SAMPLE>(p.b.sig, fm.start + min(n1, last));
+}
+
+// pre-emphasis and the edge rules on the loaded samples
+template <int SAMPLE>
+__device__ __forceinline__ Cplx finish_pair(const FrameArgs& p, const FrameMeta& fm, int used, int m,
+                                            typename RawOf<SAMPLE>::T ra, typename RawOf<SAMPLE>::T rb,
+                                            typename RawOf<SAMPLE>::T rc) {
+#pragma clang fp contract(off)  // y = x - coeff * x_prev: two roundings, as numpy's `signal[1:] - coeff * signal[:-1]`
+  const int n0 = 2 * m, n1 = n0 + 1;
+  const int lim = min(used, fm.avail);
+  const bool head = n0 == 0 && fm.first;                  // y[0] = x[0] (sigproc.py:191)
+  const double xa = (double)ra, xb = (double)rb, xc = (double)rc;
+  const double sa = p.preemph * xa, sb = p.preemph * xb;
+  const bool plain = p.preemph == 0.0;
+  Cplx v;
+  v.x = n0 < lim ? ((head || plain) ? xb : xb - sa) : 0.0;
+  v.y = n1 < lim ? (plain ? xc : xc - sb) : 0.0;
+  return v;
+}
+
 template <int SAMPLE>
 __device__ __forceinline__ Cplx sample_pair(const FrameArgs& p, const FrameMeta& fm, int used, int m) {
-  const int n0 = 2 * m;
-  Cplx v;
-  v.x = n0 < used ? emph_at<SAMPLE>(p.b.sig, fm, n0, p.preemph) : 0.0;
-  v.y = n0 + 1 < used ? emph_at<SAMPLE>(p.b.sig, fm, n0 + 1, p.preemph) : 0.0;
-  return v;
+  typename RawOf<SAMPLE>::T xa, xb, xc;
+  load_pair<SAMPLE>(p, fm, m, xa, xb, xc);
+  return finish_pair<SAMPLE>(p, fm, used, m, xa, xb, xc);
+}
+
+// radix-4 butterfly on already-twiddled inputs: outputs r = 0..3 of the 4-point transform
+__device__ __forceinline__ void bfly4(const Cplx& v0, const Cplx& v1, const Cplx& v2, const Cplx& v3, Cplx* o) {
+  const Cplx a{v0.x + v2.x, v0.y + v2.y}, b{v0.x - v2.x, v0.y - v2.y};
+  const Cplx c{v1.x + v3.x, v1.y + v3.y}, d{v1.y - v3.y, -(v1.x - v3.x)};  // d = -i (v1 - v3)
+  o[0] = Cplx{a.x + c.x, a.y + c.y};
+  o[1] = Cplx{b.x + d.x, b.y + d.y};
+  o[2] = Cplx{a.x - c.x, a.y - c.y};
+  o[3] = Cplx{b.x - d.x, b.y - d.y};
 }
 
 __global__ __launch_bounds__(256) void frame_meta_kernel(Batch b, int frame_step, FrameMeta* out) {
@@ -191,7 +232,9 @@ __device__ __forceinline__ double2 twiddle(const double2* tws, int N2, int m) {
 template <int SAMPLE>
 __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (the wave index through readfirstlane: the compiler then knows that everything per frame -- frame number, its
+  // metadata, buffer addresses -- is uniform and keeps it in scalar registers and scalar instructions)
+  const int waves = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int N2 = p.nfft >> 1, nbins = N2 + 1;
   // block-shared tables, then two [N2] complex buffers per wave
   double2* tws = (double2*)lds;
@@ -211,11 +254,12 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   if (p.dct_lds)
     for (int k = threadIdx.x; k < p.nfilt * p.ncep; k += blockDim.x) dcts[k] = p.dct[k];
   __syncthreads();
-  const int64_t f = (int64_t)blockIdx.x * waves + wave;
-  if (f >= p.b.n_frames) return;                         // no block-wide barrier below this line
-
-  const FrameMeta fm = p.fmeta[f];
+  // The grid is sized to what the chip holds at once (launch_frames); every wave then walks over its share of the
+  // frames, so the tables above are staged once per block and not once per 8 frames.  No block-wide barrier below.
   const int used = min(p.frame_len, p.nfft);             // numpy.fft.rfft(frames, nfft) truncates / zero-pads
+  const int64_t stride = (int64_t)gridDim.x * waves;
+  for (int64_t f = (int64_t)blockIdx.x * waves + wave; f < p.b.n_frames; f += stride) {
+  const FrameMeta fm = p.fmeta[f];
 
   // Half-length complex transform, Stockham autosort (natural order in and out, ping-pong between the two buffers),
   // radix 4 with one leading radix-2 pass when log2(N2) is odd.  The first pass has unit twiddles and takes its
@@ -223,10 +267,15 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   Cplx* src = bufA;
   Cplx* dst = bufB;
   int Ns;
+  const bool silent = fm.avail <= 0;                       // a frame of an empty utterance: nothing to read
+  const Cplx zero{0.0, 0.0};
   if (p.log2_n2 & 1) {
     for (int j = lane; j < (N2 >> 1); j += 64) {
-      const Cplx a = sample_pair<SAMPLE>(p, fm, used, j);
-      const Cplx b = sample_pair<SAMPLE>(p, fm, used, j + (N2 >> 1));
+      Cplx a = zero, b = zero;
+      if (!silent) {
+        a = sample_pair<SAMPLE>(p, fm, used, j);
+        b = sample_pair<SAMPLE>(p, fm, used, j + (N2 >> 1));
+      }
       dst[2 * j] = Cplx{a.x + b.x, a.y + b.y};
       dst[2 * j + 1] = Cplx{a.x - b.x, a.y - b.y};
     }
@@ -234,16 +283,17 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   } else {
     const int q = N2 >> 2;
     for (int j = lane; j < q; j += 64) {
-      const Cplx v0 = sample_pair<SAMPLE>(p, fm, used, j);
-      const Cplx v1 = sample_pair<SAMPLE>(p, fm, used, j + q);
-      const Cplx v2 = sample_pair<SAMPLE>(p, fm, used, j + 2 * q);
-      const Cplx v3 = sample_pair<SAMPLE>(p, fm, used, j + 3 * q);
-      const Cplx a{v0.x + v2.x, v0.y + v2.y}, b{v0.x - v2.x, v0.y - v2.y};
-      const Cplx c{v1.x + v3.x, v1.y + v3.y}, d{v1.y - v3.y, -(v1.x - v3.x)};  // d = -i (v1 - v3)
-      dst[4 * j] = Cplx{a.x + c.x, a.y + c.y};
-      dst[4 * j + 1] = Cplx{b.x + d.x, b.y + d.y};
-      dst[4 * j + 2] = Cplx{a.x - c.x, a.y - c.y};
-      dst[4 * j + 3] = Cplx{b.x - d.x, b.y - d.y};
+      Cplx v0 = zero, v1 = zero, v2 = zero, v3 = zero;
+      if (!silent) {                                       // one uniform branch: the twelve loads go out back to back
+        v0 = sample_pair<SAMPLE>(p, fm, used, j);
+        v1 = sample_pair<SAMPLE>(p, fm, used, j + q);
+        v2 = sample_pair<SAMPLE>(p, fm, used, j + 2 * q);
+        v3 = sample_pair<SAMPLE>(p, fm, used, j + 3 * q);
+      }
+      Cplx o[4];
+      bfly4(v0, v1, v2, v3, o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[4 * j + r] = o[r];
     }
     Ns = 4;
   }
@@ -258,17 +308,11 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
       // (twiddles of a pass are strided table reads: many lanes on few LDS banks -- they come through the L1 instead,
       // where the 4 KB table stays resident; the loads do not depend on the data and are issued ahead of it)
       const double2 w1 = p.tw[m1], w2 = p.tw[2 * m1], w3 = twiddle(p.tw, N2, 3 * m1);
-      const Cplx v0 = src[j];
-      const Cplx v1 = cmul(src[j + q], w1);
-      const Cplx v2 = cmul(src[j + 2 * q], w2);
-      const Cplx v3 = cmul(src[j + 3 * q], w3);
-      const Cplx a{v0.x + v2.x, v0.y + v2.y}, b{v0.x - v2.x, v0.y - v2.y};
-      const Cplx c{v1.x + v3.x, v1.y + v3.y}, d{v1.y - v3.y, -(v1.x - v3.x)};
-      const int o = ((j - k) << 2) + k;
-      dst[o] = Cplx{a.x + c.x, a.y + c.y};
-      dst[o + Ns] = Cplx{b.x + d.x, b.y + d.y};
-      dst[o + 2 * Ns] = Cplx{a.x - c.x, a.y - c.y};
-      dst[o + 3 * Ns] = Cplx{b.x - d.x, b.y - d.y};
+      Cplx o[4];
+      bfly4(src[j], cmul(src[j + q], w1), cmul(src[j + 2 * q], w2), cmul(src[j + 3 * q], w3), o);
+      const int at = ((j - k) << 2) + k;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[at + r * Ns] = o[r];
     }
     wave_sync();
     Cplx* tmp = src; src = dst; dst = tmp;
@@ -303,7 +347,8 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   if (p.stage) {
     double* out = (double*)p.out + f * p.ld_out;
     for (int k = lane; k <= N2; k += 64) out[k] = pw[k];
-    return;
+    wave_sync();
+    continue;
   }
   double energy = wave_sum(esum);                         // base.py:80-84
   if (energy == 0.0) energy = kEps;
@@ -382,6 +427,8 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
     const double v = p.kind == TFK_FEAT_FBANK_RAW ? energy : log(energy);
     if (p.out_f64) put<double>(p.out, row + d_static, v); else put<float>(p.out, row + d_static, v);
   }
+  wave_sync();                                             // the next frame reuses both buffers
+  }  // frames of this wave
 }
 
 // ---- base.deriv / delta / ddelta with scipy's 'reflect' boundary per utterance ----
@@ -494,7 +541,7 @@ int check_batch(const void* signal, const int64_t* sig_off, const int64_t* frame
 
 struct tfk_feat {
   tfk_feat_config cfg;
-  int nbins, d0, dim, log2_n2, fb_nnz, dct_lds, waves, n_items, n_meta;
+  int nbins, d0, dim, log2_n2, fb_nnz, dct_lds, waves, n_items, n_meta, num_cus;
   size_t lds_bytes;
   double* tables = nullptr;  // one allocation: filter values | binw | dct | lift | twiddles | filter meta (ints)
   double *fb_val = nullptr, *binw = nullptr, *dct = nullptr, *lift = nullptr;
@@ -538,7 +585,9 @@ int launch_frames(tfk_feat* f, hipStream_t st, FrameArgs& a, int sample_type) {
   HIPCHK(hipGetLastError());
   a.fmeta = f->fmeta;
   const int waves = f->waves;
-  const unsigned grid = (unsigned)((a.b.n_frames + waves - 1) / waves);
+  const int64_t blocks_needed = (a.b.n_frames + waves - 1) / waves;
+  const int64_t resident = (int64_t)f->num_cus * std::max<int64_t>(1, (int64_t)(kLdsBudget / f->lds_bytes));
+  const unsigned grid = (unsigned)std::min<int64_t>(blocks_needed, resident);
   if (sample_type == TFK_SAMPLE_I16)
     hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_I16>, dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
   else
@@ -646,6 +695,11 @@ int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const 
   int waves = 8;
   while (waves > 1 && 2 * (shared + waves * per_wave) > kLdsBudget) waves >>= 1;
   f->waves = waves;
+  f->num_cus = 256;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) f->num_cus = cus;
+  }
   f->lds_bytes = shared + waves * per_wave;
   if (f->lds_bytes > 64 * 1024) {
     hipError_t ea = hipFuncSetAttribute((const void*)feat_frames_kernel<TFK_SAMPLE_I16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
