@@ -8,13 +8,14 @@
 //   processing/sigproc.py:33-191    framesig (rectangular window, zero padding), magspec, powspec, preemphasis
 //   processing/prepare_data.py:80-118  compute_cmvn (float32 row-after-row sums)
 //
-// Shape of the work: a frame is 400 samples in, 40 numbers out, ~25 kFLOP of float64 in between -- neither an HBM nor an
-// MFMA problem; what bounds it is LDS traffic of the transform.  One WAVEFRONT owns one frame: the 512-point real
-// transform is a 256-point complex radix-2 transform over (even, odd) sample pairs, resident in that wave's 6 KB slice
-// of LDS, untangled into the half spectrum on the way to the power; the mel filterbank is a dense [bins x filters]
-// product with the filter index on the lanes (coalesced table reads, LDS-broadcast spectrum); no intermediate leaves
-// the CU except the static features of utterances that need deltas (float64, read back by the dynamics kernel with
-// the 'reflect' boundary applied per utterance).  Thousands of frames of a whole batch of utterances go in one launch.
+// Shape of the work: a frame is 400 samples in, 40 numbers out, ~16 kFLOP of float64 in between -- neither an HBM nor an
+// MFMA problem; what bounds it is instruction issue (vector ALU busy 0.78) and the LDS traffic of the transform (0.42).
+// One WAVEFRONT owns one frame: the 512-point real transform is a 256-point complex Stockham radix-4 transform over
+// (even, odd) sample pairs, ping-ponging between two 4 KB buffers in that wave's slice of LDS, untangled into the half
+// spectrum on the way to the power; the mel filterbank runs over the non-zero supports of its triangles, cut into equal
+// pieces across the lanes; no intermediate leaves the CU except the static features of utterances that need deltas
+// (float64, read back by the dynamics kernel with the 'reflect' boundary applied per utterance).  The frames of a whole
+// batch of utterances go in one launch whose waves walk over them.  Measurements and history: DESIGN.md 4b.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
