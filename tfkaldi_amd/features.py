@@ -57,13 +57,19 @@ class Packed(object):
         self.frame_off = np.concatenate(([0], np.cumsum(frames))).astype(np.int64)
         self.n_utts = len(sigs)
         self.n_frames = int(self.frame_off[-1])
-        flat = np.concatenate([s.astype(dtype, copy=False) for s in sigs]) if sigs else np.zeros(0, dtype=dtype)
-        if flat.size == 0:
-            flat = np.zeros(1, dtype=dtype)  # a valid pointer for all-empty batches
         dev = torch.device("cuda", device)
-        self.signal = torch.from_numpy(np.ascontiguousarray(flat)).to(dev)
+        total = max(int(self.sig_off[-1]), 1)  # (one element at least: a valid pointer for all-empty batches)
+        # the samples are gathered straight into pinned memory: one pass over them on the host, then a DMA at PCIe speed
+        # (a pageable array would be staged through the driver's bounce buffers at a fraction of it)
+        tdt = torch.int16 if dtype is np.int16 else torch.float64
+        staging = torch.zeros(total, dtype=tdt, pin_memory=True)
+        flat = staging.numpy()
+        for s, lo, hi in zip(sigs, self.sig_off[:-1], self.sig_off[1:]):
+            flat[lo:hi] = s
+        self.signal = staging.to(dev, non_blocking=True)
         self.d_sig_off = torch.from_numpy(self.sig_off).to(dev)
         self.d_frame_off = torch.from_numpy(self.frame_off).to(dev)
+        self._staging = staging  # alive until the copy has been consumed (the compute calls synchronise before returning)
 
     def split(self, matrix):
         return [matrix[self.frame_off[u]:self.frame_off[u + 1]] for u in range(self.n_utts)]
@@ -129,8 +135,13 @@ class FeaturePlan(object):
 
     def compute(self, signals, dtype=np.float64):
         """one [frames, dim] array per signal"""
+        torch = _torch()
         packed = self.pack(signals)
-        return packed.split(self.compute_device(packed, dtype).cpu().numpy())
+        out = self.compute_device(packed, dtype)
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(out.device).synchronize()
+        return packed.split(host.numpy())
 
     def stage(self, stage, signals):
         """TFK_STAGE_*: frames / magnitude spectrum / power spectrum of each signal, float64"""
