@@ -128,7 +128,10 @@ enum { /* flags */
   TFK_DEVICE_PTRS = 1,     /* X / y / out are device pointers (already resident in HBM) */
   TFK_LAST_MICROBATCH = 2, /* last accumulate before tfk_apply: fire the bucket callback per layer */
   TFK_LOG_DIV_PRIOR = 4,   /* tfk_posteriors: write log(posterior / prior) (nnet.py:280-286) */
-  TFK_RAW_LOGITS = 8       /* tfk_posteriors: write the logits (Classifier.__call__ output, dnn.py:108) */
+  TFK_RAW_LOGITS = 8,      /* tfk_posteriors: write the logits (Classifier.__call__ output, dnn.py:108) */
+  TFK_RAW_DEVICE = 16      /* the *_raw entry points: `raw` is a device pointer -- features that never left HBM, e.g. the output
+                            * of tfk_feat_compute; everything else (y, utt_len, cmvn, out) stays a host pointer.  The producer's
+                            * work must be complete, or ordered before the engine's stream (tfk_stream), when the call is made. */
 };
 
 /* Replaces `update_gradients_op.run(feed_dict)` (trainer.py:160-169, 325-332) for ONE micro-batch,
@@ -146,8 +149,8 @@ int tfk_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y,
  * mean, row 1 the standard deviation sqrt(E[x^2] - mean^2); the device computes (raw - mean) / std with the same
  * IEEE roundings as numpy's float32 subtract and divide, so the result is bit-identical to the host path.
  * Frames beyond an utterance's edges splice in as zeros, exactly like the host splice.  Only the unspliced frames
- * cross PCIe (11x less at context 5) and the spliced matrix is produced in HBM.  Host pointers only (raw, y,
- * utt_len, cmvn); TFK_DEVICE_PTRS is not accepted. */
+ * cross PCIe (11x less at context 5) and the spliced matrix is produced in HBM.  Host pointers (raw, y, utt_len,
+ * cmvn) -- TFK_DEVICE_PTRS is not accepted; TFK_RAW_DEVICE makes `raw` alone a device pointer. */
 int tfk_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
                        const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags);
 int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,

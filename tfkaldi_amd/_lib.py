@@ -19,7 +19,7 @@ WEIGHTS, BIASES, BN_BETA, BN_MOVING_MEAN, BN_MOVING_VAR = range(5)
 SLOT_PARAM, SLOT_GRAD, SLOT_ADAM_M, SLOT_ADAM_V = range(4)
 (GLOBAL_STEP, LEARNING_RATE_FACT, INITIALISED_LAYERS, ADAM_STEPS, BATCH_LOSS, NUM_FRAMES,
  LEARNING_RATE) = range(7)
-DEVICE_PTRS, LAST_MICROBATCH, LOG_DIV_PRIOR, RAW_LOGITS = 1, 2, 4, 8
+DEVICE_PTRS, LAST_MICROBATCH, LOG_DIV_PRIOR, RAW_LOGITS, RAW_DEVICE = 1, 2, 4, 8, 16
 DBG_LOGITS, DBG_HIDDEN, DBG_DROPOUT_MASK = range(3)
 GEMM_NN, GEMM_NT, GEMM_TN = range(3)
 EPI_BIAS, EPI_ACCUM, EPI_RELU = 1, 2, 4

@@ -613,7 +613,7 @@ int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, in
 
 // Bring unspliced frames + utterance offsets to HBM and splice them into dX[slot] there.
 int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int T, const int32_t* utt_len, int U,
-              int context, const float* cmvn, const float** Xd, int* ldx_out, const int32_t** yd) {
+              int context, const float* cmvn, const float** Xd, int* ldx_out, const int32_t** yd, bool raw_on_device = false) {
   if (context < 0) return fail(-1, "context_width %d < 0", context);
   const int win = 2 * context + 1;
   if (e->F % win != 0) return fail(-1, "input_dim %d is not a multiple of 2*context_width+1 = %d", e->F, win);
@@ -646,15 +646,17 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
     e->cmvn_cap = 2 * cmvn_floats;
   }
   if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
-  for (int t = 0; t < T; ++t) memcpy(e->hRaw[s] + (size_t)t * D, raw + (size_t)t * ldraw, (size_t)D * sizeof(float));
+  if (!raw_on_device)
+    for (int t = 0; t < T; ++t) memcpy(e->hRaw[s] + (size_t)t * D, raw + (size_t)t * ldraw, (size_t)D * sizeof(float));
   if (cmvn) memcpy(e->hCmvn[s], cmvn, cmvn_floats * sizeof(float));
   e->hSeg[s][0] = 0;
   for (int u = 0; u < U; ++u) e->hSeg[s][u + 1] = e->hSeg[s][u] + utt_len[u];
   if (y) memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
   if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
   const int ldD = (D + 3) & ~3;
-  HIPCHK(hipMemcpy2DAsync(e->dRaw[s], (size_t)ldD * 4, e->hRaw[s], (size_t)D * 4, (size_t)D * 4, T,
-                          hipMemcpyHostToDevice, e->copy_stream));
+  if (!raw_on_device)
+    HIPCHK(hipMemcpy2DAsync(e->dRaw[s], (size_t)ldD * 4, e->hRaw[s], (size_t)D * 4, (size_t)D * 4, T,
+                            hipMemcpyHostToDevice, e->copy_stream));
   HIPCHK(hipMemcpyAsync(e->dSeg[s], e->hSeg[s], (size_t)(U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
   if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
   if (cmvn)
@@ -663,8 +665,9 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
   HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
   {
     ProfScope ps(e, KF_MISC, 0, 4.0 * T * (D + e->F));
-    splice_frames(e->stream, e->dRaw[s], ldD, e->dSeg[s], U, T, D, context, cmvn ? e->dCmvn[s] : nullptr, e->dX[s],
-                  e->ldF);
+    // (TFK_RAW_DEVICE: the caller's matrix is spliced where it lies -- the kernel reads rows of any leading dimension)
+    splice_frames(e->stream, raw_on_device ? raw : e->dRaw[s], raw_on_device ? (int)ldraw : ldD, e->dSeg[s], U, T, D, context,
+                  cmvn ? e->dCmvn[s] : nullptr, e->dX[s], e->ldF);
   }
   e->slot_used[s] = true;
   *Xd = e->dX[s];
@@ -1172,12 +1175,13 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   if (!e) return fail(-1, "engine is NULL");
   if (T <= 0) return fail(-1, "empty micro-batch (T = %d)", T);
   if (!X || (!y && !ctc)) return fail(-1, "X / y is NULL");
-  if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers");
+  if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers (TFK_RAW_DEVICE: raw alone on the device)");
+  if (!raw && (flags & TFK_RAW_DEVICE)) return fail(-1, "TFK_RAW_DEVICE belongs to the *_raw entry points");
   HIPCHK(hipSetDevice(e->cfg.device));
   CHK(reserve(e, T));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
-  if (raw) CHK(stage_raw(e, X, ldx, y, T, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd));
+  if (raw) CHK(stage_raw(e, X, ldx, y, T, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd, (flags & TFK_RAW_DEVICE) != 0));
   else CHK(stage_input(e, X, ldx, y, T, flags, &Xd, &ld, &yd));
   if (e->bf16) CHK(twin_input(e, &Xd, &ld, T));
   const uint32_t call = e->call_counter++;
@@ -1542,7 +1546,8 @@ int tfk_set_prior(tfk_engine* e, const float* prior, size_t count) {
 static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags,
                            const RawSpec* raw) {
   if (!e) return fail(-1, "engine is NULL");
-  if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers");
+  if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers (TFK_RAW_DEVICE: raw alone on the device)");
+  if (!raw && (flags & TFK_RAW_DEVICE)) return fail(-1, "TFK_RAW_DEVICE belongs to the *_raw entry points");
   if (N <= 0) return fail(-1, "empty utterance (N = %d)", N);
   if (!X || !out) return fail(-1, "X / out is NULL");
   if (ldo < e->O) return fail(-1, "ldo %lld < output_dim %d", (long long)ldo, e->O);
@@ -1551,7 +1556,7 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
   CHK(reserve(e, N));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
-  if (raw) CHK(stage_raw(e, X, ldx, nullptr, N, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd));
+  if (raw) CHK(stage_raw(e, X, ldx, nullptr, N, raw->utt_len, raw->U, raw->context, raw->cmvn, &Xd, &ld, &yd, (flags & TFK_RAW_DEVICE) != 0));
   else CHK(stage_input(e, X, ldx, nullptr, N, flags, &Xd, &ld, &yd));
   if (e->bf16) CHK(twin_input(e, &Xd, &ld, N));
   const int nact = e->nact();

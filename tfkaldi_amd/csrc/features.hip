@@ -746,6 +746,7 @@ int tfk_feat_compute(tfk_feat* f, void* stream, const void* signal, int sample_t
   if (int rc = check_batch(signal, sig_off, frame_off, n_utts, n_frames, out, sample_type)) return rc;
   if (n_frames == 0 || n_utts == 0) return 0;
   if (ld_out < f->dim) return fail(-1, "ld_out %lld < feature dimension %d", (long long)ld_out, f->dim);
+  HIPCHK(hipSetDevice(f->cfg.device));
   hipStream_t st = (hipStream_t)stream;
   FrameArgs a = frame_args(f, signal, sig_off, frame_off, n_utts, n_frames);
   if (f->cfg.dynamic == TFK_DYN_NODELTA) {
@@ -773,6 +774,7 @@ int tfk_feat_stage(tfk_feat* f, void* stream, int stage, const void* signal, int
   if (n_frames == 0 || n_utts == 0) return 0;
   const int cols = stage == TFK_STAGE_FRAMES ? f->cfg.frame_len : f->nbins;
   if (ld_out < cols) return fail(-1, "ld_out %lld < %d columns of this stage", (long long)ld_out, cols);
+  HIPCHK(hipSetDevice(f->cfg.device));
   hipStream_t st = (hipStream_t)stream;
   FrameArgs a = frame_args(f, signal, sig_off, frame_off, n_utts, n_frames);
   a.out = out; a.ld_out = ld_out; a.out_f64 = 1; a.stage = stage;

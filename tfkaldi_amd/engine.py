@@ -148,6 +148,25 @@ class Engine(object):
         check(self.lib.tfk_accumulate(self._h, c_void_p(x_ptr), ldx, c_void_p(y_ptr), T, flags))
 
     # ---- device-side splice: unspliced frames in, spliced in HBM ----
+    def _raw_device(self, raw, lens):
+        """unspliced frames that already live in HBM (a float32 torch tensor, e.g. FeaturePlan.compute_device's result):
+        (pointer, leading dimension, rows, utterance lengths); the engine's stream is ordered behind the tensor's producer"""
+        import torch
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if raw.dtype != torch.float32 or raw.dim() != 2 or raw.stride(1) != 1 or int(lens.sum()) != raw.shape[0]:
+            raise ValueError("device frames must be a float32 [T, D] tensor with unit column stride whose rows match the "
+                             "utterance lengths (sum %d)" % int(lens.sum()))
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(raw.device))
+        stream = c_void_p()
+        check(self.lib.tfk_stream(self._h, byref(stream)))
+        torch.cuda.ExternalStream(stream.value, device=raw.device).wait_event(done)
+        return c_void_p(raw.data_ptr()), int(raw.stride(0)), int(raw.shape[0]), lens
+
+    @staticmethod
+    def _on_device(raw):
+        return hasattr(raw, "is_cuda") and raw.is_cuda
+
     @staticmethod
     def _raw_batch(raw, lens):
         raw = _f32(raw)
@@ -167,13 +186,25 @@ class Engine(object):
         return cmvn, cmvn.ctypes.data_as(c_void_p)
 
     def accumulate_raw(self, raw, y, lens, context_width, last=False, cmvn=None):
-        raw, lens = self._raw_batch(raw, lens)
+        """`raw`: host [T, D] frames, or a float32 CUDA tensor (TFK_RAW_DEVICE)"""
         y = np.ascontiguousarray(y, dtype=np.int32)
-        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
-        check(self.lib.tfk_accumulate_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1],
-                                          y.ctypes.data_as(c_void_p), raw.shape[0], lens.ctypes.data_as(c_void_p),
-                                          lens.size, int(context_width), cmvn_ptr,
-                                          _lib.LAST_MICROBATCH if last else 0))
+        flags = _lib.LAST_MICROBATCH if last else 0
+        if self._on_device(raw):
+            ptr, ld, rows, lens = self._raw_device(raw, lens)
+            flags |= _lib.RAW_DEVICE
+            cols = raw.shape[1]
+        else:
+            raw, lens = self._raw_batch(raw, lens)
+            ptr, ld, rows, cols = raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0], raw.shape[1]
+        if cmvn is not None:
+            cmvn = np.ascontiguousarray(cmvn, dtype=np.float32)
+            if cmvn.shape != (lens.size, 2, cols):
+                raise ValueError("cmvn table %s, expected %s" % (cmvn.shape, (lens.size, 2, cols)))
+        cmvn_ptr = cmvn.ctypes.data_as(c_void_p) if cmvn is not None else c_void_p(None)
+        if y.shape != (rows,):
+            raise ValueError("targets %s do not match %d frames" % (y.shape, rows))
+        check(self.lib.tfk_accumulate_raw(self._h, ptr, ld, y.ctypes.data_as(c_void_p), rows, lens.ctypes.data_as(c_void_p),
+                                          lens.size, int(context_width), cmvn_ptr, flags))
 
     def eval_accumulate_raw(self, raw, y, lens, context_width, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
@@ -196,13 +227,23 @@ class Engine(object):
         return np.empty((rows, self.O), dtype=np.float32)
 
     def posteriors_raw(self, raw, lens, context_width, log_div_prior=False, raw_logits=False, cmvn=None):
-        raw, lens = self._raw_batch(raw, lens)
-        out = self._out_buffer(raw.shape[0])
+        """`raw`: host [T, D] frames, or a float32 CUDA tensor (TFK_RAW_DEVICE: features that never left HBM)"""
         flags = (_lib.LOG_DIV_PRIOR if log_div_prior else 0) | (_lib.RAW_LOGITS if raw_logits else 0)
-        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
-        check(self.lib.tfk_posteriors_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0],
-                                          lens.ctypes.data_as(c_void_p), lens.size, int(context_width), cmvn_ptr,
-                                          out.ctypes.data_as(c_void_p), self.O, flags))
+        if self._on_device(raw):
+            ptr, ld, rows, lens = self._raw_device(raw, lens)
+            flags |= _lib.RAW_DEVICE
+            shape = (rows, raw.shape[1])
+        else:
+            raw, lens = self._raw_batch(raw, lens)
+            ptr, ld, rows, shape = raw.ctypes.data_as(c_void_p), raw.shape[1], raw.shape[0], raw.shape
+        out = self._out_buffer(rows)
+        if cmvn is not None:
+            cmvn = np.ascontiguousarray(cmvn, dtype=np.float32)
+            if cmvn.shape != (lens.size, 2, shape[1]):
+                raise ValueError("cmvn table %s, expected %s" % (cmvn.shape, (lens.size, 2, shape[1])))
+        cmvn_ptr = cmvn.ctypes.data_as(c_void_p) if cmvn is not None else c_void_p(None)
+        check(self.lib.tfk_posteriors_raw(self._h, ptr, ld, rows, lens.ctypes.data_as(c_void_p), lens.size,
+                                          int(context_width), cmvn_ptr, out.ctypes.data_as(c_void_p), self.O, flags))
         return out
 
     # ---- CTC loss (SURVEY 8f-4): frames [T, F] of U utterances + their label sequences ----
