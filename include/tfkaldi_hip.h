@@ -351,6 +351,14 @@ int tfk_feat_stage(tfk_feat* f, void* stream, int stage, const void* signal, int
  * utterance): out[n_rows][ld_out] = [x | d x | d d x] limited to 1 + dynamic blocks.  deriv_only: out = d x. */
 int tfk_feat_dynamic(void* stream, const double* x, int64_t ld_x, int32_t dim, const int64_t* row_off, int32_t n_utts,
                      int64_t n_rows, int dynamic, int deriv_only, void* out, int64_t ld_out, int out_f64);
+/* sigproc.deframesig (sigproc.py:69-123): overlap-add of frames[n_frames][ld] (frame_len columns used) back into a signal
+ * of (n_frames - 1) * frame_step + frame_len samples; every sample is divided by the sum of the window values (+ 1e-15 per
+ * frame, as there) of the frames that cover it, both sums taken in frame order.  win[frame_len] = NULL: rectangular. */
+int tfk_deframesig(void* stream, const double* frames, int64_t ld, int64_t n_frames, int32_t frame_len, int32_t frame_step,
+                   const double* win, double* out);
+/* The tail of sigproc.logpowspec (sigproc.py:170-178), in place on n power-spectrum values: 10 log10(max(p, 1e-30)),
+ * minus the maximum over all of them when norm != 0.  scratch: device memory for 1024 doubles. */
+int tfk_logpow(void* stream, double* p, int64_t n, int norm, double* scratch);
 /* compute_cmvn (prepare_data.py:80-118): speaker s owns the utterances [spk_off[s], spk_off[s+1]) of the list
  * (utt_row[q], utt_len[q]) = first row and row count in feats[.][ld] (float32, `dim` columns);
  * stats[s] = [[sum x | count], [sum x^2 | 0]] as [2][dim+1] doubles, the sums accumulated row after row in float32

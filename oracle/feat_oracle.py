@@ -6,7 +6,7 @@ tools/feature_bench.py -- never by tfkaldi_amd/.  It restates, in float64 numpy 
 
     processing/feat.py:7-90          FeatureComputer.__call__, snip
     processing/base.py:39-284        mfcc, fbank, logfbank, ssc, hz2mel, mel2hz, get_filterbanks, lifter, deriv, delta, ddelta
-    processing/sigproc.py:33-191     framesig, magspec, powspec, preemphasis
+    processing/sigproc.py:33-191     framesig, deframesig, magspec, powspec, logpowspec, preemphasis
     processing/prepare_data.py:80-118 compute_cmvn (float32 running sums, see cmvn_stats)
 
 Parity is PINNED: tests/golden/feat_golden.npz holds outputs of the reference's own code for the same inputs
@@ -61,6 +61,30 @@ def magspec(frames, nfft):
 def powspec(frames, nfft):
     """sigproc.py:141-153"""
     return 1.0 / nfft * np.square(magspec(frames, nfft))
+
+
+def deframesig(frames, siglen, frame_len, frame_step, winfunc=lambda n: np.ones((n,))):
+    """sigproc.py:69-123: overlap-add; the frames and the window (+ 1e-15) are accumulated frame after frame"""
+    frame_len, frame_step = py2_round(frame_len), py2_round(frame_step)
+    n = frames.shape[0]
+    assert frames.shape[1] == frame_len
+    padlen = (n - 1) * frame_step + frame_len
+    if siglen <= 0:
+        siglen = padlen
+    rec, corr, win = np.zeros(padlen), np.zeros(padlen), winfunc(frame_len)
+    for i in range(n):
+        seg = slice(i * frame_step, i * frame_step + frame_len)
+        corr[seg] = corr[seg] + win + 1e-15
+        rec[seg] = rec[seg] + frames[i]
+    return (rec / corr)[0:siglen]
+
+
+def logpowspec(frames, nfft, norm=1):
+    """sigproc.py:155-178"""
+    ps = powspec(frames, nfft)
+    ps[ps <= 1e-30] = 1e-30
+    lps = 10 * np.log10(ps)
+    return lps - np.max(lps) if norm else lps
 
 
 def hz2mel(rate):

@@ -141,6 +141,17 @@ def main():
     prep.shuffle_examples(f)
     out["prep_shuffled_sorted"] = np.array(sorted(open(os.path.join(f, "feats_shuffled.scp")).read().replace(f, "@DIR@").split("\n")))
 
+    # ---- the two sigproc functions nothing in the reference calls (sigproc.py:69-123, 155-178) ----
+    rng2 = np.random.default_rng(4242)
+    fr2 = sigproc.framesig(speechlike(rng2, 1500, 16000).astype(np.float64), 400.0, 160.0)
+    out["blk2_frames"] = fr2
+    out["blk2_deframe"] = sigproc.deframesig(fr2, 1500, 400.0, 160.0)
+    out["blk2_deframe_full"] = sigproc.deframesig(fr2, 0, 400.0, 160.0)
+    out["blk2_deframe_hamming"] = sigproc.deframesig(fr2 * np.hamming(400), 1500, 400.0, 160.0, winfunc=np.hamming)
+    out["blk2_logpowspec"] = sigproc.logpowspec(fr2, 512)
+    out["blk2_logpowspec_raw"] = sigproc.logpowspec(fr2, 512, norm=0)
+    out["blk2_logpowspec_silence"] = sigproc.logpowspec(np.zeros((3, 400)), 512, norm=0)
+
     np.savez_compressed(os.path.join(GOLD, "feat_golden.npz"), **out)
     shutil.rmtree(scratch)
     print("wrote %d arrays to %s" % (len(out), os.path.abspath(GOLD)))

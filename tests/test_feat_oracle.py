@@ -70,6 +70,17 @@ def test_oracle_building_blocks_match_reference(gold):
     assert [len(feat.snip(np.zeros(n), 16000, 0.025, 0.01)) for n in lens] == list(gold["blk_snip"])
 
 
+def test_oracle_deframesig_and_logpowspec_match_reference(gold):
+    fr = gold["blk2_frames"]
+    assert np.array_equal(fo.deframesig(fr, 1500, 400.0, 160.0), gold["blk2_deframe"])
+    assert np.array_equal(fo.deframesig(fr, 0, 400.0, 160.0), gold["blk2_deframe_full"])
+    assert np.array_equal(fo.deframesig(fr * np.hamming(400), 1500, 400.0, 160.0, winfunc=np.hamming), gold["blk2_deframe_hamming"])
+    assert np.array_equal(fo.logpowspec(fr, 512), gold["blk2_logpowspec"])
+    assert np.array_equal(fo.logpowspec(fr, 512, norm=0), gold["blk2_logpowspec_raw"])
+    assert np.array_equal(fo.logpowspec(np.zeros((3, 400)), 512, norm=0), gold["blk2_logpowspec_silence"])
+    assert (gold["blk2_logpowspec_silence"] == -300.0).all() and gold["blk2_logpowspec"].max() == 0.0
+
+
 def test_dct_matrix_is_scipys_orthonormal_dct():
     from scipy.fftpack import dct
     x = np.random.default_rng(3).standard_normal((7, 23))

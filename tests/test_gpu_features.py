@@ -130,6 +130,23 @@ def test_sigproc_blocks(gold):
         sigproc.preemphasis(np.zeros(0), 0.97)
 
 
+def test_deframesig_and_logpowspec(gold):
+    from tfkaldi_amd.processing import sigproc
+    fr = gold["blk2_frames"]
+    assert np.array_equal(sigproc.deframesig(fr, 1500, 400.0, 160.0), gold["blk2_deframe"])           # bit-exact
+    assert np.array_equal(sigproc.deframesig(fr, 0, 400.0, 160.0), gold["blk2_deframe_full"])
+    assert np.array_equal(sigproc.deframesig(fr * np.hamming(400), 1500, 400.0, 160.0, winfunc=np.hamming),
+                          gold["blk2_deframe_hamming"])
+    x = np.random.default_rng(8).standard_normal(5000)
+    assert np.allclose(sigproc.deframesig(sigproc.framesig(x, 256, 64), 5000, 256, 64), x, rtol=0, atol=1e-12)  # round trip
+    lp = sigproc.logpowspec(fr, 512)
+    assert np.allclose(lp, gold["blk2_logpowspec"], rtol=0, atol=1e-9) and lp.max() == 0.0
+    assert np.allclose(sigproc.logpowspec(fr, 512, norm=0), gold["blk2_logpowspec_raw"], rtol=0, atol=1e-9)
+    assert np.array_equal(sigproc.logpowspec(np.zeros((3, 400)), 512, norm=0), gold["blk2_logpowspec_silence"])
+    big = np.random.default_rng(9).standard_normal((3000, 400))   # more values than one reduction block
+    assert np.allclose(sigproc.logpowspec(big, 512), fo.logpowspec(big, 512), rtol=0, atol=1e-9)
+
+
 def test_parseval_and_linearity_at_full_length():
     """size-independent properties of the spectrum on ten minutes of audio: sum_k c_k P[k] = sum_n y[n]^2 / nfft * ...
     (Parseval for the real transform) and P(a x) = a^2 P(x)"""

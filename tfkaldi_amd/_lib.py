@@ -125,6 +125,8 @@ SYMBOLS = {
                                c_int64]),
     "tfk_feat_dynamic": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int64, c_int, c_int, c_void_p,
                                  c_int64, c_int]),
+    "tfk_deframesig": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "tfk_logpow": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "tfk_cmvn_stats": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
 }
 

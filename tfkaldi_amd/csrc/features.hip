@@ -529,6 +529,60 @@ __global__ __launch_bounds__(64) void cmvn_stats_kernel(const float* __restrict_
   }
 }
 
+// ---- sigproc.deframesig: thread per output sample, the covering frames added in frame order ----
+__global__ __launch_bounds__(256) void deframe_kernel(const double* __restrict__ frames, int64_t ld, int64_t n_frames,
+                                                      int frame_len, int frame_step, const double* __restrict__ win,
+                                                      int64_t padlen, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= padlen) return;
+  int64_t lo = s - frame_len + 1;
+  lo = lo <= 0 ? 0 : (lo + frame_step - 1) / frame_step;   // first frame that reaches sample s
+  int64_t hi = s / frame_step;                              // last frame that starts at or before it
+  if (hi > n_frames - 1) hi = n_frames - 1;
+  double acc = 0.0, corr = 0.0;
+  for (int64_t i = lo; i <= hi; ++i) {
+    const int j = (int)(s - i * frame_step);
+    acc = acc + frames[i * ld + j];
+    corr = (corr + (win ? win[j] : 1.0)) + 1e-15;           // sigproc.py:113-115
+  }
+  out[s] = acc / corr;                                      // (a sample no frame covers is 0/0 there as well)
+}
+
+// ---- sigproc.logpowspec's tail: 10 log10(max(p, 1e-30)) [- global maximum] ----
+__global__ __launch_bounds__(256) void logpow_kernel(double* __restrict__ p, int64_t n, double* __restrict__ block_max) {
+  __shared__ double red[256];
+  double m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = p[i];
+    if (v <= 1e-30) v = 1e-30;                              // sigproc.py:172
+    v = 10.0 * log10(v);
+    p[i] = v;
+    m = v > m ? v : m;                                      // (NaN never wins, as numpy.max would have it propagate: see below)
+    if (v != v) m = v;
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const double a = red[threadIdx.x], b = red[threadIdx.x + o];
+      red[threadIdx.x] = (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b);   // NaN propagates like numpy.max
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_max[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sub_max_kernel(double* __restrict__ p, int64_t n, const double* __restrict__ block_max,
+                                                      int blocks) {
+  double m = block_max[0];
+  for (int b = 1; b < blocks; ++b) {
+    const double v = block_max[b];
+    m = (m != m || v != v) ? (m != m ? m : v) : (v > m ? v : m);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = p[i] - m;
+}
+
 int check_batch(const void* signal, const int64_t* sig_off, const int64_t* frame_off, int32_t n_utts, int64_t n_frames,
                 const void* out, int sample_type) {
   if (n_utts < 0 || n_frames < 0) return fail(-1, "negative batch size");
@@ -798,6 +852,27 @@ int tfk_feat_dynamic(void* stream, const double* x, int64_t ld_x, int32_t dim, c
   DynArgs a{x, ld_x, dim, row_off, n_utts, n_rows, dynamic, deriv_only, out, ld_out, out_f64};
   const int64_t total = n_rows * dim;
   hipLaunchKernelGGL(dynamic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tfk_deframesig(void* stream, const double* frames, int64_t ld, int64_t n_frames, int32_t frame_len, int32_t frame_step,
+                   const double* win, double* out) {
+  if (n_frames <= 0) return 0;
+  if (!frames || !out || frame_len < 1 || frame_step < 1 || ld < frame_len) return fail(-1, "bad argument");
+  const int64_t padlen = (n_frames - 1) * frame_step + frame_len;
+  hipLaunchKernelGGL(deframe_kernel, dim3((unsigned)((padlen + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, ld,
+                     n_frames, frame_len, frame_step, win, padlen, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tfk_logpow(void* stream, double* p, int64_t n, int norm, double* scratch) {
+  if (n <= 0) return 0;
+  if (!p || !scratch) return fail(-1, "NULL argument");
+  const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(logpow_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, scratch);
+  if (norm) hipLaunchKernelGGL(sub_max_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, scratch, blocks);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,7 +1,7 @@
 """Signal framing and spectra with the reference's interface (processing/sigproc.py), computed on the GPU
-(csrc/features.hip through tfkaldi_amd/features.py; float64 in, float64 out; no CPU path).
+(csrc/features.hip through tfkaldi_amd/features.py; float64 in, float64 out; no CPU path)."""
+from ctypes import c_void_p
 
-`deframesig` and `logpowspec` of the reference module have no caller anywhere in the reference and are not provided."""
 import numpy as np
 
 from .. import _lib, features
@@ -67,5 +67,50 @@ def preemphasis(signal, coeff=0.95):
     chunk = 1024
     plan = _plan(chunk, chunk, 32, preemph=coeff)
     out = plan.stage(_lib.STAGE_FRAMES, [signal])[0].reshape(-1)[:signal.size]
+    plan.close()
+    return out
+
+
+def deframesig(frames, siglen, frame_len, frame_step, winfunc=_ones):
+    """sigproc.py:69-123: overlap-add that undoes framesig; every sample is divided by the summed window of the frames
+    covering it; truncated to siglen samples (siglen <= 0: everything)"""
+    torch = features._torch()
+    frame_len, frame_step = features.py2_round(frame_len), features.py2_round(frame_step)
+    frames = np.ascontiguousarray(frames, dtype=np.float64)
+    numframes = frames.shape[0]
+    assert frames.shape[1] == frame_len, '"frames" matrix is wrong size, 2nd dim is not equal to frame_len'
+    padlen = (numframes - 1) * frame_step + frame_len
+    if siglen <= 0:
+        siglen = padlen
+    if numframes == 0:
+        return np.zeros((0,))
+    lib = _lib.load()
+    d_frames = torch.from_numpy(frames).cuda()
+    win = None if winfunc is _ones else torch.from_numpy(np.ascontiguousarray(winfunc(frame_len), dtype=np.float64)).cuda()
+    out = torch.empty(padlen, dtype=torch.float64, device=d_frames.device)
+    stream = torch.cuda.current_stream(d_frames.device).cuda_stream
+    _lib.check(lib.tfk_deframesig(c_void_p(stream), c_void_p(d_frames.data_ptr()), frame_len, numframes, frame_len, frame_step,
+                                  c_void_p(win.data_ptr()) if win is not None else c_void_p(None), c_void_p(out.data_ptr())))
+    return out.cpu().numpy()[0:int(siglen)]
+
+
+def logpowspec(frames, nfft, norm=1):
+    """sigproc.py:155-178: 10 log10 of the power spectrum (floored at 1e-30), minus its maximum over all frames if norm"""
+    torch = features._torch()
+    frames = _rows_as_signal(frames)
+    n, width = frames.shape
+    if n == 0:
+        return np.zeros((0, int(nfft) // 2 + 1))
+    plan = _plan(width, width, nfft)
+    packed = plan.pack([frames.reshape(-1)])
+    cols = plan.nbins
+    ps = torch.empty((packed.n_frames, cols), dtype=torch.float64, device=packed.signal.device)
+    scratch = torch.empty(1024, dtype=torch.float64, device=ps.device)
+    stream = c_void_p(torch.cuda.current_stream(ps.device).cuda_stream)
+    _lib.check(plan.lib.tfk_feat_stage(plan._h, stream, _lib.STAGE_POWSPEC, c_void_p(packed.signal.data_ptr()), packed.sample_type,
+                                       c_void_p(packed.d_sig_off.data_ptr()), c_void_p(packed.d_frame_off.data_ptr()),
+                                       packed.n_utts, packed.n_frames, c_void_p(ps.data_ptr()), cols))
+    _lib.check(plan.lib.tfk_logpow(stream, c_void_p(ps.data_ptr()), ps.numel(), int(bool(norm)), c_void_p(scratch.data_ptr())))
+    out = ps.cpu().numpy()
     plan.close()
     return out
