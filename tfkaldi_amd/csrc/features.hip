@@ -230,13 +230,16 @@ __device__ __forceinline__ double2 twiddle(const double2* tws, int N2, int m) {
   return double2{-w.x, -w.y};
 }
 
-template <int SAMPLE>
+// LOG2N2 > 0: log2 of the half-length known at compile time (8 = the 512-point transform of the reference's
+// configurations) -- pass count, strides and twiddle steps fold to constants and the passes unroll; 0: any size.
+template <int SAMPLE, int LOG2N2>
 __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // (the wave index through readfirstlane: the compiler then knows that everything per frame -- frame number, its
   // metadata, buffer addresses -- is uniform and keeps it in scalar registers and scalar instructions)
   const int waves = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int N2 = p.nfft >> 1, nbins = N2 + 1;
+  const int N2 = LOG2N2 ? (1 << LOG2N2) : (p.nfft >> 1), nbins = N2 + 1;
+  const int log2_n2 = LOG2N2 ? LOG2N2 : p.log2_n2;
   // block-shared tables, then two [N2] complex buffers per wave
   double2* tws = (double2*)lds;
   double* fbv = lds + 2 * N2;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
   int Ns;
   const bool silent = fm.avail <= 0;                       // a frame of an empty utterance: nothing to read
   const Cplx zero{0.0, 0.0};
-  if (p.log2_n2 & 1) {
+  if (log2_n2 & 1) {
     for (int j = lane; j < (N2 >> 1); j += 64) {
       Cplx a = zero, b = zero;
       if (!silent) {
@@ -329,11 +332,14 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
     pw[k] = p.stage == TFK_STAGE_MAGSPEC ? sqrt(sq) : pk;
     esum += pk;
   };
-  for (int k = lane; k <= (N2 >> 1); k += 64) {
+  // (the three bins without a distinct partner -- 0, N2 and the middle one, where W^k O = -i Im Z -- are lane 0's extra
+  // work in the first trip, so that the trips cover k = 1 .. N2/2 - 1 only: two instead of three at N2 = 256)
+  for (int k = lane; k < (N2 >> 1); k += 64) {
     if (k == 0) {
-      const Cplx z = src[0];
+      const Cplx z = src[0], mid = src[N2 >> 1];
       emit(0, z.x + z.y, 0.0);
       emit(N2, z.x - z.y, 0.0);
+      emit(N2 >> 1, mid.x, -mid.y);
     } else {
       const Cplx a = src[k], bq = src[N2 - k];
       const double br = bq.x, bi = -bq.y;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(512) void feat_frames_kernel(FrameArgs p) {
       const Cplx o{0.5 * (a.y - bi), -0.5 * (a.x - br)};
       const Cplx tt = cmul(o, tws[k]);
       emit(k, er + tt.x, ei + tt.y);
-      if (2 * k != N2) emit(N2 - k, er - tt.x, ei - tt.y);
+      emit(N2 - k, er - tt.x, ei - tt.y);
     }
   }
   wave_sync();
@@ -482,7 +488,20 @@ __global__ __launch_bounds__(256) void dynamic_kernel(DynArgs p) {
   if (p.deriv_only) { store(c, d1); return; }
   store(c, x0);
   if (p.dynamic >= 1) store(p.dim + c, d1);
-  if (p.dynamic >= 2) store(2 * (int64_t)p.dim + c, deriv5(d1, D1(t - 2), D1(t - 1), D1(t + 1), D1(t + 2)));
+  if (p.dynamic >= 2) {
+    if (t >= 2 && t + 2 < n) {
+      // the five first derivatives around an interior frame come from ONE window x[t-4 .. t+4] (each index reflected on
+      // its own): 9 loads instead of 25
+      double w[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) w[i] = X(t - 4 + i);
+      const double m2 = deriv5(w[2], w[0], w[1], w[3], w[4]), m1 = deriv5(w[3], w[1], w[2], w[4], w[5]);
+      const double p1 = deriv5(w[5], w[3], w[4], w[6], w[7]), p2 = deriv5(w[6], w[4], w[5], w[7], w[8]);
+      store(2 * (int64_t)p.dim + c, deriv5(d1, m2, m1, p1, p2));
+    } else {
+      store(2 * (int64_t)p.dim + c, deriv5(d1, D1(t - 2), D1(t - 1), D1(t + 1), D1(t + 2)));
+    }
+  }
 }
 
 // ---- compute_cmvn: float32 sums accumulated row after row (numpy's axis-0 reduction of a C-contiguous matrix) ----
@@ -643,10 +662,14 @@ int launch_frames(tfk_feat* f, hipStream_t st, FrameArgs& a, int sample_type) {
   const int64_t blocks_needed = (a.b.n_frames + waves - 1) / waves;
   const int64_t resident = (int64_t)f->num_cus * std::max<int64_t>(1, (int64_t)(kLdsBudget / f->lds_bytes));
   const unsigned grid = (unsigned)std::min<int64_t>(blocks_needed, resident);
-  if (sample_type == TFK_SAMPLE_I16)
-    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_I16>, dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL(feat_frames_kernel<TFK_SAMPLE_F64>, dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
+  const bool fixed = f->cfg.nfft == 512;
+  if (sample_type == TFK_SAMPLE_I16) {
+    if (fixed) hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_I16, 8>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
+    else hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_I16, 0>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
+  } else {
+    if (fixed) hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_F64, 8>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
+    else hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_F64, 0>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -757,9 +780,11 @@ int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const 
   }
   f->lds_bytes = shared + waves * per_wave;
   if (f->lds_bytes > 64 * 1024) {
-    hipError_t ea = hipFuncSetAttribute((const void*)feat_frames_kernel<TFK_SAMPLE_I16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
-    if (ea == hipSuccess)
-      ea = hipFuncSetAttribute((const void*)feat_frames_kernel<TFK_SAMPLE_F64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
+    hipError_t ea = hipSuccess;
+    const void* variants[4] = {(const void*)feat_frames_kernel<TFK_SAMPLE_I16, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_I16, 8>,
+                               (const void*)feat_frames_kernel<TFK_SAMPLE_F64, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_F64, 8>};
+    for (int v = 0; v < 4 && ea == hipSuccess; ++v)
+      ea = hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
     if (ea != hipSuccess) { delete f; return fail((int)ea, "LDS size attribute: %s", hipGetErrorString(ea)); }
   }
   hipError_t e = hipMalloc((void**)&f->tables, host.size() * sizeof(double));
