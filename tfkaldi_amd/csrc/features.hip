@@ -9,7 +9,7 @@
 //   processing/prepare_data.py:80-118  compute_cmvn (float32 row-after-row sums)
 //
 // Shape of the work: a frame is 400 samples in, 40 numbers out, ~16 kFLOP of float64 in between -- neither an HBM nor an
-// MFMA problem; what bounds it is instruction issue (vector ALU busy 0.78) and the LDS traffic of the transform (0.42).
+// MFMA problem; what bounds it is instruction issue (vector ALU busy 0.67) and the LDS traffic of the transform (0.51).
 // One WAVEFRONT owns one frame: the 512-point real transform is a 256-point complex Stockham radix-4 transform over
 // (even, odd) sample pairs, ping-ponging between two 4 KB buffers in that wave's slice of LDS, untangled into the half
 // spectrum on the way to the power; the mel filterbank runs over the non-zero supports of its triangles, cut into equal
