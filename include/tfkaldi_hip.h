@@ -313,7 +313,9 @@ typedef struct tfk_feat tfk_feat;
 enum { TFK_FEAT_FBANK = 0, TFK_FEAT_MFCC = 1, TFK_FEAT_SSC = 2,        /* feat.py:21-28: log-fbank, mfcc, ssc */
        TFK_FEAT_FBANK_RAW = 3 };  /* base.fbank (base.py:59-98): filterbank energies and frame energy WITHOUT the log */
 enum { TFK_DYN_NODELTA = 0, TFK_DYN_DELTA = 1, TFK_DYN_DDELTA = 2 };   /* feat.py:30-37 */
-enum { TFK_SAMPLE_I16 = 0, TFK_SAMPLE_F64 = 1 };                       /* scipy.io.wavfile's int16 / anything else as float64 */
+enum { TFK_SAMPLE_I16 = 0, TFK_SAMPLE_F64 = 1,  /* scipy.io.wavfile's int16 / any other integer type promoted to float64 */
+       TFK_SAMPLE_F32 = 2 };  /* float32 wav files: numpy keeps `signal[1:] - coeff * signal[:-1]` in float32 for them (the Python
+                               * float is cast down), so the pre-emphasis is done in float32 and only then widened */
 enum { TFK_STAGE_FRAMES = 1, TFK_STAGE_MAGSPEC = 2, TFK_STAGE_POWSPEC = 3 };
 
 typedef struct tfk_feat_config {

@@ -76,7 +76,7 @@ def test_batch_equals_one_by_one_and_mixed_sample_types(gold):
         assert np.array_equal(comp(s, 16000), b)  # the batch layout changes nothing, bit for bit
         with np.errstate(all="ignore"):
             close64(b, fo.compute_features(s, 16000, "mfcc", "ddelta", comp.conf))
-    # float64 samples in the same batch as int16 ones: everything is promoted to float64 on the way in
+    # float64 samples next to int16 ones: each sample class goes in its own device pass, the results come back in order
     mixed = comp.compute_batch([sigs[0], sigs[3].astype(np.float64)], 16000, dtype=np.float64)
     assert np.array_equal(mixed[0], batch[0]) and np.array_equal(mixed[1], batch[3])
     assert comp.compute_batch([], 16000) == []
@@ -116,6 +116,10 @@ def test_sigproc_blocks(gold):
     pre = sigproc.preemphasis(x, 0.97)
     assert pre.dtype == np.float64 and np.array_equal(pre, gold["blk_preemph"])           # bit-exact
     assert np.array_equal(sigproc.preemphasis(x.astype(np.float64), 0.0), x.astype(np.float64))
+    x32 = (x / 32768.0).astype(np.float32)          # a float32 wav: numpy keeps the pre-emphasis in float32
+    pre32 = sigproc.preemphasis(x32, 0.97)
+    assert pre32.dtype == np.float32 and np.array_equal(pre32, fo.preemphasis(x32, 0.97).astype(np.float32))
+    assert np.array_equal(pre32, np.append(x32[0], x32[1:] - 0.97 * x32[:-1]))
     fr = sigproc.framesig(gold["blk_preemph"], 400.0, 160.0)
     assert np.array_equal(fr, gold["blk_frames"])                                          # bit-exact
     assert np.array_equal(sigproc.framesig(x[:333].astype(np.float64), 100.4, 33.6), gold["blk_frames_odd"])
@@ -274,6 +278,24 @@ def test_cmvn_stats_large_speakers_bit_exact():
         assert np.array_equal(g, fo.cmvn_stats(np.concatenate(spk)))
     wide = [[rng.standard_normal((50, 130)).astype(np.float32)]]  # more columns than one wavefront
     assert np.array_equal(features.cmvn_stats(wide)[0], fo.cmvn_stats(wide[0][0]))
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.float32, np.uint8, np.int64])
+def test_other_wav_sample_types(dtype):
+    """scipy.io.wavfile hands back int32 / float32 / uint8 arrays for such files: numpy promotes them to float64 in the
+    reference's pre-emphasis, and so does the packer here (only int16 travels as it is)"""
+    from tfkaldi_amd.processing import feat
+    rng = np.random.default_rng(12)
+    if dtype is np.uint8:
+        sig = rng.integers(0, 256, size=6000).astype(dtype)
+    elif dtype is np.float32:
+        sig = (rng.standard_normal(6000) * 0.2).astype(dtype)
+    else:
+        sig = rng.integers(-2 ** 20, 2 ** 20, size=6000).astype(dtype)
+    comp = feat.FeatureComputer("mfcc", "delta", AURORA_GMM)
+    with np.errstate(all="ignore"):
+        ref = fo.compute_features(sig, 16000, "mfcc", "delta", AURORA_GMM)
+    close64(comp(sig, 16000), ref, str(dtype))
 
 
 def test_plan_errors_are_loud():

@@ -53,7 +53,7 @@ class TfkFeatConfig(Structure):
 
 FEAT_KIND = {"fbank": 0, "mfcc": 1, "ssc": 2, "fbank_raw": 3}   # TFK_FEAT_*
 FEAT_DYNAMIC = {"nodelta": 0, "delta": 1, "ddelta": 2}          # TFK_DYN_*
-SAMPLE_I16, SAMPLE_F64 = 0, 1
+SAMPLE_I16, SAMPLE_F64, SAMPLE_F32 = 0, 1, 2
 STAGE_FRAMES, STAGE_MAGSPEC, STAGE_POWSPEC = 1, 2, 3
 
 BUCKET_FN = ctypes.CFUNCTYPE(None, c_void_p, c_int)

@@ -104,7 +104,21 @@ __device__ __forceinline__ int find_utt(const int64_t* off, int n, int64_t f) {
 template <int SAMPLE>
 __device__ __forceinline__ double raw_sample(const void* sig, int64_t i) {
   if (SAMPLE == TFK_SAMPLE_I16) return (double)((const int16_t*)sig)[i];
+  if (SAMPLE == TFK_SAMPLE_F32) return (double)((const float*)sig)[i];
   return ((const double*)sig)[i];
+}
+
+// y = x - coeff * x_prev with numpy's roundings: in float64, except for float32 signals, where numpy casts the Python
+// float down and both operations round to float32
+template <int SAMPLE>
+__device__ __forceinline__ double emphasise(double x, double xp, double coeff) {
+#pragma clang fp contract(off)
+  if (SAMPLE == TFK_SAMPLE_F32) {
+    const float c = (float)coeff, scaled = c * (float)xp;
+    return (double)((float)x - scaled);
+  }
+  const double scaled = coeff * xp;
+  return x - scaled;
 }
 
 // pre-emphasised sample i of the utterance at [base, base + len): sigproc.py:180-191 -- two roundings, as numpy's
@@ -115,8 +129,7 @@ __device__ __forceinline__ double emph_sample(const void* sig, int64_t base, int
   if (i >= len) return 0.0;
   const double x = raw_sample<SAMPLE>(sig, base + i);
   if (i == 0 || coeff == 0.0) return x;
-  const double scaled = coeff * raw_sample<SAMPLE>(sig, base + i - 1);
-  return x - scaled;
+  return emphasise<SAMPLE>(x, raw_sample<SAMPLE>(sig, base + i - 1), coeff);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -159,10 +172,12 @@ __device__ __forceinline__ Cplx cmul(Cplx a, double2 w) { return Cplx{a.x * w.x 
 // Requires fm.avail >= 1 (the caller skips frames of empty utterances: all their points are zero).
 template <int SAMPLE> struct RawOf { typedef int T; };        // int16 samples travel as sign-extended 32-bit registers
 template <> struct RawOf<TFK_SAMPLE_F64> { typedef double T; };
+template <> struct RawOf<TFK_SAMPLE_F32> { typedef float T; };
 
 template <int SAMPLE>
 __device__ __forceinline__ typename RawOf<SAMPLE>::T raw_load(const void* sig, int64_t i) {
   if (SAMPLE == TFK_SAMPLE_I16) return (typename RawOf<SAMPLE>::T)((const int16_t*)sig)[i];
+  if (SAMPLE == TFK_SAMPLE_F32) return (typename RawOf<SAMPLE>::T)((const float*)sig)[i];
   return (typename RawOf<SAMPLE>::T)((const double*)sig)[i];
 }
 
@@ -188,11 +203,11 @@ __device__ __forceinline__ Cplx finish_pair(const FrameArgs& p, const FrameMeta&
   const int lim = min(used, fm.avail);
   const bool head = n0 == 0 && fm.first;                  // y[0] = x[0] (sigproc.py:191)
   const double xa = (double)ra, xb = (double)rb, xc = (double)rc;
-  const double sa = p.preemph * xa, sb = p.preemph * xb;
+  const double y0 = emphasise<SAMPLE>(xb, xa, p.preemph), y1 = emphasise<SAMPLE>(xc, xb, p.preemph);
   const bool plain = p.preemph == 0.0;
   Cplx v;
-  v.x = n0 < lim ? ((head || plain) ? xb : xb - sa) : 0.0;
-  v.y = n1 < lim ? (plain ? xc : xc - sb) : 0.0;
+  v.x = n0 < lim ? ((head || plain) ? xb : y0) : 0.0;
+  v.y = n1 < lim ? (plain ? xc : y1) : 0.0;
   return v;
 }
 
@@ -607,7 +622,7 @@ int check_batch(const void* signal, const int64_t* sig_off, const int64_t* frame
   if (n_utts < 0 || n_frames < 0) return fail(-1, "negative batch size");
   if (n_frames == 0 || n_utts == 0) return 0;
   if (!signal || !sig_off || !frame_off || !out) return fail(-1, "NULL device pointer");
-  if (sample_type != TFK_SAMPLE_I16 && sample_type != TFK_SAMPLE_F64) return fail(-1, "unknown sample type %d", sample_type);
+  if (sample_type < TFK_SAMPLE_I16 || sample_type > TFK_SAMPLE_F32) return fail(-1, "unknown sample type %d", sample_type);
   return 0;
 }
 
@@ -663,13 +678,15 @@ int launch_frames(tfk_feat* f, hipStream_t st, FrameArgs& a, int sample_type) {
   const int64_t resident = (int64_t)f->num_cus * std::max<int64_t>(1, (int64_t)(kLdsBudget / f->lds_bytes));
   const unsigned grid = (unsigned)std::min<int64_t>(blocks_needed, resident);
   const bool fixed = f->cfg.nfft == 512;
-  if (sample_type == TFK_SAMPLE_I16) {
-    if (fixed) hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_I16, 8>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
-    else hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_I16, 0>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
-  } else {
-    if (fixed) hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_F64, 8>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
-    else hipLaunchKernelGGL((feat_frames_kernel<TFK_SAMPLE_F64, 0>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);
-  }
+#define TFK_LAUNCH_FRAMES(S)                                                                                              \
+  do {                                                                                                                    \
+    if (fixed) hipLaunchKernelGGL((feat_frames_kernel<S, 8>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);        \
+    else hipLaunchKernelGGL((feat_frames_kernel<S, 0>), dim3(grid), dim3(64 * waves), f->lds_bytes, st, a);              \
+  } while (0)
+  if (sample_type == TFK_SAMPLE_I16) TFK_LAUNCH_FRAMES(TFK_SAMPLE_I16);
+  else if (sample_type == TFK_SAMPLE_F32) TFK_LAUNCH_FRAMES(TFK_SAMPLE_F32);
+  else TFK_LAUNCH_FRAMES(TFK_SAMPLE_F64);
+#undef TFK_LAUNCH_FRAMES
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -781,9 +798,10 @@ int tfk_feat_create(const tfk_feat_config* cfg, const double* filterbank, const 
   f->lds_bytes = shared + waves * per_wave;
   if (f->lds_bytes > 64 * 1024) {
     hipError_t ea = hipSuccess;
-    const void* variants[4] = {(const void*)feat_frames_kernel<TFK_SAMPLE_I16, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_I16, 8>,
-                               (const void*)feat_frames_kernel<TFK_SAMPLE_F64, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_F64, 8>};
-    for (int v = 0; v < 4 && ea == hipSuccess; ++v)
+    const void* variants[6] = {(const void*)feat_frames_kernel<TFK_SAMPLE_I16, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_I16, 8>,
+                               (const void*)feat_frames_kernel<TFK_SAMPLE_F64, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_F64, 8>,
+                               (const void*)feat_frames_kernel<TFK_SAMPLE_F32, 0>, (const void*)feat_frames_kernel<TFK_SAMPLE_F32, 8>};
+    for (int v = 0; v < 6 && ea == hipSuccess; ++v)
       ea = hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes);
     if (ea != hipSuccess) { delete f; return fail((int)ea, "LDS size attribute: %s", hipGetErrorString(ea)); }
   }
@@ -861,6 +879,8 @@ int tfk_feat_stage(tfk_feat* f, void* stream, int stage, const void* signal, int
   if (n_frames > 0x7fffffffLL) return fail(-1, "too many frames for one launch");
   if (sample_type == TFK_SAMPLE_I16)
     hipLaunchKernelGGL(frames_kernel<TFK_SAMPLE_I16>, dim3((unsigned)n_frames), dim3(256), 0, st, a);
+  else if (sample_type == TFK_SAMPLE_F32)
+    hipLaunchKernelGGL(frames_kernel<TFK_SAMPLE_F32>, dim3((unsigned)n_frames), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(frames_kernel<TFK_SAMPLE_F64>, dim3((unsigned)n_frames), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());

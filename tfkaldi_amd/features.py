@@ -38,6 +38,22 @@ def _dptr(t):
     return c_void_p(t.data_ptr())
 
 
+def sample_class(sig):
+    """how numpy treats a wav array in `signal[1:] - coeff * signal[:-1]` (sigproc.py:191): int16 travels as it is and is
+    widened on the device; float32 STAYS float32 through the pre-emphasis (the Python float is cast down); every other
+    type (int32, uint8, float64, ...) is promoted to float64"""
+    dt = np.asarray(sig).dtype
+    return "i16" if dt == np.int16 else "f32" if dt == np.float32 else "f64"
+
+
+def by_sample_class(signals):
+    """indices of the signals of each class, in order"""
+    groups = {}
+    for i, s in enumerate(signals):
+        groups.setdefault(sample_class(s), []).append(i)
+    return groups
+
+
 class Packed(object):
     """a batch of signals concatenated in HBM with its utterance / frame offsets"""
 
@@ -47,10 +63,12 @@ class Packed(object):
         for s in sigs:
             if s.ndim != 1:
                 raise ValueError("a signal must be one-dimensional (mono), got shape %s" % (s.shape,))
-        if sigs and all(s.dtype == np.int16 for s in sigs):
-            self.sample_type, dtype = _lib.SAMPLE_I16, np.int16
-        else:
-            self.sample_type, dtype = _lib.SAMPLE_F64, np.float64
+        classes = set(sample_class(s) for s in sigs)
+        if len(classes) > 1:
+            raise ValueError("one batch holds one kind of samples (int16, float32 or float64-promoted): %s" % sorted(classes))
+        kind = classes.pop() if classes else "f64"
+        self.sample_type, dtype = {"i16": (_lib.SAMPLE_I16, np.int16), "f32": (_lib.SAMPLE_F32, np.float32),
+                                   "f64": (_lib.SAMPLE_F64, np.float64)}[kind]
         lens = np.array([s.size for s in sigs], dtype=np.int64)
         self.sig_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
         frames = np.array([count_frames(int(n), frame_len, frame_step) for n in lens], dtype=np.int64)
@@ -61,7 +79,7 @@ class Packed(object):
         total = max(int(self.sig_off[-1]), 1)  # (one element at least: a valid pointer for all-empty batches)
         # the samples are gathered straight into pinned memory: one pass over them on the host, then a DMA at PCIe speed
         # (a pageable array would be staged through the driver's bounce buffers at a fraction of it)
-        tdt = torch.int16 if dtype is np.int16 else torch.float64
+        tdt = {np.int16: torch.int16, np.float32: torch.float32, np.float64: torch.float64}[dtype]
         staging = torch.zeros(total, dtype=tdt, pin_memory=True)
         flat = staging.numpy()
         for s, lo, hi in zip(sigs, self.sig_off[:-1], self.sig_off[1:]):
@@ -134,18 +152,31 @@ class FeaturePlan(object):
         return out
 
     def compute(self, signals, dtype=np.float64):
-        """one [frames, dim] array per signal"""
+        """one [frames, dim] array per signal (signals of different sample classes go in separate device passes)"""
         torch = _torch()
-        packed = self.pack(signals)
-        out = self.compute_device(packed, dtype)
-        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-        host.copy_(out, non_blocking=True)
-        torch.cuda.current_stream(out.device).synchronize()
-        return packed.split(host.numpy())
+        signals = [np.asarray(s) for s in signals]
+        result = [None] * len(signals)
+        for _, idx in sorted(by_sample_class(signals).items()):
+            packed = self.pack([signals[i] for i in idx])
+            out = self.compute_device(packed, dtype)
+            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            torch.cuda.current_stream(out.device).synchronize()
+            for i, m in zip(idx, packed.split(host.numpy())):
+                result[i] = m
+        return result
 
     def stage(self, stage, signals):
         """TFK_STAGE_*: frames / magnitude spectrum / power spectrum of each signal, float64"""
         torch = _torch()
+        signals = [np.asarray(s) for s in signals]
+        groups = by_sample_class(signals)
+        if len(groups) > 1:
+            result = [None] * len(signals)
+            for _, idx in sorted(groups.items()):
+                for i, m in zip(idx, self.stage(stage, [signals[i] for i in idx])):
+                    result[i] = m
+            return result
         packed = self.pack(signals)
         cols = self.cfg.frame_len if stage == _lib.STAGE_FRAMES else self.nbins
         out = torch.empty((packed.n_frames, cols), dtype=torch.float64, device=packed.signal.device)

@@ -68,7 +68,7 @@ def preemphasis(signal, coeff=0.95):
     plan = _plan(chunk, chunk, 32, preemph=coeff)
     out = plan.stage(_lib.STAGE_FRAMES, [signal])[0].reshape(-1)[:signal.size]
     plan.close()
-    return out
+    return out.astype(np.float32) if signal.dtype == np.float32 else out  # (numpy stays in float32 for a float32 signal)
 
 
 def deframesig(frames, siglen, frame_len, frame_step, winfunc=_ones):

@@ -1,5 +1,5 @@
 """GPU tool: randomised sweep of the feature computation against the float64 oracle -- transform lengths 32..4096, 1..200
-filters, every feature type / dynamic, 4-48 kHz, utterances from 1 sample up, int16 and float64 input, batches of mixed
+filters, every feature type / dynamic, 4-48 kHz, utterances from 1 sample up, int16, float64 and float32 input, batches of mixed
 lengths.  usage: python tools/fuzz_features.py [n_configs] [seed]"""
 import os
 import sys
@@ -34,11 +34,11 @@ def main():
         if low >= (high if high > 0 else rate // 2):
             continue
         lens = [int(x) for x in rng.choice([1, 2, 17, 100, 399, 400, 401, 1000, 5000, 20000], size=int(rng.integers(1, 7)))]
-        as_float = bool(rng.integers(2))
+        as_float = int(rng.integers(3))  # 0: int16, 1: float64, 2: float32 (numpy keeps the pre-emphasis in float32 there)
         sigs = []
         for m in lens:
             x = 3000 * np.sin(2 * np.pi * rng.uniform(50, rate / 2.2) * np.arange(m) / rate) + 300 * rng.standard_normal(m)
-            sigs.append(x * 1e-3 if as_float else np.round(x).astype(np.int16))
+            sigs.append(np.round(x).astype(np.int16) if as_float == 0 else (x * 1e-3).astype(np.float64 if as_float == 1 else np.float32))
         try:
             comp = feat.FeatureComputer(ftype, dyn, conf)
             got = comp.compute_batch(sigs, rate, dtype=np.float64)
