@@ -184,6 +184,11 @@ def test_deltas_are_bit_exact(gold):
     assert np.array_equal(base.ddelta(m), gold["blk_ddelta"])
     for n in (1, 2, 3, 4, 5):
         assert np.array_equal(base.deriv(m[:n]), gold["blk_deriv_n%d" % n])
+    from scipy.ndimage import convolve1d
+    m32 = m.astype(np.float32)                       # float32 features: scipy answers in float32, stage by stage
+    d32 = convolve1d(m32, [2, 1, 0, -1, -2], 0)
+    assert base.deriv(m32).dtype == np.float32 and np.array_equal(base.deriv(m32), d32)
+    assert np.array_equal(base.ddelta(m32), np.concatenate((m32, d32, convolve1d(d32, [2, 1, 0, -1, -2], 0)), 1))
     rng = np.random.default_rng(2)
     mats = [rng.standard_normal((n, 7)) for n in (1, 2, 3, 50, 1, 977, 4)]
     for got, x in zip(features.dynamic(mats, 2), mats):

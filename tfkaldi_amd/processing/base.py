@@ -104,16 +104,25 @@ def lifter(cepstra, liftering=22):
     return cepstra
 
 
+def _same_kind(result, like):
+    """scipy.ndimage.convolve1d returns its input's dtype: float32 features give float32 derivatives (computed in double,
+    rounded on the way out); everything else is float64 here as it is in the feature pipeline"""
+    return result.astype(numpy.float32) if numpy.asarray(like).dtype == numpy.float32 else result
+
+
 def deriv(features_):
     """base.py:248-258: first-order derivative over time (kernel [2, 1, 0, -1, -2], reflected edges)"""
-    return features.dynamic([features_], 1, deriv_only=True)[0]
+    return _same_kind(features.dynamic([features_], 1, deriv_only=True)[0], features_)
 
 
 def delta(features_):
     """base.py:260-270: [features | derivative]"""
-    return features.dynamic([features_], 1)[0]
+    return _same_kind(features.dynamic([features_], 1)[0], features_)
 
 
 def ddelta(features_):
     """base.py:272-284: [features | derivative | second derivative]"""
+    if numpy.asarray(features_).dtype == numpy.float32:  # the second derivative is taken of the ROUNDED first one there
+        first = deriv(features_)
+        return numpy.concatenate((features_, first, deriv(first)), 1)
     return features.dynamic([features_], 2)[0]
