@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64-trace", action="store_true",
+                    help="skip the float64-oracle loss trace (about a minute of host numpy behind the CPU baseline)")
     ap.add_argument("--dtype", choices=["float32", "bfloat16"], default="float32",
                     help="float32 (default) is BASELINE cfg2's arithmetic and the only valid headline; bfloat16 runs "
                          "the same workload in the engine's mixed-precision mode (cfg3/cfg4 arithmetic) for reference")
@@ -162,7 +164,7 @@ def main():
 
     import torch
     from tfkaldi_amd import _lib
-    from tfkaldi_amd.dataparallel import BucketReducer, DataParallel, init_from_env
+    from tfkaldi_amd.dataparallel import DataParallel, init_from_env
     from tfkaldi_amd.engine import Engine
 
     rank, world, local_rank = init_from_env()
@@ -189,13 +191,13 @@ def main():
     dev = [(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()) for X, y in batches]
     torch.cuda.synchronize()
 
-    exchange = None
+    reducer = None
     if dp.enabled:
         import torch.distributed as dist
         # the product's exchange step (tfkaldi_amd/dataparallel.py): per-layer bucket announcements from backward,
         # coalesced into a few large asynchronous collectives launched while backward is still being enqueued
-        reducer = BucketReducer(eng, stream_ctx=lambda: torch.cuda.stream(eng.torch_stream), mode=args.exchange)
-        exchange = reducer.mode
+        dp.mode = args.exchange
+        reducer = dp.reducer(eng)  # (collective: probes what the backend can do)
         eng.set_bucket_callback(reducer.on_bucket)
         eng.set_later_microbatches(world - 1 - rank)
 
@@ -301,7 +303,15 @@ def main():
                                    "%s, Adam" % (T, "fp32 MFMA" if args.dtype == "float32" else "bf16 MFMA (mixed precision)"),
                        "frames_per_gpu": T, "global_frames": world * T,
                        "parallelism": "dp%d" % world, "flop_per_frame": FLOP_PER_FRAME},
-            "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend, "exchange": exchange,
+            "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend,
+            # what RAN, not what was asked for: the exchange mode the reducer settled on after probing the backend and
+            # the torch.distributed calls of the last timed step, in launch order
+            "exchange": reducer.mode if reducer else None,
+            "exchange_requested": (args.exchange or os.environ.get("TFK_DP_EXCHANGE", "sharded")) if reducer else None,
+            "collectives_last_step": list(reducer.last_executed) if reducer else None,
+            "collective_spans_last_step": [list(x) for x in reducer.last_launched] if reducer else None,
+            "dp_host_ms_per_step": ({k: 1e3 * v / max(1, reducer.host_calls["finish_and_apply"])
+                                     for k, v in reducer.host_s.items()} if reducer else None),
             "per_rank_ms_per_step": per_rank_ms,
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -325,6 +335,21 @@ def main():
             if n:
                 out["loss_trace_max_rel_diff"] = max(abs(a - b) / max(abs(b), 1e-30)
                                                      for a, b in zip(out["loss_trace_gpu"][:n], trace_cpu[:n]))
+            if not args.no_f64_trace and args.dtype == "float32":
+                # the referee (same leg as the CPU baseline: oracle code, after every timed region): the float64 oracle
+                # over the same weights and micro-batches -- how far each fp32 implementation is from the specified
+                # arithmetic, not merely from the other one
+                from oracle.loss_trace import distances, f64_loss_trace
+                t_ref = time.perf_counter()
+                ref = f64_loss_trace(batches, hidden, min(TRACE_STEPS, len(out["loss_trace_gpu"])), F, L, H, O)
+                out["loss_trace_f64"] = ref
+                out["loss_trace_f64_seconds"] = time.perf_counter() - t_ref
+                gpu_rel, _ = distances(out["loss_trace_gpu"], ref)
+                cpu_rel, _ = distances(trace_cpu, ref)
+                out["loss_trace_f64_max_rel_diff"] = max(gpu_rel) if gpu_rel else None
+                out["loss_trace_cpu_vs_f64_max_rel_diff"] = max(cpu_rel) if cpu_rel else None
+                out["loss_trace_f64_rel_diff_per_step"] = {"engine": gpu_rel, "cpu_fp32": cpu_rel}
+            dp.gather_parameters(eng)
             out["posterior_max_err"] = posterior_error(eng, batches[0][0][:UTT_LEN])
     eng.close()
     if dp.enabled:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 4
+#define TFK_ABI_VERSION 5
 
 typedef struct tfk_engine tfk_engine;
 
@@ -249,6 +249,22 @@ int tfk_set_layer_callback(tfk_engine* e, tfk_layer_fn fn, void* user);
  * the optimiser's back, so the bf16 weight shadow of the mixed-precision mode is rebuilt before its next use.
  * Call between the last tfk_apply_span and tfk_apply_end (or at any other time). */
 int tfk_params_touched(tfk_engine* e);
+
+/* Mixed precision + sharded exchange: the bf16 shadow of the weight matrices.  When every weight matrix has a leading
+ * dimension that is a multiple of 8, the shadow mirrors the fp32 parameter arena element for element (`mirrors_arena` = 1,
+ * `num_elems` = the length of the weight part of the arena) and lives at the tail of the state arena (tfk_state_bytes
+ * counts it), so the host can all-gather each rank's freshly updated shard of the SHADOW (tfk_apply_span writes it with
+ * the update) instead of the fp32 parameters: half the bytes, and the next forward pass -- which reads only the shadow --
+ * waits for it layer by layer through tfk_set_layer_callback.  The fp32 masters then stay valid only on the rank that
+ * owns the span until the host gathers them (checkpoints, tensor get / set).  Otherwise num_elems = 0. */
+int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* mirrors_arena);
+/* Between tfk_apply_begin and tfk_apply_end: does tfk_apply_span write the bf16 shadow along with the parameters
+ * (mixed precision, arena-mirroring shadow that was current when the step began)? */
+int tfk_apply_writes_shadow(tfk_engine* e, int* direct);
+/* Position-weighted 64-bit integer checksum of the fp32 parameter arena (which = 0), of the arena-mirroring bf16
+ * shadow (which = 1) or of the fp32 bias / beta vectors alone (which = 2), taken in engine-stream order; synchronises.  Replicas of a data-parallel job compare it after
+ * the first optimiser steps: a mis-ordered collective would otherwise train on stale weights silently. */
+int tfk_param_checksum(tfk_engine* e, int which, uint64_t* value);
 
 /* Number of micro-batches of this optimiser step that ranks AFTER this one process: weights this
  * rank's BN moving-average increment by bn_decay^later so the all-reduced result equals the

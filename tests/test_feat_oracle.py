@@ -163,6 +163,25 @@ def test_feature_computer_rejects_unknown_types():
         feat.FeatureComputer("fbank", "dddelta", {})
 
 
+def test_unsupported_transform_is_refused_before_any_file_is_touched(tmp_path):
+    """numpy's rfft takes any nfft, the device transform a power of two in [32, 4096]: the configuration is checked on the
+    host when the FeatureComputer is built -- prepare_data fails BEFORE it removes an existing feats.ark (round-2 advisor)"""
+    from tfkaldi_amd.processing import prepare_data
+    conf = dict(winlen='0.025', winstep='0.01', nfilt='40', nfft='400', lowfreq='0', highfreq='-1', preemph='0.97',
+                include_energy='False', snip_edges='True')
+    with pytest.raises(ValueError, match="power of two"):
+        feat.FeatureComputer("fbank", "nodelta", conf)
+    with pytest.raises(ValueError, match="nfilt"):
+        feat.FeatureComputer("fbank", "nodelta", dict(conf, nfft='64'))
+    datadir, featdir = tmp_path / "data", tmp_path / "feat"
+    datadir.mkdir(); featdir.mkdir()
+    (datadir / "wav.scp").write_text("u1 /nonexistent.wav\n")
+    (featdir / "feats.ark").write_bytes(b"precious")
+    with pytest.raises(ValueError, match="power of two"):
+        prepare_data.prepare_data(str(datadir), str(featdir), conf, "fbank", "nodelta")
+    assert (featdir / "feats.ark").read_bytes() == b"precious"
+
+
 def test_reference_import_line_resolves_to_the_gpu_backed_modules():
     """main.py:7 `from processing import ark, prepare_data, feature_reader, batchdispenser, target_coder`"""
     import sys

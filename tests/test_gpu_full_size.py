@@ -135,90 +135,106 @@ def test_large_and_growing_micro_batches(gpu):
     eng.close()
 
 
-def test_cfg3_per_gpu_size_bf16_against_oracle(gpu):
-    """BASELINE configs[2] as one rank sees it: 6x2048 + BN, 440 -> 4000 pdfs, 1024 frames, bf16 MFMA contractions.
-    Checked against the oracle that rounds every matmul operand to bfloat16 (tanh: no ReLU-kink sign flips)."""
+def _write_report(name, report):
+    """measured parity figures land in gpurun_out/parity_reports/ (scratch, merged back from the GPU box): the bounds
+    asserted below are 3x what a run measured, and this is where the measurement is read from"""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_reports")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as fid:
+            json.dump({k: float(v) for k, v in report.items()}, fid, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _bf16_parity(name, kw, T, keys, hidden_layers, bounds, seed):
+    """One micro-batch of a mixed-precision engine against the float64 oracle that rounds every matmul operand to
+    bfloat16, given the engine's dropout masks and -- for ReLU -- its on/off pattern (operand values within fp32
+    round-off of a bf16 rounding boundary round to different neighbours on the two sides, which moves pre-activations by
+    ~1e-3 and would otherwise flip ReLUs near the kink: the test bounds how many).  Gradients are compared by norm AND
+    element-wise on sampled rows / columns, so that no isolated wrong tile (or one k-step with a wrong scale) hides in a
+    norm.  `bounds`: name -> limit, each 3x the value a run on MI355X measured (profiles/r03_parity_reports.txt)."""
     from tfkaldi_amd import _lib
-    rng = np.random.default_rng(23)
-    kw = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=4000, nonlin="tanh", batch_norm=True,
-              init_learning_rate=1e-3, num_steps=100, max_frames=1024, compute_dtype="bfloat16")
+    rng = np.random.default_rng(seed)
+    L, O = kw["num_layers"], kw["output_dim"]
     eng, oracle = make_pair(rng, **kw)
-    T = 1024
-    X, y = batch(rng, T, 440, 4000)
+    X, y = batch(rng, T, kw["input_dim"], O)
     eng.accumulate(X, y)
-    oracle.accumulate(X, y)
-    np.testing.assert_allclose(eng.scalar(_lib.BATCH_LOSS), oracle.batch_loss, rtol=5e-4)
+    relu = kw["nonlin"] == "relu"
+    drop = kw.get("keep_prob", 1.0) < 1.0
+    masks = [eng.debug_fetch(_lib.DBG_DROPOUT_MASK, l, T) for l in range(L)] if drop else None
+    hidden = [eng.debug_fetch(_lib.DBG_HIDDEN, l, T) for l in range(L)]
+    report = {}
+    if relu:
+        # a dropped unit reads 0 whatever its sign: take the pattern from (a > 0) where kept and from the oracle where
+        # dropped (there it cannot influence anything: forward value and derivative are both multiplied by the mask)
+        active = [np.where(masks[l] > 0, hidden[l] > 0, True) if drop else hidden[l] > 0 for l in range(L)]
+        oracle.accumulate(X, y, masks=masks, relu_active=active)
+        worst = 0.0
+        for l, c in enumerate(oracle.last_cache):
+            dis = c["own_active"] != active[l]
+            if drop:
+                dis &= masks[l] > 0
+            worst = max(worst, float(dis.mean()))
+            if dis.any():
+                assert np.abs(c["u"][dis]).max() < 0.05, (l, np.abs(c["u"][dis]).max())
+        report["relu_disagreement"] = worst
+    else:
+        oracle.accumulate(X, y, masks=masks)
     rel = lambda got, want: float(np.linalg.norm(got - want) / np.linalg.norm(want))
-    for l in (0, 5):
-        assert rel(eng.debug_fetch(_lib.DBG_HIDDEN, l, T), oracle.last_cache[l]["a"]) < 2e-3, l
+    report["batch_loss"] = abs(eng.scalar(_lib.BATCH_LOSS) - oracle.batch_loss) / abs(oracle.batch_loss)
+    for l in hidden_layers:
+        report["hidden%d" % l] = rel(hidden[l], oracle.last_cache[l]["a"])
     got = engine_grads(eng)
-    # operands within fp32 round-off of a bf16 rounding boundary round to different neighbours on the two sides
-    # (one bf16 ulp = 0.4 % of that operand); the handful of such flips per GEMM compounds through the six layers
-    for k in ("W6", "b6", "W5", "beta5", "W3", "beta2", "W0", "beta0"):
-        assert rel(got[k], oracle.G[k]) < (5e-3 if k in ("W6", "b6") else 2e-2), (k, rel(got[k], oracle.G[k]))
-    np.testing.assert_allclose(eng.apply(), oracle.apply(), rtol=5e-4)
+    for k in keys:
+        want = oracle.G[k]
+        assert np.abs(want).max() > 0, k  # non-trivial data in every contraction
+        report["G[%s]" % k] = rel(got[k], want)
+        if got[k].ndim == 2:
+            rows = rng.choice(got[k].shape[0], size=8, replace=False)
+            cols = rng.choice(got[k].shape[1], size=8, replace=False)
+            scale = np.abs(want).max()
+            report["G[%s] sampled" % k] = max(np.abs(got[k][rows] - want[rows]).max(),
+                                              np.abs(got[k][:, cols] - want[:, cols]).max()) / scale
+    avg_e, avg_o = eng.apply(), oracle.apply()
+    report["avg_loss"] = abs(avg_e - avg_o) / abs(avg_o)
     eng.close()
+    _write_report(name, report)
+    print("%s parity report:" % name, {k: float("%.3g" % v) for k, v in report.items()})
+    bad = {}
+    for k, v in report.items():
+        limit = bounds.get(k, bounds.get("G sampled" if k.endswith("sampled") else "G" if k.startswith("G[") else
+                                         "hidden" if k.startswith("hidden") else k))
+        assert limit is not None, "no bound for %s" % k
+        if not v <= limit:
+            bad[k] = (v, limit)
+    assert not bad, bad
+    return report
+
+
+CFG3 = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=4000, batch_norm=True, init_learning_rate=1e-3,
+            num_steps=100, max_frames=1024, compute_dtype="bfloat16")
+CFG3_KEYS = ("W6", "b6", "W5", "beta5", "W3", "beta2", "W1", "W0", "beta0")
+
+
+@pytest.mark.parametrize("nonlin", ["relu", "tanh"])
+def test_cfg3_per_gpu_size_bf16_against_oracle(gpu, nonlin):
+    """BASELINE configs[2] as one rank sees it: 6x2048 + BN, 440 -> 4000 pdfs, 1024 frames, bf16 MFMA contractions, ReLU (the
+    configuration's own nonlinearity, with the engine's on/off pattern handed to the oracle) and tanh (no kink at all).
+    Bounds = 3x the measured values (profiles/r03_parity_reports.txt)."""
+    bounds = {"relu_disagreement": 3e-3, "batch_loss": 6e-4, "avg_loss": 6e-4, "hidden": 3e-3, "G": 1.5e-2, "G sampled": 3e-2,
+              "G[W6]": 5e-3, "G[b6]": 5e-3}
+    _bf16_parity("cfg3_bf16_" + nonlin, dict(CFG3, nonlin=nonlin), 1024, CFG3_KEYS, (0, 3, 5), bounds, seed=23)
 
 
 def test_cfg4_per_gpu_size_bf16_against_oracle(gpu):
     """BASELINE configs[3] as one rank sees it, in its stated arithmetic: 8x4096 ReLU + BN + dropout(0.5), 440 ->
     8000 pdfs, 2048 frames, bf16 MFMA contractions, at a GENERIC point (non-zero output layer: every 4096-wide
-    backward contraction carries real data).  Checker: the float64 oracle with bfloat16-rounded matmul operands,
-    given the engine's dropout masks and ReLU on/off pattern (operand values within fp32 round-off of a bf16
-    boundary round differently on the two sides, which moves pre-activations by ~1e-3 and would otherwise flip
-    ReLUs near the kink: the test bounds how many)."""
-    from tfkaldi_amd import _lib
-    rng = np.random.default_rng(29)
-    L, H, O, T = 8, 4096, 8000, 2048
-    kw = dict(input_dim=440, num_layers=L, num_units=H, output_dim=O, nonlin="relu", batch_norm=True, keep_prob=0.5,
-              init_learning_rate=1e-3, num_steps=100, max_frames=T, compute_dtype="bfloat16")
-    eng, oracle = make_pair(rng, **kw)
-    X, y = batch(rng, T, 440, O)
-    eng.accumulate(X, y)
-    masks = [eng.debug_fetch(_lib.DBG_DROPOUT_MASK, l, T) for l in range(L)]
-    # a dropped unit reads 0 whatever its sign: take the pattern from (a > 0) where kept and from the oracle where
-    # dropped (there it cannot influence anything: forward value and derivative are both multiplied by the mask)
-    hidden = [eng.debug_fetch(_lib.DBG_HIDDEN, l, T) for l in range(L)]
-    active = [np.where(masks[l] > 0, hidden[l] > 0, True) for l in range(L)]
-    oracle.accumulate(X, y, masks=masks, relu_active=active)
-    worst = 0.0
-    for l, c in enumerate(oracle.last_cache):
-        dis = (c["own_active"] != active[l]) & (masks[l] > 0)
-        worst = max(worst, float(dis.mean()))
-        if dis.any():
-            assert np.abs(c["u"][dis]).max() < 0.05, (l, np.abs(c["u"][dis]).max())
-    assert worst < 5e-3, worst
-    rel = lambda got, want: float(np.linalg.norm(got - want) / np.linalg.norm(want))
-    np.testing.assert_allclose(eng.scalar(_lib.BATCH_LOSS), oracle.batch_loss, rtol=1e-3)
-    # Tolerances: operand values within fp32 round-off of a bf16 rounding boundary round to different neighbours on
-    # the two sides (1 bf16 ulp = 0.4 % of that operand); the flips of every contraction compound through the eight
-    # layers forwards and backwards, so the bound grows with the distance from the data / from the loss.
-    report = {"relu_disagreement": worst}
-    bad = []
-    for l in (0, 3, 7):
-        r = rel(hidden[l], oracle.last_cache[l]["a"])
-        report["hidden%d" % l] = r
-        if r > 2e-3 + 5e-4 * l:
-            bad.append("hidden%d" % l)
-    got = engine_grads(eng)
-    for k in ("W8", "b8", "W7", "beta7", "W5", "W4", "beta3", "W1", "W0", "beta0"):
-        want = oracle.G[k]
-        assert np.abs(want).max() > 0, k  # non-trivial data in every contraction
-        r = rel(got[k], want)
-        report["G[%s]" % k] = r
-        depth = 8 - int(k.lstrip("Wbeta"))  # layers between this gradient and the loss
-        if r > 6e-3 + 4e-3 * depth:
-            bad.append("G[%s]" % k)
-        # and element-wise on a sample of rows / columns: no isolated wrong tile can hide in a norm
-        if got[k].ndim == 2:
-            rows = rng.choice(got[k].shape[0], size=8, replace=False)
-            cols = rng.choice(got[k].shape[1], size=8, replace=False)
-            scale = np.abs(want).max()
-            e = max(np.abs(got[k][rows] - want[rows]).max(), np.abs(got[k][:, cols] - want[:, cols]).max()) / scale
-            report["G[%s] sampled max err / max" % k] = e
-            if e > 0.05:
-                bad.append("G[%s] sampled" % k)
-    print("cfg4 bf16 parity report:", {k: float("%.3g" % v) for k, v in report.items()})
-    assert not bad, (bad, report)
-    np.testing.assert_allclose(eng.apply(), oracle.apply(), rtol=1e-3)
-    eng.close()
+    backward contraction carries real data).  Bounds = 3x the measured values (profiles/r03_parity_reports.txt)."""
+    kw = dict(input_dim=440, num_layers=8, num_units=4096, output_dim=8000, nonlin="relu", batch_norm=True, keep_prob=0.5,
+              init_learning_rate=1e-3, num_steps=100, max_frames=2048, compute_dtype="bfloat16")
+    bounds = {"relu_disagreement": 2e-3, "batch_loss": 1e-3, "avg_loss": 1e-3, "hidden": 4e-3, "G": 1.2e-2, "G sampled": 3e-2}
+    _bf16_parity("cfg4_bf16", kw, 2048, ("W8", "b8", "W7", "beta7", "W5", "W4", "beta3", "W1", "W0", "beta0"), (0, 3, 7),
+                 bounds, seed=29)

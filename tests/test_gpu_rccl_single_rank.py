@@ -79,6 +79,10 @@ def test_bench_dp_branch_over_rccl(gpu):
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
     assert line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl" and line["exchange"] == "sharded"
+    # what RAN: RCCL's own reduce-scatter / all-gather on views of the engine state, the 24 MB coalescing of cfg2's spans
+    assert line["collectives_last_step"].count("reduce_scatter_tensor") == 4, line["collectives_last_step"]
+    assert line["collectives_last_step"].count("all_gather_into_tensor") == 4
+    assert [n for _, n in line["collective_spans_last_step"] if n > 1 << 20] == [8290304, 8388608, 8388608]
     assert line["host_fed_value"] > 0 and len(line["loss_trace_gpu"]) == 7
 
 
@@ -99,6 +103,31 @@ def test_bench_self_launches_its_ranks(gpu):
     assert line["n_gpus"] == 2 and line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 2
     assert line["config"]["global_frames"] == 2048 and line["scaling"] == "weak"
     assert line["rccl_ranks"] == (2 if real else 0) and line["dist_backend"] == ("nccl" if real else "gloo")
+    assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
+    if not real:  # gloo cannot reduce-scatter device tensors: the line must say what really ran
+        assert line["exchange"] == "allreduce" and line["exchange_requested"] == "sharded"
+        assert set(line["collectives_last_step"]) == {"all_reduce"}
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_dry_run(gpu):
+    """the driver's `bench.py --gpus 8` on one GPU: eight ranks share the device over gloo (TFK_SHARE_DEVICE), the
+    sharded protocol runs with the reduce-scatter emulated -- every code path of the 8-rank bench line executes: the
+    self-launch, the per-rank batches, the n / 8 shards of cfg2's spans, barrier + MAX over ranks, the report"""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("a real 8-GPU node runs the real thing (test_bench_self_launches_its_ranks covers the launcher)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo", TFK_DP_EMULATE_RS="1", TFK_BENCH_PREWARM_MS="0",
+               OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup",
+                          "2"], env=env, capture_output=True, text=True, timeout=1100)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 8
+    assert line["config"]["global_frames"] == 8192 and line["scaling"] == "weak"
+    assert line["exchange"] == "sharded" and "all_reduce(emulating reduce_scatter)" in line["collectives_last_step"]
+    assert all(n % 32 == 0 for _, n in line["collective_spans_last_step"][1:5])
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
 
 

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_flo
 
 from .build import lib_path
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
@@ -105,6 +105,9 @@ SYMBOLS = {
     "tfk_set_later_microbatches": (c_int, [_E, c_int32]),
     "tfk_params_touched": (c_int, [_E]),
     "tfk_set_layer_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
+    "tfk_shadow_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
+    "tfk_apply_writes_shadow": (c_int, [_E, POINTER(c_int)]),
+    "tfk_param_checksum": (c_int, [_E, c_int, POINTER(c_uint64)]),
     "tfk_synchronize": (c_int, [_E]),
     "tfk_stream": (c_int, [_E, POINTER(c_void_p)]),
     "tfk_profile_begin": (c_int, [_E]),

@@ -22,12 +22,18 @@ def lib_path():
     return os.path.join(LIBDIR, LIBNAME)
 
 
+TRAFFIC_STAMP_SOURCES = ("gemm_f32.hip", "gemm_f32.h")
+
+
 def csrc_hash():
-    """sha256 (first 16 hex digits) over the kernel sources: stamps measurements that are only valid for the kernels
-    they were taken on (profiles/hbm_traffic.json, read by bench.py)"""
+    """sha256 (first 16 hex digits) over the sources the fp32 GEMM kernels compile from -- nothing else.  It stamps
+    profiles/hbm_traffic.json, the PMC traffic figure of bench.py's dominant kernel (gemm_f32_dual / gemm_f32_kernel):
+    the figure is valid exactly as long as those kernels are unchanged.  (Round 2 hashed every source plus the public
+    header, so an enum added for the feature path invalidated the GEMM's traffic record; tests/test_host_logic.py now
+    fails when the committed record and this hash disagree.)"""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted([s for s in SOURCES if s != "features.hip"] + HEADERS):  # (the training step never runs features.hip)
+    for name in sorted(TRAFFIC_STAMP_SOURCES):
         with open(os.path.join(CSRC, name), "rb") as fid:
             h.update(name.encode() + b"\0" + fid.read())
     return h.hexdigest()[:16]

@@ -102,7 +102,7 @@ struct tfk_engine {
   float* state = nullptr;
   bool own_state = false;
   size_t P = 0, E = 0, state_floats = 0;
-  size_t off_param = 0, off_grad = 0, off_scalars = 0, off_ema = 0, off_m = 0, off_v = 0, off_mov = 0;
+  size_t off_param = 0, off_grad = 0, off_scalars = 0, off_ema = 0, off_m = 0, off_v = 0, off_mov = 0, off_shadow = 0;
   size_t reduce_floats = 0;
   std::vector<LayerLayout> lay;  // L + 1
 
@@ -171,6 +171,8 @@ struct tfk_engine {
   std::vector<size_t> wb_off;
   std::vector<int> wb_ld;
   bool wb_aligned = false;           // shadow offsets == fp32 arena offsets: Adam writes it with the update
+  bool own_wb = false;               // packed shadow in its own allocation (else it is the tail of the state arena)
+  unsigned long long* d_checksum = nullptr;
   bool shadow_dirty = true;
   hipEvent_t copy_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
   bool slot_used[2] = {false, false};
@@ -269,7 +271,20 @@ void compute_layout(const tfk_config* c, std::vector<LayerLayout>& lay, size_t& 
 }
 
 constexpr size_t kScalarFloats = 64;
-size_t total_state_floats(size_t P, size_t E) { return 4 * P + kScalarFloats + 2 * E; }
+// Mixed precision: when every weight matrix has a leading dimension that is a multiple of 8 the bf16 shadow mirrors the
+// fp32 arena element for element and lives at the END of the state arena (w_end bf16 values = w_end / 2 floats), so a
+// host that owns the arena (torch.distributed) can all-gather SHARDS OF THE SHADOW ITSELF -- half the bytes of the
+// fp32 parameters, and the next forward pass waits for them layer by layer.  Otherwise it is packed in its own allocation.
+bool shadow_mirrors(const tfk_config* c, const std::vector<LayerLayout>& lay) {
+  if (c->compute_dtype != TFK_DTYPE_BF16) return false;
+  for (const LayerLayout& y : lay)
+    if (y.ld_out % 8) return false;
+  return true;
+}
+size_t shadow_floats(const tfk_config* c, const std::vector<LayerLayout>& lay) {
+  return shadow_mirrors(c, lay) ? up(lay[0].b_off, 128) / 2 : 0;
+}
+size_t total_state_floats(size_t P, size_t E, size_t S) { return 4 * P + kScalarFloats + 2 * E + S; }
 
 // ---- profiling helpers ----
 hipEvent_t get_event(tfk_engine* e) {
@@ -988,7 +1003,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   e->adam_eps = cfg->adam_epsilon > 0.f ? cfg->adam_epsilon : 1e-8f;
   e->dropout = cfg->keep_prob < 1.f;
   compute_layout(cfg, e->lay, e->P, e->E);
-  e->state_floats = total_state_floats(e->P, e->E);
+  e->state_floats = total_state_floats(e->P, e->E, shadow_floats(cfg, e->lay));
   e->off_param = 0;
   e->off_grad = e->P;
   e->off_scalars = 2 * e->P;
@@ -997,6 +1012,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   e->off_m = e->off_ema + e->E;
   e->off_v = e->off_m + e->P;
   e->off_mov = e->off_v + e->P;
+  e->off_shadow = e->off_mov + e->E;
 
   auto bail = [&](int rc) { tfk_destroy(e); return rc; };
 #define HIPB(expr)                                                                                          \
@@ -1045,10 +1061,9 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   }
   if (alloc_zero(&e->prior, (size_t)e->ldO)) return bail(-1);
   if (e->bf16) {
-    // shadow arena: when every weight matrix has a leading dimension that is already a multiple of 8 it mirrors
-    // the fp32 arena element for element (the optimiser then writes it with the update), else it is packed
-    e->wb_aligned = true;
-    for (int l = 0; l <= e->L; ++l) e->wb_aligned = e->wb_aligned && (e->lay[l].ld_out % 8 == 0);
+    // shadow: mirrors the fp32 arena element for element inside the state arena when every leading dimension is a
+    // multiple of 8 (the optimiser then writes it with the update and the sharded exchange gathers it), else packed
+    e->wb_aligned = shadow_mirrors(cfg, e->lay);
     e->wb_off.assign(e->L + 1, 0);
     e->wb_ld.assign(e->L + 1, 0);
     size_t off = 0;
@@ -1058,8 +1073,12 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
       e->wb_off[l] = e->wb_aligned ? y.w_off : off;
       off += up((size_t)y.d_in * e->wb_ld[l], 64);
     }
-    const size_t elems = e->wb_aligned ? e->lay[0].b_off : off;
-    if (alloc_zero_b(&e->Wb, elems)) return bail(-1);
+    if (e->wb_aligned) {
+      e->Wb = reinterpret_cast<bf16_t*>(e->state + e->off_shadow);  // (zeroed with the arena)
+    } else {
+      if (alloc_zero_b(&e->Wb, off)) return bail(-1);
+      e->own_wb = true;
+    }
     e->shadow_dirty = true;
   }
   const int cap0 = cfg->max_frames > 0 ? cfg->max_frames : 1024;
@@ -1245,7 +1264,7 @@ int tfk_state_bytes(const tfk_config* cfg, size_t* bytes) {
   std::vector<LayerLayout> lay;
   size_t P, E;
   compute_layout(cfg, lay, P, E);
-  *bytes = total_state_floats(P, E) * sizeof(float);
+  *bytes = total_state_floats(P, E, shadow_floats(cfg, lay)) * sizeof(float);
   return 0;
 }
 
@@ -1267,7 +1286,8 @@ int tfk_destroy(tfk_engine* e) {
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
-  if (e->Wb) hipFree(e->Wb);
+  if (e->Wb && e->own_wb) hipFree(e->Wb);
+  if (e->d_checksum) hipFree(e->d_checksum);
   if (e->ws_splitk) hipFree(e->ws_splitk);
   for (void* p : {(void*)e->ctc_seg, (void*)e->ctc_lab_off, (void*)e->ctc_lab, (void*)e->ctc_lp, (void*)e->ctc_ab,
                   (void*)e->ctc_utt_loss, (void*)e->ctc_lse, (void*)e->ctc_off, (void*)e->ctc_bb, (void*)e->ctc_offb,
@@ -1529,7 +1549,13 @@ int tfk_init_last_layer(tfk_engine* e) {
   need_params(e, -1);
   HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
-  e->shadow_dirty = true;
+  if (e->bf16 && e->wb_aligned && !e->shadow_dirty) {
+    // a current arena-mirroring shadow stays current: zero its output-layer span too instead of rebuilding it from
+    // every fp32 master (under the sharded exchange the masters of other ranks' spans are not valid here)
+    HIPCHK(hipMemsetAsync(e->Wb + o.w_off, 0, o.w_sz * sizeof(bf16_t), e->stream));
+  } else {
+    e->shadow_dirty = true;
+  }
   return 0;
 }
 
@@ -1723,6 +1749,46 @@ int tfk_params_touched(tfk_engine* e) {
   if (!e) return fail(-1, "engine is NULL");
   e->shadow_dirty = true;
   if (e->apply_open) e->apply_direct = false;  // tfk_apply_end must not declare the shadow current
+  return 0;
+}
+int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* mirrors_arena) {
+  if (!e || !device_ptr || !num_elems || !mirrors_arena) return fail(-1, "NULL argument");
+  *device_ptr = e->bf16 ? (void*)e->Wb : nullptr;
+  *num_elems = (e->bf16 && e->wb_aligned) ? e->lay[0].b_off : 0;
+  *mirrors_arena = (e->bf16 && e->wb_aligned) ? 1 : 0;
+  return 0;
+}
+int tfk_apply_writes_shadow(tfk_engine* e, int* direct) {
+  if (!e || !direct) return fail(-1, "NULL argument");
+  if (!e->apply_open) return fail(-1, "tfk_apply_writes_shadow outside tfk_apply_begin / tfk_apply_end");
+  *direct = e->apply_direct ? 1 : 0;
+  return 0;
+}
+int tfk_param_checksum(tfk_engine* e, int which, uint64_t* value) {
+  if (!e || !value) return fail(-1, "NULL argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const uint32_t* p;
+  size_t words;
+  if (which == 0) {
+    p = reinterpret_cast<const uint32_t*>(e->p_param());
+    words = e->P;
+  } else if (which == 1) {
+    if (!e->bf16 || !e->wb_aligned) return fail(-1, "no arena-mirroring bf16 shadow to checksum");
+    p = reinterpret_cast<const uint32_t*>(e->Wb);
+    words = e->lay[0].b_off / 2;
+  } else if (which == 2) {
+    p = reinterpret_cast<const uint32_t*>(e->p_param() + e->lay[0].b_off);
+    words = e->P - e->lay[0].b_off;
+  } else {
+    return fail(-1, "tfk_param_checksum: which must be 0 (fp32 parameters), 1 (bf16 shadow) or 2 (fp32 bias / beta vectors)");
+  }
+  if (!e->d_checksum) HIPCHK(hipMalloc((void**)&e->d_checksum, sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(e->d_checksum, 0, sizeof(unsigned long long), e->stream));
+  checksum_words(e->stream, p, words, e->d_checksum);
+  unsigned long long h = 0;
+  HIPCHK(hipMemcpyAsync(&h, e->d_checksum, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *value = (uint64_t)h;
   return 0;
 }
 int tfk_set_later_microbatches(tfk_engine* e, int32_t later) {

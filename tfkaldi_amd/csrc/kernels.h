@@ -119,6 +119,8 @@ void fill(hipStream_t s, float* x, size_t n, float value);
 // (raw - mean) / std, IEEE-rounded like numpy's float32 subtract / divide (feature_reader.py:109-115).
 void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg, int U, int T, int D, int context,
                    const float* cmvn, float* out, int ldo);
+// *out += sum_i p[i] * ((i & 0xffff) + 1) over n 32-bit words (unsigned 64-bit arithmetic; *out zeroed by the caller)
+void checksum_words(hipStream_t s, const uint32_t* p, size_t n, unsigned long long* out);
 // debug: regenerate the keep mask of a layer as 0/1 floats [T, ld]
 void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld);
 

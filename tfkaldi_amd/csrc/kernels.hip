@@ -1039,6 +1039,19 @@ splice_kernel(const float* __restrict__ raw, int ldr, const int32_t* __restrict_
   st4(out + (size_t)t * ldo + (c4 << 2), o);
 }
 
+// position-weighted integer checksum of a span of 32-bit words (replica-consistency check of the data-parallel exchange:
+// integer arithmetic, so the value does not depend on the order the blocks finish in)
+__global__ void __launch_bounds__(256)
+checksum_kernel(const uint32_t* __restrict__ p, size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    acc += (unsigned long long)p[i] * (unsigned long long)((i & 0xffffu) + 1u);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 inline dim3 ct_grid(int ld, int rs) { return dim3((ld / 4 + CT_X - 1) / CT_X, rs); }
 inline dim3 ct_block() { return dim3(CT_X, CT_Y); }
 
@@ -1203,6 +1216,12 @@ void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg,
   if (n == 0) return;
   hipLaunchKernelGGL(splice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, ldr, seg, U, T, D, context,
                      cmvn, out, ldo);
+}
+void checksum_words(hipStream_t s, const uint32_t* p, size_t n, unsigned long long* out) {
+  if (n == 0) return;
+  size_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, out);
 }
 void dropout_mask(hipStream_t s, const ActDesc& d, float* out, int T, int H, int ld) {
   const size_t n = (size_t)T * (ld / 4);

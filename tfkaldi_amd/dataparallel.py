@@ -15,6 +15,8 @@ process groups on CPU.
 """
 import contextlib
 import os
+import time
+import weakref
 
 
 def init_from_env():
@@ -133,10 +135,24 @@ class BucketReducer(object):
                  optimiser-bound at BASELINE cfg3 / cfg4 sizes).  Adam is element-wise, so the result is
                  identical to the replicated update.  Spans that do not divide (or are tiny: the bias / beta
                  vectors, the scalar + BN tail) are all-reduced and updated on every rank.
-      "allreduce"  SUM all-reduce of every span, full optimiser on every rank (round 1)."""
+                 Mixed precision (engine.shadow_view() is not None): what is gathered is the rank's shard of the
+                 bf16 weight SHADOW that tfk_apply_span wrote with the update -- 2 B per parameter instead of 4, and the
+                 next forward pass (which reads only the shadow) waits for it layer by layer.  The fp32 masters of a
+                 span then stay valid on its owner only; gather_masters() (collective) brings them home before a
+                 checkpoint or a tensor get / set, and until then the engine's param_access_hook refuses such an access.
+      "allreduce"  SUM all-reduce of every span, full optimiser on every rank (round 1).
+
+    Whether the backend can reduce-scatter / all-gather tensors of this kind is decided ONCE, at construction, by a
+    probe collective on a scratch tensor next to the engine state, agreed over all ranks (gloo on device memory, used by
+    the single-GPU tests, cannot): without it the reducer runs "allreduce" and says so; with TFK_DP_EMULATE_RS=1
+    (tests) the sharded protocol runs with the reduce-scatter emulated by an all-reduce.  Errors of the collectives
+    themselves are never swallowed.
+
+    The first TFK_DP_VERIFY_STEPS (default 2) sharded steps end with a replica check: every rank's checksum of the
+    gathered parameters (tfk_param_checksum) must agree, otherwise the step raises -- a mis-ordered collective would
+    train on stale weights silently (round-2 advisor finding)."""
 
     MIN_SHARD_FLOATS = int(os.environ.get("TFK_DP_MIN_SHARD", str(1 << 14)))  # smaller spans are all-reduced
-    _rs_supported = True
 
     def __init__(self, engine, group=None, min_bytes=None, stream_ctx=None, mode=None):
         import torch.distributed as dist
@@ -149,6 +165,14 @@ class BucketReducer(object):
             raise ValueError("exchange mode %r" % (mode,))
         if mode == "sharded" and not (hasattr(engine, "param_view") and hasattr(engine, "apply_span")):
             mode = "allreduce"
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        self.rank = dist.get_rank(group) if ready else 0
+        self.rs_impl = self.ag_impl = None  # "native" | "emulated"
+        if mode == "sharded" and ready:
+            self._probe()
+            if self.rs_impl is None:
+                mode = "allreduce"
         self.mode = mode
         if min_bytes is None:
             # sharded: the parameter gathers are consumed layer by layer by the next forward pass, so finer spans
@@ -157,15 +181,14 @@ class BucketReducer(object):
             default_mb = "24" if mode == "sharded" else "48"
             min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", default_mb)) * (1 << 20))
         self.min_floats = max(1, min_bytes // 4)
-        ready = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if ready else 1
-        self.rank = dist.get_rank(group) if ready else 0
         self.num_params = self.buckets[-1][0]  # the scalar + BN tail starts where the gradient arena ends
         self.vec_off = self.buckets[-2][0] if len(self.buckets) >= 2 else self.num_params  # bias / beta vectors
         self.handles, self.errors = [], []
         self._lo = self._hi = None
         self.launched = []  # (offset, floats) of every collective of the current step (tests / diagnostics)
         self.kinds = []     # "rs" (reduce-scatter: only sub-span `rank` is valid afterwards) or "ar" per collective
+        self.executed = []  # the torch.distributed calls actually issued this step, by name (bench.py reports them)
+        self.last_launched, self.last_kinds, self.last_executed = [], [], []
         # Parameter all-gathers of the last sharded step that nobody has waited for yet, in launch order (ascending
         # offsets = forward order).  With an engine that announces parameter reads (tfk_set_layer_callback) they stay
         # in flight across the step boundary and the NEXT forward pass waits layer by layer: the gather of layer l+1's
@@ -174,6 +197,56 @@ class BucketReducer(object):
         self.async_gather = mode == "sharded" and hasattr(engine, "set_layer_callback")
         if self.async_gather:
             engine.set_layer_callback(self.on_layer)
+        # mixed precision: gather the bf16 shadow instead of the fp32 parameters (masters stay with their owner)
+        self.shadow = engine.shadow_view() if (mode == "sharded" and hasattr(engine, "shadow_view")) else None
+        self.masters_stale = False
+        self.shard_spans = set()
+        if self.shadow is not None:
+            engine.param_access_hook = self._param_access
+        self.verify_left = int(os.environ.get("TFK_DP_VERIFY_STEPS", "2")) if (mode == "sharded" and ready) else 0
+        # host time spent inside the callbacks / the apply pipeline (tools/dp_overhead.py)
+        self.host_s = {"on_bucket": 0.0, "on_layer": 0.0, "finish_and_apply": 0.0}
+        self.host_calls = {"on_bucket": 0, "on_layer": 0, "finish_and_apply": 0}
+
+    # ---- what the backend can do, decided once ----
+    def _probe(self):
+        """reduce_scatter_tensor / all_gather_into_tensor, in place, on a scratch tensor of the state's kind; the outcome
+        is agreed over the ranks (MIN), so that every rank issues the same collectives for the life of the reducer"""
+        import torch
+        d = self._dist
+        n = 4 * self.world
+        scratch = self.view.new_zeros(n) if hasattr(self.view, "new_zeros") else None
+        if scratch is None:
+            return
+        own = scratch[self.rank * 4:(self.rank + 1) * 4]
+        ok_rs = ok_ag = 1
+        with self._stream_ctx():
+            try:
+                d.reduce_scatter_tensor(own, scratch, op=d.ReduceOp.SUM, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                ok_rs = 0
+            try:
+                d.all_gather_into_tensor(scratch, own, group=self.group)
+            except (RuntimeError, NotImplementedError):
+                ok_ag = 0
+            flags = scratch.new_tensor([float(ok_rs), float(ok_ag)])
+            d.all_reduce(flags, op=d.ReduceOp.MIN, group=self.group)
+            ok_rs, ok_ag = (int(v) for v in flags.tolist())
+        emulate = os.environ.get("TFK_DP_EMULATE_RS") == "1"
+        self.rs_impl = "native" if ok_rs else ("emulated" if emulate else None)
+        self.ag_impl = "native" if ok_ag else "emulated"  # (list-form all_gather into views: always available)
+        if self.rs_impl is None and self.rank == 0:
+            import sys
+            sys.stderr.write("tfkaldi_amd.dataparallel: backend %r cannot reduce-scatter %s tensors in place; the exchange "
+                             "step runs as all-reduce + replicated optimiser\n"
+                             % (d.get_backend(self.group), self.view.device))
+
+    def _param_access(self):
+        if self.masters_stale:
+            raise RuntimeError(
+                "the fp32 master weights are sharded over the data-parallel ranks (mixed-precision sharded exchange: each "
+                "rank holds the masters of its own spans, everyone holds the bf16 shadow); call "
+                "DataParallel.gather_parameters(engine) on EVERY rank before reading or writing parameters")
 
     def _shardable(self, lo, hi):
         n = hi - lo
@@ -197,27 +270,24 @@ class BucketReducer(object):
                     return
         d = self._dist
         with self._stream_ctx():
-            h = None
-            if self._shardable(lo, hi) and BucketReducer._rs_supported:
+            if self._shardable(lo, hi) and self.rs_impl == "native":
                 c = (hi - lo) // self.world
                 own = self.view[lo + self.rank * c:lo + (self.rank + 1) * c]
-                try:
-                    h = d.reduce_scatter_tensor(own, self.view[lo:hi], op=d.ReduceOp.SUM, group=self.group,
-                                                async_op=True)
-                except (RuntimeError, NotImplementedError):
-                    # the backend has no reduce-scatter for this tensor type (gloo on device memory: tests only);
-                    # every rank takes the same branch, so the collectives still match
-                    BucketReducer._rs_supported = False
-            if h is not None:
-                self.handles.append(h)
+                self.handles.append(d.reduce_scatter_tensor(own, self.view[lo:hi], op=d.ReduceOp.SUM, group=self.group,
+                                                            async_op=True))
                 self.kinds.append("rs")
+                self.executed.append("reduce_scatter_tensor")
             else:
+                # (emulated reduce-scatter, tests: every rank receives the whole sum and uses its own sub-span only)
+                emu = self._shardable(lo, hi) and self.rs_impl == "emulated"
                 self.handles.append(d.all_reduce(self.view[lo:hi], op=d.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
-                self.kinds.append("ar")
+                self.kinds.append("rs" if emu else "ar")
+                self.executed.append("all_reduce(emulating reduce_scatter)" if emu else "all_reduce")
         self.launched.append((lo, hi - lo))
 
     def on_bucket(self, b):
+        t0 = time.perf_counter()
         try:  # exceptions cannot propagate through the C callback
             off, n = self.buckets[b]
             if self._lo is not None and off + n == self._lo:
@@ -231,6 +301,14 @@ class BucketReducer(object):
                 self._launch()
         except Exception as exc:  # noqa: BLE001
             self.errors.append(exc)
+        self.host_s["on_bucket"] += time.perf_counter() - t0
+        self.host_calls["on_bucket"] += 1
+
+    def _raise_errors(self):
+        if self.errors:
+            exc = self.errors[0]
+            del self.errors[:]  # reported once; the reducer stays usable for a caller that handles it
+            raise exc
 
     def drain(self):
         """make the engine's stream wait for every parameter all-gather still in flight"""
@@ -244,22 +322,25 @@ class BucketReducer(object):
         about to be enqueued -- wait for the gathers that cover them (weights of the layer + the bias / beta vectors)"""
         if not self.pending:
             return
+        t0 = time.perf_counter()
         try:
             if layer < 0:
                 self.drain()
-                return
-            num_layers = len(self.buckets) - 3
-            spans = [self.buckets[num_layers - layer], self.buckets[num_layers + 1]]
-            last = -1
-            for i, (off, n, _) in enumerate(self.pending):
-                if any(off < so + sn and off + n > so for so, sn in spans):
-                    last = i
-            if last >= 0:
-                with self._stream_ctx():
-                    self.pending[last][2].wait()  # (and, in launch order, everything before it)
-                del self.pending[:last + 1]
+            else:
+                num_layers = len(self.buckets) - 3
+                spans = [self.buckets[num_layers - layer], self.buckets[num_layers + 1]]
+                last = -1
+                for i, (off, n, _) in enumerate(self.pending):
+                    if any(off < so + sn and off + n > so for so, sn in spans):
+                        last = i
+                if last >= 0:
+                    with self._stream_ctx():
+                        self.pending[last][2].wait()  # (and, in launch order, everything before it)
+                    del self.pending[:last + 1]
         except Exception as exc:  # noqa: BLE001  (cannot propagate through the C callback)
             self.errors.append(exc)
+        self.host_s["on_layer"] += time.perf_counter() - t0
+        self.host_calls["on_layer"] += 1
 
     def finish(self):
         """launch what is still pending, make the engine's stream wait for every collective of the step (all-reduce
@@ -267,29 +348,38 @@ class BucketReducer(object):
         if self.mode != "allreduce":
             raise RuntimeError("BucketReducer.finish() needs mode='allreduce'; use finish_and_apply()")
         self._launch()
-        if self.errors:
-            raise self.errors[0]
+        self._raise_errors()
         with self._stream_ctx():
             for h in self.handles:
                 h.wait()
         del self.handles[:]
-        del self.kinds[:]
-        launched, self.launched = self.launched, []
-        return launched
+        self.last_kinds, self.kinds = self.kinds, []
+        self.last_executed, self.executed = self.executed, []
+        self.last_launched, self.launched = self.launched, []
+        return self.last_launched
+
+    def _all_gather(self, whole, own):
+        d = self._dist
+        if self.ag_impl == "emulated":  # (gloo on device memory, tests) list form, straight into the sub-span views
+            self.executed.append("all_gather(list)")
+            return d.all_gather(list(whole.chunk(self.world)), own, group=self.group, async_op=True)
+        self.executed.append("all_gather_into_tensor(bf16 shadow)" if whole.element_size() == 2
+                             else "all_gather_into_tensor")
+        return d.all_gather_into_tensor(whole, own, group=self.group, async_op=True)
 
     def finish_and_apply(self, engine):
         """The optimiser step pipelined behind the collectives: the engine's stream waits for the (small, early)
         collective that carries the scalars, starts the step (tfk_apply_begin), then waits for each remaining
         collective in launch order and runs Adam on exactly the span of parameters whose gradient sum this rank now
         holds (tfk_apply_span) while the later collectives are still in flight; a reduce-scattered span's updated
-        parameters are all-gathered behind its Adam.  Returns the average loss (tfk_apply_end)."""
+        parameters (mixed precision: its bf16 shadow) are all-gathered behind its Adam.  Returns the average loss
+        (tfk_apply_end)."""
         if not hasattr(engine, "apply_span"):
             self.finish()
             return engine.apply()
+        t0 = time.perf_counter()
         self._launch()
-        if self.errors:
-            raise self.errors[0]
-        d = self._dist
+        self._raise_errors()
         head_off, head_n = self.buckets[-1]
         waited = set()
 
@@ -304,6 +394,9 @@ class BucketReducer(object):
                 wait(i)
         self.drain()  # (gathers of the previous step that no forward pass has consumed: none in a training loop)
         engine.apply_begin()
+        # mixed precision: does this step's Adam write the shadow (it does unless parameters were set from outside
+        # since the last forward pass)?  Then the shadow is what travels.
+        via_shadow = self.shadow is not None and engine.apply_writes_shadow()
         sharded = []
         for i, (off, n) in enumerate(self.launched):
             wait(i)
@@ -314,21 +407,68 @@ class BucketReducer(object):
             else:
                 engine.apply_span(off, n)  # (spans beyond the parameter arena are clipped by the engine)
         if sharded:
-            params = engine.param_view()
+            if self.masters_stale and not via_shadow:
+                # (parameters were injected between two sharded steps without gather_parameters: refused by the hook
+                # long before this point; kept as a guard)
+                raise RuntimeError("sharded fp32 masters and a step that does not write the shadow")
+            target = self.shadow if via_shadow else engine.param_view()
             with self._stream_ctx():  # behind the optimiser kernels on the engine stream, lowest offsets (layer 0) first
                 for off, n in sorted(sharded):
                     c = n // self.world
                     lo = off + self.rank * c
-                    h = d.all_gather_into_tensor(params[off:off + n], params[lo:lo + c], group=self.group, async_op=True)
-                    self.pending.append((off, n, h))
-            if hasattr(engine, "params_touched"):
+                    self.pending.append((off, n, self._all_gather(target[off:off + n], target[lo:lo + c])))
+            if via_shadow:
+                self.masters_stale = True
+                self.shard_spans.update(sharded)
+            elif hasattr(engine, "params_touched"):
                 engine.params_touched()  # parameters outside this rank's spans change behind the optimiser's back
             if not self.async_gather:
                 self.drain()
         del self.handles[:]
         self.last_launched, self.launched = self.launched, []
         self.last_kinds, self.kinds = self.kinds, []
-        return engine.apply_end()
+        self.last_executed, self.executed = self.executed, []
+        loss = engine.apply_end()
+        if self.verify_left > 0 and sharded:
+            self.verify_left -= 1
+            self.verify_replicas(engine, via_shadow)
+        self.host_s["finish_and_apply"] += time.perf_counter() - t0
+        self.host_calls["finish_and_apply"] += 1
+        return loss
+
+    def verify_replicas(self, engine, via_shadow):
+        """every rank must hold the same parameters after the gathers (tfk_param_checksum); collective"""
+        if not hasattr(engine, "param_checksum"):
+            return
+        import torch
+        self.drain()
+        sums = [engine.param_checksum(1), engine.param_checksum(2)] if via_shadow else [engine.param_checksum(0)]
+        d = self._dist
+        dev = self.view.device
+        mine = torch.tensor([s & 0x7FFFFFFFFFFFFFFF for s in sums], dtype=torch.int64, device=dev)
+        lo, hi = mine.clone(), mine.clone()
+        with self._stream_ctx():
+            d.all_reduce(lo, op=d.ReduceOp.MIN, group=self.group)
+            d.all_reduce(hi, op=d.ReduceOp.MAX, group=self.group)
+        if lo.tolist() != hi.tolist():
+            raise RuntimeError("data-parallel replicas diverged after the sharded exchange step: rank %d holds parameter "
+                               "checksum %s, the ranks' values span %s .. %s" % (self.rank, mine.tolist(), lo.tolist(),
+                                                                               hi.tolist()))
+
+    def gather_masters(self, engine):
+        """Collective.  Mixed-precision sharded exchange: all-gather the fp32 masters of every sharded span (each rank
+        holds only its own shard up to date), so that parameters can be read / written from outside the optimiser."""
+        if not self.masters_stale:
+            return
+        self.drain()
+        params = engine.param_view()
+        with self._stream_ctx():
+            for off, n in sorted(self.shard_spans):
+                c = n // self.world
+                lo = off + self.rank * c
+                self._all_gather(params[off:off + n], params[lo:lo + c]).wait()
+        del self.executed[:]
+        self.masters_stale = False
 
 
 class DataParallel(object):
@@ -339,7 +479,10 @@ class DataParallel(object):
         self.mode = mode  # exchange step of BucketReducer (None: TFK_DP_EXCHANGE or "sharded")
         self.rank, self.world = 0, 1
         self._forced = False
-        self._reducers = {}  # one BucketReducer per engine: it carries the in-flight parameter gathers across steps
+        # one BucketReducer per engine: it carries the in-flight parameter gathers across steps.  Keyed weakly (and
+        # dropped by Engine.close): a later engine that happens to get the same id() must not inherit views into a
+        # closed engine's state.
+        self._reducers = weakref.WeakKeyDictionary()
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -361,17 +504,38 @@ class DataParallel(object):
         return torch.cuda.stream(stream)
 
     def reducer(self, engine):
-        r = self._reducers.get(id(engine))
+        """the engine's BucketReducer; created on first use -- COLLECTIVELY (it probes the backend), i.e. at the same
+        point of the program on every rank, which the first train_step is"""
+        r = self._reducers.get(engine)
         if r is None:
-            r = self._reducers[id(engine)] = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(engine),
-                                                           mode=self.mode)
+            ref = weakref.ref(engine)
+            r = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(ref()), mode=self.mode)
+            self._reducers[engine] = r
+            if hasattr(engine, "on_close"):
+                engine.on_close.append(lambda: self._forget(ref()))
         return r
+
+    def _forget(self, engine):
+        if engine is not None:
+            r = self._reducers.pop(engine, None)
+            if r is not None:
+                r.drain()
 
     def drain(self, engine):
         """wait (on the engine's stream) for parameter all-gathers still in flight: before the engine is closed or its
         state tensor is read behind the engine's back"""
-        r = self._reducers.get(id(engine))
+        r = self._reducers.get(engine)
         if r is not None:
+            r.drain()
+
+    def gather_parameters(self, engine):
+        """COLLECTIVE (every rank must call it): make the fp32 parameters whole on every rank.  Only the mixed-precision
+        sharded exchange leaves them sharded (each rank keeps the masters of its own spans; all ranks share the bf16
+        shadow the forward pass reads); everywhere else this only waits for the gathers in flight.  Call it before
+        checkpointing, tensor get / set, or handing the engine to code that reads parameters."""
+        r = self._reducers.get(engine)
+        if r is not None:
+            r.gather_masters(engine)
             r.drain()
 
     def train_step(self, engine, microbatches):
@@ -398,8 +562,9 @@ class DataParallel(object):
         finally:
             engine.set_bucket_callback(None)
         loss = reducer.finish_and_apply(engine)
-        self.last_collectives = getattr(reducer, "last_launched", None)
-        self.last_kinds = getattr(reducer, "last_kinds", None)
+        self.last_collectives = reducer.last_launched
+        self.last_kinds = reducer.last_kinds
+        self.last_executed = reducer.last_executed  # names of the torch.distributed calls that really ran
         return loss
 
     def eval_step(self, engine, microbatches):

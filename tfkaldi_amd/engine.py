@@ -3,7 +3,7 @@
 This is plumbing only -- every FLOP of the hot path runs in libtfkaldi_hip.so.  The classes of
 tfkaldi_amd.neuralNetworks (Trainer / Decoder / DNN) are built on it.
 """
-from ctypes import byref, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import byref, c_double, c_float, c_int, c_size_t, c_uint64, c_void_p
 
 import numpy as np
 
@@ -31,6 +31,12 @@ class Engine(object):
         self._stream = None
         self._cb = None
         self._layer_cb = None
+        # Called before anything reads or writes the fp32 PARAMETERS from outside the optimiser (tensor get / set, the
+        # layer-wise growth control ops).  The mixed-precision sharded exchange (dataparallel.BucketReducer) keeps the
+        # fp32 masters of a span only on the rank that owns it; its hook refuses such an access until the masters have
+        # been gathered collectively (DataParallel.gather_parameters) instead of handing out stale values.
+        self.param_access_hook = None
+        self.on_close = []
         if torch_state:
             import torch
             nbytes = c_size_t()
@@ -47,6 +53,9 @@ class Engine(object):
     # ---- lifetime ----
     def close(self):
         if self._h:
+            for fn in self.on_close:
+                fn()
+            del self.on_close[:]
             check(self.lib.tfk_destroy(self._h))
             self._h = c_void_p()
 
@@ -72,7 +81,12 @@ class Engine(object):
             return (self.O if layer == self.L else self.H,)
         return (self.H,)
 
+    def _param_access(self, slot=SLOT_PARAM):
+        if slot == SLOT_PARAM and self.param_access_hook is not None:
+            self.param_access_hook()
+
     def get(self, kind, layer, slot=SLOT_PARAM):
+        self._param_access(slot)
         out = np.empty(self._shape(kind, layer), dtype=np.float32)
         check(self.lib.tfk_tensor_get(self._h, kind, slot, layer, out.ctypes.data_as(c_void_p), out.size))
         return out
@@ -81,6 +95,7 @@ class Engine(object):
         v = _f32(value)
         if v.shape != self._shape(kind, layer):
             raise ValueError("tensor shape %s != %s" % (v.shape, self._shape(kind, layer)))
+        self._param_access(slot)
         check(self.lib.tfk_tensor_set(self._h, kind, slot, layer, v.ctypes.data_as(c_void_p), v.size))
 
     def scalar(self, which):
@@ -160,7 +175,13 @@ class Engine(object):
         done.record(torch.cuda.current_stream(raw.device))
         stream = c_void_p()
         check(self.lib.tfk_stream(self._h, byref(stream)))
-        torch.cuda.ExternalStream(stream.value, device=raw.device).wait_event(done)
+        ext = torch.cuda.ExternalStream(stream.value, device=raw.device)
+        ext.wait_event(done)
+        # Lifetime contract: the call returns while the splice kernel that reads `raw` is still pending on the ENGINE's
+        # stream, which torch's caching allocator knows nothing about.  record_stream tells it: if the caller drops the
+        # tensor, its block is not handed out again before the work enqueued on the engine stream so far has finished
+        # (round-2 advisor finding: the block could be reused and overwritten under the pending kernel).
+        raw.record_stream(ext)
         return c_void_p(raw.data_ptr()), int(raw.stride(0)), int(raw.shape[0]), lens
 
     @staticmethod
@@ -368,6 +389,31 @@ class Engine(object):
 
     def params_touched(self):
         check(self.lib.tfk_params_touched(self._h))
+
+    def shadow_view(self):
+        """torch bfloat16 view of the arena-mirroring weight shadow (mixed precision, every leading dimension a multiple
+        of 8; requires torch_state=True), element offsets = those of the fp32 weight arena; None when there is none"""
+        if self._state is None:
+            raise RuntimeError("shadow_view needs Engine(..., torch_state=True)")
+        import torch
+        ptr, n, mirrors = c_void_p(), c_size_t(), c_int()
+        check(self.lib.tfk_shadow_region(self._h, byref(ptr), byref(n), byref(mirrors)))
+        if not mirrors.value or not n.value:
+            return None
+        off = (ptr.value - self._state.data_ptr()) // 4
+        return self._state[off:off + (n.value + 1) // 2].view(torch.bfloat16)[:n.value]
+
+    def apply_writes_shadow(self):
+        """between apply_begin and apply_end: does apply_span write the bf16 shadow with the update?"""
+        d = c_int()
+        check(self.lib.tfk_apply_writes_shadow(self._h, byref(d)))
+        return bool(d.value)
+
+    def param_checksum(self, which=0):
+        """64-bit integer checksum of the fp32 parameter arena (0) or the bf16 shadow (1); synchronises"""
+        v = c_uint64()
+        check(self.lib.tfk_param_checksum(self._h, int(which), byref(v)))
+        return int(v.value)
 
     def set_bucket_callback(self, fn):
         """fn(bucket) is called from accumulate(last=True) once the bucket's kernels are enqueued."""

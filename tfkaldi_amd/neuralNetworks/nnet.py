@@ -137,7 +137,15 @@ class _Schedule(object):
         self.retries = 0
 
     # ---- persistence: every rank holds the same state, rank 0 writes, all wait ----
+    def _gather(self):
+        """collective: the fp32 masters may be sharded over the ranks (mixed-precision sharded exchange); a trainer
+        with the reference's plain interface has nothing to gather"""
+        gather = getattr(self.trainer, "gather_parameters", None)
+        if gather is not None:
+            gather()
+
     def save(self, name):
+        self._gather()
         if self.net.rank == 0:
             self.trainer.save_trainer(self.training_dir + name)
         self.net._barrier()
@@ -208,6 +216,7 @@ class _Schedule(object):
                 self.grow()
                 if self.step % int(conf['check_freq']) == 0:
                     self.save('step%d' % self.step)
+            self._gather()
             if self.net.rank == 0:
                 trainer.save_model(conf['savedir'] + '/final')
             self.net._barrier()

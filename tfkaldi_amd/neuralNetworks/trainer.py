@@ -83,6 +83,17 @@ class Trainer(object, metaclass=ABCMeta):
         self.input_dim = input_dim
         self._seed = seed if seed is not None else int.from_bytes(os.urandom(4), "little")
         self.dp = DataParallel()
+        if self.dp.enabled:
+            # every rank adopts rank 0's seed BEFORE the engine is built: the per-rank dropout keys are derived from it
+            # (rank_seed), so a multi-rank run is reproducible from the one logged seed (round-2 advisor finding: ranks
+            # > 0 keyed their dropout from a private os.urandom value that nothing recorded)
+            import torch
+            import torch.distributed as dist
+            seed_t = torch.tensor([self._seed], dtype=torch.int64)
+            if dist.get_backend(self.dp.group) == "nccl":
+                seed_t = seed_t.cuda(device if device is not None else int(os.environ.get("LOCAL_RANK", "0")))
+            dist.broadcast(seed_t, src=0, group=self.dp.group)
+            self._seed = int(seed_t.item())
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if self.dp.enabled else 0
         self.graph = _Graph()
@@ -94,7 +105,7 @@ class Trainer(object, metaclass=ABCMeta):
         self.engine = classifier.create_engine(
             input_dim, torch_state=self.dp.enabled, init_learning_rate=init_learning_rate,
             learning_rate_decay=learning_rate_decay, num_steps=num_steps, max_frames=min(max_frames, 1 << 16),
-            seed=rank_seed(self._seed, self.dp.rank), device=device)  # per-rank dropout stream
+            seed=rank_seed(self._seed, self.dp.rank), device=device)  # per-rank dropout stream from the SHARED seed
         self.modelsaver = ModelSaver(self.engine)
         self.control_ops = classifier.control_ops(self.engine)
         self.global_step = _StepVariable(self.engine)
@@ -109,14 +120,7 @@ class Trainer(object, metaclass=ABCMeta):
     def initialize(self):
         """Initialize all the variables (reference trainer.py:244-247): random hidden weights, zero output
         layer, step counters, Adam state.  Every data-parallel rank draws the same weights."""
-        if self.dp.enabled:
-            import torch
-            import torch.distributed as dist
-            seed = torch.tensor([self._seed], dtype=torch.int64)
-            if dist.get_backend(self.dp.group) == "nccl":
-                seed = seed.cuda(self.engine.cfg.device)
-            dist.broadcast(seed, src=0, group=self.dp.group)
-            self._seed = int(seed.item())
+        self.dp.gather_parameters(self.engine)
         self.classifier.initialize(self.engine, np.random.default_rng(self._seed))
         for l in range(self.engine.L + 1):
             for kind in (_lib.WEIGHTS, _lib.BIASES) + ((_lib.BN_BETA,) if self.engine.batch_norm and l < self.engine.L else ()):
@@ -212,10 +216,16 @@ class Trainer(object, metaclass=ABCMeta):
         self.engine.halve_learning_rate()
 
     # ---- persistence (path prefixes chosen by the caller: nnet.py:140, 148, 206, 233, 238) ----
+    def gather_parameters(self):
+        """COLLECTIVE under data parallelism: make the fp32 parameters whole on this rank (the mixed-precision sharded
+        exchange keeps each span's masters on its owner).  Every rank calls it before any rank saves."""
+        self.dp.gather_parameters(self.engine)
+
     def save_model(self, filename):
         self.modelsaver.save(None, filename)
 
     def restore_model(self, filename):
+        self.dp.gather_parameters(self.engine)  # (every rank restores: collective)
         self.modelsaver.restore(None, filename)
 
     def save_trainer(self, filename):
@@ -229,6 +239,7 @@ class Trainer(object, metaclass=ABCMeta):
         os.replace(tmp, filename + "_trainvars")
 
     def restore_trainer(self, filename):
+        self.dp.gather_parameters(self.engine)  # (every rank restores: collective)
         self.modelsaver.restore(None, filename)
         with np.load(filename + "_trainvars") as data:
             self.engine.set_scalar(_lib.GLOBAL_STEP, int(data["global_step"]))

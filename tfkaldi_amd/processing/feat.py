@@ -15,6 +15,15 @@ class FeatureComputer(object):
             raise Exception('unknown dynamic type')
         self.feature_type, self.dynamic, self.conf = featureType, dynamic, conf
         self._plans = {}
+        # What the device transform supports is checked HERE, on the host, before any file is touched (the device plan is
+        # built at the first batch, per sample rate): numpy's rfft takes any length, csrc/features.hip a power of two in
+        # [32, 4096] with nfilt <= nfft / 2, and there is no CPU path to fall back to.
+        nfft, nfilt = int(conf.get('nfft', 512)), int(conf.get('nfilt', 1))  # (missing keys: KeyError at first use, as the reference)
+        if nfft < 32 or nfft > 4096 or nfft & (nfft - 1):
+            raise ValueError("nfft = %d: the GPU feature computation needs a power of two in [32, 4096] (the reference's "
+                             "configurations use 512)" % nfft)
+        if nfilt < 1 or nfilt > nfft // 2:
+            raise ValueError("nfilt = %d must lie in [1, nfft / 2 = %d]" % (nfilt, nfft // 2))
 
     def plan(self, rate):
         if rate not in self._plans:

@@ -35,11 +35,13 @@ def prepare_data(datadir, featdir, conf, feat_type, dynamic):
             seperate utterance''')
         found_segments = False
 
+    # (the configuration is validated before the old feature file is removed: an unsupported transform length must not
+    # cost the user the features that are already there)
+    comp = feat.FeatureComputer(feat_type, dynamic, conf)
     if os.path.isfile(featdir + '/feats.ark'):
         os.remove(featdir + '/feats.ark')
     writer = ark.ArkWriter(featdir + '/feats.scp', featdir + '/feats.ark')
     wavfiles = readfiles.read_wavfiles(datadir + '/wav.scp')
-    comp = feat.FeatureComputer(feat_type, dynamic, conf)
 
     max_length = 0
     pending = {}  # sample rate -> [(utterance id, samples)]

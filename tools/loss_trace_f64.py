@@ -1,0 +1,59 @@
+"""GPU tool: the first 20 optimiser steps of bench.py's workload (BASELINE cfg2, the bench's weights and micro-batches)
+through the engine, the PyTorch-CPU fp32 stand-in and the float64 oracle; prints the three traces and each fp32
+implementation's distance to the float64 referee (reference neuralNetworks/trainer.py:336-346).
+
+    python tools/loss_trace_f64.py [steps] > profiles/rNN_loss_trace_f64.json
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from oracle.loss_trace import distances, f64_loss_trace  # noqa: E402
+from oracle.torch_cpu_step import TorchCpuTrainer  # noqa: E402
+from tfkaldi_amd import _lib  # noqa: E402
+from tfkaldi_amd.engine import Engine  # noqa: E402
+
+
+def traces(steps=20, dtype="float32"):
+    F, L, H, O, T = bench.F, bench.L, bench.H, bench.O, bench.T
+    with tempfile.TemporaryDirectory(prefix="tfkaldi_trace_") as d:
+        batches = bench.make_batches(0, 1, min(steps, bench.MAX_RING), d)
+    rng = np.random.default_rng(7)
+    hidden = [(rng.standard_normal((F if l == 0 else H, H)) / np.sqrt(F if l == 0 else H)).astype(np.float32)
+              for l in range(L)]
+    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, init_learning_rate=1e-3, num_steps=3 * steps,
+                           max_frames=T, compute_dtype=dtype)
+    eng = Engine(cfg)
+    for l, w in enumerate(hidden):
+        eng.set(_lib.WEIGHTS, l, w)
+    gpu = []
+    for i in range(steps):
+        X, y = batches[i % len(batches)]
+        eng.accumulate(X, y, last=True)
+        gpu.append(eng.apply())
+    eng.close()
+    cpu_t = TorchCpuTrainer(F, L, H, O, nonlin="relu", batch_norm=True)
+    cpu_t.set_hidden_weights(hidden)
+    cpu = []
+    for i in range(steps):
+        X, y = batches[i % len(batches)]
+        cpu_t.accumulate(X, y)
+        cpu.append(cpu_t.apply())
+    ref = f64_loss_trace(batches, hidden, steps, F, L, H, O)
+    return gpu, cpu, ref
+
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    gpu, cpu, ref = traces(steps)
+    g_rel, g_run = distances(gpu, ref)
+    c_rel, c_run = distances(cpu, ref)
+    print(json.dumps({"steps": steps, "engine": gpu, "cpu_fp32": cpu, "float64": ref,
+                      "engine_vs_f64_rel": g_rel, "cpu_fp32_vs_f64_rel": c_rel,
+                      "engine_vs_f64_max": max(g_rel), "cpu_fp32_vs_f64_max": max(c_rel)}, indent=1))
