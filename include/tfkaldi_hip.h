@@ -301,6 +301,13 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
  * leading dimensions (in elements) that are multiples of 8 and zero padding (gemm_bf16.h). */
 int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   int M, int N, int K, const float* bias, int epi);
+/* The backward pair of one layer in ONE launch (gemm_bf16.h: gemm_bf16_dual): C_nt[M_nt, N_nt] = A_nt . B_nt^T and
+ * C_tn[M_tn, N_tn] (+)= A_tn^T . B_tn (epi_tn: 0 or 2 = accumulate).  Fails when the pair of shapes is not eligible
+ * (tfk_gemm_bf16_dual_config == 0).  Block geometry: env TFK_BF16_DUAL_CFG (3: 128x64, 4: 128x128, 5: 256x128, 0: off). */
+int tfk_gemm_bf16_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uint16_t* B_nt, int ldb_nt, float* C_nt,
+                       int ldc_nt, int M_nt, int N_nt, int K_nt, const uint16_t* A_tn, int lda_tn, const uint16_t* B_tn,
+                       int ldb_tn, float* C_tn, int ldc_tn, int M_tn, int N_tn, int K_tn, int epi_tn);
+int tfk_gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn);
 /* Tile configuration of the bf16 GEMM (gemm_bf16.h: 0-2 register-staged, 3-6 LDS-DMA staged): force one for every
  * later call (cfg < 0 restores the heuristic) / ask which one the heuristic gives an [M, N] result.  Tools and
  * tests only. */

@@ -90,7 +90,9 @@ class LayoutEngine(object):
         self.m = np.zeros(P, dtype=np.float32)
         self.v = np.zeros(P, dtype=np.float32)
         self.mov = np.zeros(layout.E, dtype=np.float32)
-        self.shadow = self.params[:layout.vec_off].to(torch.bfloat16) if (bf16 and layout.mirrors) else None
+        # (as the real engine: the shadow exists but is NOT current until the first forward pass or optimiser step)
+        self.shadow = torch.zeros(layout.vec_off, dtype=torch.bfloat16) if (bf16 and layout.mirrors) else None
+        self._shadow_dirty = self.shadow is not None
         self.later = 0
         self.cb = self.layer_cb = None
         self.param_access_hook = None
@@ -145,7 +147,7 @@ class LayoutEngine(object):
 
     # ---- "forward": announce the read of each layer, then digest what is there ----
     def _read_layers(self):
-        if getattr(self, "_shadow_dirty", False):
+        if self._shadow_dirty:
             if self.layer_cb:
                 self.layer_cb(-1)
             self.shadow[:] = self.params[:self.lay.vec_off].to(torch.bfloat16)
@@ -205,7 +207,12 @@ class LayoutEngine(object):
         self.t += 1
         b1, b2 = 0.9, 0.999
         self._lr_t = np.float32(self.lr * np.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t))
-        self._direct = self.shadow is not None and not getattr(self, "_shadow_dirty", False)
+        if self.shadow is not None and self._shadow_dirty:  # (tfk_apply_begin: an arena-mirroring shadow is made current)
+            if self.layer_cb:
+                self.layer_cb(-1)
+            self.shadow[:] = self.params[:self.lay.vec_off].to(torch.bfloat16)
+            self._shadow_dirty = False
+        self._direct = self.shadow is not None
         self.apply_open = True
 
     def apply_writes_shadow(self):
@@ -232,8 +239,6 @@ class LayoutEngine(object):
     def apply_end(self):
         assert self.apply_open
         self.apply_open = False
-        if not self._direct and self.shadow is not None:
-            self._shadow_dirty = True
         self.fresh = True
         self.global_step += 1
         return self._loss / self._frames

@@ -104,3 +104,46 @@ def test_gemm_bf16_epilogues(gpu, layout, epi):
     from tfkaldi_amd import _lib
     for M, N, K in ((70, 90, 200), (256, 128, 64)):
         _run(_lib.load(), torch, layout, M, N, K, epi=epi, seed=7)
+
+
+# the backward pair of a layer in one launch (gemm_bf16_dual): dA = dZ . W^T (NT) and dW (+)= in^T . dZ (TN) share dZ
+DUAL_SHAPES = [  # (T, d_in, d_out): NT is [T, d_in] over K = d_out, TN is [d_in, d_out] over K = T
+    (1024, 2048, 2048), (1024, 2048, 4000), (300, 520, 264), (129, 257, 136), (2048, 1024, 1000)]
+
+
+@pytest.mark.parametrize("shape", DUAL_SHAPES)
+@pytest.mark.parametrize("epi_tn", [0, EPI_ACCUM])
+def test_gemm_bf16_dual(gpu, shape, epi_tn):
+    """every block geometry of the dual launch (the environment switch is read once per process, so the geometry is
+    chosen by the heuristic here; tools/gemm_bf16_dual_bench.py sweeps the others with the same check)"""
+    import torch
+    from tfkaldi_amd import _lib
+    lib = _lib.load()
+    T, d_in, d_out = shape
+    if lib.tfk_gemm_bf16_dual_config(T, d_in, d_in, d_out) == 0:
+        pytest.skip("pair not eligible for the dual launch")
+    rng = np.random.default_rng(T + d_in + d_out + epi_tn)
+    dz, ld_dz, dzr = _bf16_dev(torch, rng.standard_normal((T, d_out)))
+    W, ld_w, Wr = _bf16_dev(torch, rng.standard_normal((d_in, d_out)))
+    X, ld_x, Xr = _bf16_dev(torch, rng.standard_normal((T, d_in)))
+    ldc_a, ldc_w = _pad(d_in, 4), _pad(d_out, 4)
+    dA = torch.zeros((T, ldc_a), dtype=torch.float32, device="cuda")
+    G0 = np.zeros((d_in, ldc_w), dtype=np.float32)
+    G0[:, :d_out] = rng.standard_normal((d_in, d_out))
+    G = torch.from_numpy(G0.copy()).cuda()
+    torch.cuda.synchronize()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.tfk_gemm_bf16_dual(st, p(dz), ld_dz, p(W), ld_w, p(dA), ldc_a, T, d_in, d_out,
+                                p(X), ld_x, p(dz), ld_dz, p(G), ldc_w, d_in, d_out, T, epi_tn)
+    assert rc == 0, lib.tfk_last_error()
+    torch.cuda.synchronize()
+    ref_a, abs_a = dzr @ Wr.T, np.abs(dzr) @ np.abs(Wr).T
+    ref_w, abs_w = Xr.T @ dzr, np.abs(Xr).T @ np.abs(dzr)
+    if epi_tn:
+        ref_w, abs_w = ref_w + G0[:, :d_out], abs_w + np.abs(G0[:, :d_out])
+    for name, out, ref, absref in (("dA", dA.cpu().numpy()[:, :d_in], ref_a, abs_a),
+                                   ("dW", G.cpu().numpy()[:, :d_out], ref_w, abs_w)):
+        err = np.abs(out - ref)
+        bound = 4e-7 * absref + 1e-6
+        assert (err <= bound).all(), "%s %s: max err/bound %.2f" % (name, shape, float((err / bound).max()))

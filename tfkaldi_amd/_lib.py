@@ -117,6 +117,9 @@ SYMBOLS = {
                              c_int, c_void_p, c_int, c_int]),
     "tfk_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int]),
+    "tfk_gemm_bf16_dual": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "tfk_gemm_bf16_dual_config": (c_int, [c_int, c_int, c_int, c_int]),
     "tfk_gemm_bf16_force_config": (c_int, [c_int]),
     "tfk_gemm_bf16_config": (c_int, [c_int, c_int]),
     "tfk_feat_create": (c_int, [POINTER(TfkFeatConfig), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(_E)]),

@@ -93,6 +93,15 @@ struct tfk_engine {
   // gradient GEMMs or the optimiser on a side stream was measured slower (profiles/r01_overlap_experiment.txt:
   // every GEMM already fills all 256 CUs, a concurrent kernel only evicts its L2 working set) and was removed;
   // the independent dA / dW pair of a layer shares one LAUNCH instead (gemm_f32_dual).
+  // The optimiser of tfk_apply runs layer by layer on its OWN stream: the step is HBM-bound there (28 B per parameter)
+  // while the next step's forward contractions are bound by the L2 -> LDS fill / the matrix pipes, and the next forward
+  // pass only waits, layer by layer, for the update of the layer it is about to read (env TFK_ADAM_OVERLAP).
+  hipStream_t opt_stream = nullptr;
+  hipEvent_t ev_opt_begin = nullptr, ev_opt_vec = nullptr;
+  std::vector<hipEvent_t> ev_adam;   // [L + 1]: the update of W_l (and its bf16 shadow) is complete
+  bool opt_overlap = false;          // decided at create
+  bool opt_pending = false;          // updates of the last tfk_apply may still be running on opt_stream
+  float* d_snap = nullptr;           // (loss, frames, #micro-batches) of the step being applied (step_finish)
   hipEvent_t ev_loss = nullptr;
   hipEvent_t ev_grow = nullptr;          // orders the copy stream behind a stream-ordered (re)allocation
   std::vector<void*> host_garbage;       // outgrown pinned staging buffers: released at tfk_destroy (hipHostFree
@@ -317,6 +326,25 @@ struct ProfScope {
 int sync_streams(tfk_engine* e) {
   HIPCHK(hipStreamSynchronize(e->copy_stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->opt_stream) HIPCHK(hipStreamSynchronize(e->opt_stream));
+  e->opt_pending = false;
+  return 0;
+}
+// the engine stream behind every optimiser launch still in flight on the optimiser stream (anything that reads or writes
+// parameters, moments or gradient sums outside the layer-by-layer forward pass)
+int join_optimizer(tfk_engine* e) {
+  if (e->opt_pending) {
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam[e->L], 0));  // recorded last: implies every earlier launch
+    e->opt_pending = false;
+  }
+  return 0;
+}
+// the forward pass is about to read the parameters of `layer`
+int wait_layer_update(tfk_engine* e, int layer, bool first) {
+  if (!e->opt_pending) return 0;
+  if (first) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_opt_vec, 0));  // bias / beta vectors of every layer
+  HIPCHK(hipStreamWaitEvent(e->stream, e->ev_adam[layer], 0));
+  if (layer == e->L) e->opt_pending = false;  // updates are launched in layer order: the last one covers all
   return 0;
 }
 
@@ -448,8 +476,50 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
 // ONE launch (gemm_f32_dual).  Returns 1 when the pair is not eligible (the caller launches them separately).
 int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int ldw, float* da_out, int ld_da, int T,
                   int N_da, int K_da, const ActEpi* act, float* stats, const float* in, int ld_in, float* Gw, int ld_g,
-                  int d_in, int d_out, int epi_w) {
-  if (e->bf16 || !e->dual_gemm) return 1;
+                  int d_in, int d_out, int epi_w, int* chunk_rows) {
+  if (!e->dual_gemm) return 1;
+  const double flops = 2.0 * T * N_da * K_da + 2.0 * d_in * d_out * T;
+  if (e->bf16) {
+    const int dcfg = gemm_bf16_dual_config(T, N_da, d_in, d_out);
+    const int bm = gemm_bf16_dual_tile_rows(dcfg);
+    if (!dcfg || (act && (T + bm - 1) / bm > kMaxRowSplits)) return 1;
+    GemmArgsB a = {}, w = {};
+    int ld_a = 0, ld_b = 0, ld_c = 0, ld_d = 0;
+    a.A = twin_of(e, dz, &ld_a);
+    a.B = twin_of(e, W, &ld_b);
+    w.A = twin_of(e, in, &ld_c);
+    w.B = twin_of(e, dz, &ld_d);
+    if (!a.A || !a.B || !w.A || !w.B) return fail(-1, "internal: GEMM operand without a bf16 twin");
+    a.C = da_out; a.stats = stats;
+    a.act_a = act ? act->a : nullptr; a.act_z = act ? act->z : nullptr;
+    a.act_mean = act ? act->mean : nullptr; a.act_rstd = act ? act->rstd : nullptr;
+    a.act_nonlin = act ? act->nonlin : 0;
+    a.act_scale = act ? act->scale : 1.f;
+    a.act_keep = act ? 1.f / act->scale : 1.f;
+    a.act_beta = act ? act->beta : nullptr;
+    a.stats_stride = kMaxRowSplits;
+    a.M = T; a.N = N_da; a.K = K_da; a.lda = ld_a; a.ldb = ld_b; a.ldc = ld_da; a.epi = act ? EPI_DACT : 0;
+    w.C = Gw;
+    w.M = d_in; w.N = d_out; w.K = T; w.lda = ld_c; w.ldb = ld_d; w.ldc = ld_g; w.epi = epi_w;
+    const double bytes = 2.0 * ((double)T * K_da + (double)K_da * N_da) + 4.0 * (double)T * N_da +
+                         2.0 * ((double)T * d_in + (double)T * d_out) + 4.0 * (double)d_in * d_out * ((epi_w & EPI_ACCUM) ? 2 : 1);
+    hipEvent_t pa = nullptr, pb = nullptr;
+    if (e->profiling) {
+      pa = get_event(e); pb = get_event(e);
+      hipEventRecord(pa, e->stream);
+    }
+    const int rc = gemm_bf16_dual(a, w, e->stream);
+    if (rc == -1) return 1;
+    if (rc != 0) return fail(rc, "gemm_bf16_dual launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (e->profiling) {
+      hipEventRecord(pb, e->stream);
+      ProfRec r;
+      r.family = KF_GEMM_DUAL; r.flops = flops; r.bytes = bytes; r.a = pa; r.b = pb;
+      e->prof.push_back(r);
+    }
+    if (chunk_rows) *chunk_rows = bm;
+    return 0;
+  }
   GemmArgs a, w;
   a.A = dz; a.B = W; a.C = da_out; a.bias = nullptr; a.stats = stats;
   a.act_a = act ? act->a : nullptr; a.act_z = act ? act->z : nullptr;
@@ -463,7 +533,6 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
   w.A = in; w.B = dz; w.C = Gw; w.bias = nullptr; w.stats = nullptr;
   w.act_a = w.act_z = w.act_mean = w.act_rstd = nullptr; w.act_nonlin = 0; w.stats_stride = 0;
   w.M = d_in; w.N = d_out; w.K = T; w.lda = ld_in; w.ldb = ld_dz; w.ldc = ld_g; w.epi = epi_w;
-  const double flops = 2.0 * T * N_da * K_da + 2.0 * d_in * d_out * T;
   const double bytes = 4.0 * ((double)T * K_da + (double)K_da * N_da + (double)T * N_da) +
                        4.0 * ((double)T * d_in + (double)T * d_out + (double)d_in * d_out * ((epi_w & EPI_ACCUM) ? 2 : 1));
   hipEvent_t pa = nullptr, pb = nullptr;
@@ -730,12 +799,14 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   const int H = e->H, ldH = e->ldH;
   if (e->bf16 && e->shadow_dirty) {
     need_params(e, -1);  // the shadow is rebuilt from every weight matrix
+    CHK(join_optimizer(e));
     CHK(refresh_shadow(e));
   }
   auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; } return t; };
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
     need_params(e, l);
+    CHK(wait_layer_update(e, l, l == 0));
     if (train && e->cfg.batch_norm && !e->cfg.l2_norm) {
       // fused path: the GEMM epilogue emits the per-tile column statistics, ONE column-tiled kernel merges them
       // and applies BN + nonlinearity + dropout (4 kernels per layer -> 2)
@@ -799,6 +870,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
   }
   const LayerLayout& o = e->lay[e->L];
   need_params(e, e->L);
+  CHK(wait_layer_update(e, e->L, nfw == 0));
   CHK(run_gemm(e, GEMM_NN, e->a[nact - 1], ldH, e->p_param() + o.w_off, o.ld_out, e->logits, e->ldO, T, e->O, H,
                e->p_param() + o.b_off, EPI_BIAS));
   HIPCHK(hipGetLastError());
@@ -845,6 +917,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   const float dscale = drop ? 1.f / e->cfg.keep_prob : 1.f;
   const bool fuse_hb = e->cfg.batch_norm && !e->cfg.l2_norm && (!drop || e->cfg.nonlin == TFK_NONLIN_RELU) &&
                        e->fuse_hb_enabled && chunks_h <= kMaxRowSplits && chunks_o <= kMaxRowSplits;
+  int chunks_first = chunks_o;  // row chunks of the EPI_DACT partial sums of the GEMM that produced the current `da`
   auto dact_gemm = [&](const float* dz, int ld_dz, const float* W, int ldw, float* out, int K, int target, int cfg) {
     if (!fuse_hb) return run_gemm(e, GEMM_NT, dz, ld_dz, W, ldw, out, ldH, T, H, K, nullptr, 0);
     ActEpi act = {e->a[target], e->z[target], e->mean[target], e->rstd[target], e->cfg.nonlin};
@@ -857,11 +930,13 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     ActEpi act = {e->a[nact - 1], e->z[nact - 1], e->mean[nact - 1], e->rstd[nact - 1], e->cfg.nonlin};
     act.scale = dscale;
     act.beta = e->cfg.batch_norm ? e->p_param() + e->lay[nact - 1].beta_off : nullptr;
+    int bm = rows_o;
     const int rc = run_gemm_dual(e, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O,
                                  fuse_hb ? &act : nullptr, fuse_hb ? ws_of(nact - 1) : nullptr, e->a[nact - 1], ldH,
-                                 G + o.w_off, o.ld_out, H, e->O, epi_w);
+                                 G + o.w_off, o.ld_out, H, e->O, epi_w, &bm);
     if (rc < 0) return rc;
     out_dw_done = rc == 0;
+    if (out_dw_done) chunks_first = (T + bm - 1) / bm;
   }
   if (!out_dw_done) {
     CHK(run_gemm(e, GEMM_TN, e->a[nact - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr,
@@ -875,7 +950,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     // whatever the active depth is: a rank without micro-batches replays exactly that order (dataparallel.py).
     for (int l = L - 1; l >= nact; --l) e->cb(e->cb_user, L - l);
   }
-  int chunks_in = chunks_o;
+  int chunks_in = chunks_first;
   for (int l = nact - 1; l >= 0; --l) {
     const LayerLayout& y = e->lay[l];
     float* da = e->dA[pp];
@@ -907,21 +982,24 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     const float* in = l == 0 ? Xd : e->a[l - 1];
     const int ld_in = l == 0 ? ldx : ldH;
     bool fused = false;
+    int chunks_next = chunks_h;
     if (l > 0) {  // dW_l and the dA that feeds layer l - 1 both read dz_l: one launch when eligible
       ActEpi act = {e->a[l - 1], e->z[l - 1], e->mean[l - 1], e->rstd[l - 1], e->cfg.nonlin};
       act.scale = dscale;
       act.beta = e->cfg.batch_norm ? e->p_param() + e->lay[l - 1].beta_off : nullptr;
+      int bm = rows_h;
       const int rc = run_gemm_dual(e, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H,
                                    fuse_hb ? &act : nullptr, fuse_hb ? ws_of(l - 1) : nullptr, in, ld_in, G + y.w_off,
-                                   y.ld_out, y.d_in, H, epi_w);
+                                   y.ld_out, y.d_in, H, epi_w, &bm);
       if (rc < 0) return rc;
       fused = rc == 0;
+      chunks_next = (T + bm - 1) / bm;
     }
     if (!fused) {
       CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w));
       if (l > 0) CHK(dact_gemm(da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], H, l - 1, cfg_h));
     }
-    if (l > 0) chunks_in = chunks_h;
+    if (l > 0) chunks_in = fused ? chunks_next : chunks_h;
     if (fire && e->cb) e->cb(e->cb_user, L - l);
     pp ^= 1;
   }
@@ -1034,6 +1112,21 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
     if ((v = getenv("TFK_FUSE_EVAL"))) e->fuse_eval = atoi(v) != 0;
   }
+  {
+    // default: on in mixed precision (at BASELINE cfg3 / cfg4 sizes the optimiser is a quarter of a one-GPU step and the
+    // forward contractions leave HBM idle), off in fp32 (round 1 measured a concurrent kernel only evicting the GEMM's L2
+    // working set there); TFK_ADAM_OVERLAP=0/1 overrides
+    const char* v = getenv("TFK_ADAM_OVERLAP");
+    e->opt_overlap = v ? atoi(v) != 0 : e->bf16;
+  }
+  if (e->opt_overlap) {
+    HIPB(hipStreamCreateWithFlags(&e->opt_stream, hipStreamNonBlocking));
+    HIPB(hipEventCreateWithFlags(&e->ev_opt_begin, hipEventDisableTiming));
+    HIPB(hipEventCreateWithFlags(&e->ev_opt_vec, hipEventDisableTiming));
+    e->ev_adam.assign(e->L + 1, nullptr);
+    for (int l = 0; l <= e->L; ++l) HIPB(hipEventCreateWithFlags(&e->ev_adam[l], hipEventDisableTiming));
+  }
+  HIPB(hipMalloc((void**)&e->d_snap, 16 * sizeof(float)));
   HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
   HIPB(hipEventCreateWithFlags(&e->ev_grow, hipEventDisableTiming));
   for (int s = 0; s < 2; ++s) {
@@ -1278,11 +1371,17 @@ int tfk_destroy(tfk_engine* e) {
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
+  if (e->opt_stream) hipStreamSynchronize(e->opt_stream);
   free_activations(e);
   for (void* p : e->host_garbage) (void)hipHostFree(p);
   e->host_garbage.clear();
   if (e->ev_loss) hipEventDestroy(e->ev_loss);
   if (e->ev_grow) hipEventDestroy(e->ev_grow);
+  if (e->ev_opt_begin) hipEventDestroy(e->ev_opt_begin);
+  if (e->ev_opt_vec) hipEventDestroy(e->ev_opt_vec);
+  for (hipEvent_t ev : e->ev_adam) if (ev) hipEventDestroy(ev);
+  if (e->opt_stream) hipStreamDestroy(e->opt_stream);
+  if (e->d_snap) hipFree(e->d_snap);
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
@@ -1446,6 +1545,7 @@ int tfk_eval_accumulate_ctc_raw(tfk_engine* e, const float* raw, int64_t ldraw, 
 //   end    waits for the loss on the host, re-initialises the accumulators (lazily), global_step += 1
 int apply_begin(tfk_engine* e) {
   if (e->apply_open) return fail(-1, "tfk_apply_begin called twice without tfk_apply_end");
+  CHK(join_optimizer(e));  // (a second step without a forward pass in between)
   const double lr = current_lr(e);
   e->adam_t += 1;
   // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); w -= lr_t * m / (sqrt(v) + eps)
@@ -1457,23 +1557,47 @@ int apply_begin(tfk_engine* e) {
   // BN moving averages + re-initialisation of their increments + the loss hand-over, one launch
   {
     ProfScope ps(e, KF_EMA, 0, 16.0 * e->E);
-    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev);
+    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev, e->d_snap);
   }
   HIPCHK(hipEventRecord(e->ev_loss, e->stream));
-  e->apply_direct = e->bf16 && e->wb_aligned && !e->shadow_dirty;
+  // An arena-mirroring shadow is ALWAYS written with the update: if it is not current (no forward pass since the
+  // parameters were last set from outside -- e.g. a data-parallel rank that had no micro-batch in its first step) it is
+  // made current first.  The decision must not depend on what this rank happened to run: under the sharded exchange
+  // every rank has to gather the same thing (the shadow), or the collectives mismatch.
+  if (e->bf16 && e->wb_aligned && e->shadow_dirty) {
+    need_params(e, -1);
+    CHK(refresh_shadow(e));
+  }
+  e->apply_direct = e->bf16 && e->wb_aligned;
   e->apply_open = true;
   return 0;
 }
-int apply_span(tfk_engine* e, size_t off, size_t n) {
+int apply_span(tfk_engine* e, size_t off, size_t n, hipStream_t st = nullptr) {
   if (!e->apply_open) return fail(-1, "tfk_apply_span outside tfk_apply_begin / tfk_apply_end");
   if (off >= e->P || n == 0) return 0;
   if (off + n > e->P) n = e->P - off;
   if ((off | n) & 3) return fail(-1, "parameter span [%zu, +%zu) is not a multiple of 4 floats", off, n);
   const size_t w_end = e->lay[0].b_off;  // the weight matrices (and their bf16 shadow) come first
   const size_t n_wb = (e->apply_direct && off < w_end) ? ((off + n < w_end ? off + n : w_end) - off) : 0;
-  ProfScope ps(e, KF_ADAM, 0, 28.0 * n);
-  adam_apply(e->stream, e->p_param() + off, e->p_grad() + off, e->p_m() + off, e->p_v() + off, n, e->p_scalars(),
-             e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0, n_wb ? e->Wb + off : nullptr, n_wb);
+  // on the optimiser stream the launch may run past the next micro-batch's loss_reduce: it reads the step's frame count
+  // from the snapshot step_finish took
+  ProfScope ps(e, KF_ADAM, 0, 28.0 * n, st);
+  adam_apply(st ? st : e->stream, e->p_param() + off, e->p_grad() + off, e->p_m() + off, e->p_v() + off, n,
+             st ? e->d_snap : e->p_scalars(), e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0, n_wb ? e->Wb + off : nullptr, n_wb);
+  return 0;
+}
+// the whole optimiser step of tfk_apply, layer by layer on the optimiser stream (vectors first: every layer reads them)
+int apply_overlapped(tfk_engine* e) {
+  HIPCHK(hipEventRecord(e->ev_opt_begin, e->stream));
+  HIPCHK(hipStreamWaitEvent(e->opt_stream, e->ev_opt_begin, 0));
+  const size_t vec = e->lay[0].b_off;
+  CHK(apply_span(e, vec, e->P - vec, e->opt_stream));
+  HIPCHK(hipEventRecord(e->ev_opt_vec, e->opt_stream));
+  for (int l = 0; l <= e->L; ++l) {
+    CHK(apply_span(e, e->lay[l].w_off, e->lay[l].w_sz, e->opt_stream));
+    HIPCHK(hipEventRecord(e->ev_adam[l], e->opt_stream));
+  }
+  e->opt_pending = true;
   return 0;
 }
 int apply_end(tfk_engine* e, float* average_loss) {
@@ -1517,7 +1641,8 @@ int tfk_apply(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
   CHK(apply_begin(e));
-  CHK(apply_span(e, 0, e->P));  // one Adam launch over the whole parameter arena
+  if (e->opt_overlap) CHK(apply_overlapped(e));
+  else CHK(apply_span(e, 0, e->P));  // one Adam launch over the whole parameter arena
   return apply_end(e, average_loss);
 }
 
@@ -1547,6 +1672,7 @@ int tfk_init_last_layer(tfk_engine* e) {
   const LayerLayout& o = e->lay[e->L];
   HIPCHK(hipSetDevice(e->cfg.device));
   need_params(e, -1);
+  CHK(join_optimizer(e));
   HIPCHK(hipMemsetAsync(e->p_param() + o.w_off, 0, o.w_sz * sizeof(float), e->stream));
   HIPCHK(hipMemsetAsync(e->p_param() + o.b_off, 0, o.b_sz * sizeof(float), e->stream));
   if (e->bf16 && e->wb_aligned && !e->shadow_dirty) {
@@ -1728,6 +1854,7 @@ int tfk_reduce_bucket(tfk_engine* e, int bucket, size_t* offset_floats, size_t* 
 int tfk_zero_accumulators(tfk_engine* e) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(join_optimizer(e));
   HIPCHK(hipMemsetAsync(e->p_grad(), 0, e->reduce_floats * sizeof(float), e->stream));
   e->grads_fresh = false;  // physically zero now
   e->scalars_fresh = false;
@@ -1782,6 +1909,7 @@ int tfk_param_checksum(tfk_engine* e, int which, uint64_t* value) {
   } else {
     return fail(-1, "tfk_param_checksum: which must be 0 (fp32 parameters), 1 (bf16 shadow) or 2 (fp32 bias / beta vectors)");
   }
+  CHK(join_optimizer(e));
   if (!e->d_checksum) HIPCHK(hipMalloc((void**)&e->d_checksum, sizeof(unsigned long long)));
   HIPCHK(hipMemsetAsync(e->d_checksum, 0, sizeof(unsigned long long), e->stream));
   checksum_words(e->stream, p, words, e->d_checksum);
@@ -1899,6 +2027,20 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
   if (rc != 0) return fail(rc, "gemm_bf16 failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
+
+int tfk_gemm_bf16_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uint16_t* B_nt, int ldb_nt, float* C_nt,
+                       int ldc_nt, int M_nt, int N_nt, int K_nt, const uint16_t* A_tn, int lda_tn, const uint16_t* B_tn,
+                       int ldb_tn, float* C_tn, int ldc_tn, int M_tn, int N_tn, int K_tn, int epi_tn) {
+  GemmArgsB a = {}, w = {};
+  a.A = A_nt; a.B = B_nt; a.C = C_nt; a.M = M_nt; a.N = N_nt; a.K = K_nt; a.lda = lda_nt; a.ldb = ldb_nt; a.ldc = ldc_nt;
+  w.A = A_tn; w.B = B_tn; w.C = C_tn; w.M = M_tn; w.N = N_tn; w.K = K_tn; w.lda = lda_tn; w.ldb = ldb_tn; w.ldc = ldc_tn;
+  w.epi = epi_tn;
+  const int rc = gemm_bf16_dual(a, w, (hipStream_t)stream);
+  if (rc == -1) return fail(-1, "gemm_bf16_dual: this pair of shapes is not eligible for the dual launch");
+  if (rc != 0) return fail(rc, "gemm_bf16_dual failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+int tfk_gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn) { return gemm_bf16_dual_config(M_nt, N_nt, M_tn, N_tn); }
 
 int tfk_gemm_bf16_force_config(int cfg) {
   gemm_bf16_force_config(cfg);

@@ -51,6 +51,14 @@ constexpr int kNumGemmBf16Configs = 7;
 // Returns hipError_t as int.
 int gemm_bf16(GemmLayout layout, const GemmArgsB& args, hipStream_t stream);
 
+// An NT contraction (epi 0 / EPI_DACT) and a TN contraction (epi 0 / EPI_ACCUM) that do not depend on each other, in ONE
+// launch (gemm_bf16_dual_kernel).  Returns -1 when the pair is not eligible: the caller launches them one after the other.
+int gemm_bf16_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t stream);
+// block geometry gemm_bf16_dual picks for an [M_nt, N_nt] and an [M_tn, N_tn] result (0: not eligible) and its tile rows
+// (= rows per EPI_DACT chunk of the NT half)
+int gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn);
+int gemm_bf16_dual_tile_rows(int cfg);
+
 // rows of the block tile gemm_bf16 uses for an [M, N] result (= rows per EPI_COLSTATS / EPI_DACT chunk)
 int gemm_bf16_tile_rows(int M, int N);
 

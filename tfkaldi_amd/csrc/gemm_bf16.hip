@@ -47,9 +47,8 @@ constexpr int NUM_XCD = 8;
 // `group_rows` tile rows, column-major inside a group), i.e. a patch of about group_rows x (run / group_rows) tiles that
 // share A row-panels and B column-panels in that XCD's L2.  The host picks group_rows so that the patch is square in
 // BYTES (group_rows * BM ~ columns * BN), which minimises what the eight private L2s fetch from the fabric.
-__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int group_rows, int& tm, int& tn) {
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int group_rows, int bid, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
   const int xcd = bid % NUM_XCD, loc = bid / NUM_XCD;
   const int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
   const int seq = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -324,9 +323,7 @@ struct Frag {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "n"(n) : "memory")
 
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
-__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
-gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
   typedef DmaOperand<A_KC, BM, NTH> OA;
@@ -342,7 +339,7 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tm, tn;
-  tile_of_block(tiles_m, tiles_n, group_rows, tm, tn);
+  tile_of_block(tiles_m, tiles_n, group_rows, bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
@@ -434,6 +431,30 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   }
   TFKB_WAIT_BARRIER(0);  // the epilogue reuses the ring as scratch: nothing may still be landing in it
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
+}
+
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
+gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
+}
+
+// Two INDEPENDENT contractions in one launch -- backward: dA = dZ . W^T (NT, optionally EPI_DACT) of a layer and the
+// dW = in^T . dZ (TN) that consumes the same dZ.  At 1024 frames per GPU (BASELINE cfg3) each of them alone has 256 tiles
+// of 128x64 -- one per CU -- and is bound by the L2 -> LDS fill of that small tile (bytes per flop ~ 1/BM + 1/BN); together
+// they have enough tiles for 128x128 blocks on every CU (2/3 of the bytes per flop), and one kernel's ramp and epilogue
+// overlap the other's K loop.  The NT tiles (the longer K: K = d_out vs K = frames) come first in block order.
+template <int EPI_NT, int EPI_TN, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
+gemm_bf16_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, int group1, int tiles_m2, int tiles_n2,
+                      int group2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n1 = tiles_m1 * tiles_n1;
+  if ((int)blockIdx.x < n1)
+    dma_tile<true, true, EPI_NT, WAVES_M, WAVES_N, FM, FN, NS>(p1, tiles_m1, tiles_n1, group1, blockIdx.x, smem);
+  else
+    dma_tile<false, false, EPI_TN, WAVES_M, WAVES_N, FM, FN, NS>(p2, tiles_m2, tiles_n2, group2, blockIdx.x - n1, smem);
 }
 
 // ================================================================================================================
@@ -533,7 +554,7 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  tile_of_block(tiles_m, tiles_n, group_rows, tm, tn);
+  tile_of_block(tiles_m, tiles_n, group_rows, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
@@ -681,7 +702,82 @@ int launch(const GemmArgsB& p, hipStream_t stream) {
   return (int)hipErrorInvalidValue;
 }
 
+int pick_group_rows(int tiles_m, int tiles_n, int bm, int bn) {
+  // tile rows per XCD patch: ~sqrt(tiles per XCD * BN / BM) makes the patch square in bytes
+  int group_rows = g_group_rows;
+  if (group_rows <= 0) {
+    const double per_xcd = (double)tiles_m * tiles_n / NUM_XCD;
+    group_rows = (int)(sqrt(per_xcd * bn / bm) + 0.5);
+  }
+  if (group_rows < 1) group_rows = 1;
+  if (group_rows > tiles_m) group_rows = tiles_m;
+  return group_rows;
+}
+
+template <int EPI_NT, int EPI_TN, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+int launch_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
+  constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
+  constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto kern = &gemm_bf16_dual_kernel<EPI_NT, EPI_TN, WAVES_M, WAVES_N, FM, FN, NS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int tma = (a.M + BM - 1) / BM, tna = (a.N + BN - 1) / BN, tmw = (w.M + BM - 1) / BM, tnw = (w.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(WAVES_M * WAVES_N * 64), lds, stream, a, w, tma, tna,
+                     pick_group_rows(tma, tna, BM, BN), tmw, tnw, pick_group_rows(tmw, tnw, BM, BN));
+  return (int)hipGetLastError();
+}
+
+template <int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+int launch_dual_epi(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
+  const int key = (a.epi == EPI_DACT ? 2 : 0) + (w.epi == EPI_ACCUM ? 1 : 0);
+  switch (key) {
+    case 0: return launch_dual<0, 0, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
+    case 1: return launch_dual<0, EPI_ACCUM, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
+    case 2: return launch_dual<EPI_DACT, 0, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
+    default: return launch_dual<EPI_DACT, EPI_ACCUM, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
+  }
+}
+
+int g_dual_cfg = -2;  // env TFK_BF16_DUAL_CFG: -1 heuristic, 0 off, 3 / 4 / 5 force that block geometry
+
 }  // namespace
+
+// Block geometry of the dual (NT + TN) launch for these shapes: 5 = 256x128 (8 waves), 4 = 128x128, 3 = 128x64 (gemm_bf16.h
+// numbering), 0 = not worth it / not eligible.  The largest block that still gives every CU about two rounds of work.
+int gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn) {
+  if (g_dual_cfg == -2) {
+    const char* q = getenv("TFK_BF16_DUAL_CFG");
+    g_dual_cfg = q ? atoi(q) : -1;
+  }
+  if (g_dual_cfg == 0) return 0;
+  if (g_dual_cfg == 3 || g_dual_cfg == 4 || g_dual_cfg == 5) return g_dual_cfg;
+  auto tiles = [](int M, int N, int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  if (tiles(M_nt, N_nt, 256, 128) + tiles(M_tn, N_tn, 256, 128) >= 512) return 5;
+  if (tiles(M_nt, N_nt, 128, 128) + tiles(M_tn, N_tn, 128, 128) >= 256) return 4;
+  if (tiles(M_nt, N_nt, 128, 64) + tiles(M_tn, N_tn, 128, 64) >= 256) return 3;
+  return 0;
+}
+int gemm_bf16_dual_tile_rows(int cfg) { return cfg == 5 ? 256 : (cfg == 3 || cfg == 4) ? 128 : 0; }
+
+int gemm_bf16_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t stream) {
+  if (nt.M <= 0 || nt.N <= 0 || nt.K <= 0 || tn.M <= 0 || tn.N <= 0 || tn.K <= 0) return (int)hipErrorInvalidValue;
+  if ((nt.lda & 7) || (nt.ldb & 7) || (nt.ldc & 3) || (tn.lda & 7) || (tn.ldb & 7) || (tn.ldc & 3)) return (int)hipErrorInvalidValue;
+  if ((long)nt.M * nt.lda * 2 >= (1L << 31) || (long)nt.N * nt.ldb * 2 >= (1L << 31) ||
+      (long)tn.K * tn.lda * 2 >= (1L << 31) || (long)tn.K * tn.ldb * 2 >= (1L << 31)) return (int)hipErrorInvalidValue;
+  if ((nt.epi != 0 && nt.epi != EPI_DACT) || (tn.epi != 0 && tn.epi != EPI_ACCUM)) return -1;
+  switch (gemm_bf16_dual_config(nt.M, nt.N, tn.M, tn.N)) {
+    case 3: return launch_dual_epi<2, 2, 2, 1, 5>(nt, tn, stream);
+    case 4: return launch_dual_epi<2, 2, 2, 2, 4>(nt, tn, stream);
+    case 5: return launch_dual_epi<4, 2, 2, 2, 3>(nt, tn, stream);
+  }
+  return -1;
+}
 
 void gemm_bf16_force_config(int cfg) { g_forced_b = (cfg >= 0 && cfg < kNumGemmBf16Configs) ? cfg : -1; }
 

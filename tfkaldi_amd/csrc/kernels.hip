@@ -958,13 +958,15 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
 // the step), re-initialisation of the increments, and the step's (loss, frames, k) handed to the host through
 // mapped pinned memory (no copy kernel, no memset).
 __global__ void step_finish_kernel(float* __restrict__ mov, float* __restrict__ e, size_t n,
-                                   const float* __restrict__ scalars, float decay, float* __restrict__ host) {
+                                   const float* __restrict__ scalars, float decay, float* __restrict__ host,
+                                   float* __restrict__ snap) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     mov[i] = powf(decay, scalars[2]) * mov[i] + e[i];
     e[i] = 0.f;
   }
   if (i < 4) {
+    if (snap) snap[i] = scalars[i];  // the step's (loss, frames, k) for an optimiser that runs past the next loss_reduce
     host[i] = scalars[i];
     __threadfence_system();
   }
@@ -1192,9 +1194,10 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
 #undef TFK_ADAM_LAUNCH
 }
 
-void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host) {
+void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host,
+                 float* snap) {
   const size_t blocks = n ? (n + 255) / 256 : 1;
-  hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host);
+  hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host, snap);
 }
 void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols) {
   const size_t n = (size_t)rows * (ldd / 8);

@@ -396,7 +396,11 @@ class BucketReducer(object):
         engine.apply_begin()
         # mixed precision: does this step's Adam write the shadow (it does unless parameters were set from outside
         # since the last forward pass)?  Then the shadow is what travels.
-        via_shadow = self.shadow is not None and engine.apply_writes_shadow()
+        via_shadow = self.shadow is not None
+        if via_shadow and not engine.apply_writes_shadow():
+            # (cannot happen: tfk_apply_begin makes an arena-mirroring shadow current on every rank -- the choice of what
+            # is gathered must never depend on what one rank happened to run)
+            raise RuntimeError("mixed-precision engine with an arena-mirroring shadow that the optimiser does not write")
         sharded = []
         for i, (off, n) in enumerate(self.launched):
             wait(i)
