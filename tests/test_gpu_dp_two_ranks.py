@@ -146,10 +146,10 @@ def _serial(num_mb, dtype, kw, mode, frames=None):
     return ref
 
 
-def _compare(tmp_path, world, ref, lr, steps):
+def _compare(tmp_path, world, ref, lr, steps, loss_rtol=3e-6):
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
-        assert np.allclose(got["losses"], ref["losses"], rtol=3e-6, atol=0), (got["losses"], ref["losses"])
+        assert np.allclose(got["losses"], ref["losses"], rtol=loss_rtol, atol=0), (got["losses"], ref["losses"])
         for k in ref:
             if k == "losses":
                 continue
@@ -204,4 +204,6 @@ def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(world, port, num_mb, str(tmp_path), dtype, "sharded", CFG2, 96), nprocs=world, join=True)
     ref = _serial(num_mb, dtype, CFG2, "sharded", frames=96)
-    _compare(tmp_path, world, ref, CFG2["init_learning_rate"], 5)
+    # (26 M parameters, generic starting point: after a few Adam steps the summation order of eight partial gradient sums
+    # shows in the fifth digit of the loss, as the single-GPU loss traces do against float64 -- profiles/r03_loss_trace_f64.json)
+    _compare(tmp_path, world, ref, CFG2["init_learning_rate"], 5, loss_rtol=1e-4 if dtype == "float32" else 2e-3)

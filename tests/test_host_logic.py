@@ -394,7 +394,7 @@ def test_async_gather_waits_layer_by_layer():
 
     log = fresh()
     red.on_layer(0)          # W_0 is in gather 0, but the bias / beta vectors travel in gather 2: all three are needed
-    assert log == [2] and red.pending == []
+    assert log == [0, 1, 2] and red.pending == []  # (each one is waited for: gloo completes out of launch order)
     # with the vectors in a span of their own (an all-reduced tail: nothing pending for them) layers wait one by one
     log = []
     red.pending = [(0, 10 * k, Handle(log, 0)), (10 * k, 8 * k, Handle(log, 1)), (18 * k, 4 * k, Handle(log, 2))]
@@ -410,7 +410,7 @@ def test_async_gather_waits_layer_by_layer():
     assert log == [0, 1, 2]
     log = fresh()
     red.on_layer(-1)
-    assert log == [2] and red.pending == [] and not red.errors
+    assert log == [0, 1, 2] and red.pending == [] and not red.errors
 
 
 def test_traffic_record_is_stamped_for_the_gemm_sources_of_this_tree():

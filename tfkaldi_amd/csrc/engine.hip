@@ -1113,11 +1113,12 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_FUSE_EVAL"))) e->fuse_eval = atoi(v) != 0;
   }
   {
-    // default: on in mixed precision (at BASELINE cfg3 / cfg4 sizes the optimiser is a quarter of a one-GPU step and the
-    // forward contractions leave HBM idle), off in fp32 (round 1 measured a concurrent kernel only evicting the GEMM's L2
-    // working set there); TFK_ADAM_OVERLAP=0/1 overrides
+    // Measured (profiles/r03_ablation.txt) and NOT adopted as the default: the optimiser's 28 B per parameter and the forward
+    // contractions share the L2 -> CU path (the forward GEMMs of the 1024-frame configurations are bound by exactly that
+    // fill), so running them side by side slows both -- cfg2 fp32 1.480 -> 1.522 ms, cfg3/GPU bf16 0.591 -> 0.636 ms; only at
+    // cfg4/GPU size (MFMA-bound 256x128 tiles) it gains, 3.02 -> 2.94 ms.  TFK_ADAM_OVERLAP=1 switches it on.
     const char* v = getenv("TFK_ADAM_OVERLAP");
-    e->opt_overlap = v ? atoi(v) != 0 : e->bf16;
+    e->opt_overlap = v ? atoi(v) != 0 : false;
   }
   if (e->opt_overlap) {
     HIPB(hipStreamCreateWithFlags(&e->opt_stream, hipStreamNonBlocking));

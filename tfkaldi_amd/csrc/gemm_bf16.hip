@@ -397,37 +397,50 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
         for (int e = 0; e < 8; ++e) fb[q][b][e] = (__bf16)(float)(lane - e);
     }
   }
+  auto mfma_step = [&](int cur) {
+    if (TFKB_ABL & 1) {  // keep the fragment reads alive without the MFMAs
+#pragma unroll
+      for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][a]));
+#pragma unroll
+      for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][b]));
+    } else {
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+    }
+  };
+  // The K loop is ROTATED by one 16-k step (round 3): the per-tile barrier sits between the third and the fourth step of a
+  // tile.  The fourth step's fragments are in registers by then, so its MFMAs run right AFTER the barrier -- under them the
+  // first fragments of the next tile make their LDS round trip.  Round 2 fetched those fragments after the barrier and
+  // every wave of the block then waited for them at the same moment (all waves leave a barrier together): ~300 idle
+  // matrix-pipe cycles per 64-k tile on the 8-wave 256x128 block, where MFMAs + fragment reads cost 53 us against 43.5 us
+  // of MFMAs alone (profiles/r02_gemm_bf16_ablation.txt).
   int rs = 0, ws = NS - 1;
+  read_frags(0, smem, 0);
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     const char* st = smem + rs * STAGE;
-    read_frags(0, st, 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 3; ++ks) {
       const int cur = ks & 1;
-      if (ks + 1 < 4) read_frags(cur ^ 1, st, ks + 1);
-      // this 16-k step's share of the pieces of tile kt+NS-1 (into the slot tile kt-1 left at the last barrier)
+      read_frags(cur ^ 1, st, ks + 1);
+      // this step's share of the pieces of tile kt+NS-1 (into the slot tile kt-1 left at the last barrier); all of them go
+      // out BEFORE the barrier, so that every piece keeps between one and two tile times to land
 #pragma unroll
-      for (int j = ks * NP / 4; j < (ks + 1) * NP / 4; ++j) piece(j, ws, kt + NS - 1);
-      if (TFKB_ABL & 1) {  // keep the fragment reads alive without the MFMAs
-#pragma unroll
-        for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][a]));
-#pragma unroll
-        for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][b]));
-      } else {
-#pragma unroll
-        for (int a = 0; a < FM; ++a)
-#pragma unroll
-          for (int b = 0; b < FN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
-      }
+      for (int j = ks * NP / 3; j < (ks + 1) * NP / 3; ++j) piece(j, ws, kt + NS - 1);
+      mfma_step(cur);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // this wave's pieces of tile kt+1 have landed (the NS-2 younger tiles stay in flight); the barrier makes every
-    // wave's pieces visible and retires all reads of tile kt
+    // every fragment read of tile kt is complete (lgkmcnt(0)), this wave's pieces of tile kt+1 have landed (the NS-2
+    // younger tiles stay in flight); the barrier makes every wave's pieces visible and frees tile kt's slot
     TFKB_WAIT_BARRIER((NS - 2) * NP);
     rs = rs + 1 == NS ? 0 : rs + 1;
     ws = ws + 1 == NS ? 0 : ws + 1;
+    if (kt + 1 < nk) read_frags(0, smem + rs * STAGE, 0);
+    mfma_step(1);  // the fourth 16-k step of tile kt
+    __builtin_amdgcn_sched_barrier(0);
   }
   TFKB_WAIT_BARRIER(0);  // the epilogue reuses the ring as scratch: nothing may still be landing in it
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));

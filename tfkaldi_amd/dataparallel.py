@@ -314,7 +314,8 @@ class BucketReducer(object):
         """make the engine's stream wait for every parameter all-gather still in flight"""
         if self.pending:
             with self._stream_ctx():
-                self.pending[-1][2].wait()  # collectives complete in launch order
+                for _, _, h in self.pending:  # each one: a backend may complete collectives out of launch order (gloo
+                    h.wait()                  # runs them on a thread pool; the 8-rank cfg2-size test caught exactly that)
             del self.pending[:]
 
     def on_layer(self, layer):
@@ -335,7 +336,8 @@ class BucketReducer(object):
                         last = i
                 if last >= 0:
                     with self._stream_ctx():
-                        self.pending[last][2].wait()  # (and, in launch order, everything before it)
+                        for _, _, h in self.pending[:last + 1]:  # (everything launched before it as well: see drain)
+                            h.wait()
                     del self.pending[:last + 1]
         except Exception as exc:  # noqa: BLE001  (cannot propagate through the C callback)
             self.errors.append(exc)
