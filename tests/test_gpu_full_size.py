@@ -224,8 +224,10 @@ def test_cfg3_per_gpu_size_bf16_against_oracle(gpu, nonlin):
     """BASELINE configs[2] as one rank sees it: 6x2048 + BN, 440 -> 4000 pdfs, 1024 frames, bf16 MFMA contractions, ReLU (the
     configuration's own nonlinearity, with the engine's on/off pattern handed to the oracle) and tanh (no kink at all).
     Bounds = 3x the measured values (profiles/r03_parity_reports.txt)."""
-    bounds = {"relu_disagreement": 3e-3, "batch_loss": 6e-4, "avg_loss": 6e-4, "hidden": 3e-3, "G": 1.5e-2, "G sampled": 3e-2,
-              "G[W6]": 5e-3, "G[b6]": 5e-3}
+    # measured (MI355X, round 3): relu 7.9e-4 of the units disagree; loss 4.7e-6; hidden <= 2.7e-3; G by norm <= 4.6e-3 (relu) /
+    # 6.6e-3 (tanh: beta0), sampled elements <= 5.1e-3 of the tensor's maximum; the output layer's bias gradient 3.8e-5
+    bounds = {"relu_disagreement": 2.4e-3, "batch_loss": 1.5e-5, "avg_loss": 1.5e-5, "hidden": 8e-3, "G": 2e-2, "G sampled": 1.6e-2,
+              "G[W6]": 1e-2, "G[b6]": 1.2e-4}
     _bf16_parity("cfg3_bf16_" + nonlin, dict(CFG3, nonlin=nonlin), 1024, CFG3_KEYS, (0, 3, 5), bounds, seed=23)
 
 
@@ -235,6 +237,9 @@ def test_cfg4_per_gpu_size_bf16_against_oracle(gpu):
     backward contraction carries real data).  Bounds = 3x the measured values (profiles/r03_parity_reports.txt)."""
     kw = dict(input_dim=440, num_layers=8, num_units=4096, output_dim=8000, nonlin="relu", batch_norm=True, keep_prob=0.5,
               init_learning_rate=1e-3, num_steps=100, max_frames=2048, compute_dtype="bfloat16")
-    bounds = {"relu_disagreement": 2e-3, "batch_loss": 1e-3, "avg_loss": 1e-3, "hidden": 4e-3, "G": 1.2e-2, "G sampled": 3e-2}
+    # measured (MI355X, round 3): 5.8e-4 of the units disagree; loss 1.3e-5; hidden <= 3.8e-3; G by norm <= 5.7e-3, sampled
+    # elements <= 6.0e-3 of the tensor's maximum; the output layer's bias gradient 7.7e-5
+    bounds = {"relu_disagreement": 1.8e-3, "batch_loss": 4e-5, "avg_loss": 4e-5, "hidden": 1.2e-2, "G": 1.7e-2, "G sampled": 1.8e-2,
+              "G[b8]": 2.4e-4}
     _bf16_parity("cfg4_bf16", kw, 2048, ("W8", "b8", "W7", "beta7", "W5", "W4", "beta3", "W1", "W0", "beta0"), (0, 3, 7),
                  bounds, seed=29)

@@ -104,9 +104,13 @@ def test_bench_self_launches_its_ranks(gpu):
     assert line["config"]["global_frames"] == 2048 and line["scaling"] == "weak"
     assert line["rccl_ranks"] == (2 if real else 0) and line["dist_backend"] == ("nccl" if real else "gloo")
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
-    if not real:  # gloo cannot reduce-scatter device tensors: the line must say what really ran
-        assert line["exchange"] == "allreduce" and line["exchange_requested"] == "sharded"
-        assert set(line["collectives_last_step"]) == {"all_reduce"}
+    if not real:  # the line says what really ran: the sharded protocol when this gloo build can reduce-scatter device
+        # tensors (the reducer probes it), else all-reduce + replicated optimiser
+        assert line["exchange_requested"] == "sharded"
+        if line["exchange"] == "sharded":
+            assert "reduce_scatter_tensor" in line["collectives_last_step"]
+        else:
+            assert line["exchange"] == "allreduce" and set(line["collectives_last_step"]) == {"all_reduce"}
 
 
 @pytest.mark.timeout(1200)
@@ -126,7 +130,10 @@ def test_bench_eight_ranks_dry_run(gpu):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 8 and line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 8
     assert line["config"]["global_frames"] == 8192 and line["scaling"] == "weak"
-    assert line["exchange"] == "sharded" and "all_reduce(emulating reduce_scatter)" in line["collectives_last_step"]
+    assert line["exchange"] == "sharded"
+    assert ("reduce_scatter_tensor" in line["collectives_last_step"]
+            or "all_reduce(emulating reduce_scatter)" in line["collectives_last_step"])
+    assert any(c.startswith("all_gather") for c in line["collectives_last_step"])
     assert all(n % 32 == 0 for _, n in line["collective_spans_last_step"][1:5])
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
 

@@ -92,6 +92,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t strea
 // split-K): the caller then launches them one after the other.
 int gemm_f32_dual(const GemmArgs& nt, const GemmArgs& tn, hipStream_t stream);
 
+int gemm_f32_splitk_min_k();  // shortest contraction the split-K path cuts (env TFK_SPLITK_MIN_K, default 2048)
+
 // Heuristic used when cfg < 0 (exposed for tests / the sweep tool).
 int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K);
 

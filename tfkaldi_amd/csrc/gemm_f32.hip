@@ -895,6 +895,12 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
   return tiles128 >= 512 ? (g_dma ? 12 : 0) : (g_dma ? 9 : 3);
 }
 
+// shortest contraction that is cut (env TFK_SPLITK_MIN_K; two launches -- the partial GEMM and the reduction -- must beat one)
+int gemm_f32_splitk_min_k() {
+  static const int v = [] { const char* q = getenv("TFK_SPLITK_MIN_K"); const int x = q ? atoi(q) : 2048; return x >= 1024 ? x : 1024; }();
+  return v;
+}
+
 int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t stream) {
   if (cfg < 0) cfg = gemm_f32_pick_config(layout, args.M, args.N, args.K);
   if ((args.lda & 3) || (args.ldb & 3)) return (int)hipErrorInvalidValue;
@@ -907,7 +913,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& args, int cfg, hipStream_t strea
   // split-K for chip-starved, long contractions (only the plain / accumulating epilogues)
   const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
   const int tiles = ((args.M + bm - 1) / bm) * ((args.N + bn - 1) / bn);
-  if (args.splitk_ws && (args.epi == 0 || args.epi == EPI_ACCUM) && tiles < 256 && args.K >= 2048) {
+  if (args.splitk_ws && (args.epi == 0 || args.epi == EPI_ACCUM) && tiles < 256 && args.K >= gemm_f32_splitk_min_k()) {
     int nsplit = (512 + tiles - 1) / tiles;
     if (nsplit > args.K / 512) nsplit = args.K / 512;
     if (nsplit > 32) nsplit = 32;

@@ -37,6 +37,8 @@ class Engine(object):
         # been gathered collectively (DataParallel.gather_parameters) instead of handing out stale values.
         self.param_access_hook = None
         self.on_close = []
+        self._raw_inflight = []   # (device tensor, event): inputs adopted in place that the engine may still be reading
+        self._raw_pending = None
         if torch_state:
             import torch
             nbytes = c_size_t()
@@ -51,8 +53,28 @@ class Engine(object):
             check(self.lib.tfk_create(byref(cfg), byref(self._h)))
 
     # ---- lifetime ----
+    def _raw_release(self, wait=False):
+        """after a call that adopted a device tensor in place: mark the end of its use on the engine stream; drop the
+        references whose work has completed (all of them with wait=True)"""
+        if self._raw_pending is not None:
+            import torch
+            raw, ext = self._raw_pending
+            ev = torch.cuda.Event()
+            ev.record(ext)
+            self._raw_inflight.append((raw, ev))
+            self._raw_pending = None
+        keep = []
+        for raw, ev in self._raw_inflight:
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((raw, ev))
+        self._raw_inflight = keep
+
     def close(self):
         if self._h:
+            if self._raw_inflight or self._raw_pending:
+                self._raw_release(wait=True)
             for fn in self.on_close:
                 fn()
             del self.on_close[:]
@@ -177,11 +199,12 @@ class Engine(object):
         check(self.lib.tfk_stream(self._h, byref(stream)))
         ext = torch.cuda.ExternalStream(stream.value, device=raw.device)
         ext.wait_event(done)
-        # Lifetime contract: the call returns while the splice kernel that reads `raw` is still pending on the ENGINE's
-        # stream, which torch's caching allocator knows nothing about.  record_stream tells it: if the caller drops the
-        # tensor, its block is not handed out again before the work enqueued on the engine stream so far has finished
-        # (round-2 advisor finding: the block could be reused and overwritten under the pending kernel).
-        raw.record_stream(ext)
+        # Lifetime contract (round-2 advisor finding): the call returns while the splice kernel that reads `raw` is still
+        # pending on the ENGINE's stream, which torch's caching allocator knows nothing about -- if the caller dropped the
+        # tensor, its block could be handed out again and overwritten under the pending kernel.  The engine therefore keeps
+        # a reference until an event recorded behind the consuming work has completed (_raw_release).  (Not
+        # Tensor.record_stream: the allocator would later touch a stream that dies with the engine.)
+        self._raw_pending = (raw, ext)
         return c_void_p(raw.data_ptr()), int(raw.stride(0)), int(raw.shape[0]), lens
 
     @staticmethod
@@ -224,8 +247,11 @@ class Engine(object):
         cmvn_ptr = cmvn.ctypes.data_as(c_void_p) if cmvn is not None else c_void_p(None)
         if y.shape != (rows,):
             raise ValueError("targets %s do not match %d frames" % (y.shape, rows))
-        check(self.lib.tfk_accumulate_raw(self._h, ptr, ld, y.ctypes.data_as(c_void_p), rows, lens.ctypes.data_as(c_void_p),
-                                          lens.size, int(context_width), cmvn_ptr, flags))
+        try:
+            check(self.lib.tfk_accumulate_raw(self._h, ptr, ld, y.ctypes.data_as(c_void_p), rows,
+                                              lens.ctypes.data_as(c_void_p), lens.size, int(context_width), cmvn_ptr, flags))
+        finally:
+            self._raw_release()
 
     def eval_accumulate_raw(self, raw, y, lens, context_width, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
@@ -263,8 +289,11 @@ class Engine(object):
             if cmvn.shape != (lens.size, 2, shape[1]):
                 raise ValueError("cmvn table %s, expected %s" % (cmvn.shape, (lens.size, 2, shape[1])))
         cmvn_ptr = cmvn.ctypes.data_as(c_void_p) if cmvn is not None else c_void_p(None)
-        check(self.lib.tfk_posteriors_raw(self._h, ptr, ld, rows, lens.ctypes.data_as(c_void_p), lens.size,
-                                          int(context_width), cmvn_ptr, out.ctypes.data_as(c_void_p), self.O, flags))
+        try:
+            check(self.lib.tfk_posteriors_raw(self._h, ptr, ld, rows, lens.ctypes.data_as(c_void_p), lens.size,
+                                              int(context_width), cmvn_ptr, out.ctypes.data_as(c_void_p), self.O, flags))
+        finally:
+            self._raw_release()
         return out
 
     # ---- CTC loss: frames [T, F] of U utterances + their label sequences ----
