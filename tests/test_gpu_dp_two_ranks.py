@@ -146,7 +146,7 @@ def _serial(num_mb, dtype, kw, mode, frames=None):
     return ref
 
 
-def _compare(tmp_path, world, ref, lr, steps, loss_rtol=3e-6, flip_threshold=0.02):
+def _compare(tmp_path, world, ref, lr, steps, loss_rtol=3e-6, flip_threshold=0.02, stat_tol=(1e-5, 1e-7)):
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         assert np.allclose(got["losses"], ref["losses"], rtol=loss_rtol, atol=0), (got["losses"], ref["losses"])
@@ -159,7 +159,7 @@ def _compare(tmp_path, world, ref, lr, steps, loss_rtol=3e-6, flip_threshold=0.0
                 scale = np.abs(ref[k]).max() + 1e-30
                 assert np.abs(got[k] - ref[k]).max() <= 1e-5 * scale, (k, np.abs(got[k] - ref[k]).max(), scale)
             elif k.startswith("m"):
-                assert np.allclose(got[k], ref[k], rtol=1e-5, atol=1e-7), k
+                assert np.allclose(got[k], ref[k], rtol=stat_tol[0], atol=stat_tol[1]), k
             else:  # Adam amplifies summation-order noise of near-zero gradients: see test_gpu_engine_parity
                 err = np.abs(got[k] - ref[k])
                 assert np.mean(err > flip_threshold * lr * steps) < 0.01 and err.max() <= 2 * lr * steps, (
@@ -211,4 +211,4 @@ def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
     # way; over five steps and 26 M parameters these are more numerous than in the toy nets above -- still under 1 % of the
     # elements beyond a fifth of the distance five full steps cover, none beyond twice that distance
     _compare(tmp_path, world, ref, CFG2["init_learning_rate"], 5, loss_rtol=1e-4 if dtype == "float32" else 2e-3,
-             flip_threshold=0.2)
+             flip_threshold=0.2, stat_tol=(1e-3, 1e-5))  # (BN moving statistics follow the drifting parameters)

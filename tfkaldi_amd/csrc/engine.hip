@@ -102,7 +102,6 @@ struct tfk_engine {
   bool opt_overlap = false;          // decided at create
   bool opt_pending = false;          // updates of the last tfk_apply may still be running on opt_stream
   float* d_snap = nullptr;           // (loss, frames, #micro-batches) of the step being applied (step_finish)
-  int* d_ticket = nullptr;           // last-block ticket of softmax_xent (0 between launches)
   hipEvent_t ev_loss = nullptr;
   hipEvent_t ev_grow = nullptr;          // orders the copy stream behind a stream-ordered (re)allocation
   std::vector<void*> host_garbage;       // outgrown pinned staging buffers: released at tfk_destroy (hipHostFree
@@ -1129,8 +1128,6 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     for (int l = 0; l <= e->L; ++l) HIPB(hipEventCreateWithFlags(&e->ev_adam[l], hipEventDisableTiming));
   }
   HIPB(hipMalloc((void**)&e->d_snap, 16 * sizeof(float)));
-  HIPB(hipMalloc((void**)&e->d_ticket, 64));
-  HIPB(hipMemset(e->d_ticket, 0, 64));
   HIPB(hipEventCreateWithFlags(&e->ev_loss, hipEventDisableTiming));
   HIPB(hipEventCreateWithFlags(&e->ev_grow, hipEventDisableTiming));
   for (int s = 0; s < 2; ++s) {
@@ -1313,9 +1310,13 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
       ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
       Twin tw;
       if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
-      // (the loss / frame accumulators are updated by the same launch: round 2 ran loss_reduce behind it)
-      softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw, e->p_scalars(), e->scalars_fresh,
-                   e->d_ticket);
+      softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw);
+    }
+    {
+      // (folding this sum into softmax_xent -- the block that finishes last adds up the frames' losses -- was measured in
+      // round 3 and is SLOWER than the second launch: 21.4 vs 9.3 + 6.3 us at cfg2, profiles/r03_fusion_experiments.txt)
+      ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
+      loss_reduce(e->stream, e->row_loss, T, e->p_scalars(), e->scalars_fresh);
       e->scalars_fresh = false;
     }
   }
@@ -1384,7 +1385,6 @@ int tfk_destroy(tfk_engine* e) {
   for (hipEvent_t ev : e->ev_adam) if (ev) hipEventDestroy(ev);
   if (e->opt_stream) hipStreamDestroy(e->opt_stream);
   if (e->d_snap) hipFree(e->d_snap);
-  if (e->d_ticket) hipFree(e->d_ticket);
   for (auto p : e->mean) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
