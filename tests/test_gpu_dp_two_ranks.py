@@ -211,4 +211,5 @@ def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
     # way; over five steps and 26 M parameters these are more numerous than in the toy nets above -- still under 1 % of the
     # elements beyond a fifth of the distance five full steps cover, none beyond twice that distance
     _compare(tmp_path, world, ref, CFG2["init_learning_rate"], 5, loss_rtol=1e-4 if dtype == "float32" else 2e-3,
-             flip_threshold=0.2, stat_tol=(1e-3, 1e-5))  # (BN moving statistics follow the drifting parameters)
+             flip_threshold=0.2,  # (BN moving statistics follow the drifting parameters; bf16 operands drift further)
+             stat_tol=(1e-3, 1e-5) if dtype == "float32" else (2e-2, 5e-4))

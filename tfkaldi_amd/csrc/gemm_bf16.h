@@ -46,7 +46,9 @@ struct GemmArgsB {
 //   4: 128x128 block, 4 waves (64x64 each), 4-slot ring
 //   5: 256x128 block, 8 waves (64x64 each), 3-slot ring
 //   6: 128x64  block, 4 waves (64x32 each), 3-slot ring  (two blocks per CU)
-constexpr int kNumGemmBf16Configs = 7;
+//   7: 256x128 block, 4 waves (128x64 each), 3-slot ring (round-3 experiment: a quarter fewer fragment reads per flop, one
+//      wave per SIMD)
+constexpr int kNumGemmBf16Configs = 8;
 
 // Returns hipError_t as int.
 int gemm_bf16(GemmLayout layout, const GemmArgsB& args, hipStream_t stream);

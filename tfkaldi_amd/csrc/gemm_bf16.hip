@@ -659,7 +659,7 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 struct CfgB {
   int bm, bn;
 };
-const CfgB kCfgB[kNumGemmBf16Configs] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}, {128, 128}, {256, 128}, {128, 64}};
+const CfgB kCfgB[kNumGemmBf16Configs] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}, {128, 128}, {256, 128}, {128, 64}, {256, 128}};
 int g_forced_b = -2;  // -2: env not read yet; -1: heuristic
 int g_group_rows = 0;  // env TFK_BF16_GROUP_ROWS (experiments): tile rows per XCD patch; 0 = balanced, large = column-major
 
@@ -711,6 +711,7 @@ int launch(const GemmArgsB& p, hipStream_t stream) {
     case 4: return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 4>(p, stream);
     case 5: return launch_dma<A_KC, B_KC, EPI, 4, 2, 2, 2, 3>(p, stream);
     case 6: return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 3>(p, stream);
+    case 7: return launch_dma<A_KC, B_KC, EPI, 2, 2, 4, 2, 3>(p, stream);
   }
   return (int)hipErrorInvalidValue;
 }

@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace tfk {
 namespace {
@@ -1085,7 +1086,9 @@ inline dim3 ct_block() { return dim3(CT_X, CT_Y); }
 }  // namespace
 
 int row_splits(int T) {
-  int rs = (T + 31) / 32;
+  // rows per block of the column-tiled kernels (env TFK_CT_ROWS, experiments; 32 = four rows per thread, one batch of loads)
+  static const int rows = [] { const char* q = getenv("TFK_CT_ROWS"); const int v = q ? atoi(q) : 32; return v >= 8 ? v : 32; }();
+  int rs = (T + rows - 1) / rows;
   if (rs < 1) rs = 1;
   if (rs > kMaxRowSplits) rs = kMaxRowSplits;
   return rs;
