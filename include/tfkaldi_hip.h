@@ -303,12 +303,13 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
                   int M, int N, int K, const float* bias, int epi);
 /* The backward pair of one layer in ONE launch (gemm_bf16.h: gemm_bf16_dual): C_nt[M_nt, N_nt] = A_nt . B_nt^T and
  * C_tn[M_tn, N_tn] (+)= A_tn^T . B_tn (epi_tn: 0 or 2 = accumulate).  Fails when the pair of shapes is not eligible
- * (tfk_gemm_bf16_dual_config == 0).  Block geometry: env TFK_BF16_DUAL_CFG (3: 128x64, 4: 128x128, 5: 256x128, 0: off). */
+ * (tfk_gemm_bf16_dual_config == 0).  Block geometry: env TFK_BF16_DUAL_CFG (3: 128x64, 4: 128x128, 5: 256x128,
+ * 8: 256x128 for the NT half + 256x256 for the TN half, 0: off). */
 int tfk_gemm_bf16_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uint16_t* B_nt, int ldb_nt, float* C_nt,
                        int ldc_nt, int M_nt, int N_nt, int K_nt, const uint16_t* A_tn, int lda_tn, const uint16_t* B_tn,
                        int ldb_tn, float* C_tn, int ldc_tn, int M_tn, int N_tn, int K_tn, int epi_tn);
 int tfk_gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn);
-/* Tile configuration of the bf16 GEMM (gemm_bf16.h: 0-2 register-staged, 3-6 LDS-DMA staged): force one for every
+/* Tile configuration of the bf16 GEMM (gemm_bf16.h: 0-2 register-staged, 3-8 LDS-DMA staged): force one for every
  * later call (cfg < 0 restores the heuristic) / ask which one the heuristic gives an [M, N] result.  Tools and
  * tests only. */
 int tfk_gemm_bf16_force_config(int cfg);

@@ -87,7 +87,7 @@ def test_gemm_bf16(gpu, layout, shape):
 CFG_SHAPES = [(37, 29, 13), (130, 70, 200), (300, 200, 136), (257, 129, 520), (512, 512, 1088)]
 
 
-@pytest.mark.parametrize("cfg", range(8))
+@pytest.mark.parametrize("cfg", range(9))
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_gemm_bf16_every_config(gpu, layout, cfg):
     import torch

@@ -48,7 +48,9 @@ struct GemmArgsB {
 //   6: 128x64  block, 4 waves (64x32 each), 3-slot ring  (two blocks per CU)
 //   7: 256x128 block, 4 waves (128x64 each), 3-slot ring (round-3 experiment: a quarter fewer fragment reads per flop, one
 //      wave per SIMD)
-constexpr int kNumGemmBf16Configs = 8;
+//   8: 256x256 block, 8 waves (64x128 each), 32 k per slot, 4-slot ring -- the TN layout (weight gradient) only: half the
+//      staged bytes per flop of 256x128; other layouts run 5 instead
+constexpr int kNumGemmBf16Configs = 9;
 
 // Returns hipError_t as int.
 int gemm_bf16(GemmLayout layout, const GemmArgsB& args, hipStream_t stream);

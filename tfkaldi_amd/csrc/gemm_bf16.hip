@@ -229,11 +229,13 @@ __device__ __forceinline__ int ks_swz(int r) {
   return EXT == 64 ? (((r >> 1) & 1) << 2) : ((r & 3) << 2);
 }
 
-// One operand's share of a stage: EXT rows (k-contiguous) or 64 k-rows of EXT elements; EXT * 128 bytes either way.
-template <bool KC, int EXT, int NTH>
+// One operand's share of a stage: EXT rows of BKT k (k-contiguous; BKT = 64 only) or BKT k-rows of EXT elements;
+// EXT * BKT * 2 bytes either way.
+template <bool KC, int EXT, int NTH, int BKT = 64>
 struct DmaOperand {
-  static constexpr int NP = EXT * 8 / NTH;  // 16-byte pieces per thread per tile
-  static_assert((EXT * 8) % NTH == 0 && NP >= 1, "pieces per thread");
+  static_assert(!KC || BKT == 64, "k-contiguous images have 128-byte rows");
+  static constexpr int NP = EXT * BKT / 8 / NTH;  // 16-byte pieces per thread per tile
+  static_assert((EXT * BKT / 8) % NTH == 0 && NP >= 1, "pieces per thread");
   i32x4 rsrc;
   int voff[NP];  // byte offset of the piece's source inside the matrix, k-tile term excluded; kOOB outside along ext
   int kidx[NP];  // its first k inside a tile
@@ -322,14 +324,18 @@ struct Frag {
 #define TFKB_WAIT_BARRIER(n) \
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : : "n"(n) : "memory")
 
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+// BKT: k per ring slot -- 64 (four 16-k MFMA steps), or 32 (two steps) for the 256x256 block of two k-strided operands,
+// whose 64-k stage (64 KB) would leave room for two slots only
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64>
 __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
-  typedef DmaOperand<A_KC, BM, NTH> OA;
-  typedef DmaOperand<B_KC, BN, NTH> OB;
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  typedef DmaOperand<A_KC, BM, NTH, BKT> OA;
+  typedef DmaOperand<B_KC, BN, NTH, BKT> OB;
+  constexpr int A_BYTES = BM * BKT * 2, STAGE = (BM + BN) * BKT * 2;
   constexpr int NPA = OA::NP, NP = OA::NP + OB::NP;
+  constexpr int KSPT = BKT / 16;  // 16-k MFMA steps per ring slot
+  static_assert(KSPT == 4 || KSPT == 2, "ring slot of 64 or 32 k");
   static_assert(NS >= 3 && (NS - 2) * NP <= 63, "ring depth / vmcnt range");
   static_assert(FM * FN >= 2, "two independent accumulator chains per wave");
 
@@ -343,6 +349,8 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
+  const int nk = (p.K + BKT - 1) / BKT;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
   OA la;
   OB lb;
   // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
@@ -362,13 +370,11 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
   auto piece = [&](int j, int slot, int kt) {
     if (TFKB_ABL & 2) return;
-    if (j < NPA) la.issue(j, lds0 + (unsigned)(slot * STAGE), kt * BK, wave);
-    else lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + A_BYTES), kt * BK, wave);
+    if (j < NPA) la.issue(j, lds0 + (unsigned)(slot * STAGE), kt * BKT, wave);
+    else lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + A_BYTES), kt * BKT, wave);
   };
-  const int nk = (p.K + BK - 1) / BK;
   // prologue: tiles 0 .. NS-2 (tiles beyond K land as zeros without touching memory)
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
@@ -423,13 +429,13 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   for (int kt = 0; kt < nk; ++kt) {
     const char* st = smem + rs * STAGE;
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
+    for (int ks = 0; ks < KSPT - 1; ++ks) {
       const int cur = ks & 1;
       read_frags(cur ^ 1, st, ks + 1);
       // this step's share of the pieces of tile kt+NS-1 (into the slot tile kt-1 left at the last barrier); all of them go
       // out BEFORE the barrier, so that every piece keeps between one and two tile times to land
 #pragma unroll
-      for (int j = ks * NP / 3; j < (ks + 1) * NP / 3; ++j) piece(j, ws, kt + NS - 1);
+      for (int j = ks * NP / (KSPT - 1); j < (ks + 1) * NP / (KSPT - 1); ++j) piece(j, ws, kt + NS - 1);
       mfma_step(cur);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -439,18 +445,18 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     rs = rs + 1 == NS ? 0 : rs + 1;
     ws = ws + 1 == NS ? 0 : ws + 1;
     if (kt + 1 < nk) read_frags(0, smem + rs * STAGE, 0);
-    mfma_step(1);  // the fourth 16-k step of tile kt
+    mfma_step((KSPT - 1) & 1);  // the last 16-k step of tile kt
     __builtin_amdgcn_sched_barrier(0);
   }
   TFKB_WAIT_BARRIER(0);  // the epilogue reuses the ring as scratch: nothing may still be landing in it
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
+  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
 }
 
 // Two INDEPENDENT contractions in one launch -- backward: dA = dZ . W^T (NT, optionally EPI_DACT) of a layer and the
@@ -458,16 +464,20 @@ gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 // of 128x64 -- one per CU -- and is bound by the L2 -> LDS fill of that small tile (bytes per flop ~ 1/BM + 1/BN); together
 // they have enough tiles for 128x128 blocks on every CU (2/3 of the bytes per flop), and one kernel's ramp and epilogue
 // overlap the other's K loop.  The NT tiles (the longer K: K = d_out vs K = frames) come first in block order.
-template <int EPI_NT, int EPI_TN, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
-__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
+// G*: block geometry of the NT half (WAVES_M, WAVES_N, FM, FN, ring slots; 64 k per slot); H*: of the TN half (+ k per slot).
+// Both halves have the same number of waves.
+template <int EPI_NT, int EPI_TN, int GWM, int GWN, int GFM, int GFN, int GNS, int HWM, int HWN, int HFM, int HFN, int HNS,
+          int HBK>
+__global__ void __launch_bounds__(GWM * GWN * 64)
 gemm_bf16_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, int group1, int tiles_m2, int tiles_n2,
                       int group2) {
+  static_assert(GWM * GWN == HWM * HWN, "both halves run on the same block size");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n1 = tiles_m1 * tiles_n1;
   if ((int)blockIdx.x < n1)
-    dma_tile<true, true, EPI_NT, WAVES_M, WAVES_N, FM, FN, NS>(p1, tiles_m1, tiles_n1, group1, blockIdx.x, smem);
+    dma_tile<true, true, EPI_NT, GWM, GWN, GFM, GFN, GNS>(p1, tiles_m1, tiles_n1, group1, blockIdx.x, smem);
   else
-    dma_tile<false, false, EPI_TN, WAVES_M, WAVES_N, FM, FN, NS>(p2, tiles_m2, tiles_n2, group2, blockIdx.x - n1, smem);
+    dma_tile<false, false, EPI_TN, HWM, HWN, HFM, HFN, HNS, HBK>(p2, tiles_m2, tiles_n2, group2, blockIdx.x - n1, smem);
 }
 
 // ================================================================================================================
@@ -659,7 +669,8 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 struct CfgB {
   int bm, bn;
 };
-const CfgB kCfgB[kNumGemmBf16Configs] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}, {128, 128}, {256, 128}, {128, 64}, {256, 128}};
+const CfgB kCfgB[kNumGemmBf16Configs] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}, {128, 128}, {256, 128}, {128, 64}, {256, 128},
+                                         {256, 256}};
 int g_forced_b = -2;  // -2: env not read yet; -1: heuristic
 int g_group_rows = 0;  // env TFK_BF16_GROUP_ROWS (experiments): tile rows per XCD patch; 0 = balanced, large = column-major
 
@@ -691,19 +702,27 @@ int launch_reg(const GemmArgsB& p, hipStream_t stream) {
   static bool attr_done = false;
   return launch_grid(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>, p, BM, BN, NT, lds, stream, &attr_done);
 }
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64>
 int launch_dma(const GemmArgsB& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
-  const size_t lds = (size_t)NS * (BM + BN) * 128;
-  static_assert((size_t)NS * (BM + BN) * 128 <= 160 * 1024, "LDS");
+  const size_t lds = (size_t)NS * (BM + BN) * BKT * 2;
+  static_assert((size_t)NS * (BM + BN) * BKT * 2 <= 160 * 1024, "LDS");
   static bool attr_done = false;
-  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS>, p, BM, BN,
+  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT>, p, BM, BN,
                      WAVES_M * WAVES_N * 64, lds, stream, &attr_done);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgsB& p, hipStream_t stream) {
-  switch (gemm_bf16_pick_config(p.M, p.N)) {
+  int cfg = gemm_bf16_pick_config(p.M, p.N);
+  if constexpr (!A_KC && !B_KC) {
+    // the weight gradient (both operands k-strided): a 256x256 block when the result has a tile of it for (nearly) every
+    // CU -- half the staged bytes per flop of 256x128, which makes this contraction MFMA-bound instead of fill-bound
+    if (cfg == 8 || (g_forced_b < 0 && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 200))
+      return launch_dma<false, false, EPI, 4, 2, 2, 4, 4, 32>(p, stream);
+  }
+  if (cfg == 8) cfg = 5;  // (the 256x256 block exists for the TN layout only)
+  switch (cfg) {
     case 0: return launch_reg<A_KC, B_KC, EPI, 1, 1>(p, stream);
     case 1: return launch_reg<A_KC, B_KC, EPI, 2, 1>(p, stream);
     case 2: return launch_reg<A_KC, B_KC, EPI, 2, 2>(p, stream);
@@ -728,12 +747,13 @@ int pick_group_rows(int tiles_m, int tiles_n, int bm, int bn) {
   return group_rows;
 }
 
-template <int EPI_NT, int EPI_TN, int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+template <int EPI_NT, int EPI_TN, int GWM, int GWN, int GFM, int GFN, int GNS, int HWM, int HWN, int HFM, int HFN, int HNS, int HBK>
 int launch_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
-  constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
-  constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
+  constexpr int BMA = GWM * GFM * 32, BNA = GWN * GFN * 32, BMW = HWM * HFM * 32, BNW = HWN * HFN * 32;
+  constexpr size_t lds_a = (size_t)GNS * (BMA + BNA) * 128, lds_w = (size_t)HNS * (BMW + BNW) * HBK * 2;
+  constexpr size_t lds = lds_a > lds_w ? lds_a : lds_w;
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = &gemm_bf16_dual_kernel<EPI_NT, EPI_TN, WAVES_M, WAVES_N, FM, FN, NS>;
+  auto kern = &gemm_bf16_dual_kernel<EPI_NT, EPI_TN, GWM, GWN, GFM, GFN, GNS, HWM, HWN, HFM, HFN, HNS, HBK>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -741,20 +761,20 @@ int launch_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int tma = (a.M + BM - 1) / BM, tna = (a.N + BN - 1) / BN, tmw = (w.M + BM - 1) / BM, tnw = (w.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(WAVES_M * WAVES_N * 64), lds, stream, a, w, tma, tna,
-                     pick_group_rows(tma, tna, BM, BN), tmw, tnw, pick_group_rows(tmw, tnw, BM, BN));
+  const int tma = (a.M + BMA - 1) / BMA, tna = (a.N + BNA - 1) / BNA, tmw = (w.M + BMW - 1) / BMW, tnw = (w.N + BNW - 1) / BNW;
+  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(GWM * GWN * 64), lds, stream, a, w, tma, tna,
+                     pick_group_rows(tma, tna, BMA, BNA), tmw, tnw, pick_group_rows(tmw, tnw, BMW, BNW));
   return (int)hipGetLastError();
 }
 
-template <int WAVES_M, int WAVES_N, int FM, int FN, int NS>
+template <int GWM, int GWN, int GFM, int GFN, int GNS, int HWM, int HWN, int HFM, int HFN, int HNS, int HBK>
 int launch_dual_epi(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
   const int key = (a.epi == EPI_DACT ? 2 : 0) + (w.epi == EPI_ACCUM ? 1 : 0);
   switch (key) {
-    case 0: return launch_dual<0, 0, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
-    case 1: return launch_dual<0, EPI_ACCUM, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
-    case 2: return launch_dual<EPI_DACT, 0, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
-    default: return launch_dual<EPI_DACT, EPI_ACCUM, WAVES_M, WAVES_N, FM, FN, NS>(a, w, stream);
+    case 0: return launch_dual<0, 0, GWM, GWN, GFM, GFN, GNS, HWM, HWN, HFM, HFN, HNS, HBK>(a, w, stream);
+    case 1: return launch_dual<0, EPI_ACCUM, GWM, GWN, GFM, GFN, GNS, HWM, HWN, HFM, HFN, HNS, HBK>(a, w, stream);
+    case 2: return launch_dual<EPI_DACT, 0, GWM, GWN, GFM, GFN, GNS, HWM, HWN, HFM, HFN, HNS, HBK>(a, w, stream);
+    default: return launch_dual<EPI_DACT, EPI_ACCUM, GWM, GWN, GFM, GFN, GNS, HWM, HWN, HFM, HFN, HNS, HBK>(a, w, stream);
   }
 }
 
@@ -770,14 +790,16 @@ int gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn) {
     g_dual_cfg = q ? atoi(q) : -1;
   }
   if (g_dual_cfg == 0) return 0;
-  if (g_dual_cfg == 3 || g_dual_cfg == 4 || g_dual_cfg == 5) return g_dual_cfg;
+  if (g_dual_cfg == 3 || g_dual_cfg == 4 || g_dual_cfg == 5 || g_dual_cfg == 8) return g_dual_cfg;
   auto tiles = [](int M, int N, int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  // 8: the dA half on 256x128 blocks, the dW half on 256x256 (MFMA-bound instead of fill-bound) -- when both fill the chip
+  if (tiles(M_nt, N_nt, 256, 128) >= 200 && tiles(M_tn, N_tn, 256, 256) >= 200) return 8;
   if (tiles(M_nt, N_nt, 256, 128) + tiles(M_tn, N_tn, 256, 128) >= 512) return 5;
   if (tiles(M_nt, N_nt, 128, 128) + tiles(M_tn, N_tn, 128, 128) >= 256) return 4;
   if (tiles(M_nt, N_nt, 128, 64) + tiles(M_tn, N_tn, 128, 64) >= 256) return 3;
   return 0;
 }
-int gemm_bf16_dual_tile_rows(int cfg) { return cfg == 5 ? 256 : (cfg == 3 || cfg == 4) ? 128 : 0; }
+int gemm_bf16_dual_tile_rows(int cfg) { return (cfg == 5 || cfg == 8) ? 256 : (cfg == 3 || cfg == 4) ? 128 : 0; }
 
 int gemm_bf16_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t stream) {
   if (nt.M <= 0 || nt.N <= 0 || nt.K <= 0 || tn.M <= 0 || tn.N <= 0 || tn.K <= 0) return (int)hipErrorInvalidValue;
@@ -786,9 +808,10 @@ int gemm_bf16_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t stream)
       (long)tn.K * tn.lda * 2 >= (1L << 31) || (long)tn.K * tn.ldb * 2 >= (1L << 31)) return (int)hipErrorInvalidValue;
   if ((nt.epi != 0 && nt.epi != EPI_DACT) || (tn.epi != 0 && tn.epi != EPI_ACCUM)) return -1;
   switch (gemm_bf16_dual_config(nt.M, nt.N, tn.M, tn.N)) {
-    case 3: return launch_dual_epi<2, 2, 2, 1, 5>(nt, tn, stream);
-    case 4: return launch_dual_epi<2, 2, 2, 2, 4>(nt, tn, stream);
-    case 5: return launch_dual_epi<4, 2, 2, 2, 3>(nt, tn, stream);
+    case 3: return launch_dual_epi<2, 2, 2, 1, 5, 2, 2, 2, 1, 5, 64>(nt, tn, stream);
+    case 4: return launch_dual_epi<2, 2, 2, 2, 4, 2, 2, 2, 2, 4, 64>(nt, tn, stream);
+    case 5: return launch_dual_epi<4, 2, 2, 2, 3, 4, 2, 2, 2, 3, 64>(nt, tn, stream);
+    case 8: return launch_dual_epi<4, 2, 2, 2, 3, 4, 2, 2, 4, 4, 32>(nt, tn, stream);
   }
   return -1;
 }

@@ -76,7 +76,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         return child()
     table = {}
-    for cfg in ("-1", "3", "4", "5"):
+    for cfg in ("-1", "3", "4", "5", "8"):
         env = dict(os.environ, TFK_BF16_DUAL_CFG=cfg)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True,
                            timeout=600)
@@ -87,7 +87,7 @@ def main():
         table[cfg] = json.loads(line[0][len("DUALBENCH "):])
     print("dA (NT) + dW (TN) of one layer, bf16 operands: two launches (each with its own heuristic tile) vs one dual launch; us and TFLOP/s of the pair")
     print("%-12s %5s %5s %5s | %14s | %s" % ("layer", "T", "d_in", "d_out", "two launches", "  ".join(
-        "dual %-9s" % {"-1": "heuristic", "3": "128x64", "4": "128x128", "5": "256x128"}[c] for c in table)))
+        "dual %-9s" % {"-1": "heuristic", "3": "128x64", "4": "128x128", "5": "256x128", "8": "256x128+256x256"}[c] for c in table)))
     for name, T, d_in, d_out in SHAPES:
         base = None
         cells = []
