@@ -51,7 +51,10 @@ def bench(layout, M, N, K, cfg, iters=20):
 
 def main():
     out = {}
-    for tag, (T, F, H, O) in {"cfg2": (1024, 440, 2048, 2000), "cfg4/gpu": (2048, 440, 4096, 8000)}.items():
+    confs = {"cfg2": (1024, 440, 2048, 2000), "cfg4/gpu": (2048, 440, 4096, 8000)}
+    if os.environ.get("TFK_SWEEP_ONLY"):  # e.g. TFK_SWEEP_ONLY=cfg2
+        confs = {k: v for k, v in confs.items() if k in os.environ["TFK_SWEEP_ONLY"].split(",")}
+    for tag, (T, F, H, O) in confs.items():
         print("== %s  T=%d F=%d H=%d O=%d" % (tag, T, F, H, O))
         print("%-6s %-3s %6s %6s %6s | " % ("op", "lay", "M", "N", "K") + " ".join("%11s" % n for n in NAMES))
         for name, layout, M, N, K in shapes(T, F, H, O):
