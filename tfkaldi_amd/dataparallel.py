@@ -215,12 +215,12 @@ class BucketReducer(object):
         import torch
         d = self._dist
         n = 4 * self.world
-        scratch = self.view.new_zeros(n) if hasattr(self.view, "new_zeros") else None
-        if scratch is None:
+        if not hasattr(self.view, "new_zeros"):
             return
-        own = scratch[self.rank * 4:(self.rank + 1) * 4]
         ok_rs = ok_ag = 1
-        with self._stream_ctx():
+        with self._stream_ctx():  # (the scratch tensor too: operands and collectives on one stream)
+            scratch = self.view.new_zeros(n)
+            own = scratch[self.rank * 4:(self.rank + 1) * 4]
             try:
                 d.reduce_scatter_tensor(own, scratch, op=d.ReduceOp.SUM, group=self.group)
             except (RuntimeError, NotImplementedError):
@@ -451,15 +451,20 @@ class BucketReducer(object):
         sums = [engine.param_checksum(1), engine.param_checksum(2)] if via_shadow else [engine.param_checksum(0)]
         d = self._dist
         dev = self.view.device
-        mine = torch.tensor([s & 0x7FFFFFFFFFFFFFFF for s in sums], dtype=torch.int64, device=dev)
-        lo, hi = mine.clone(), mine.clone()
+        mine = [s & 0x7FFFFFFFFFFFFFFF for s in sums]
+        # Everything on ONE stream -- the upload, the collectives (a backend orders itself against the stream that is
+        # current when it is called) and the read-back: built on the default stream and reduced under the engine's, the
+        # operands could reach the collective before their values did (seen as a rank reporting checksum 0 with eight
+        # gloo ranks on one GPU).
         with self._stream_ctx():
+            lo = torch.tensor(mine, dtype=torch.int64, device=dev)
+            hi = lo.clone()
             d.all_reduce(lo, op=d.ReduceOp.MIN, group=self.group)
             d.all_reduce(hi, op=d.ReduceOp.MAX, group=self.group)
-        if lo.tolist() != hi.tolist():
+            lo, hi = lo.tolist(), hi.tolist()
+        if lo != hi:
             raise RuntimeError("data-parallel replicas diverged after the sharded exchange step: rank %d holds parameter "
-                               "checksum %s, the ranks' values span %s .. %s" % (self.rank, mine.tolist(), lo.tolist(),
-                                                                               hi.tolist()))
+                               "checksum %s, the ranks' values span %s .. %s" % (self.rank, mine, lo, hi))
 
     def gather_masters(self, engine):
         """Collective.  Mixed-precision sharded exchange: all-gather the fp32 masters of every sharded span (each rank
