@@ -75,6 +75,45 @@ def test_gradients_match_autograd(chain):
             assert mu.shape == (KW["num_units"],)
 
 
+@pytest.mark.parametrize("chain", [c for c in CHAINS if c.get("nonlin") != "relu" or not c.get("l2_norm")],
+                         ids=lambda c: "-".join("%s=%s" % kv for kv in sorted(c.items())))
+def test_gradients_match_finite_differences(chain):
+    """A third, torch-free pin of the backward pass: central differences of the oracle's OWN summed loss (batch statistics,
+    L2 branch selection and dropout masks held as the forward pass holds them) against its analytic gradient sums.  Chains
+    with a kink that a finite step can cross (ReLU next to the L2 threshold) are left to the autograd test."""
+    import copy
+    rng = np.random.default_rng(11)
+    o = OracleDNN(**dict(KW, **chain))
+    randomize(o, rng, scale=1.5)
+    T = 17
+    X = rng.standard_normal((T, KW["input_dim"]))
+    y = rng.integers(0, KW["output_dim"], size=T)
+    masks = [(rng.random((T, KW["num_units"])) < o.keep).astype(np.float64) for _ in range(o.L)] if o.dropout else None
+
+    def loss_at(name, idx, delta):
+        q = copy.deepcopy(o)
+        q.params()[name][idx] += delta
+        q.accumulate(X, y, masks)
+        return q.batch_loss
+
+    ref = copy.deepcopy(o)
+    g = ref.accumulate(X, y, masks)
+    h = 1e-5
+    checked = kinks = 0
+    for name, arr in o.params().items():
+        if not np.any(g[name]):  # (layers above the active depth: the zero branch)
+            continue
+        for _ in range(4):
+            idx = tuple(int(rng.integers(0, n)) for n in arr.shape)
+            fd = (loss_at(name, idx, h) - loss_at(name, idx, -h)) / (2 * h)
+            if o.nonlin == "relu" and abs(fd - g[name][idx]) > 1e-5 * max(1.0, abs(fd)):
+                kinks += 1  # a ReLU kink inside the step: not a statement about the gradient (rare: bounded below)
+                continue
+            assert abs(fd - g[name][idx]) <= 2e-6 * max(1.0, abs(fd)), (name, idx, fd, g[name][idx])
+            checked += 1
+    assert checked >= 8 and kinks <= 2, (checked, kinks)
+
+
 def test_adam_matches_torch_adam():
     """TF's Adam (epsilon outside the bias correction, folded lr_t) vs torch.optim.Adam, whose epsilon is added
     to sqrt(v_hat): equal when epsilon is rescaled, which pins the formula."""
