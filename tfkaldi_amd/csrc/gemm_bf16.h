@@ -48,8 +48,9 @@ struct GemmArgsB {
 //   6: 128x64  block, 4 waves (64x32 each), 3-slot ring  (two blocks per CU)
 //   7: 256x128 block, 4 waves (128x64 each), 3-slot ring (round-3 experiment: a quarter fewer fragment reads per flop, one
 //      wave per SIMD)
-//   8: 256x256 block, 8 waves (64x128 each), 32 k per slot, 4-slot ring -- the TN layout (weight gradient) only: half the
-//      staged bytes per flop of 256x128; other layouts run 5 instead
+//   8: 256x256 block, 8 waves (64x128 each), 32 k per slot, 4-slot ring, PING-PONG schedule (the two waves of a SIMD run half a
+//      slot apart: one multiplies out of registers, the other fetches fragments and issues its LDS-DMA pieces) -- the TN layout
+//      (weight gradient) only: half the staged bytes per flop of 256x128; other layouts run 5 instead
 constexpr int kNumGemmBf16Configs = 9;
 
 // Returns hipError_t as int.

@@ -326,7 +326,10 @@ struct Frag {
 
 // BKT: k per ring slot -- 64 (four 16-k MFMA steps), or 32 (two steps) for the 256x256 block of two k-strided operands,
 // whose 64-k stage (64 KB) would leave room for two slots only
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64>
+// SCHED 2 = "ping-pong" (8-wave blocks): the two waves that share a SIMD run half a tile apart -- while one multiplies a whole
+// ring slot out of registers (nothing but MFMAs), its partner fetches every fragment of its next slot and issues its LDS-DMA
+// pieces; a block-wide barrier separates the half-steps and the two swap roles.  See the loop.
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0>
 __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
@@ -424,6 +427,53 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   // matrix-pipe cycles per 64-k tile on the 8-wave 256x128 block, where MFMAs + fragment reads cost 53 us against 43.5 us
   // of MFMAs alone (profiles/r02_gemm_bf16_ablation.txt).
   int rs = 0, ws = NS - 1;
+  if constexpr (SCHED == 2) {
+    // Half-steps are numbered by the barriers between them.  Waves 0 .. 3 (group 0, one per SIMD): LOAD(0) | MUL(0) | LOAD(1) | ..;
+    // waves 4 .. 7 (group 1, their SIMD partners): idle | LOAD(0) | MUL(0) | ..  LOAD(t) reads every fragment of slot t into
+    // registers, issues the wave's pieces of tile t+NS-1 into the slot tile t-1 occupied (its last reader, the other group,
+    // finished one half-step earlier) and waits for its own pieces of tile t+1; MUL(t) is KSPT * FM * FN MFMAs and nothing else.
+    static_assert(WAVES_M * WAVES_N == 8, "two waves per SIMD");
+    const int group = wave >> 2;
+    bf16x8 wa[KSPT][FM], wb[KSPT][FN];
+    if (group == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" : : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* st = smem + rs * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < KSPT; ++ks) {
+#pragma unroll
+        for (int a = 0; a < FM; ++a) wa[ks][a] = qa.read(st, a, ks);
+#pragma unroll
+        for (int b = 0; b < FN; ++b) wb[ks][b] = qb.read(st + A_BYTES, b, ks);
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) piece(j, ws, kt + NS - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      TFKB_WAIT_BARRIER((NS - 2) * NP);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KSPT; ++ks)
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks][a], wb[ks][b], acc[a][b], 0, 0, 0);
+      rs = rs + 1 == NS ? 0 : rs + 1;
+      ws = ws + 1 == NS ? 0 : ws + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" : : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (group == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" : : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   read_frags(0, smem, 0);
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
@@ -448,15 +498,16 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     mfma_step((KSPT - 1) & 1);  // the last 16-k step of tile kt
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
   TFKB_WAIT_BARRIER(0);  // the epilogue reuses the ring as scratch: nothing may still be landing in it
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64>
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
+  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
 }
 
 // Two INDEPENDENT contractions in one launch -- backward: dA = dZ . W^T (NT, optionally EPI_DACT) of a layer and the
@@ -477,7 +528,8 @@ gemm_bf16_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, in
   if ((int)blockIdx.x < n1)
     dma_tile<true, true, EPI_NT, GWM, GWN, GFM, GFN, GNS>(p1, tiles_m1, tiles_n1, group1, blockIdx.x, smem);
   else
-    dma_tile<false, false, EPI_TN, HWM, HWN, HFM, HFN, HNS, HBK>(p2, tiles_m2, tiles_n2, group2, blockIdx.x - n1, smem);
+    dma_tile<false, false, EPI_TN, HWM, HWN, HFM, HFN, HNS, HBK, (HBK == 32 ? 2 : 0)>(p2, tiles_m2, tiles_n2, group2, blockIdx.x - n1,
+                                                                                      smem);
 }
 
 // ================================================================================================================
@@ -702,13 +754,13 @@ int launch_reg(const GemmArgsB& p, hipStream_t stream) {
   static bool attr_done = false;
   return launch_grid(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>, p, BM, BN, NT, lds, stream, &attr_done);
 }
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64>
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0>
 int launch_dma(const GemmArgsB& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
   const size_t lds = (size_t)NS * (BM + BN) * BKT * 2;
   static_assert((size_t)NS * (BM + BN) * BKT * 2 <= 160 * 1024, "LDS");
   static bool attr_done = false;
-  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT>, p, BM, BN,
+  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED>, p, BM, BN,
                      WAVES_M * WAVES_N * 64, lds, stream, &attr_done);
 }
 
@@ -719,7 +771,7 @@ int launch(const GemmArgsB& p, hipStream_t stream) {
     // the weight gradient (both operands k-strided): a 256x256 block when the result has a tile of it for (nearly) every
     // CU -- half the staged bytes per flop of 256x128, which makes this contraction MFMA-bound instead of fill-bound
     if (cfg == 8 || (g_forced_b < 0 && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 200))
-      return launch_dma<false, false, EPI, 4, 2, 2, 4, 4, 32>(p, stream);
+      return launch_dma<false, false, EPI, 4, 2, 2, 4, 4, 32, 2>(p, stream);
   }
   if (cfg == 8) cfg = 5;  // (the 256x256 block exists for the TN layout only)
   switch (cfg) {

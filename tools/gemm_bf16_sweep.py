@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tfkaldi_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-NAMES = ["r64x64", "r128x64", "r128x128", "d128x64s5", "d128x128s4", "d256x128s3", "d128x64s3", "d256x128w4", "d256x256k32"]
+NAMES = ["r64x64", "r128x64", "r128x128", "d128x64s5", "d128x128s4", "d256x128s3", "d128x64s3", "d256x128w4", "d256x256k32pp"]
 # TFK_SWEEP_CFGS="3,5": only these configurations
 SEL = [int(x) for x in os.environ["TFK_SWEEP_CFGS"].split(",")] if os.environ.get("TFK_SWEEP_CFGS") else list(range(len(NAMES)))
 LAY = ["NN", "NT", "TN"]
