@@ -5,7 +5,7 @@
 //
 // Two kernel families share one epilogue:
 //
-// (1) LDS-DMA staged (configs 3-6, the default).  A bf16 contraction does 16x the flops of the fp32 one per byte
+// (1) LDS-DMA staged (configs 3-8, the default).  A bf16 contraction does 16x the flops of the fp32 one per byte
 //     of operand, so what bounds it at the sizes of this path is how fast operand tiles reach LDS (~38 B/clk/CU
 //     from L2, profiles/r01_gemm_dma.txt), i.e. the BLOCK tile: bytes per flop fall as 1/BM + 1/BN.  Blocks are
 //     128x64 (the 1024-frame shapes: 256 tiles = one per CU), 128x128 or 256x128 (4 / 8 waves, each wave a
@@ -24,6 +24,10 @@
 //         16-k steps) into the slot tile t-1 left, multiplies tile t, then waits with a COUNTED s_waitcnt vmcnt for
 //         its own pieces of tile t+1 only -- the younger tiles stay in flight across the barrier, so the fill path
 //         never drains.  hipcc does not model these loads (inline asm): completion is that wait + s_barrier.
+//         (round 3) the K loop is rotated by one 16-k step -- the barrier sits before a tile's LAST step, whose MFMAs
+//         cover the LDS round trip of the next tile's first fragments.
+//       * (round 3) the weight gradient at BASELINE cfg4's size runs on 256x256 blocks with 32-k ring slots (both of its
+//         operands are k-strided, so a slot may be any multiple of 16 k deep) on a PING-PONG schedule: see SCHED 2.
 // (2) register-staged ring of round 1 (configs 0-2; kept for A/B runs: tools/gemm_bf16_sweep.py).
 #include "gemm_bf16.h"
 
