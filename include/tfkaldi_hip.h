@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 5
+#define TFK_ABI_VERSION 6
 
 typedef struct tfk_engine tfk_engine;
 
@@ -90,6 +90,9 @@ int tfk_destroy(tfk_engine* e);
 
 const char* tfk_last_error(void);
 int tfk_abi_version(void);
+/* Build provenance: the hash of the sources this library was compiled from (tfkaldi_amd/build.py source_id(): every
+ * .hip / .h under csrc/, this header, the compiler flags).  The binding refuses a library whose id is not its tree's. */
+const char* tfk_build_id(void);
 
 /* ---- state access (checkpointing, weight injection, parity tests) ------------------------------ */
 

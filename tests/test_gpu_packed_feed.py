@@ -1,0 +1,73 @@
+"""Nnet.train fed through the packed path (rank-local reads, CMVN + splice in HBM, one batch prefetched) against
+the same run fed the reference's way, trainer.update(*dispenser.get_batch()): the device-side normalisation and
+splice are bit-identical to the host's, so every printed loss, the checkpoints and the final model must be EQUAL."""
+import configparser
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F_RAW, CONTEXT, O = 8, 2, 12
+
+
+def _corpus(tmp_path, num_utt=70):
+    from tfkaldi_amd import synthetic
+    lengths = np.random.default_rng(3).integers(5, 30, size=num_utt)
+    lengths[5] = 3  # too short to splice with context 2 -> skipped with a WARNING
+    return synthetic.write_corpus(str(tmp_path / "data"), num_utt, O, feat_dim=F_RAW, lengths=lengths, num_speakers=3)
+
+
+def _train(tmp_path, paths, name, capsys, **over):
+    from tfkaldi_amd.neuralNetworks import nnet
+    from tfkaldi_amd.processing import batchdispenser, feature_reader, target_coder
+    conf = configparser.ConfigParser()
+    conf.add_section("directories"); conf.set("directories", "expdir", str(tmp_path / name))
+    conf.add_section("nnet")
+    values = dict(name="dnn", context_width=str(CONTEXT), num_hidden_units="32", num_hidden_layers="2",
+                  add_layer_period="0", starting_step="0", nonlin="relu", l2_norm="False", dropout="1",
+                  batch_norm="True", num_epochs="2", initial_learning_rate="0.01", learning_rate_decay="0.5",
+                  batch_size="6", numutterances_per_minibatch="4", valid_batches="2", valid_frequency="3",
+                  valid_adapt="True", valid_retries="2", check_freq="4", visualise="False", seed="77")
+    values.update(over)
+    for k, v in values.items():
+        conf.set("nnet", k, v)
+    reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, 30)
+    disp = batchdispenser.AlignmentBatchDispenser(reader, target_coder.AlignmentCoder(lambda x, y: x, O), 6,
+                                                  paths["alignments"])
+    capsys.readouterr()
+    nnet.Nnet(conf, F_RAW, O).train(disp)
+    out = capsys.readouterr().out
+    model = dict(np.load(os.path.join(str(tmp_path / name), "dnn", "final")))
+    return out, model, reader.reader.bytes_read
+
+
+@pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}, {"compute_dtype": "bfloat16"},
+                                  {"add_layer_period": "5", "valid_adapt": "False"}])
+def test_packed_feed_equals_list_feed(gpu, tmp_path, capsys, over):
+    """6 utterances per batch in micro-batches of 4 (the reference's quirk: the last two are one micro-batch), a
+    held-out set of 2 batches, validation every 3 steps with rollback -- every printed line and the final model"""
+    paths = _corpus(tmp_path)
+    out_p, model_p, bytes_p = _train(tmp_path, paths, "packed", capsys, packed_feed="True", **over)
+    out_l, model_l, bytes_l = _train(tmp_path, paths, "lists", capsys, packed_feed="False", **over)
+    assert "step 0/" in out_p and "validation loss at step 0" in out_p and "too short to splice" in out_p
+    assert out_p == out_l
+    assert sorted(model_p) == sorted(model_l)
+    for k in model_p:
+        assert model_p[k].tobytes() == model_l[k].tobytes(), k
+    rollbacks = out_l.count("the validation loss is worse")
+    assert bytes_p <= bytes_l + (1 + rollbacks) * 6 * 30 * F_RAW * 4  # (a rollback puts an unused prefetched batch back)
+
+
+def test_rollback_with_a_prefetched_batch(gpu, tmp_path, capsys):
+    """a learning rate large enough that validation gets worse: the schedule rewinds the dispenser while a prefetched
+    batch is waiting; the packed run must still print what the list-fed run prints"""
+    paths = _corpus(tmp_path)
+    over = dict(initial_learning_rate="0.5", valid_frequency="2", valid_retries="3", num_epochs="3")
+    out_p, model_p, _ = _train(tmp_path, paths, "packed", capsys, packed_feed="True", **over)
+    out_l, model_l, _ = _train(tmp_path, paths, "lists", capsys, packed_feed="False", **over)
+    assert "the validation loss is worse" in out_l
+    assert out_p == out_l
+    for k in model_p:
+        assert model_p[k].tobytes() == model_l[k].tobytes(), k

@@ -8,9 +8,9 @@ import os
 from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
                     c_size_t, c_uint64, c_void_p)
 
-from .build import lib_path
+from .build import lib_path, source_id
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
@@ -63,6 +63,7 @@ _E = c_void_p
 SYMBOLS = {
     "tfk_abi_version": (c_int, []),
     "tfk_last_error": (c_char_p, []),
+    "tfk_build_id": (c_char_p, []),
     "tfk_state_bytes": (c_int, [POINTER(TfkConfig), POINTER(c_size_t)]),
     "tfk_create": (c_int, [POINTER(TfkConfig), POINTER(_E)]),
     "tfk_create_ex": (c_int, [POINTER(TfkConfig), c_void_p, c_size_t, c_void_p, POINTER(_E)]),
@@ -166,6 +167,10 @@ def load():
         fn.argtypes = args
     if lib.tfk_abi_version() != ABI_VERSION:
         raise ImportError("libtfkaldi_hip.so ABI %d != binding ABI %d" % (lib.tfk_abi_version(), ABI_VERSION))
+    built_from, tree = lib.tfk_build_id().decode(), source_id()
+    if built_from != tree and os.environ.get("TFK_ALLOW_STALE_LIB") != "1":
+        raise ImportError("%s was built from other sources (its build id %s, this tree %s): rebuild it with python -m "
+                          "tfkaldi_amd.build (TFK_ALLOW_STALE_LIB=1 loads it anyway)" % (path, built_from, tree))
     _lib = lib
     return lib
 

@@ -46,32 +46,72 @@ def _hipcc():
     return exe
 
 
+def _digest(names, extra=b""):
+    import hashlib
+    h = hashlib.sha256(extra)
+    for name in names:
+        with open(os.path.join(CSRC, name), "rb") as fid:
+            h.update(os.path.basename(name).encode() + b"\0" + fid.read() + b"\0")
+    return h.hexdigest()
+
+
+def source_id():
+    """Build provenance: sha256 (first 32 hex digits) over every source and header the library compiles from, the
+    public header included, and the compiler flags.  hipcc bakes it into the library (TFK_BUILD_ID; tfk_build_id()
+    returns it), _lib.load() refuses a library whose id is not this tree's, and build_native rebuilds on that --
+    not on file times, which say nothing once the .so has travelled to another box."""
+    return _digest(sorted(SOURCES) + sorted(HEADERS), " ".join(FLAGS).encode())[:32]
+
+
+_ID_MARK = b"TFK_BUILD_ID="
+
+
+def library_id(path=None):
+    """the id baked into a built library, read from the file (no dlopen); None when there is none"""
+    path = path or lib_path()
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as fid:
+        blob = fid.read()
+    at = blob.find(_ID_MARK)
+    if at < 0:
+        return None
+    return blob[at + len(_ID_MARK):at + len(_ID_MARK) + 32].decode("ascii", "replace")
+
+
 def _stale():
-    out = lib_path()
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return library_id() != source_id()
 
 
 def build_native(force=False, verbose=False):
-    """Compile csrc/*.hip -> lib/libtfkaldi_hip.so (skipped when up to date). Returns the path."""
+    """Compile csrc/*.hip -> lib/libtfkaldi_hip.so (skipped when the library's build id is this tree's).  Objects are
+    cached per translation unit under build/obj, keyed by the hash of the unit's source + every header + the flags.
+    Returns the path."""
     if not force and not _stale():
         return lib_path()
     hipcc = _hipcc()
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "..", "build", "obj")
     os.makedirs(objdir, exist_ok=True)
+    build_id = source_id()
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        flags = list(FLAGS)
+        if src == "engine.hip":  # the unit that exports tfk_build_id()
+            flags.append('-DTFK_BUILD_ID="%s"' % build_id)
+        key = _digest([src] + sorted(HEADERS), " ".join(flags).encode())
+        stamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
+            return obj
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
         if verbose and r.stderr:
             sys.stderr.write(r.stderr)
+        with open(stamp, "w") as fid:
+            fid.write(key)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -82,6 +122,8 @@ def build_native(force=False, verbose=False):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     os.replace(tmp, lib_path())
+    if library_id() != build_id:
+        raise RuntimeError("the linked library does not carry build id %s" % build_id)
     return lib_path()
 
 

@@ -1352,6 +1352,12 @@ int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 extern "C" {
 
 int tfk_abi_version(void) { return TFK_ABI_VERSION; }
+#ifndef TFK_BUILD_ID
+#error "compile engine.hip through tfkaldi_amd/build.py: it passes -DTFK_BUILD_ID=<hash of the sources>"
+#endif
+// (the marker makes the id findable in the file without loading it: tfkaldi_amd/build.py library_id)
+static const char kBuildId[] = "TFK_BUILD_ID=" TFK_BUILD_ID;
+const char* tfk_build_id(void) { return kBuildId + 13; }
 const char* tfk_last_error(void) { return g_err.c_str(); }
 
 int tfk_state_bytes(const tfk_config* cfg, size_t* bytes) {

@@ -553,13 +553,22 @@ class DataParallel(object):
         """`microbatches`: the (X[T, F], y[T]) micro-batches of the WHOLE step, identical on every rank.
         Returns the average loss over all of them (reference Trainer.update's return value)."""
         if not self.enabled:
-            for i, mb in enumerate(microbatches):
-                _accumulate(engine, mb, i == len(microbatches) - 1)
-            return engine.apply()
-        import torch.distributed as dist
+            return self.train_own(engine, microbatches, 0)
         start, end = partition(len(microbatches), self.world)[self.rank]
-        mine = microbatches[start:end]
-        engine.set_later_microbatches(len(microbatches) - end)
+        return self.train_own(engine, microbatches[start:end], len(microbatches) - end)
+
+    def train_own(self, engine, mine, later, overlap=None):
+        """One optimiser step from THIS rank's micro-batches only (`later` = micro-batches of the step that belong to
+        higher ranks: the BN moving averages compose in the reference's serial order).  `overlap`, if given, is called once
+        the rank's last micro-batch is enqueued and before the host waits for the step: the place for host work that
+        should run while the GPU is busy (the dispenser's prefetch of the next batch)."""
+        if not self.enabled:
+            for i, mb in enumerate(mine):
+                _accumulate(engine, mb, i == len(mine) - 1)
+            if overlap is not None:
+                overlap()
+            return engine.apply()
+        engine.set_later_microbatches(later)
         reducer = self.reducer(engine)
         engine.set_bucket_callback(reducer.on_bucket)
         try:
@@ -572,6 +581,8 @@ class DataParallel(object):
                     reducer.on_bucket(b)
         finally:
             engine.set_bucket_callback(None)
+        if overlap is not None:
+            overlap()
         loss = reducer.finish_and_apply(engine)
         self.last_collectives = reducer.last_launched
         self.last_kinds = reducer.last_kinds
@@ -581,14 +592,18 @@ class DataParallel(object):
     def eval_step(self, engine, microbatches):
         """average validation loss (reference Trainer.evaluate); only the scalar tail is reduced"""
         if not self.enabled:
-            for mb in microbatches:
-                _eval_accumulate(engine, mb)
+            return self.eval_own(engine, microbatches)
+        start, end = partition(len(microbatches), self.world)[self.rank]
+        return self.eval_own(engine, microbatches[start:end])
+
+    def eval_own(self, engine, mine):
+        """validation loss from THIS rank's micro-batches (all of them in a single-process run)"""
+        for mb in mine:
+            _eval_accumulate(engine, mb)
+        if not self.enabled:
             return engine.eval_finish()
         import torch.distributed as dist
-        start, end = partition(len(microbatches), self.world)[self.rank]
-        for mb in microbatches[start:end]:
-            _eval_accumulate(engine, mb)
-        if start == end:  # nothing on this rank: contribute physical zeros (the accumulators reset lazily)
+        if not mine:  # nothing on this rank: contribute physical zeros (the accumulators reset lazily)
             engine.zero_accumulators()
         off, n = engine.buckets()[-1]
         with self._stream_ctx(engine):

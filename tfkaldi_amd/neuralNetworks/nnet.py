@@ -16,7 +16,7 @@ from ..dataparallel import init_from_env
 from .classifiers import activation as act
 from .classifiers.dnn import DNN
 from .decoder import Decoder
-from .trainer import CrossEnthropyTrainer
+from .trainer import CrossEnthropyTrainer, MicrobatchSelector
 
 _NONLINEARITIES = ('relu', 'sigmoid', 'tanh', 'linear')  # nnet.py:48-62
 
@@ -117,9 +117,21 @@ class _Schedule(object):
         self.net, self.conf, self.dispenser = net, net.conf, dispenser
         self.training_dir = net.conf['savedir'] + '/training/'
         n_valid = int(self.conf['valid_batches'])
+        per_minibatch = self.conf['numutterances_per_minibatch']
+        per_minibatch = dispenser.size if per_minibatch == '-1' else int(per_minibatch)
+        # The packed feed (optional [nnet] key packed_feed, default True; needs this package's dispenser): every rank
+        # reads only the utterances of ITS micro-batches, straight into one batch buffer, CMVN + splice happen in HBM,
+        # and the next batch is produced while the GPU works on the current one.  Same batches, same order, same
+        # arithmetic as trainer.update(*dispenser.get_batch()).
+        self.packed = self.conf.get('packed_feed', 'True') == 'True' and getattr(dispenser, 'packed', False)
+        self.select = MicrobatchSelector(per_minibatch, net.rank, net.world)
         # the first batches of the data are held out for validation, then cut off (nnet.py:88-96)
-        held_out = [dispenser.get_batch() for _ in range(n_valid)]
-        self.valid = tuple(list(itertools.chain.from_iterable(part)) for part in zip(*held_out)) if held_out else None
+        if self.packed:
+            self.valid = dispenser.next_packed(self.select, n_valid * dispenser.size) if n_valid else None
+        else:
+            held_out = [dispenser.get_batch() for _ in range(n_valid)]
+            self.valid = (tuple(list(itertools.chain.from_iterable(part)) for part in zip(*held_out))
+                          if held_out else None)
         dispenser.split()
         self.total_steps = int(dispenser.num_batches * int(self.conf['num_epochs']))
         # resume from the checkpoint at or below starting_step, at the matching position in the data (:101-108)
@@ -127,12 +139,16 @@ class _Schedule(object):
         self.step = start - start % every
         for _ in range(self.step):
             dispenser.skip_batch()
-        per_minibatch = self.conf['numutterances_per_minibatch']
-        per_minibatch = dispenser.size if per_minibatch == '-1' else int(per_minibatch)
+        # optional [nnet] key seed: weight initialisation and dropout masks reproducible from the configuration (the
+        # reference seeds nothing; without the key the trainer draws a seed from the OS)
+        seed = {'seed': int(self.conf['seed'])} if 'seed' in self.conf else {}
         self.trainer = CrossEnthropyTrainer(
             net.dnn, net.input_dim, dispenser.max_input_length, dispenser.max_target_length,
             float(self.conf['initial_learning_rate']), float(self.conf['learning_rate_decay']), self.total_steps,
-            per_minibatch)
+            per_minibatch, **seed)
+        if self.packed and not hasattr(self.trainer, 'update_packed'):
+            raise TypeError("packed_feed needs a trainer with update_packed / evaluate_packed; set packed_feed = False "
+                            "in [nnet] for %s" % type(self.trainer).__name__)
         self.best_loss = self.best_step = None
         self.retries = 0
 
@@ -155,8 +171,11 @@ class _Schedule(object):
         self.best_loss, self.best_step, self.retries = loss, self.step, 0
         self.save('validated')
 
+    def _prefetch(self):
+        self.dispenser.prefetch(self.select)
+
     def validate(self):
-        loss = self.trainer.evaluate(*self.valid)
+        loss = self.trainer.evaluate_packed(self.valid) if self.packed else self.trainer.evaluate(*self.valid)
         self.net._say('validation loss at step %d: %f' % (self.step, loss))
         return loss
 
@@ -202,7 +221,13 @@ class _Schedule(object):
                 self.accept(self.validate())
             adaptive = conf['valid_adapt'] == 'True'
             while self.step < self.total_steps:
-                loss = trainer.update(*self.dispenser.get_batch())
+                if self.packed:
+                    # (the batch after this one is read while the GPU is busy with this one; nothing is read past the
+                    # last step, and a rollback puts an unused prefetch back: BatchDispenser.return_batch)
+                    ahead = self._prefetch if self.step + 1 < self.total_steps else None
+                    loss = trainer.update_packed(self.dispenser.next_packed(self.select), overlap=ahead)
+                else:
+                    loss = trainer.update(*self.dispenser.get_batch())
                 self.net._say('step %d/%d loss: %f' % (self.step, self.total_steps, loss))
                 self.step += 1
                 if self.valid is not None and self.step % int(conf['valid_frequency']) == 0:

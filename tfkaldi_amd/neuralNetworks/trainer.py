@@ -20,7 +20,7 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .. import _lib
-from ..dataparallel import CtcMicroBatch, DataParallel, RawMicroBatch, rank_seed
+from ..dataparallel import CtcMicroBatch, DataParallel, RawMicroBatch, partition, rank_seed
 from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
 
@@ -57,6 +57,26 @@ def microbatch_indices(num_utt, per_minibatch):
     U = per_minibatch
     total = num_utt + (num_utt % U)
     return [[i for i in range(k * U, (k + 1) * U) if i < num_utt] for k in range(total // U)]
+
+
+class MicrobatchSelector(object):
+    """Which utterances of a batch does data-parallel rank `rank` need?  The selector the trainer hands to
+    BatchDispenser.next_packed: the batch is cut into the reference's micro-batches (microbatch_indices), the
+    micro-batches are dealt to the ranks in contiguous blocks (dataparallel.partition: rank order = the reference's
+    serial order) and only this rank's come back -- the dispenser never reads the other ranks' frames."""
+
+    def __init__(self, per_minibatch, rank=0, world=1):
+        self.per_minibatch, self.rank, self.world = int(per_minibatch), int(rank), int(world)
+
+    def __call__(self, frames):
+        """frames: frame count of every usable utterance of the batch, in order -> (this rank's micro-batches as
+        lists of positions, (micro-batches in the whole step, this rank's first, this rank's end))"""
+        plan = microbatch_indices(len(frames), self.per_minibatch)
+        if sum(len(idx) for idx in plan) < len(frames):
+            Trainer._warn_truncation(len(frames), self.per_minibatch, sum(len(idx) for idx in plan))
+        groups = [idx for idx in plan if idx and any(frames[i] for i in idx)]
+        start, end = partition(len(groups), self.world)[self.rank]
+        return groups[start:end], (len(groups), start, end)
 
 
 class Trainer(object, metaclass=ABCMeta):
@@ -140,17 +160,22 @@ class Trainer(object, metaclass=ABCMeta):
     # ---- batching ----
     _warned_truncation = False
 
+    @staticmethod
+    def _warn_truncation(num_utt, per_minibatch, used):
+        # the reference's padding arithmetic (trainer.py:280-294) silently drops the tail of a batch whose size
+        # is not a multiple of numutterances_per_minibatch; kept for parity, but said once
+        if not Trainer._warned_truncation:
+            print("WARNING batch of %d utterances with numutterances_per_minibatch = %d: the last %d utterance(s) of "
+                  "every such batch are not used (reference behaviour: trainer.py:280-294)"
+                  % (num_utt, per_minibatch, num_utt - used))
+            Trainer._warned_truncation = True
+
     def _microbatches(self, inputs, targets):
         out = []
         plan = microbatch_indices(len(inputs), self.numutterances_per_minibatch)
         used = sum(len(idx) for idx in plan)
-        if used < len(inputs) and not Trainer._warned_truncation:
-            # the reference's padding arithmetic (trainer.py:280-294) silently drops the tail of a batch whose size
-            # is not a multiple of numutterances_per_minibatch; kept for parity, but said once
-            print("WARNING batch of %d utterances with numutterances_per_minibatch = %d: the last %d utterance(s) of "
-                  "every such batch are not used (reference behaviour: trainer.py:280-294)"
-                  % (len(inputs), self.numutterances_per_minibatch, len(inputs) - used))
-            Trainer._warned_truncation = True
+        if used < len(inputs):
+            self._warn_truncation(len(inputs), self.numutterances_per_minibatch, used)
         for idx in plan:
             if not idx:
                 continue
@@ -200,17 +225,61 @@ class Trainer(object, metaclass=ABCMeta):
             raise ValueError("Trainer.update: the batch holds no frames (no micro-batch could be built from %d "
                              "utterance(s))" % len(inputs))
         loss = self.dp.train_step(self.engine, microbatches)
+        self._summarise(loss)
+        return loss
+
+    def _summarise(self, loss):
         if self.summarywriter is not None:
             self.summarywriter.write(json.dumps({"step": self.engine.global_step, "loss": loss,
                                                  "learning_rate": self.engine.scalar(_lib.LEARNING_RATE)}) + "\n")
             self.summarywriter.flush()
-        return loss
 
     def evaluate(self, inputs, targets):
         """the loss of the batch in evaluation mode; None when there is no data (trainer.py:372-373)"""
         if inputs is None or targets is None:
             return None
         return self.dp.eval_step(self.engine, self._microbatches(inputs, targets))
+
+    # ---- the packed feed (BatchDispenser.next_packed): this rank's utterances only, CMVN + splice in HBM ----
+    def selector(self):
+        """the selector to hand to BatchDispenser.next_packed for batches meant for update_packed / evaluate_packed"""
+        if getattr(self, "_selector", None) is None:
+            self._selector = MicrobatchSelector(self.numutterances_per_minibatch, self.dp.rank, self.dp.world)
+        return self._selector
+
+    def _packed_microbatches(self, batch):
+        out = []
+        ce = self.loss_kind != "ctc"
+        if ce and not np.array_equal(batch.lens, batch.target_lens):
+            bad = int(np.flatnonzero(batch.lens != batch.target_lens)[0])
+            raise ValueError("utterance %s: %d input frames but %d targets (the cross-enthropy trainer needs equal "
+                             "lengths)" % (batch.utt_ids[bad], batch.lens[bad], batch.target_lens[bad]))
+        for u0, u1, r0, r1, t0, t1 in batch.groups:
+            cmvn = None if batch.cmvn is None else batch.cmvn[u0:u1]
+            if ce:
+                out.append(RawMicroBatch(batch.frames[r0:r1], batch.targets[t0:t1], batch.lens[u0:u1],
+                                         batch.context_width, cmvn))
+            else:
+                out.append(CtcMicroBatch(batch.frames[r0:r1], batch.lens[u0:u1], batch.targets[t0:t1],
+                                         batch.target_lens[u0:u1], context_width=batch.context_width, cmvn=cmvn))
+        return out
+
+    def update_packed(self, batch, overlap=None):
+        """Trainer.update for a PackedBatch selected with self.selector(): the same optimiser step from this rank's
+        utterances alone.  `overlap()` runs once the step is enqueued and before the host waits for its loss."""
+        total, _, end = batch.info
+        if total == 0:
+            raise ValueError("Trainer.update: the batch holds no frames (no micro-batch could be built from %d "
+                             "utterance(s))" % batch.batch_utts)
+        loss = self.dp.train_own(self.engine, self._packed_microbatches(batch), total - end, overlap)
+        self._summarise(loss)
+        return loss
+
+    def evaluate_packed(self, batch):
+        """Trainer.evaluate for a PackedBatch selected with self.selector(); None when there is no data"""
+        if batch is None:
+            return None
+        return self.dp.eval_own(self.engine, self._packed_microbatches(batch))
 
     def halve_learning_rate(self):
         self.engine.halve_learning_rate()

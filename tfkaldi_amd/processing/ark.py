@@ -8,6 +8,7 @@ On-disk format (reference processing/ark.py:59-94 reader, :190-211 writer), per 
 scp line: "<utt_id> <ark path>:<offset>" (ark.py:51-54, 210).  Compressed ('C') and text archives are
 rejected the way the reference does: message + exit(1) (ark.py:73-78).
 """
+import os
 import struct
 import sys
 
@@ -15,63 +16,100 @@ import numpy as np
 
 _HEADER = struct.Struct("<xcccc")
 _DIM = struct.Struct("<bi")
+_F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
 
 
 class ArkReader(object):
-    """Reads matrices addressed by an scp file; keeps a cursor (`scp_position`) with wrap-around."""
+    """Reads matrices addressed by an scp file; keeps a cursor (`scp_position`) with wrap-around.
+
+    The reference opens, seeks and reads the archive once per utterance and copies the bytes twice (ark.py:59-94).
+    Here every archive is opened once, the 15 header bytes of an entry are parsed the first time it is touched and
+    cached (`entry`: descriptor, data offset, rows, cols, dtype), and the matrix body is ONE positioned read -- into a
+    fresh array (`read_utt_data`) or straight into a caller's batch buffer (`read_into`), which is what the batch
+    dispenser's packed path uses."""
 
     def __init__(self, scp_path):
         self.scp_position = 0
         self.utt_ids = []
         self.scp_data = []
-        self._files = {}
+        self._fds = {}
+        self._entries = []   # per scp line: None or (fd, data offset, rows, cols, dtype)
+        self._lookup = None  # utterance id -> index, built on the first read_utt
+        self.bytes_read = 0  # matrix bytes fetched from the archives (tests: a rank touches only its own utterances)
         with open(scp_path, "r") as fid:
             for line in fid:
                 utt_id, path_pos = line.rstrip("\n").split(" ")
                 path, pos = path_pos.split(":")
                 self.utt_ids.append(utt_id)
                 self.scp_data.append((path, pos))
+        self._entries = [None] * len(self.scp_data)
 
-    def _handle(self, path):
-        fh = self._files.get(path)
-        if fh is None:
-            fh = self._files[path] = open(path, "rb")
-        return fh
+    def _fd(self, path):
+        fd = self._fds.get(path)
+        if fd is None:
+            fd = self._fds[path] = os.open(path, os.O_RDONLY)
+        return fd
+
+    def entry(self, index):
+        """(descriptor, offset of the matrix body, rows, cols, dtype) of scp entry `index`; reads the 15-byte header
+        on the first call only"""
+        ent = self._entries[index]
+        if ent is None:
+            path, pos = self.scp_data[index]
+            fd = self._fd(path)
+            head = os.pread(fd, 15, int(pos))
+            binary, kind, _, _ = _HEADER.unpack(head[:5])
+            if binary != b"B":
+                print("Input .ark file is not binary")
+                sys.exit(1)
+            if kind == b"C":
+                print("Input .ark file is compressed")
+                sys.exit(1)
+            _, rows = _DIM.unpack(head[5:10])
+            _, cols = _DIM.unpack(head[10:15])
+            ent = self._entries[index] = (fd, int(pos) + 15, rows, cols, _F32 if kind == b"F" else _F64)
+        return ent
+
+    def read_into(self, index, out):
+        """the matrix body of entry `index` into `out`, a C-contiguous array of the entry's dtype and size"""
+        fd, offset, rows, cols, dtype = self.entry(index)
+        nbytes = rows * cols * dtype.itemsize
+        if out.dtype != dtype or out.nbytes != nbytes or not out.flags.c_contiguous:
+            raise ValueError("read_into: the buffer does not match the %d x %d %s matrix" % (rows, cols, dtype))
+        got = os.preadv(fd, [memoryview(out).cast("B")], offset) if nbytes else 0
+        if got != nbytes:
+            raise IOError("short read in %s: %d of %d bytes" % (self.scp_data[index][0], got, nbytes))
+        self.bytes_read += nbytes
 
     def read_utt_data(self, index):
         """the matrix of scp entry `index` (float32 or float64, as stored)"""
-        path, pos = self.scp_data[index]
-        fh = self._handle(path)
-        fh.seek(int(pos), 0)
-        binary, kind, _, _ = _HEADER.unpack(fh.read(5))
-        if binary != b"B":
-            print("Input .ark file is not binary")
-            sys.exit(1)
-        if kind == b"C":
-            print("Input .ark file is compressed")
-            sys.exit(1)
-        _, rows = _DIM.unpack(fh.read(5))
-        _, cols = _DIM.unpack(fh.read(5))
-        dtype = np.float32 if kind == b"F" else np.float64
-        data = np.frombuffer(fh.read(rows * cols * np.dtype(dtype).itemsize), dtype=dtype)
-        return data.reshape(rows, cols)
+        _, _, rows, cols, dtype = self.entry(index)
+        out = np.empty((rows, cols), dtype=dtype)
+        self.read_into(index, out)
+        return out
+
+    def _advance(self):
+        looped = self.scp_position >= len(self.scp_data)
+        if looped:
+            self.scp_position = 0
+        self.scp_position += 1
+        return self.scp_position - 1, looped
 
     def read_next_utt(self):
         """(utt_id, matrix, looped): `looped` is True on the read that wrapped to the first entry."""
         if len(self.scp_data) == 0:
             return None, None, True
-        looped = self.scp_position >= len(self.scp_data)
-        if looped:
-            self.scp_position = 0
-        self.scp_position += 1
-        return self.utt_ids[self.scp_position - 1], self.read_utt_data(self.scp_position - 1), looped
+        index, looped = self._advance()
+        return self.utt_ids[index], self.read_utt_data(index), looped
+
+    def next_entry(self):
+        """advance the cursor like read_next_utt but fetch nothing: (index, utt_id, looped)"""
+        index, looped = self._advance()
+        return index, self.utt_ids[index], looped
 
     def read_next_scp(self):
         """advance the cursor and return the utterance id without touching the archive"""
-        if self.scp_position >= len(self.scp_data):
-            self.scp_position = 0
-        self.scp_position += 1
-        return self.utt_ids[self.scp_position - 1]
+        return self.utt_ids[self._advance()[0]]
 
     def read_previous_scp(self):
         """move the cursor back by one; returns the id the cursor pointed at BEFORE the move (the
@@ -82,18 +120,33 @@ class ArkReader(object):
         return self.utt_ids[self.scp_position + 1]
 
     def read_utt(self, utt_id):
-        return self.read_utt_data(self.utt_ids.index(utt_id))
+        if self._lookup is None:  # (first occurrence wins, as list.index does in the reference: ark.py:159)
+            self._lookup = {}
+            for index, key in enumerate(self.utt_ids):
+                self._lookup.setdefault(key, index)
+        if utt_id not in self._lookup:
+            raise ValueError("%r is not in list" % (utt_id,))
+        return self.read_utt_data(self._lookup[utt_id])
 
     def split(self):
         """Drop what has been read so far.  As in the reference (ark.py:161-165) the LAST entry is dropped
         too (`[scp_position:-1]`) and the cursor is left where it was."""
         self.scp_data = self.scp_data[self.scp_position:-1]
         self.utt_ids = self.utt_ids[self.scp_position:-1]
+        self._entries = self._entries[self.scp_position:-1]
+        self._lookup = None
 
     def close(self):
-        for fh in self._files.values():
-            fh.close()
-        self._files = {}
+        for fd in self._fds.values():
+            os.close(fd)
+        self._fds = {}
+        self._entries = [None] * len(self.scp_data)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class ArkWriter(object):

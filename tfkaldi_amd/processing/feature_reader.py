@@ -63,21 +63,58 @@ class FeatureReader(object):
         self.utt2spk = readfiles.read_utt2spk(utt2spkfile)
         self.context_width = context_width
         self.max_input_length = max_input_length
+        self._stats = {}   # speaker -> accumulated statistics (the reference re-reads them for every utterance)
+        self._tables = {}  # speaker -> [2, D] float32 (mean, std), or None when the statistics are not float32
+
+    def speaker_stats(self, utt_id):
+        """the accumulated CMVN statistics of the utterance's speaker; read from the archive once per speaker"""
+        spk = self.utt2spk[utt_id]
+        stats = self._stats.get(spk)
+        if stats is None:
+            stats = self._stats[spk] = self.reader_cmvn.read_utt(spk)
+        return stats
+
+    def speaker_table(self, utt_id):
+        """[2, D] float32 (mean, standard deviation) of the utterance's speaker in the arithmetic numpy uses on float32
+        statistics -- the operand of the device-side normalisation; None when the statistics are stored as float64
+        (the host then normalises in float64, as the reference does)"""
+        spk = self.utt2spk[utt_id]
+        if spk not in self._tables:
+            stats = self.speaker_stats(utt_id)
+            self._tables[spk] = np.stack(cmvn_params(stats)) if stats.dtype == np.float32 else None
+        return self._tables[spk]
 
     def get_utt(self):
         """(utt_id, spliced features or None if too short, looped) -- reference feature_reader.py:42-60"""
         utt_id, utt_mat, looped = self.reader.read_next_utt()
-        stats = self.reader_cmvn.read_utt(self.utt2spk[utt_id])
-        if self.cmvn_on_device and utt_mat.dtype == np.float32 and stats.dtype == np.float32:
-            if utt_mat.shape[0] < 1 + 2 * self.context_width:
-                return utt_id, None, looped
-            return utt_id, Unspliced(utt_mat, self.context_width, cmvn=np.stack(cmvn_params(stats))), looped
-        normalised = apply_cmvn(utt_mat, stats)
+        return utt_id, self.finish(utt_id, utt_mat), looped
+
+    def finish(self, utt_id, utt_mat):
+        """what get_utt returns for the frames `utt_mat` as read from the archive: normalised and spliced, or the
+        deferred (`Unspliced`) form"""
+        if self.cmvn_on_device and utt_mat.dtype == np.float32:
+            table = self.speaker_table(utt_id)
+            if table is not None:
+                if utt_mat.shape[0] < 1 + 2 * self.context_width:
+                    return None
+                return Unspliced(utt_mat, self.context_width, cmvn=table)
+        normalised = apply_cmvn(utt_mat, self.speaker_stats(utt_id))
         if self.splice_on_device:
             if normalised.shape[0] < 1 + 2 * self.context_width:
-                return utt_id, None, looped
-            return utt_id, Unspliced(normalised, self.context_width), looped
-        return utt_id, splice(normalised, self.context_width), looped
+                return None
+            return Unspliced(normalised, self.context_width)
+        return splice(normalised, self.context_width)
+
+    # ---- planning interface of the batch dispenser's packed path: walk the cursor without fetching ----
+    def next_entry(self):
+        """advance like get_utt but read only the entry's header: (scp index, utt_id, frames, looped)"""
+        index, utt_id, looped = self.reader.next_entry()
+        return index, utt_id, self.reader.entry(index)[2], looped
+
+    @property
+    def min_frames(self):
+        """utterances shorter than this cannot be spliced (get_utt returns None for them)"""
+        return 1 + 2 * self.context_width
 
     def next_id(self):
         return self.reader.read_next_scp()
