@@ -12,7 +12,12 @@ of DISTINCT micro-batches (a different one every step) is resident in HBM before
 `--gpus N` with N > 1 from a bare shell launches N ranks itself (torch.distributed.run, one rank per GPU over RCCL);
 under torchrun / the driver's own launcher (WORLD_SIZE set) it joins that group.  Prints ONE JSON line on rank 0.
 
-Besides the contract's fields the line carries: `roofline` (dominant kernel, live HIP-event timing),
+`--config cfg3|cfg4` (or TFK_BENCH_CONFIG) runs BASELINE configs[2] / [3] as one GPU of their 8-GPU runs sees them
+(bf16 MFMA, 4000 / 8000 pdfs, 1024 / 2048 frames per GPU); `--gpus 8 --config cfg3` is configs[2] itself.
+
+Besides the contract's fields the line carries: `api_fed_value` (frames/s of Nnet.train itself over ark
+files: dispenser, host, PCIe, engine -- tools/nnet_train_bench.py), `decode` (log-likelihood passes host to host + the
+forward contractions' roofline), `roofline` (dominant kernel, live HIP-event timing),
 `host_fed_value` (the same step fed from HOST numpy through tfk_accumulate: PCIe inclusive, never `value`),
 `loss_trace_gpu` / `loss_trace_cpu` (per-step average_loss of the first 20 steps from the engine and from the CPU
 stand-in on the same micro-batch sequence) with their largest relative difference, `posterior_max_err` (decoder
@@ -32,16 +37,36 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_RAW, CONTEXT, L, H, O = 40, 5, 6, 2048, 2000
-UTT_PER_GPU, UTT_LEN = 16, 64
+F_RAW, CONTEXT, UTT_PER_GPU = 40, 5, 16
 F = F_RAW * (2 * CONTEXT + 1)
-T = UTT_PER_GPU * UTT_LEN
-M_MACS = F * H + (L - 1) * H * H + H * O
-FLOP_PER_FRAME = 6 * M_MACS - 2 * F * H  # fwd 2M, dW 2M, dA 2M minus the unneeded layer-0 dA
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0           # v_mfma_f32_32x32x16_bf16, dense (--dtype bfloat16 only)
+PEAK_BF16_MFMA_TFLOPS = 2500.0           # v_mfma_f32_32x32x16_bf16, dense
 TRACE_STEPS = 20                         # per-step average_loss of the first 20 steps
 MAX_RING = 16                            # distinct micro-batches resident per rank
+
+
+class Workload(object):
+    """One BASELINE.json configuration as ONE GPU sees it (weak scaling: the per-GPU micro-batch is fixed).
+    cfg2 = configs[1], the configuration the metric is quoted on and the default; cfg3 / cfg4 = configs[2] / [3], defined
+    as 8-GPU data-parallel runs (global batch 8192 / 16384 frames = 1024 / 2048 per GPU)."""
+
+    TABLE = {  # name: (hidden layers, units, pdfs, frames per GPU per step, dropout keep, arithmetic, description)
+        "cfg2": (6, 2048, 2000, 1024, 1.0, "float32", "cfg2: 6x2048 ReLU+BN DNN, 440-in (40 fbank +-5), 2000 pdf"),
+        "cfg3": (6, 2048, 4000, 1024, 1.0, "bfloat16", "cfg3: 6x2048 ReLU+BN DNN, 440-in, 4000 pdf (lda_mllt), "
+                                                        "global batch 8192 over 8 GPUs"),
+        "cfg4": (8, 4096, 8000, 2048, 0.5, "bfloat16", "cfg4: 8x4096 ReLU+BN+Dropout(0.5) DNN, 440-in, 8000 pdf "
+                                                        "(CGN scale), global batch 16384 over 8 GPUs"),
+    }
+
+    def __init__(self, name, dtype=None):
+        self.name = name
+        self.L, self.H, self.O, self.T, self.keep, default_dtype, self.text = self.TABLE[name]
+        self.dtype = dtype or default_dtype
+        self.utt_len = self.T // UTT_PER_GPU
+        self.macs = F * self.H + (self.L - 1) * self.H * self.H + self.H * self.O
+        # SURVEY 8d: fwd 2M, dW 2M, dA 2M minus the unneeded layer-0 dA
+        self.flop_per_frame = 6 * self.macs - 2 * F * self.H
+        self.peak = PEAK_FP32_MFMA_TFLOPS if self.dtype == "float32" else PEAK_BF16_MFMA_TFLOPS
 
 
 def self_launch(args):
@@ -63,15 +88,15 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def make_batches(rank, world, count, workdir):
+def make_batches(w, rank, world, count, workdir):
     """`count` micro-batches of this rank through the product I/O path (ark -> CMVN -> splice -> dispenser): step i
     of the job is the reference's batch i (world * 16 utterances in dispenser order), of which rank r takes the
     r-th 16-utterance micro-batch."""
     from tfkaldi_amd import synthetic
     from tfkaldi_amd.processing import batchdispenser, feature_reader, target_coder
-    paths = synthetic.write_corpus(workdir, UTT_PER_GPU * world * count, O, feat_dim=F_RAW, utt_len=UTT_LEN)
-    reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, UTT_LEN)
-    coder = target_coder.AlignmentCoder(lambda x, y: x, O)
+    paths = synthetic.write_corpus(workdir, UTT_PER_GPU * world * count, w.O, feat_dim=F_RAW, utt_len=w.utt_len)
+    reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, w.utt_len)
+    coder = target_coder.AlignmentCoder(lambda x, y: x, w.O)
     disp = batchdispenser.AlignmentBatchDispenser(reader, coder, UTT_PER_GPU, paths["alignments"])
     out = []
     for g in range(world * count):
@@ -81,13 +106,14 @@ def make_batches(rank, world, count, workdir):
     return out
 
 
-def cpu_baseline(batches, hidden_weights, budget_s=20.0):
+def cpu_baseline(w, batches, hidden_weights, budget_s=20.0):
     """the same optimiser steps on the host cores (PyTorch-CPU restatement; TensorFlow is not installable here)"""
     import torch
     from oracle.torch_cpu_step import TorchCpuTrainer
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 64)  # beyond ~64 threads the 1024-row GEMMs of this step stop scaling on the host
-    t = TorchCpuTrainer(F, L, H, O, nonlin="relu", batch_norm=True, threads=cores)
+    t = TorchCpuTrainer(F, w.L, w.H, w.O, nonlin="relu", batch_norm=True, threads=cores)
+    T = w.T
     t.set_hidden_weights(hidden_weights)
     trace, steps, t0 = [], 0, time.perf_counter()
     while True:
@@ -101,14 +127,17 @@ def cpu_baseline(batches, hidden_weights, budget_s=20.0):
     return {"value": steps * T / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d optimiser steps from the same initial weights over the same micro-batch sequence (%d frames "
                       "each), no warm-up, PyTorch-CPU fp32 restatement of CrossEnthropyTrainer.update (a stand-in: "
-                      "TensorFlow, the reference's CPU path, is absent)" % (steps, T)}, trace[:TRACE_STEPS]
+                      "TensorFlow, the reference's CPU path, is absent)%s" % (
+                          steps, T, "" if w.keep >= 1 else "; the stand-in has no dropout layer (the masks cost it "
+                          "nothing measurable)")}, trace[:TRACE_STEPS]
 
 
-def posterior_error(eng, X):
+def posterior_error(w, eng, X):
     """max |engine posterior - float64 oracle posterior| on one utterance, the oracle holding the engine's parameters"""
     from oracle.dnn_oracle import OracleDNN
     from tfkaldi_amd import _lib
-    orc = OracleDNN(F, L, H, O, nonlin="relu", batch_norm=True)
+    L = w.L
+    orc = OracleDNN(F, L, w.H, w.O, nonlin="relu", batch_norm=True)
     for l in range(L + 1):
         orc.W[l] = eng.get(_lib.WEIGHTS, l).astype(np.float64)
         orc.b[l] = eng.get(_lib.BIASES, l).astype(np.float64)
@@ -139,6 +168,77 @@ def measured_traffic(kernel_name):
         % (meta.get("csrc_sha16"), meta.get("measured", "?")))
 
 
+def decode_leg(w, eng, batches):
+    """The decode half of the path (reference neuralNetworks/decoder.py:49-71, nnet.py:270-286): evaluation-mode forward
+    + softmax / prior + log -> log-likelihoods on the HOST, for one batched pass of 8 micro-batches and for
+    utterance-sized passes.  Host frames in, host log-likelihoods out (PCIe both ways inside the clock); the roofline of
+    the forward contractions (2 * M flop per frame) from the engine's HIP-event profile of the batched pass."""
+    X = np.ascontiguousarray(np.concatenate([b[0] for b in batches[:8]], 0))
+    eng.set_prior(np.full(w.O, 1.0 / w.O, dtype=np.float32))
+    out = {"unit": "frames/s", "flop_per_frame": 2 * w.macs, "passes": {}}
+
+    def rate(frames, reps):
+        Xp = X[:frames]
+        eng.posteriors(Xp, log_div_prior=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.posteriors(Xp, log_div_prior=True)
+        return reps * frames / (time.perf_counter() - t0)
+
+    for frames, reps in ((300, 20), (1000, 10), (2000, 8), (X.shape[0], 5)):
+        if frames <= X.shape[0]:
+            out["passes"]["%d frames" % frames] = rate(frames, reps)
+    out["value"] = out["passes"]["%d frames" % X.shape[0]]
+    out["batched_pass_frames"] = int(X.shape[0])
+    eng.profile_begin()
+    for _ in range(3):
+        eng.posteriors(X, log_div_prior=True)
+    eng.synchronize()
+    stats = eng.profile_end()
+    gemms = [s for s in stats if s["name"].startswith("gemm_")]
+    if gemms:
+        dom = max(gemms, key=lambda s: s["total_ms"])
+        tf = dom["flops"] / dom["total_ms"] / 1e9
+        device_ms = sum(s["total_ms"] for s in stats) / 3
+        out["roofline"] = {"bound": "mfma", "kernel": kernel_label(w, dom["name"]), "achieved": tf, "peak": w.peak,
+                           "unit": "TFLOP/s", "frac": tf / w.peak,
+                           "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
+                           "device_ms_per_batched_pass": device_ms,
+                           "device_only_frames_per_s": X.shape[0] / (device_ms * 1e-3),
+                           "device_only_step_frac": X.shape[0] / (device_ms * 1e-3) * 2 * w.macs / 1e12 / w.peak}
+        out["note"] = ("`value` and `passes` are host-to-host (frames over PCIe in, %d B of log-likelihoods per frame out); "
+                       "device_only_* is the same batched pass from the engine's kernel times alone" % (4 * w.O))
+    return out
+
+
+def kernel_label(w, family):
+    """the engine names its kernel families after the fp32 kernels; say which arithmetic actually ran"""
+    return family if w.dtype == "float32" else family.replace("gemm_f32", "gemm_bf16")
+
+
+def api_fed_leg(w, world, steps):
+    """`Nnet.train` itself (tools/nnet_train_bench.py): the reference's entry point over ark files, dispenser included.
+    COLLECTIVE under data parallelism: every rank calls it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from nnet_train_bench import measure
+    out = {}
+    # the same work per step as `value`: one 16-utterance micro-batch per GPU per optimiser step
+    r = measure(w.name, UTT_PER_GPU * world, UTT_PER_GPU, steps + 8, 8, packed=True, utt_len=w.utt_len,
+                compute_dtype=w.dtype)
+    out["api_fed_value"], out["api_fed_ms_per_step"] = r["value"], r["ms_per_step"]
+    if world == 1:
+        # the reference's recipe (config_AURORA4.cfg:134-141): 128 utterances per step in micro-batches of 16, fed the
+        # packed way and the reference's way (trainer.update(*dispenser.get_batch()))
+        for key, packed in (("api_fed_value_recipe", True), ("api_fed_value_recipe_list_feed", False)):
+            out[key] = measure(w.name, 8 * UTT_PER_GPU, UTT_PER_GPU, 20 + 4, 4, packed=packed, utt_len=w.utt_len,
+                               compute_dtype=w.dtype)["value"]
+    out["api_fed_note"] = ("frames/s of Nnet.train (reference nnet.py:80-244) on a synthetic ark corpus: ark reads, batch "
+                           "dispenser, micro-batch construction, PCIe, engine, printed loss line -- everything between two "
+                           "optimiser steps.  api_fed_value: %d utterances x %d frames per GPU per step (the work of "
+                           "`value`); *_recipe: 128 utterances per step in 8 micro-batches" % (UTT_PER_GPU, w.utt_len))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,14 +247,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64-trace", action="store_true",
                     help="skip the float64-oracle loss trace (about a minute of host numpy behind the CPU baseline)")
-    ap.add_argument("--dtype", choices=["float32", "bfloat16"], default="float32",
-                    help="float32 (default) is BASELINE cfg2's arithmetic and the only valid headline; bfloat16 runs "
-                         "the same workload in the engine's mixed-precision mode (cfg3/cfg4 arithmetic) for reference")
+    ap.add_argument("--config", choices=sorted(Workload.TABLE), default=os.environ.get("TFK_BENCH_CONFIG", "cfg2"),
+                    help="BASELINE.json configuration as one GPU sees it: cfg2 (default; configs[1], the one the metric is "
+                         "quoted on, fp32), cfg3 / cfg4 (configs[2] / [3]: the 8-GPU bf16 runs, --gpus 8).  Also "
+                         "TFK_BENCH_CONFIG")
+    ap.add_argument("--dtype", choices=["float32", "bfloat16"], default=None,
+                    help="arithmetic of the GEMMs; default = the configuration's own (cfg2 float32, cfg3 / cfg4 bfloat16)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (N = 1 only)")
+    ap.add_argument("--no-api-fed", action="store_true",
+                    help="skip the Nnet.train leg (api_fed_value; also TFK_BENCH_API_FED=0)")
     ap.add_argument("--exchange", choices=["sharded", "allreduce"], default=None,
                     help="N > 1: reduce-scatter + sharded Adam + all-gather (default) or all-reduce + full Adam")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    w = Workload(args.config, args.dtype)
+    args.dtype = w.dtype
+    L, H, O, T = w.L, w.H, w.O, w.T
 
     # stdout carries exactly ONE line, the JSON record: libraries that chat on stdout (RCCL prints its library
     # path from C stdio at teardown) are diverted to stderr until the record is written
@@ -176,10 +285,10 @@ def main():
     total_steps = args.steps + args.warmup
     ring = max(1, min(total_steps, MAX_RING))
     with tempfile.TemporaryDirectory(prefix="tfkaldi_bench_") as workdir:
-        batches = make_batches(rank, world, ring, os.path.join(workdir, "rank%d" % rank))
+        batches = make_batches(w, rank, world, ring, os.path.join(workdir, "rank%d" % rank))
     assert all(X.shape == (T, F) and X.dtype == np.float32 and y.shape == (T,) for X, y in batches)
 
-    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, init_learning_rate=1e-3,
+    cfg = _lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, keep_prob=w.keep, init_learning_rate=1e-3,
                            num_steps=3 * total_steps, max_frames=T, device=local_rank, compute_dtype=args.dtype)
     eng = Engine(cfg, torch_state=dp.enabled)
     rng = np.random.default_rng(7)
@@ -282,12 +391,12 @@ def main():
         backend = dist.get_backend()
 
     if rank == 0:
-        gemms = [s for s in stats if s["name"].startswith("gemm_f32")]
+        gemms = [s for s in stats if s["name"].startswith("gemm_")]
         dom = max(gemms, key=lambda s: s["total_ms"])
         achieved = dom["flops"] / dom["total_ms"] / 1e9  # TFLOP/s
         all_gemm_tf = sum(s["flops"] for s in gemms) / sum(s["total_ms"] for s in gemms) / 1e9
         value = world * T * args.steps / elapsed
-        peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "float32" else PEAK_BF16_MFMA_TFLOPS
+        peak = w.peak
         traffic, traffic_src = (None, "fp32 only") if args.dtype != "float32" else measured_traffic(dom["name"])
         out = {
             "metric": "acoustic frames/sec (train step)", "value": value, "unit": "frames/s", "n_gpus": world,
@@ -299,10 +408,11 @@ def main():
             "data": "synthetic ark/scp/alignment files (SURVEY 8d) read through the feature reader + dispenser, %d "
                     "distinct micro-batches per rank cycled (a different one every step); random-init weights "
                     "N(0,1/sqrt(d_in)), zero output layer" % ring,
-            "config": {"workload": "cfg2: 6x2048 ReLU+BN DNN, 440-in (40 fbank +-5), 2000 pdf, %d frames/GPU/step, "
-                                   "%s, Adam" % (T, "fp32 MFMA" if args.dtype == "float32" else "bf16 MFMA (mixed precision)"),
-                       "frames_per_gpu": T, "global_frames": world * T,
-                       "parallelism": "dp%d" % world, "flop_per_frame": FLOP_PER_FRAME},
+            "lib_build_id": eng.lib.tfk_build_id().decode(),
+            "config": {"workload": "%s, %d frames/GPU/step, %s, Adam" % (
+                           w.text, T, "fp32 MFMA" if args.dtype == "float32" else "bf16 MFMA (mixed precision)"),
+                       "name": w.name, "frames_per_gpu": T, "global_frames": world * T,
+                       "parallelism": "dp%d" % world, "flop_per_frame": w.flop_per_frame},
             "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend,
             # what RAN, not what was asked for: the exchange mode the reducer settled on after probing the backend and
             # the torch.distributed calls of the last timed step, in launch order
@@ -313,29 +423,29 @@ def main():
             "dp_host_ms_per_step": ({k: 1e3 * v / max(1, reducer.host_calls["finish_and_apply"])
                                      for k, v in reducer.host_s.items()} if reducer else None),
             "per_rank_ms_per_step": per_rank_ms,
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": kernel_label(w, dom["name"]), "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                          "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
                          "all_gemm_tflops": all_gemm_tf,
-                         "step_tflops": value / world * FLOP_PER_FRAME / 1e12,
-                         "step_frac": value / world * FLOP_PER_FRAME / 1e12 / peak},
+                         "step_tflops": value / world * w.flop_per_frame / 1e12,
+                         "step_frac": value / world * w.flop_per_frame / 1e12 / peak},
             "host_fed_value": world * T * args.steps / elapsed_host,
-            "host_fed_note": "same step, micro-batch handed over as HOST numpy [1024, 440] + targets through "
-                             "tfk_accumulate (PCIe inclusive; never `value`)",
+            "host_fed_note": "same step, micro-batch handed over as HOST numpy [%d, 440] + targets through "
+                             "tfk_accumulate (PCIe inclusive; never `value`)" % T,
             "loss_first_last": [losses[0], losses[-1]],
             "loss_trace_gpu": losses[:TRACE_STEPS],
-            "kernel_ms_per_step": {s["name"]: s["total_ms"] / args.steps for s in stats},
+            "kernel_ms_per_step": {kernel_label(w, s["name"]): s["total_ms"] / args.steps for s in stats},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], trace_cpu = cpu_baseline(batches, hidden)
+            out["cpu_baseline"], trace_cpu = cpu_baseline(w, batches, hidden)
             out["loss_trace_cpu"] = trace_cpu
             n = min(len(trace_cpu), len(out["loss_trace_gpu"]))
             if n:
                 out["loss_trace_max_rel_diff"] = max(abs(a - b) / max(abs(b), 1e-30)
                                                      for a, b in zip(out["loss_trace_gpu"][:n], trace_cpu[:n]))
-            if not args.no_f64_trace and args.dtype == "float32":
+            if not args.no_f64_trace and args.dtype == "float32" and w.name == "cfg2":
                 # the referee (same leg as the CPU baseline: oracle code, after every timed region): the float64 oracle
                 # over the same weights and micro-batches -- how far each fp32 implementation is from the specified
                 # arithmetic, not merely from the other one
@@ -350,8 +460,17 @@ def main():
                 out["loss_trace_cpu_vs_f64_max_rel_diff"] = max(cpu_rel) if cpu_rel else None
                 out["loss_trace_f64_rel_diff_per_step"] = {"engine": gpu_rel, "cpu_fp32": cpu_rel}
             dp.gather_parameters(eng)
-            out["posterior_max_err"] = posterior_error(eng, batches[0][0][:UTT_LEN])
+            out["posterior_max_err"] = posterior_error(w, eng, batches[0][0][:w.utt_len])
+        if world == 1 and not args.no_decode:
+            out["decode"] = decode_leg(w, eng, batches)
     eng.close()
+    if not args.no_api_fed and os.environ.get("TFK_BENCH_API_FED", "1") != "0":
+        try:
+            fed = api_fed_leg(w, world, min(max(args.steps, 20), 60))
+        except Exception as exc:  # noqa: BLE001  (the contract's line must still be printed)
+            fed = {"api_fed_value": None, "api_fed_error": "%s: %s" % (type(exc).__name__, exc)}
+        if rank == 0:
+            out.update(fed)
     if dp.enabled:
         dist.destroy_process_group()
     if rank == 0:

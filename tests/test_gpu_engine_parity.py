@@ -7,6 +7,8 @@ Tolerances (fp32 arithmetic on the GPU vs float64 oracle; BASELINE.json asks for
   parameters after Adam        see test_multi_step_training (Adam divides by sqrt(v): it amplifies round-off of
                                near-zero gradients, in TF as much as here)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -361,3 +363,17 @@ def test_apply_without_frames_fails_loudly(gpu):
     assert_close("loss", eng.apply(), oracle.apply(), 2e-5, 0)
     assert eng.global_step == 1
     eng.close()
+
+
+def test_parity_with_the_optimiser_on_its_own_stream():
+    """TFK_ADAM_OVERLAP=1 (off by default: measured no faster, profiles/r03_fusion_experiments.txt) moves Adam to a second
+    stream behind per-layer events; every reader of parameters, gradients or moments must join it.  The training, Adam
+    known-answer, evaluation / tensor-get and layer-wise growth tests of this file, run again with the switch on."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TFK_ADAM_OVERLAP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "multi_step_training or adam_known_answer or eval_and_posteriors or layerwise_growth or "
+                        "data_parallel_equivalence"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

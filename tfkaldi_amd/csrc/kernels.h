@@ -91,10 +91,10 @@ void grad_final(hipStream_t s, const FinalBatch& b);
 
 // ---- softmax cross-entropy (trainer.py:526-531): row_loss[t] = logsumexp(z_t) - z_t[y_t];
 // with_grad: logits <- softmax(z) - onehot(y) in place (sum-reduced loss => no 1/T factor).
-// scalars != nullptr: the loss accumulators are updated in the same launch (what loss_reduce does), by the block that
-// finishes last -- ticket: a device int that is 0 between launches; overwrite as loss_reduce
+// (the variant that also sums the losses in the same launch -- last block by ticket -- was measured slower than the
+// second launch and is archived: tools/experiments/r03_softmax_xent_ticket.patch)
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
-                  int with_grad, Twin tw = Twin(), float* scalars = nullptr, bool overwrite = false, int* ticket = nullptr);
+                  int with_grad, Twin tw = Twin());
 // scalars[0] += sum(row_loss), scalars[1] += T, scalars[2] += 1
 // overwrite: the accumulators were logically re-initialised since the last call (no memset needed)
 void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite);

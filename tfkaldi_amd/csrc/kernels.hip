@@ -724,10 +724,8 @@ colsum_partial_kernel(const float* __restrict__ x, int T, int ld, int rows_per, 
 template <int NV>  // float4 per thread; NV == 0: generic (re-reads global)
 __global__ void __launch_bounds__(256)
 softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, int O, int ld,
-                    float* __restrict__ row_loss, int with_grad, Twin tw, float* __restrict__ scalars, int overwrite,
-                    int* __restrict__ ticket) {
+                    float* __restrict__ row_loss, int with_grad, Twin tw) {
   __shared__ float sm[4];
-  __shared__ int is_last;
   const int row = blockIdx.x;
   float* zr = logits + (size_t)row * ld;
   const int label = y[row];
@@ -769,8 +767,7 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
     for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
   }
   se = block_sum(se, sm);
-  // the frame's loss, written through (the LAST block to finish sums all of them: see below)
-  if (threadIdx.x == 0) __hip_atomic_store(&row_loss[row], (mx + logf(se)) - zy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) row_loss[row] = (mx + logf(se)) - zy;  // summed by loss_reduce (a second, 6 us launch)
   if (with_grad) {
     const float inv = 1.f / se;
     if (NV > 0) {
@@ -795,27 +792,6 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
         if (tw.p) tw.p[(size_t)row * tw.ld + c] = to_bf16(g);
       }
     }
-  }
-  // batch_loss += sum of the frames' losses, num_frames += T (trainer.py:165-169) WITHOUT a second launch (round 3): every
-  // block takes a ticket once its loss is out (written through, drained); the block that draws the last ticket sums the T
-  // losses in a fixed order -- the result does not depend on which block that is -- and hands the ticket counter back at
-  // zero.  No block waits for another one.
-  if (!scalars) return;
-  const int T = (int)gridDim.x;
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    is_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == T - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < T; i += 256) s += __hip_atomic_load(&row_loss[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  s = block_sum(s, sm);
-  if (threadIdx.x == 0) {
-    scalars[0] = overwrite ? s : scalars[0] + s;
-    scalars[1] = overwrite ? (float)T : scalars[1] + (float)T;
-    scalars[2] = overwrite ? 1.f : scalars[2] + 1.f;
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1170,12 +1146,10 @@ void grad_final(hipStream_t s, const FinalBatch& b) {
 }
 
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
-                  int with_grad, Twin tw, float* scalars, bool overwrite, int* ticket) {
+                  int with_grad, Twin tw) {
   const int nc4 = ld / 4;
   const dim3 g(T), b(256);
-  const int ow = overwrite ? 1 : 0;
-#define TFK_SMX(NV) \
-  hipLaunchKernelGGL(softmax_xent_kernel<NV>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw, scalars, ow, ticket)
+#define TFK_SMX(NV) hipLaunchKernelGGL(softmax_xent_kernel<NV>, g, b, 0, s, logits, y, O, ld, row_loss, with_grad, tw)
   if (nc4 <= 256) TFK_SMX(1);
   else if (nc4 <= 512) TFK_SMX(2);
   else if (nc4 <= 1024) TFK_SMX(4);

@@ -32,7 +32,6 @@ def init_from_env():
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             use_gpu = torch.cuda.is_available()
             if use_gpu:
                 # TFK_SHARE_DEVICE=1 (tests only): several ranks on one GPU -- RCCL refuses that, so pair it
@@ -42,6 +41,11 @@ def init_from_env():
                 torch.cuda.set_device(local_rank)
             backend = os.environ.get("TFK_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
             if backend == "nccl":
+                if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+                    # (tfkaldi_amd/__init__.py sets it unless the launcher exported another value)
+                    raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=%r: RCCL between processes needs dmabuf IPC on this "
+                                       "driver -- export HSA_ENABLE_IPC_MODE_LEGACY=0 before the first HIP call"
+                                       % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
                 dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                         device_id=torch.device("cuda", local_rank))
             else:
@@ -146,7 +150,7 @@ class BucketReducer(object):
     probe collective on a scratch tensor next to the engine state, agreed over all ranks (gloo on device memory, used by
     the single-GPU tests, cannot): without it the reducer runs "allreduce" and says so; with TFK_DP_EMULATE_RS=1
     (tests) the sharded protocol runs with the reduce-scatter emulated by an all-reduce.  Errors of the collectives
-    themselves are never swallowed.
+    themselves are never swallowed -- the probe's included when the backend is RCCL.
 
     The first TFK_DP_VERIFY_STEPS (default 2) sharded steps end with a replica check: every rank's checksum of the
     gathered parameters (tfk_param_checksum) must agree, otherwise the step raises -- a mis-ordered collective would
@@ -221,13 +225,22 @@ class BucketReducer(object):
         with self._stream_ctx():  # (the scratch tensor too: operands and collectives on one stream)
             scratch = self.view.new_zeros(n)
             own = scratch[self.rank * 4:(self.rank + 1) * 4]
+            # Only a backend that CANNOT do the operation on this kind of tensor is a reason to fall back (gloo on device
+            # memory: the single-GPU tests).  On RCCL a failing probe is a fault of the job -- a RuntimeError like any
+            # other -- and is raised: swallowed, it would silently turn the whole run into all-reduce + replicated optimiser
+            # (and ranks that did not fail would wait inside the probe for ever).
+            can_fall_back = d.get_backend(self.group) != "nccl"
             try:
                 d.reduce_scatter_tensor(own, scratch, op=d.ReduceOp.SUM, group=self.group)
             except (RuntimeError, NotImplementedError):
+                if not can_fall_back:
+                    raise
                 ok_rs = 0
             try:
                 d.all_gather_into_tensor(scratch, own, group=self.group)
             except (RuntimeError, NotImplementedError):
+                if not can_fall_back:
+                    raise
                 ok_ag = 0
             flags = scratch.new_tensor([float(ok_rs), float(ok_ag)])
             d.all_reduce(flags, op=d.ReduceOp.MIN, group=self.group)
@@ -235,11 +248,11 @@ class BucketReducer(object):
         emulate = os.environ.get("TFK_DP_EMULATE_RS") == "1"
         self.rs_impl = "native" if ok_rs else ("emulated" if emulate else None)
         self.ag_impl = "native" if ok_ag else "emulated"  # (list-form all_gather into views: always available)
-        if self.rs_impl is None and self.rank == 0:
+        if self.rs_impl is None:  # (said by EVERY rank: the log of any one of them shows the mode the job settled on)
             import sys
-            sys.stderr.write("tfkaldi_amd.dataparallel: backend %r cannot reduce-scatter %s tensors in place; the exchange "
-                             "step runs as all-reduce + replicated optimiser\n"
-                             % (d.get_backend(self.group), self.view.device))
+            sys.stderr.write("tfkaldi_amd.dataparallel[rank %d]: backend %r cannot reduce-scatter %s tensors in place; the "
+                             "exchange step runs as all-reduce + replicated optimiser\n"
+                             % (self.rank, d.get_backend(self.group), self.view.device))
 
     def _param_access(self):
         if self.masters_stale:

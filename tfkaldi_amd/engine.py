@@ -360,9 +360,11 @@ class Engine(object):
         check(self.lib.tfk_halve_learning_rate(self._h))
 
     def add_layer(self):
+        self._param_access()  # (a control op on the parameters: refused while the fp32 masters are sharded)
         check(self.lib.tfk_add_layer(self._h))
 
     def init_last_layer(self):
+        self._param_access()
         check(self.lib.tfk_init_last_layer(self._h))
 
     # ---- decoding ----

@@ -160,11 +160,30 @@ class _Schedule(object):
         if gather is not None:
             gather()
 
+    def _on_rank0(self, write):
+        """rank 0 writes, everybody learns whether it worked: a failure (disk full, parameters not gathered) raised on rank
+        0 alone would leave the other ranks waiting in the barrier for ever"""
+        error = None
+        if self.net.rank == 0:
+            try:
+                write()
+            except Exception as exc:  # noqa: BLE001  (re-raised below, on every rank)
+                error = exc
+        if self.net.world > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([0 if error is None else 1], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if error is None and int(flag.item()):
+                raise RuntimeError("rank 0 failed to write the checkpoint (see its log)")
+        if error is not None:
+            raise error
+
     def save(self, name):
         self._gather()
-        if self.net.rank == 0:
-            self.trainer.save_trainer(self.training_dir + name)
-        self.net._barrier()
+        self._on_rank0(lambda: self.trainer.save_trainer(self.training_dir + name))
 
     def accept(self, loss):
         """the current model becomes the one to fall back to"""
@@ -201,6 +220,7 @@ class _Schedule(object):
         if period <= 0 or self.step % period or self.step // period >= depth:
             return
         self.net._say('adding layer, the model now holds %d/%d layers' % (self.step // period + 1, depth))
+        self._gather()  # (the control ops touch the fp32 masters: whole on every rank first)
         self.trainer.control_ops['add'].run()
         self.trainer.control_ops['init'].run()
         if self.valid is not None:
@@ -242,8 +262,6 @@ class _Schedule(object):
                 if self.step % int(conf['check_freq']) == 0:
                     self.save('step%d' % self.step)
             self._gather()
-            if self.net.rank == 0:
-                trainer.save_model(conf['savedir'] + '/final')
-            self.net._barrier()
+            self._on_rank0(lambda: trainer.save_model(conf['savedir'] + '/final'))
         finally:
             trainer.close()

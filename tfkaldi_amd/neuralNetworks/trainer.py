@@ -290,16 +290,24 @@ class Trainer(object, metaclass=ABCMeta):
         exchange keeps each span's masters on its owner).  Every rank calls it before any rank saves."""
         self.dp.gather_parameters(self.engine)
 
+    # Collective contract under data parallelism (one process per GPU):
+    #   __init__ (seed broadcast), initialize, restore_model, restore_trainer, gather_parameters, update*, evaluate*
+    #       are COLLECTIVE: every rank calls them at the same point of the program (a rank that restores or initialises
+    #       alone deadlocks the others -- the reference is single-process and has no such rule).
+    #   save_model / save_trainer are LOCAL (rank 0 alone writes) but read the fp32 parameters: every rank must have
+    #       called gather_parameters() since the last update (Nnet's schedule does); otherwise they raise on the caller.
     def save_model(self, filename):
+        """LOCAL; needs gather_parameters() on every rank first when the fp32 masters are sharded"""
         self.modelsaver.save(None, filename)
 
     def restore_model(self, filename):
-        self.dp.gather_parameters(self.engine)  # (every rank restores: collective)
+        """COLLECTIVE under data parallelism: every rank restores"""
+        self.dp.gather_parameters(self.engine)
         self.modelsaver.restore(None, filename)
 
     def save_trainer(self, filename):
         """model + the `train_variables` scope: global_step and learning_rate_fact.  As in the reference
-        (trainer.py:204-205) the Adam moments and beta powers are NOT part of a checkpoint."""
+        (trainer.py:204-205) the Adam moments and beta powers are NOT part of a checkpoint.  LOCAL (see save_model)."""
         self.modelsaver.save(None, filename)
         tmp = filename + "_trainvars.tmp%d" % os.getpid()
         with open(tmp, "wb") as fid:
@@ -308,7 +316,8 @@ class Trainer(object, metaclass=ABCMeta):
         os.replace(tmp, filename + "_trainvars")
 
     def restore_trainer(self, filename):
-        self.dp.gather_parameters(self.engine)  # (every rank restores: collective)
+        """COLLECTIVE under data parallelism: every rank restores"""
+        self.dp.gather_parameters(self.engine)
         self.modelsaver.restore(None, filename)
         with np.load(filename + "_trainvars") as data:
             self.engine.set_scalar(_lib.GLOBAL_STEP, int(data["global_step"]))

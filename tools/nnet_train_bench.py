@@ -30,8 +30,9 @@ MODELS = {"cfg2": (6, 2048, 2000, 1.0, "float32"), "cfg3": (6, 2048, 4000, 1.0, 
 F_RAW, CONTEXT, UTT_LEN = 40, 5, 64
 
 
-def _conf(expdir, model, batch_utts, per_minibatch, epochs, packed):
+def _conf(expdir, model, batch_utts, per_minibatch, epochs, packed, compute_dtype=None):
     layers, units, _, keep, dtype = MODELS[model]
+    dtype = compute_dtype or dtype
     c = configparser.ConfigParser()
     c.add_section("directories")
     c.set("directories", "expdir", expdir)
@@ -47,7 +48,7 @@ def _conf(expdir, model, batch_utts, per_minibatch, epochs, packed):
 
 
 def measure(model="cfg2", batch_utts=128, per_minibatch=16, steps=40, warmup=8, packed=True, workdir=None,
-            utt_len=UTT_LEN):
+            utt_len=UTT_LEN, compute_dtype=None):
     """Run Nnet.train for `steps` optimiser steps of `batch_utts` utterances x `utt_len` frames; returns a dict with
     frames/s over the steps after `warmup` (whole job: all ranks' frames / slowest rank's time)."""
     from tfkaldi_amd import synthetic
@@ -83,8 +84,8 @@ def measure(model="cfg2", batch_utts=128, per_minibatch=16, steps=40, warmup=8, 
         reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, utt_len)
         coder = target_coder.AlignmentCoder(lambda x, y: x, pdfs)
         disp = batchdispenser.AlignmentBatchDispenser(reader, coder, batch_utts, paths["alignments"])
-        net = nnet_mod.Nnet(_conf(os.path.join(workdir, "exp_rank%d" % rank), model, batch_utts, per_minibatch, 1, packed),
-                            F_RAW, pdfs)
+        net = nnet_mod.Nnet(_conf(os.path.join(workdir, "exp_rank%d" % rank), model, batch_utts, per_minibatch, 1, packed,
+                                  compute_dtype), F_RAW, pdfs)
         original = nnet_mod.CrossEnthropyTrainer
         nnet_mod.CrossEnthropyTrainer = Timed
         try:
