@@ -294,8 +294,8 @@ def main():
     rng = np.random.default_rng(7)
     hidden = [(rng.standard_normal((F if l == 0 else H, H)) / np.sqrt(F if l == 0 else H)).astype(np.float32)
               for l in range(L)]
-    for l, w in enumerate(hidden):
-        eng.set(_lib.WEIGHTS, l, w)
+    for l, weights in enumerate(hidden):
+        eng.set(_lib.WEIGHTS, l, weights)
 
     dev = [(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()) for X, y in batches]
     torch.cuda.synchronize()
@@ -306,8 +306,10 @@ def main():
         # the product's exchange step (tfkaldi_amd/dataparallel.py): per-layer bucket announcements from backward,
         # coalesced into a few large asynchronous collectives launched while backward is still being enqueued
         dp.mode = args.exchange
-        reducer = dp.reducer(eng)  # (collective: probes what the backend can do)
-        eng.set_bucket_callback(reducer.on_bucket)
+        # on RCCL: NativeExchange, the collectives launched by the library itself (csrc/exchange.hip); on other backends
+        # (the single-GPU dry runs over gloo) BucketReducer over torch.distributed -- same protocol
+        reducer = dp.reducer(eng)  # (collective: RCCL bootstrap / probes what the backend can do)
+        reducer.begin_step(eng)
         eng.set_later_microbatches(world - 1 - rank)
 
     counter = [0]
@@ -417,6 +419,8 @@ def main():
             # what RAN, not what was asked for: the exchange mode the reducer settled on after probing the backend and
             # the torch.distributed calls of the last timed step, in launch order
             "exchange": reducer.mode if reducer else None,
+            "exchange_driver": (("library (csrc/exchange.hip, %s)" % reducer.backend) if getattr(reducer, "native", False)
+                                else "torch.distributed (dataparallel.BucketReducer)") if reducer else None,
             "exchange_requested": (args.exchange or os.environ.get("TFK_DP_EXCHANGE", "sharded")) if reducer else None,
             "collectives_last_step": list(reducer.last_executed) if reducer else None,
             "collective_spans_last_step": [list(x) for x in reducer.last_launched] if reducer else None,

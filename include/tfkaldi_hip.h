@@ -273,6 +273,59 @@ int tfk_param_checksum(tfk_engine* e, int which, uint64_t* value);
  * rank's BN moving-average increment by bn_decay^later so the all-reduced result equals the
  * reference's sequential per-micro-batch EMA updates. */
 int tfk_set_later_microbatches(tfk_engine* e, int32_t later);
+/* The fp32 parameter arena [P] (same float offsets as the gradient part of the reduce region): what a sharded exchange
+ * step all-gathers into. */
+int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
+
+/* ---- the exchange step inside the library: RCCL over xGMI, no host language in the step ------------------------
+ *
+ * Replaces, for N > 1 GPUs, what a single reference process does between `update_gradients_op` and
+ * `apply_gradients_op` (trainer.py:165-184): the micro-batches of a step run on different GPUs, so G, batch_loss,
+ * num_frames and the BN moving-average increments are SUMMED over the ranks before mean -> clip -> Adam.  A tfk_comm
+ * attaches to one engine, installs itself behind the engine's bucket / layer hooks (tfk_set_bucket_callback /
+ * tfk_set_layer_callback: do not set your own while one is attached) and from then on
+ *     tfk_accumulate*(..., TFK_LAST_MICROBATCH)  launches the collectives while backward is still being enqueued,
+ *     tfk_comm_apply                             replaces tfk_apply          (Adam per reduced span, parameter gathers),
+ *     tfk_comm_eval_finish                       replaces tfk_eval_finish    (scalar tail summed over the ranks),
+ *     tfk_comm_idle                              a rank without a micro-batch in this step contributes zeros.
+ * Every rank makes the same calls in the same order.  Exchange modes as tfkaldi_amd/dataparallel.py (which drives the
+ * same protocol through torch.distributed for backends without RCCL):
+ *   TFK_EXCHANGE_SHARDED    in-place reduce-scatter of every coalesced span of weight gradients, Adam on this rank's
+ *                           1/world of it, in-place all-gather of the updated parameters -- in mixed precision of the
+ *                           bf16 shadow (2 B per parameter; the fp32 masters of a span then live on its owner until
+ *                           tfk_comm_gather_masters) -- consumed layer by layer by the next forward pass;
+ *   TFK_EXCHANGE_ALLREDUCE  SUM all-reduce of every span, full Adam on every rank.
+ * bucket_bytes: adjacent gradient buckets are coalesced until a collective carries at least this much (0: default,
+ * 24 MiB sharded / 48 MiB all-reduce -- xGMI is point-to-point: few large collectives beat one per layer).
+ * Bootstrap: rank 0 calls tfk_comm_unique_id, the host distributes the bytes any way it likes (torch.distributed, MPI, a
+ * file), every rank calls tfk_comm_create with them (collective: ncclCommInitRank). */
+enum { TFK_EXCHANGE_SHARDED = 0, TFK_EXCHANGE_ALLREDUCE = 1 };
+typedef struct tfk_comm tfk_comm;
+int tfk_comm_unique_id(void* id, size_t capacity, size_t* size);  /* 128 bytes */
+int tfk_comm_create(tfk_engine* e, const void* id, size_t id_size, int rank, int world, int mode, size_t bucket_bytes,
+                    tfk_comm** out);
+int tfk_comm_destroy(tfk_comm* c);  /* before tfk_destroy of its engine */
+int tfk_comm_info(tfk_comm* c, int* rank, int* world, int* mode, int* gathers_shadow);
+const char* tfk_comm_backend(tfk_comm* c);  /* "rccl" | "loopback" */
+int tfk_comm_apply(tfk_comm* c, float* average_loss);
+int tfk_comm_eval_finish(tfk_comm* c, float* average_loss);
+int tfk_comm_idle(tfk_comm* c);
+/* make the engine stream wait for parameter gathers still in flight (before the state is read behind the engine's back) */
+int tfk_comm_drain(tfk_comm* c);
+/* mixed-precision sharded exchange: are the fp32 masters currently valid on their owners only? / COLLECTIVE: bring them
+ * home (all-gather of every sharded span) before a checkpoint or a tensor get / set */
+int tfk_comm_masters_stale(tfk_comm* c, int* stale);
+int tfk_comm_gather_masters(tfk_comm* c);
+/* collectives of the last completed step: counts by kind and the (offset, floats) spans in launch order */
+int tfk_comm_last_step(tfk_comm* c, int* reduce_scatters, int* all_gathers, int* all_reduces, size_t* spans, int capacity,
+                       int* num_spans);
+/* Tests: a group of `world` engines of ONE process on ONE device; each rank is driven by its own host thread and the
+ * collectives are a rendezvous + plain kernels.  This is how the protocol above runs at world 2 / 4 / 8 on a single-GPU
+ * box (RCCL refuses two ranks on one device). */
+typedef struct tfk_loopback tfk_loopback;
+int tfk_loopback_create(int world, tfk_loopback** out);
+int tfk_loopback_destroy(tfk_loopback* group);
+int tfk_comm_create_loopback(tfk_engine* e, tfk_loopback* group, int rank, int mode, size_t bucket_bytes, tfk_comm** out);
 
 /* ---- streams, profiling, debugging ------------------------------------------------------------- */
 

@@ -1,0 +1,223 @@
+"""The exchange step INSIDE the library (csrc/exchange.hip, include/tfkaldi_hip.h: tfk_comm) at world 2 / 4 / 8 on the
+one GPU of the test box: the ranks are THREADS of this process, each driving its own engine through the product's
+DataParallel + NativeExchange; the group is the library's loopback backend (rendezvous + plain kernels instead of RCCL,
+which refuses two ranks per device) -- everything else is the code an 8-GPU job runs: bucket announcements coalesced
+into spans, in-place reduce-scatter, Adam on the rank's 1/world of every span, in-place all-gather of the parameters
+(of the bf16 shadow in mixed precision) consumed layer by layer by the next forward pass, sharded fp32 masters and
+their gather, the replica checksum, idle ranks, evaluation.  Must reproduce the single-engine run that processes all
+micro-batches serially (KAT 8c-3; reference neuralNetworks/trainer.py:165-184).  With one RCCL rank the same class
+runs over real RCCL: tests/test_gpu_rccl_single_rank.py."""
+import ctypes
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from test_gpu_dp_two_ranks import KW, _collect, _data, _engine
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Group(object):
+    """a loopback group + one (engine, DataParallel, NativeExchange) per rank"""
+
+    def __init__(self, world, mode, dtype="float32", kw=None, min_bytes=1 << 12):
+        from tfkaldi_amd import _lib
+        from tfkaldi_amd.dataparallel import DataParallel, NativeExchange
+        self.lib = _lib.load()
+        self.world = world
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.tfk_loopback_create(world, ctypes.byref(self.handle)))
+        self.engines, self.dps = [], []
+        for rank in range(world):
+            eng = _engine(torch_state=False, dtype=dtype, kw=kw)
+            dp = DataParallel(mode=mode)
+            dp.rank, dp.world, dp._forced = rank, world, True
+            dp._reducers[eng] = NativeExchange(eng, mode=mode, min_bytes=min_bytes, loopback=(self.handle, rank))
+            self.engines.append(eng)
+            self.dps.append(dp)
+
+    def run(self, fn):
+        """fn(rank, engine, dp) on every rank, each in its own thread (a collective blocks until every rank has posted it)"""
+        out, errors = [None] * self.world, []
+
+        def body(rank):
+            try:
+                out[rank] = fn(rank, self.engines[rank], self.dps[rank])
+            except BaseException as exc:  # noqa: BLE001
+                errors.append((rank, exc))
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in threads), "a rank is stuck in a collective"
+        if errors:
+            raise errors[0][1]
+        return out
+
+    def close(self):
+        from tfkaldi_amd import _lib
+        for eng in self.engines:
+            eng.close()  # (closes its comm first)
+        _lib.check(self.lib.tfk_loopback_destroy(self.handle))
+
+
+def _serial(num_mb, dtype="float32", kw=None, data=_data):
+    eng = _engine(torch_state=False, dtype=dtype, kw=kw)
+    losses = []
+    for step in (0, 1, 2):
+        mbs = data(num_mb, step)
+        for i, (X, y) in enumerate(mbs):
+            eng.accumulate(X, y, last=(i == len(mbs) - 1))
+        losses.append(eng.apply())
+    for X, y in data(num_mb, 9):
+        eng.eval_accumulate(X, y)
+    losses.append(eng.eval_finish())
+    mbs = data(num_mb, 5)
+    for i, (X, y) in enumerate(mbs):
+        eng.accumulate(X, y, last=(i == len(mbs) - 1))
+    losses.append(eng.apply())
+    out = _collect(eng, losses)
+    eng.close()
+    return out
+
+
+def _rank_program(num_mb, data=_data):
+    def program(rank, eng, dp):
+        losses = [dp.train_step(eng, data(num_mb, step)) for step in (0, 1, 2)]
+        red = dp.reducer(eng)
+        assert red.native and red.backend == "loopback"
+        info = dict(executed=list(dp.last_executed), spans=list(dp.last_collectives))
+        losses.append(dp.eval_step(eng, data(num_mb, 9)))
+        losses.append(dp.train_step(eng, data(num_mb, 5)))  # (consumes the gathers that crossed the evaluation)
+        info["stale"] = red.masters_stale
+        if info["stale"]:  # mixed precision: reading sharded fp32 masters must be refused until they are gathered
+            with pytest.raises(RuntimeError, match="gather_parameters"):
+                eng.get(0, 0)
+        dp.gather_parameters(eng)
+        assert not red.masters_stale
+        return _collect(eng, losses), info
+    return program
+
+
+def _compare(ref, got, loss_rtol, param_atol, tag):
+    assert np.allclose(got["losses"], ref["losses"], rtol=loss_rtol, atol=0), (tag, got["losses"], ref["losses"])
+    for k, v in ref.items():
+        if k == "losses":
+            continue
+        err = np.abs(got[k].astype(np.float64) - v.astype(np.float64)).max()
+        assert err <= param_atol, (tag, k, err)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("world,num_mb", [(2, 2), (2, 5), (4, 4), (4, 3), (8, 8), (8, 3)])
+def test_loopback_ranks_equal_the_serial_run_fp32(gpu, world, num_mb, mode):
+    """even shards, uneven shards, idle ranks (fewer micro-batches than ranks); every rank ends with the same parameters,
+    equal to the serial run's up to the fp32 summation order of G (ranks add their sums, the serial run adds micro-batch
+    after micro-batch), which Adam amplifies: bounds as tests/test_gpu_dp_two_ranks.py"""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    group = _Group(world, mode)
+    try:
+        results = group.run(_rank_program(num_mb))
+    finally:
+        group.close()
+    ref = _serial(num_mb)
+    for rank, (got, info) in enumerate(results):
+        _compare(ref, got, 2e-5, 2e-4, "rank %d" % rank)
+        for k, v in results[0][0].items():  # replicas: bit-identical to each other
+            np.testing.assert_array_equal(got[k], v, err_msg="rank %d %s" % (rank, k))
+        if mode == "sharded":
+            assert any("reduce_scatter" in n for n in info["executed"]) and any("all_gather" in n for n in info["executed"])
+        else:
+            assert set(info["executed"]) == {"loopback:all_reduce"}
+        assert not info["stale"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,num_mb", [(2, 2), (4, 6), (8, 8), (8, 2)])
+def test_loopback_ranks_mixed_precision_sharded_masters(gpu, world, num_mb):
+    """bf16 GEMMs: what travels back is the bf16 SHADOW (2 B per parameter); the fp32 masters of a span stay on the rank
+    that owns it until gather_parameters -- afterwards every rank holds the same masters, close to the serial run's"""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    kw = dict(KW, num_units=64, output_dim=24)  # (every leading dimension a multiple of 8: the shadow mirrors the arena)
+    group = _Group(world, "sharded", dtype="bfloat16", kw=kw)
+    try:
+        results = group.run(_rank_program(num_mb))
+    finally:
+        group.close()
+    ref = _serial(num_mb, dtype="bfloat16", kw=kw)
+    for rank, (got, info) in enumerate(results):
+        assert info["stale"], "the bf16 sharded exchange leaves the masters with their owners"
+        assert any("bf16 shadow" in n for n in info["executed"]), info["executed"]
+        _compare(ref, got, 2e-3, 2e-3, "rank %d" % rank)
+        for k, v in results[0][0].items():
+            np.testing.assert_array_equal(got[k], v, err_msg="rank %d %s" % (rank, k))
+
+
+def _data_cfg2(num_mb, seed):
+    rng = np.random.default_rng(1000 + seed)
+    return [((rng.standard_normal((256, 440)) * 1.5).astype(np.float32),
+             rng.integers(0, 2000, size=256).astype(np.int32)) for _ in range(num_mb)]
+
+
+@pytest.mark.timeout(900)
+def test_eight_loopback_ranks_at_cfg2_size(gpu):
+    """BASELINE cfg2's network (26 M parameters, 16 MB hidden-layer spans, the default 24 MB coalescing): the spans an
+    8-GPU job exchanges -- [scalar tail], W6+W5, W4+W3, W2+W1, W0, [vectors] -- every one dividing by 4 x 8"""
+    os.environ.pop("TFK_DP_MIN_SHARD", None)
+    kw = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=2000, nonlin="relu", batch_norm=True,
+              init_learning_rate=1e-3, num_steps=10, max_frames=256)
+    group = _Group(8, "sharded", kw=kw, min_bytes=None)
+    try:
+        results = group.run(_rank_program(8, data=_data_cfg2))
+    finally:
+        group.close()
+    ref = _serial(8, kw=kw, data=_data_cfg2)
+    spans = results[0][1]["spans"]
+    assert [n for _, n in spans if n > 1 << 20] == [8290304, 8388608, 8388608]  # (as bench.py's line reports them)
+    assert results[0][1]["executed"].count("loopback:reduce_scatter") == 4
+    for rank, (got, info) in enumerate(results):
+        _compare(ref, got, 2e-5, 5e-4, "rank %d" % rank)
+        for k, v in results[0][0].items():
+            np.testing.assert_array_equal(got[k], v, err_msg="rank %d %s" % (rank, k))
+
+
+def test_mismatched_collectives_fail_loudly(gpu):
+    """two ranks that launch DIFFERENT collectives (here: different exchange modes) must not hang or mix data"""
+    from tfkaldi_amd import _lib
+    from tfkaldi_amd.dataparallel import DataParallel, NativeExchange
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    lib = _lib.load()
+    handle = ctypes.c_void_p()
+    _lib.check(lib.tfk_loopback_create(2, ctypes.byref(handle)))
+    engines = [_engine(torch_state=False) for _ in range(2)]
+    reds = [NativeExchange(engines[r], mode=("sharded", "allreduce")[r], min_bytes=1 << 12, loopback=(handle, r))
+            for r in range(2)]
+    errors = []
+
+    def body(rank):
+        dp = DataParallel()
+        dp.rank, dp.world, dp._forced = rank, 2, True
+        dp._reducers[engines[rank]] = reds[rank]
+        try:
+            dp.train_step(engines[rank], _data(2, 0))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(str(exc))
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads)
+    assert errors and any("different collectives" in e or "failed earlier" in e for e in errors), errors
+    for eng in engines:
+        eng.close()
+    _lib.check(lib.tfk_loopback_destroy(handle))

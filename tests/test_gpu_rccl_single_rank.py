@@ -24,9 +24,9 @@ def _free_port():
     return port
 
 
-def _worker(rank, port, num_mb, out_dir, mode="sharded"):
+def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64")
+                      TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64", TFK_DP_COMM=comm)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
@@ -36,8 +36,12 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded"):
     assert dp.enabled
     eng = _engine(torch_state=True)
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
+    # who launched the collectives: the library itself (csrc/exchange.hip) or BucketReducer through torch.distributed
+    assert dp.reducer(eng).native == (comm == "native")
     if mode == "sharded":  # RCCL's reduce-scatter / all-gather really carried the step
         assert "rs" in dp.last_kinds, dp.last_kinds
+        assert any("reduce_scatter" in name for name in dp.last_executed), dp.last_executed
+        assert any("all_gather" in name for name in dp.last_executed), dp.last_executed
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
     np.savez(os.path.join(out_dir, "rccl.npz"), **_collect(eng, losses))
     eng.close()
@@ -45,11 +49,12 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded"):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("comm", ["native", "torch"])
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
-def test_single_rank_rccl_is_identity(gpu, tmp_path, mode):
+def test_single_rank_rccl_is_identity(gpu, tmp_path, mode, comm):
     import torch.multiprocessing as mp
     num_mb = 3
-    mp.spawn(_worker, args=(_free_port(), num_mb, str(tmp_path), mode), nprocs=1, join=True)
+    mp.spawn(_worker, args=(_free_port(), num_mb, str(tmp_path), mode, comm), nprocs=1, join=True)
     eng = _engine(torch_state=False)
     want = []
     for step in range(3):
@@ -80,8 +85,10 @@ def test_bench_dp_branch_over_rccl(gpu):
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
     assert line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl" and line["exchange"] == "sharded"
     # what RAN: RCCL's own reduce-scatter / all-gather on views of the engine state, the 24 MB coalescing of cfg2's spans
-    assert line["collectives_last_step"].count("reduce_scatter_tensor") == 4, line["collectives_last_step"]
-    assert line["collectives_last_step"].count("all_gather_into_tensor") == 4
+    assert line["exchange_driver"].startswith("library"), line["exchange_driver"]
+    assert line["collectives_last_step"].count("rccl:reduce_scatter") == 4, line["collectives_last_step"]
+    assert line["collectives_last_step"].count("rccl:all_gather") == 4
+    assert line["collectives_last_step"].count("rccl:all_reduce") == 2
     assert [n for _, n in line["collective_spans_last_step"] if n > 1 << 20] == [8290304, 8388608, 8388608]
     assert line["host_fed_value"] > 0 and len(line["loss_trace_gpu"]) == 7
 

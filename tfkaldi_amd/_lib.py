@@ -23,6 +23,7 @@ DEVICE_PTRS, LAST_MICROBATCH, LOG_DIV_PRIOR, RAW_LOGITS, RAW_DEVICE = 1, 2, 4, 8
 DBG_LOGITS, DBG_HIDDEN, DBG_DROPOUT_MASK = range(3)
 GEMM_NN, GEMM_NT, GEMM_TN = range(3)
 EPI_BIAS, EPI_ACCUM, EPI_RELU = 1, 2, 4
+EXCHANGE = {"sharded": 0, "allreduce": 1}  # TFK_EXCHANGE_*
 
 
 class TfkConfig(Structure):
@@ -109,6 +110,23 @@ SYMBOLS = {
     "tfk_shadow_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "tfk_apply_writes_shadow": (c_int, [_E, POINTER(c_int)]),
     "tfk_param_checksum": (c_int, [_E, c_int, POINTER(c_uint64)]),
+    "tfk_param_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t)]),
+    "tfk_comm_unique_id": (c_int, [c_void_p, c_size_t, POINTER(c_size_t)]),
+    "tfk_comm_create": (c_int, [_E, c_void_p, c_size_t, c_int, c_int, c_int, c_size_t, POINTER(c_void_p)]),
+    "tfk_comm_destroy": (c_int, [c_void_p]),
+    "tfk_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "tfk_comm_backend": (c_char_p, [c_void_p]),
+    "tfk_comm_apply": (c_int, [c_void_p, POINTER(c_float)]),
+    "tfk_comm_eval_finish": (c_int, [c_void_p, POINTER(c_float)]),
+    "tfk_comm_idle": (c_int, [c_void_p]),
+    "tfk_comm_drain": (c_int, [c_void_p]),
+    "tfk_comm_masters_stale": (c_int, [c_void_p, POINTER(c_int)]),
+    "tfk_comm_gather_masters": (c_int, [c_void_p]),
+    "tfk_comm_last_step": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_int,
+                                   POINTER(c_int)]),
+    "tfk_loopback_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "tfk_loopback_destroy": (c_int, [c_void_p]),
+    "tfk_comm_create_loopback": (c_int, [_E, c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p)]),
     "tfk_synchronize": (c_int, [_E]),
     "tfk_stream": (c_int, [_E, POINTER(c_void_p)]),
     "tfk_profile_begin": (c_int, [_E]),

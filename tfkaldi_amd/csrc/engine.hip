@@ -1839,6 +1839,12 @@ int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {
   *num_floats = e->reduce_floats;
   return 0;
 }
+int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {
+  if (!e || !device_ptr || !num_floats) return fail(-1, "NULL argument");
+  *device_ptr = e->p_param();
+  *num_floats = e->P;
+  return 0;
+}
 int tfk_num_buckets(tfk_engine* e, int* n) {
   if (!e || !n) return fail(-1, "NULL argument");
   *n = e->L + 3;

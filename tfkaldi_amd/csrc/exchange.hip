@@ -1,0 +1,782 @@
+// The exchange step of data-parallel training INSIDE the library (include/tfkaldi_hip.h, "tfk_comm"): the reference's
+// only coupling between micro-batches -- G += g, batch_loss += loss, num_frames += n (neuralNetworks/trainer.py:165-169)
+// followed by one mean -> clip -> Adam (:174-184) -- as collectives over RCCL / xGMI, launched from C++ on a stream the
+// library owns, with no host language in the step.
+//
+// Protocol (the one tfkaldi_amd/dataparallel.py BucketReducer runs through torch.distributed; that class stays as the
+// gloo test double and as the fallback, this file is what runs on RCCL):
+//   backward announces gradient buckets (engine hook, tfk_set_bucket_callback) -> adjacent buckets are coalesced until a
+//   collective carries >= bucket_bytes -> "sharded": in-place reduce-scatter of the span, Adam on this rank's 1/world of
+//   it (tfk_apply_span), in-place all-gather of the updated parameters (mixed precision: of the bf16 weight shadow the
+//   forward pass reads, half the bytes; the fp32 masters stay with their owner) -- "allreduce": SUM all-reduce + full Adam.
+//   The bias / beta vectors and the scalar + BN tail are always all-reduced.  The next forward pass waits layer by layer
+//   for the gather that covers the layer it is about to read (engine hook, tfk_set_layer_callback).
+// Streams: collectives run on ONE comm stream per engine, in launch order; the engine stream and the comm stream are
+// ordered against each other by events only (gradients ready -> collective -> done -> Adam -> gather -> done -> forward).
+//
+// Built on the PUBLIC engine ABI only (the same calls a host language would make).  RCCL is bound at run time
+// (dlopen "librccl.so.1": the copy the process already holds, e.g. PyTorch's), so the library has no link dependency on it.
+// TFK_COMM_LOOPBACK (tests): N engines of ONE process on one GPU form a group; collectives are rendezvous + plain kernels.
+// That is how the C++ protocol is exercised at world 2 / 4 / 8 on a single-GPU box (RCCL refuses two ranks per device).
+#include "../../include/tfkaldi_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace tfk {
+int set_error(int code, const char* msg);  // engine.hip: the library's thread-local error message
+}
+
+namespace {
+
+int failx(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return tfk::set_error(code ? code : -1, buf);
+}
+#define XHIP(expr)                                                                                          \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) return failx((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define XCHK(expr)           \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+// ---- RCCL, bound at run time ----
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // by SONAME: a process that already holds a copy (PyTorch ships its own next to its HIP runtime) gets THAT one
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) {
+      r.error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+      return;
+    }
+#define BIND(field, sym)                                                    \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym));     \
+  if (!r.field && r.error.empty()) r.error = std::string("librccl lacks ") + sym
+    BIND(GetUniqueId, "ncclGetUniqueId");
+    BIND(CommInitRank, "ncclCommInitRank");
+    BIND(CommDestroy, "ncclCommDestroy");
+    BIND(AllReduce, "ncclAllReduce");
+    BIND(ReduceScatter, "ncclReduceScatter");
+    BIND(AllGather, "ncclAllGather");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+  });
+  return &r;
+}
+#define XNCCL(expr)                                                                                              \
+  do {                                                                                                           \
+    ncclResult_t r_ = (expr);                                                                                    \
+    if (r_ != ncclSuccess) return failx((int)r_, "%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---- the collectives the protocol needs; every one IN PLACE on `world` equal shards ----
+struct Backend {
+  int rank = 0, world = 1;
+  virtual ~Backend() {}
+  // buf[0 : world * per_rank) -> this rank's shard [rank * per_rank, +per_rank) holds the SUM over ranks
+  virtual int reduce_scatter(float* buf, size_t per_rank, hipStream_t st) = 0;
+  // every rank's shard (bytes_per_rank at rank * bytes_per_rank) -> all shards everywhere
+  virtual int all_gather(void* buf, size_t bytes_per_rank, hipStream_t st) = 0;
+  virtual int all_reduce(float* buf, size_t count, hipStream_t st) = 0;
+  // host-level: v[0] = min over ranks, v[1] = max over ranks of the value passed in v[0] (blocks the calling thread)
+  virtual int min_max(unsigned long long* v, hipStream_t st) = 0;
+  virtual const char* name() const = 0;
+};
+
+struct RcclBackend : Backend {
+  ncclComm_t comm = nullptr;
+  unsigned long long* d_pair = nullptr;
+  ~RcclBackend() override {
+    if (comm) rccl()->CommDestroy(comm);
+    if (d_pair) (void)hipFree(d_pair);
+  }
+  int reduce_scatter(float* buf, size_t per_rank, hipStream_t st) override {
+    XNCCL(rccl()->ReduceScatter(buf, buf + (size_t)rank * per_rank, per_rank, ncclFloat32, ncclSum, comm, st));
+    return 0;
+  }
+  int all_gather(void* buf, size_t bytes_per_rank, hipStream_t st) override {
+    char* b = static_cast<char*>(buf);
+    XNCCL(rccl()->AllGather(b + (size_t)rank * bytes_per_rank, b, bytes_per_rank, ncclInt8, comm, st));
+    return 0;
+  }
+  int all_reduce(float* buf, size_t count, hipStream_t st) override {
+    XNCCL(rccl()->AllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, st));
+    return 0;
+  }
+  int min_max(unsigned long long* v, hipStream_t st) override {
+    if (!d_pair) XHIP(hipMalloc((void**)&d_pair, 2 * sizeof(unsigned long long)));
+    const unsigned long long in[2] = {v[0], v[0]};
+    XHIP(hipMemcpyAsync(d_pair, in, sizeof(in), hipMemcpyHostToDevice, st));
+    XNCCL(rccl()->AllReduce(d_pair, d_pair, 1, ncclUint64, ncclMin, comm, st));
+    XNCCL(rccl()->AllReduce(d_pair + 1, d_pair + 1, 1, ncclUint64, ncclMax, comm, st));
+    XHIP(hipMemcpyAsync(v, d_pair, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    XHIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  const char* name() const override { return "rccl"; }
+};
+
+// ---- loopback: the ranks are threads of one process on one device ----
+constexpr int kLoopMaxWorld = 16;
+struct SrcList {
+  const float* p[kLoopMaxWorld];
+};
+__global__ void loop_sum_kernel(float* __restrict__ dst, SrcList src, int world, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = src.p[0][i];
+    for (int q = 1; q < world; ++q) s += src.p[q][i];  // rank order: the order a serial run adds micro-batches in
+    dst[i] = s;
+  }
+}
+
+}  // namespace
+
+struct tfk_loopback {
+  int world = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long long generation = 0;
+  struct Slot {
+    int kind = 0;  // 0 reduce-scatter, 1 all-gather, 2 all-reduce, 3 min / max
+    void* buf = nullptr;
+    size_t count = 0;  // per-rank floats (0), per-rank bytes (1), floats (2)
+    hipStream_t st = nullptr;
+    hipEvent_t arrive = nullptr, finish = nullptr;
+    unsigned long long value = 0;
+  };
+  std::vector<Slot> slot;
+  float* scratch = nullptr;
+  size_t scratch_floats = 0;
+  hipEvent_t sum_done = nullptr;
+  unsigned long long vmin = 0, vmax = 0;
+  int error = 0;
+  std::string error_text;
+};
+
+namespace {
+
+struct LoopBackend : Backend {
+  tfk_loopback* g = nullptr;
+  hipEvent_t arrive = nullptr, finish = nullptr;
+  ~LoopBackend() override {
+    if (arrive) (void)hipEventDestroy(arrive);
+    if (finish) (void)hipEventDestroy(finish);
+  }
+  // run by the LAST rank to arrive, with the group's mutex held: enqueue the operation for every rank
+  static int run(tfk_loopback* g) {
+    const int W = g->world;
+    const tfk_loopback::Slot& s0 = g->slot[0];
+    for (int r = 1; r < W; ++r)
+      if (g->slot[r].kind != s0.kind || g->slot[r].count != s0.count)
+        return failx(-1, "loopback group: rank %d posted collective kind %d x %zu, rank 0 kind %d x %zu -- the ranks "
+                         "launched different collectives", r, g->slot[r].kind, g->slot[r].count, s0.kind, s0.count);
+    if (s0.kind == 3) {
+      g->vmin = g->vmax = g->slot[0].value;
+      for (int r = 1; r < W; ++r) {
+        g->vmin = std::min(g->vmin, g->slot[r].value);
+        g->vmax = std::max(g->vmax, g->slot[r].value);
+      }
+      return 0;
+    }
+    for (int r = 0; r < W; ++r)  // nobody starts before every rank's operand is ready
+      for (int q = 0; q < W; ++q) XHIP(hipStreamWaitEvent(g->slot[r].st, g->slot[q].arrive, 0));
+    const size_t n = s0.count;
+    if (s0.kind == 0) {
+      for (int r = 0; r < W; ++r) {
+        SrcList src;
+        for (int q = 0; q < W; ++q) src.p[q] = static_cast<const float*>(g->slot[q].buf) + (size_t)r * n;
+        float* dst = static_cast<float*>(g->slot[r].buf) + (size_t)r * n;
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(loop_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, g->slot[r].st, dst, src, W, n);
+      }
+    } else if (s0.kind == 1) {
+      for (int r = 0; r < W; ++r)
+        for (int q = 0; q < W; ++q)
+          if (q != r)
+            XHIP(hipMemcpyAsync(static_cast<char*>(g->slot[r].buf) + (size_t)q * n,
+                                static_cast<const char*>(g->slot[q].buf) + (size_t)q * n, n, hipMemcpyDeviceToDevice,
+                                g->slot[r].st));
+    } else {
+      if (n > g->scratch_floats) {
+        if (g->scratch) XHIP(hipFree(g->scratch));  // (synchronises the device: every earlier operation is over)
+        g->scratch = nullptr;
+        XHIP(hipMalloc((void**)&g->scratch, n * sizeof(float)));
+        g->scratch_floats = n;
+      }
+      SrcList src;
+      for (int q = 0; q < W; ++q) src.p[q] = static_cast<const float*>(g->slot[q].buf);
+      const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+      hipLaunchKernelGGL(loop_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, g->slot[0].st, g->scratch, src, W, n);
+      XHIP(hipEventRecord(g->sum_done, g->slot[0].st));
+      for (int r = 0; r < W; ++r) {
+        XHIP(hipStreamWaitEvent(g->slot[r].st, g->sum_done, 0));
+        XHIP(hipMemcpyAsync(g->slot[r].buf, g->scratch, n * sizeof(float), hipMemcpyDeviceToDevice, g->slot[r].st));
+      }
+    }
+    XHIP(hipGetLastError());
+    // ... and nobody's operation is complete before every rank has finished reading its peers' buffers
+    for (int r = 0; r < W; ++r) XHIP(hipEventRecord(g->slot[r].finish, g->slot[r].st));
+    for (int r = 0; r < W; ++r)
+      for (int q = 0; q < W; ++q)
+        if (q != r) XHIP(hipStreamWaitEvent(g->slot[r].st, g->slot[q].finish, 0));
+    return 0;
+  }
+  int post(int kind, void* buf, size_t count, hipStream_t st, unsigned long long value = 0) {
+    if (!arrive) {
+      XHIP(hipEventCreateWithFlags(&arrive, hipEventDisableTiming));
+      XHIP(hipEventCreateWithFlags(&finish, hipEventDisableTiming));
+    }
+    if (kind != 3) XHIP(hipEventRecord(arrive, st));
+    std::unique_lock<std::mutex> lock(g->m);
+    if (g->error) return failx(g->error, "loopback group failed earlier: %s", g->error_text.c_str());
+    tfk_loopback::Slot& s = g->slot[rank];
+    s.kind = kind; s.buf = buf; s.count = count; s.st = st; s.arrive = arrive; s.finish = finish; s.value = value;
+    const unsigned long long gen = g->generation;
+    if (++g->arrived == g->world) {
+      const int rc = run(g);
+      if (rc) {
+        g->error = rc;
+        g->error_text = tfk_last_error();
+      }
+      g->arrived = 0;
+      g->generation += 1;
+      g->cv.notify_all();
+    } else {
+      g->cv.wait(lock, [&] { return g->generation != gen; });
+    }
+    if (g->error) return failx(g->error, "%s", g->error_text.c_str());
+    return 0;
+  }
+  int reduce_scatter(float* buf, size_t per_rank, hipStream_t st) override { return post(0, buf, per_rank, st); }
+  int all_gather(void* buf, size_t bytes_per_rank, hipStream_t st) override { return post(1, buf, bytes_per_rank, st); }
+  int all_reduce(float* buf, size_t count, hipStream_t st) override { return post(2, buf, count, st); }
+  int min_max(unsigned long long* v, hipStream_t st) override {
+    XCHK(post(3, nullptr, 0, st, v[0]));
+    // (the values stay valid until the next operation completes, which needs this rank again)
+    v[0] = g->vmin;
+    v[1] = g->vmax;
+    return 0;
+  }
+  const char* name() const override { return "loopback"; }
+};
+
+struct Span {
+  size_t off = 0, n = 0;
+  bool rs = false;
+  hipEvent_t ready = nullptr, done = nullptr;
+  bool waited = false;
+};
+struct Gather {
+  size_t off = 0, n = 0;
+  hipEvent_t done = nullptr;
+};
+
+}  // namespace
+
+struct tfk_comm {
+  tfk_engine* e = nullptr;
+  Backend* be = nullptr;
+  int mode = TFK_EXCHANGE_SHARDED;
+  int device = 0;  // the engine's device: events and the comm stream are created on it, every entry point selects it
+  size_t min_floats = 0, min_shard_floats = 1 << 14;
+  hipStream_t comm_stream = nullptr, engine_stream = nullptr;
+  float *grad = nullptr, *param = nullptr;
+  void* shadow = nullptr;  // bf16 weight shadow mirroring the arena (mixed precision), else NULL
+  size_t reduce_floats = 0, num_params = 0, vec_off = 0;
+  std::vector<std::pair<size_t, size_t>> buckets;  // (offset, floats), index = the engine's bucket number
+  int L = 0;
+
+  bool have_range = false;
+  size_t lo = 0, hi = 0;
+  std::vector<Span> spans;  // collectives of the current step, launch order
+  size_t num_spans = 0;
+  std::vector<Gather> pending;  // parameter gathers nobody has waited for yet (ascending offsets = forward order)
+  std::vector<hipEvent_t> gather_events;
+  size_t gathers_used = 0;
+  hipEvent_t ev_adam = nullptr;
+  bool masters_stale = false;
+  std::vector<std::pair<size_t, size_t>> shard_spans;
+  int verify_left = 2;
+  int error = 0;  // a failure inside an engine hook (cannot propagate through the hook): raised by the next call
+  std::string error_text;
+  // what ran in the last completed step (tfk_comm_last_step)
+  int last_rs = 0, last_ag = 0, last_ar = 0, cur_rs = 0, cur_ag = 0, cur_ar = 0;
+  std::vector<std::pair<size_t, size_t>> last_spans;
+};
+
+namespace {
+
+int new_event(hipEvent_t* ev) {
+  XHIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  return 0;
+}
+
+bool shardable(const tfk_comm* c, size_t lo, size_t hi) {
+  const size_t n = hi - lo;
+  return c->mode == TFK_EXCHANGE_SHARDED && hi <= c->vec_off && n % (4 * (size_t)c->be->world) == 0 &&
+         n >= c->min_shard_floats;
+}
+
+int launch_range(tfk_comm* c, size_t lo, size_t hi) {
+  if (c->mode == TFK_EXCHANGE_SHARDED) {
+    // a coalesced range that runs from the weight matrices into the bias / beta vectors, or from the gradient arena into
+    // the scalar + BN tail, is cut there: only weight matrices are sharded (the vectors are a few thousand values,
+    // all-reduced and updated on every rank, so that no layer ever waits for THEIR gather)
+    for (size_t cut : {c->vec_off, c->num_params})
+      if (lo < cut && cut < hi) {
+        XCHK(launch_range(c, lo, cut));
+        return launch_range(c, cut, hi);
+      }
+  }
+  if (c->num_spans == c->spans.size()) {
+    Span s;
+    XCHK(new_event(&s.ready));
+    XCHK(new_event(&s.done));
+    c->spans.push_back(s);
+  }
+  Span& s = c->spans[c->num_spans++];
+  s.off = lo; s.n = hi - lo; s.waited = false;
+  s.rs = shardable(c, lo, hi);
+  XHIP(hipEventRecord(s.ready, c->engine_stream));
+  XHIP(hipStreamWaitEvent(c->comm_stream, s.ready, 0));
+  if (s.rs) {
+    XCHK(c->be->reduce_scatter(c->grad + lo, s.n / c->be->world, c->comm_stream));
+    c->cur_rs += 1;
+  } else {
+    XCHK(c->be->all_reduce(c->grad + lo, s.n, c->comm_stream));
+    c->cur_ar += 1;
+  }
+  XHIP(hipEventRecord(s.done, c->comm_stream));
+  return 0;
+}
+
+int flush_range(tfk_comm* c) {
+  if (!c->have_range) return 0;
+  c->have_range = false;
+  return launch_range(c, c->lo, c->hi);
+}
+
+int announce(tfk_comm* c, int b) {
+  if (b < 0 || b >= (int)c->buckets.size()) return failx(-1, "bucket %d out of range", b);
+  const size_t off = c->buckets[b].first, n = c->buckets[b].second;
+  if (c->have_range && off + n == c->lo) {
+    c->lo = off;
+  } else if (c->have_range && off == c->hi) {
+    c->hi = off + n;
+  } else {
+    XCHK(flush_range(c));
+    c->have_range = true;
+    c->lo = off;
+    c->hi = off + n;
+  }
+  if (c->hi - c->lo >= c->min_floats) XCHK(flush_range(c));
+  return 0;
+}
+
+void remember(tfk_comm* c, int rc) {
+  if (rc && !c->error) {
+    c->error = rc;
+    c->error_text = tfk_last_error();
+  }
+}
+int raise_remembered(tfk_comm* c) {
+  if (!c->error) return 0;
+  const int rc = c->error;
+  c->error = 0;
+  return failx(rc, "%s", c->error_text.c_str());
+}
+
+void on_bucket(void* user, int b) {
+  tfk_comm* c = static_cast<tfk_comm*>(user);
+  remember(c, announce(c, b));
+}
+
+int drain(tfk_comm* c) {
+  for (const Gather& g : c->pending) XHIP(hipStreamWaitEvent(c->engine_stream, g.done, 0));
+  c->pending.clear();
+  return 0;
+}
+
+int wait_layer(tfk_comm* c, int layer) {
+  if (c->pending.empty()) return 0;
+  if (layer < 0) return drain(c);
+  const std::pair<size_t, size_t> want[2] = {c->buckets[c->L - layer], c->buckets[c->L + 1]};
+  int last = -1;
+  for (size_t i = 0; i < c->pending.size(); ++i)
+    for (const auto& w : want)
+      if (c->pending[i].off < w.first + w.second && c->pending[i].off + c->pending[i].n > w.first) last = (int)i;
+  if (last < 0) return 0;
+  // (the gathers run in launch order on one stream: the last one that matters implies the earlier ones)
+  XHIP(hipStreamWaitEvent(c->engine_stream, c->pending[last].done, 0));
+  c->pending.erase(c->pending.begin(), c->pending.begin() + last + 1);
+  return 0;
+}
+
+void on_layer(void* user, int layer) {
+  tfk_comm* c = static_cast<tfk_comm*>(user);
+  remember(c, wait_layer(c, layer));
+}
+
+int wait_span(tfk_comm* c, Span& s) {
+  if (!s.waited) {
+    XHIP(hipStreamWaitEvent(c->engine_stream, s.done, 0));
+    s.waited = true;
+  }
+  return 0;
+}
+
+int verify_replicas(tfk_comm* c, bool via_shadow) {
+  XCHK(drain(c));
+  const int which[2] = {via_shadow ? 1 : 0, 2};
+  for (int k = 0; k < (via_shadow ? 2 : 1); ++k) {
+    uint64_t sum = 0;
+    XCHK(tfk_param_checksum(c->e, which[k], &sum));
+    unsigned long long v[2] = {(unsigned long long)sum, 0};
+    XCHK(c->be->min_max(v, c->comm_stream));
+    if (v[0] != v[1])
+      return failx(-1, "data-parallel replicas diverged after the sharded exchange step: rank %d holds checksum %llu of "
+                       "the %s, the ranks' values span %llu .. %llu", c->be->rank, (unsigned long long)sum,
+                   which[k] == 0 ? "fp32 parameters" : which[k] == 1 ? "bf16 shadow" : "bias / beta vectors", v[0], v[1]);
+  }
+  return 0;
+}
+
+int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm** out) {
+  tfk_comm* c = new tfk_comm;
+  c->e = e;
+  c->be = be;
+  auto bail = [&](int rc) {
+    tfk_comm_destroy(c);
+    return rc;
+  };
+  if (mode != TFK_EXCHANGE_SHARDED && mode != TFK_EXCHANGE_ALLREDUCE) return bail(failx(-1, "unknown exchange mode %d", mode));
+  c->mode = mode;
+  if (bucket_bytes == 0) bucket_bytes = (size_t)(mode == TFK_EXCHANGE_SHARDED ? 24 : 48) << 20;
+  c->min_floats = std::max<size_t>(1, bucket_bytes / 4);
+  if (const char* v = getenv("TFK_DP_MIN_SHARD")) c->min_shard_floats = (size_t)atol(v);
+  if (const char* v = getenv("TFK_DP_VERIFY_STEPS")) c->verify_left = atoi(v);
+  void* st = nullptr;
+  if (tfk_stream(e, &st)) return bail(-1);
+  c->engine_stream = (hipStream_t)st;
+  void* p = nullptr;
+  size_t n = 0;
+  if (tfk_reduce_region(e, &p, &n)) return bail(-1);
+  c->grad = static_cast<float*>(p);
+  c->reduce_floats = n;
+  {
+    hipPointerAttribute_t attr;
+    hipError_t he = hipPointerGetAttributes(&attr, p);
+    if (he != hipSuccess) return bail(failx((int)he, "hipPointerGetAttributes(engine state) failed: %s", hipGetErrorString(he)));
+    c->device = attr.device;
+    he = hipSetDevice(c->device);
+    if (he != hipSuccess) return bail(failx((int)he, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(he)));
+  }
+  if (tfk_param_region(e, &p, &n)) return bail(-1);
+  c->param = static_cast<float*>(p);
+  int nb = 0, mirrors = 0;
+  if (tfk_num_buckets(e, &nb)) return bail(-1);
+  c->L = nb - 3;
+  for (int b = 0; b < nb; ++b) {
+    size_t off = 0, cnt = 0;
+    if (tfk_reduce_bucket(e, b, &off, &cnt)) return bail(-1);
+    c->buckets.push_back({off, cnt});
+  }
+  c->num_params = c->buckets[nb - 1].first;
+  c->vec_off = c->buckets[nb - 2].first;
+  if (tfk_shadow_region(e, &p, &n, &mirrors)) return bail(-1);
+  c->shadow = (mirrors && n && mode == TFK_EXCHANGE_SHARDED) ? p : nullptr;
+  hipError_t he = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  if (he != hipSuccess) return bail(failx((int)he, "hipStreamCreate failed: %s", hipGetErrorString(he)));
+  if (new_event(&c->ev_adam)) return bail(-1);
+  if (tfk_set_bucket_callback(e, on_bucket, c) || tfk_set_layer_callback(e, mode == TFK_EXCHANGE_SHARDED ? on_layer : nullptr, c))
+    return bail(-1);
+  *out = c;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfk_comm_unique_id(void* id, size_t capacity, size_t* size) {
+  if (!id || capacity < sizeof(ncclUniqueId)) return failx(-1, "tfk_comm_unique_id needs %zu bytes", sizeof(ncclUniqueId));
+  Rccl* r = rccl();
+  if (!r->error.empty()) return failx(-1, "%s", r->error.c_str());
+  ncclUniqueId uid;
+  XNCCL(r->GetUniqueId(&uid));
+  memcpy(id, &uid, sizeof(uid));
+  if (size) *size = sizeof(uid);
+  return 0;
+}
+
+int tfk_comm_create(tfk_engine* e, const void* id, size_t id_size, int rank, int world, int mode, size_t bucket_bytes,
+                    tfk_comm** out) {
+  if (!e || !id || !out) return failx(-1, "NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return failx(-1, "rank %d of world %d", rank, world);
+  if (id_size != sizeof(ncclUniqueId)) return failx(-1, "unique id of %zu bytes, expected %zu", id_size, sizeof(ncclUniqueId));
+  Rccl* r = rccl();
+  if (!r->error.empty()) return failx(-1, "%s", r->error.c_str());
+  {  // the communicator binds to the CURRENT device: the engine's
+    void* p = nullptr;
+    size_t n = 0;
+    XCHK(tfk_reduce_region(e, &p, &n));
+    hipPointerAttribute_t attr;
+    XHIP(hipPointerGetAttributes(&attr, p));
+    XHIP(hipSetDevice(attr.device));
+  }
+  RcclBackend* be = new RcclBackend;
+  be->rank = rank;
+  be->world = world;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t rc = r->CommInitRank(&be->comm, world, uid, rank);
+  if (rc != ncclSuccess) {
+    be->comm = nullptr;
+    delete be;
+    return failx((int)rc, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, r->GetErrorString(rc));
+  }
+  return attach(e, be, mode, bucket_bytes, out);
+}
+
+int tfk_loopback_create(int world, tfk_loopback** out) {
+  if (!out || world < 1 || world > kLoopMaxWorld) return failx(-1, "loopback group of %d ranks (1 .. %d)", world, kLoopMaxWorld);
+  tfk_loopback* g = new tfk_loopback;
+  g->world = world;
+  g->slot.resize(world);
+  hipError_t he = hipEventCreateWithFlags(&g->sum_done, hipEventDisableTiming);
+  if (he != hipSuccess) {
+    delete g;
+    return failx((int)he, "hipEventCreate failed: %s", hipGetErrorString(he));
+  }
+  *out = g;
+  return 0;
+}
+int tfk_loopback_destroy(tfk_loopback* g) {
+  if (!g) return 0;
+  if (g->scratch) (void)hipFree(g->scratch);
+  if (g->sum_done) (void)hipEventDestroy(g->sum_done);
+  delete g;
+  return 0;
+}
+int tfk_comm_create_loopback(tfk_engine* e, tfk_loopback* group, int rank, int mode, size_t bucket_bytes, tfk_comm** out) {
+  if (!e || !group || !out) return failx(-1, "NULL argument");
+  if (rank < 0 || rank >= group->world) return failx(-1, "rank %d of a loopback group of %d", rank, group->world);
+  LoopBackend* be = new LoopBackend;
+  be->rank = rank;
+  be->world = group->world;
+  be->g = group;
+  return attach(e, be, mode, bucket_bytes, out);
+}
+
+int tfk_comm_destroy(tfk_comm* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  if (c->e) {
+    (void)tfk_set_bucket_callback(c->e, nullptr, nullptr);
+    (void)tfk_set_layer_callback(c->e, nullptr, nullptr);
+  }
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  for (Span& s : c->spans) {
+    if (s.ready) (void)hipEventDestroy(s.ready);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  for (hipEvent_t ev : c->gather_events) (void)hipEventDestroy(ev);
+  if (c->ev_adam) (void)hipEventDestroy(c->ev_adam);
+  delete c->be;
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  delete c;
+  return 0;
+}
+
+int tfk_comm_info(tfk_comm* c, int* rank, int* world, int* mode, int* gathers_shadow) {
+  if (!c) return failx(-1, "comm is NULL");
+  if (rank) *rank = c->be->rank;
+  if (world) *world = c->be->world;
+  if (mode) *mode = c->mode;
+  if (gathers_shadow) *gathers_shadow = c->shadow ? 1 : 0;
+  return 0;
+}
+
+int tfk_comm_idle(tfk_comm* c) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  XCHK(tfk_zero_accumulators(c->e));
+  // the order accumulate(TFK_LAST_MICROBATCH) announces them in: scalars + BN increments, the weight matrices from the
+  // output layer down, the bias / beta gradients -- every rank must launch the same collectives in the same order
+  XCHK(announce(c, c->L + 2));
+  for (int b = 0; b <= c->L; ++b) XCHK(announce(c, b));
+  XCHK(announce(c, c->L + 1));
+  return 0;
+}
+
+int tfk_comm_apply(tfk_comm* c, float* average_loss) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  XCHK(flush_range(c));
+  const size_t head_off = c->buckets.back().first, head_n = c->buckets.back().second;
+  for (size_t i = 0; i < c->num_spans; ++i) {
+    Span& s = c->spans[i];
+    if (s.off < head_off + head_n && s.off + s.n > head_off) XCHK(wait_span(c, s));
+  }
+  XCHK(drain(c));  // (gathers of the previous step that no forward pass has consumed: none in a training loop)
+  XCHK(tfk_apply_begin(c->e));
+  bool via_shadow = c->shadow != nullptr;
+  if (via_shadow) {
+    int direct = 0;
+    XCHK(tfk_apply_writes_shadow(c->e, &direct));
+    if (!direct) return failx(-1, "mixed-precision engine with an arena-mirroring shadow that the optimiser does not write");
+  }
+  const int W = c->be->world, R = c->be->rank;
+  std::vector<std::pair<size_t, size_t>> sharded;
+  for (size_t i = 0; i < c->num_spans; ++i) {
+    Span& s = c->spans[i];
+    XCHK(wait_span(c, s));
+    if (s.rs) {
+      const size_t per = s.n / W;
+      XCHK(tfk_apply_span(c->e, s.off + (size_t)R * per, per));
+      sharded.push_back({s.off, s.n});
+    } else {
+      XCHK(tfk_apply_span(c->e, s.off, s.n));  // (spans beyond the parameter arena are clipped by the engine)
+    }
+  }
+  if (!sharded.empty()) {
+    if (c->masters_stale && !via_shadow) return failx(-1, "sharded fp32 masters and a step that does not write the shadow");
+    std::sort(sharded.begin(), sharded.end());  // lowest offsets (layer 0) first: the order the next forward pass reads in
+    XHIP(hipEventRecord(c->ev_adam, c->engine_stream));
+    XHIP(hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
+    char* target = static_cast<char*>(via_shadow ? c->shadow : (void*)c->param);
+    const size_t elem = via_shadow ? 2 : 4;
+    c->gathers_used = 0;
+    for (const auto& s : sharded) {
+      if (c->gathers_used == c->gather_events.size()) {
+        hipEvent_t ev;
+        XCHK(new_event(&ev));
+        c->gather_events.push_back(ev);
+      }
+      hipEvent_t done = c->gather_events[c->gathers_used++];
+      XCHK(c->be->all_gather(target + s.first * elem, s.second / W * elem, c->comm_stream));
+      XHIP(hipEventRecord(done, c->comm_stream));
+      Gather g;
+      g.off = s.first; g.n = s.second; g.done = done;
+      c->pending.push_back(g);
+      c->cur_ag += 1;
+    }
+    if (via_shadow) {
+      c->masters_stale = true;
+      for (const auto& s : sharded)
+        if (std::find(c->shard_spans.begin(), c->shard_spans.end(), s) == c->shard_spans.end()) c->shard_spans.push_back(s);
+    } else {
+      XCHK(tfk_params_touched(c->e));  // parameters outside this rank's spans change behind the optimiser's back
+    }
+  }
+  c->last_spans.clear();
+  for (size_t i = 0; i < c->num_spans; ++i) c->last_spans.push_back({c->spans[i].off, c->spans[i].n});
+  c->last_rs = c->cur_rs; c->last_ag = c->cur_ag; c->last_ar = c->cur_ar;
+  c->cur_rs = c->cur_ag = c->cur_ar = 0;
+  c->num_spans = 0;
+  XCHK(tfk_apply_end(c->e, average_loss));
+  if (c->verify_left > 0 && !sharded.empty()) {
+    c->verify_left -= 1;
+    XCHK(verify_replicas(c, via_shadow));
+  }
+  return 0;
+}
+
+int tfk_comm_eval_finish(tfk_comm* c, float* average_loss) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  const size_t off = c->buckets.back().first, n = c->buckets.back().second;
+  if (c->num_spans || c->have_range) return failx(-1, "tfk_comm_eval_finish in the middle of a training step");
+  XCHK(launch_range(c, off, off + n));
+  XCHK(wait_span(c, c->spans[0]));
+  c->num_spans = 0;
+  c->cur_ar = 0;
+  return tfk_eval_finish(c->e, average_loss);
+}
+
+int tfk_comm_drain(tfk_comm* c) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  return drain(c);
+}
+
+int tfk_comm_masters_stale(tfk_comm* c, int* stale) {
+  if (!c || !stale) return failx(-1, "NULL argument");
+  *stale = c->masters_stale ? 1 : 0;
+  return 0;
+}
+
+int tfk_comm_gather_masters(tfk_comm* c) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  XCHK(drain(c));
+  if (!c->masters_stale) return 0;
+  std::sort(c->shard_spans.begin(), c->shard_spans.end());
+  XHIP(hipEventRecord(c->ev_adam, c->engine_stream));
+  XHIP(hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
+  for (const auto& s : c->shard_spans)
+    XCHK(c->be->all_gather(c->param + s.first, s.second / c->be->world * sizeof(float), c->comm_stream));
+  XHIP(hipEventRecord(c->ev_adam, c->comm_stream));
+  XHIP(hipStreamWaitEvent(c->engine_stream, c->ev_adam, 0));
+  c->masters_stale = false;
+  return 0;
+}
+
+int tfk_comm_last_step(tfk_comm* c, int* reduce_scatters, int* all_gathers, int* all_reduces, size_t* spans, int capacity,
+                       int* num_spans) {
+  if (!c) return failx(-1, "comm is NULL");
+  if (reduce_scatters) *reduce_scatters = c->last_rs;
+  if (all_gathers) *all_gathers = c->last_ag;
+  if (all_reduces) *all_reduces = c->last_ar;
+  if (num_spans) *num_spans = (int)c->last_spans.size();
+  if (spans)
+    for (int i = 0; i < capacity && i < (int)c->last_spans.size(); ++i) {
+      spans[2 * i] = c->last_spans[i].first;
+      spans[2 * i + 1] = c->last_spans[i].second;
+    }
+  return 0;
+}
+
+const char* tfk_comm_backend(tfk_comm* c) { return c ? c->be->name() : "?"; }
+
+}  // extern "C"

@@ -299,6 +299,29 @@ class BucketReducer(object):
                 self.executed.append("all_reduce(emulating reduce_scatter)" if emu else "all_reduce")
         self.launched.append((lo, hi - lo))
 
+    # ---- the three things DataParallel asks of a reducer around a step (NativeExchange has the same) ----
+    native = False
+
+    def begin_step(self, engine):
+        engine.set_bucket_callback(self.on_bucket)
+
+    def end_step(self, engine):
+        engine.set_bucket_callback(None)
+
+    def idle(self, engine):
+        """a rank without a micro-batch in this step: contribute zeros, announced in the engine's own order (every rank
+        must launch the same collectives in the same order)"""
+        engine.zero_accumulators()
+        order = engine.bucket_order() if hasattr(engine, "bucket_order") else range(len(self.buckets))
+        for b in order:
+            self.on_bucket(b)
+
+    def eval_finish(self, engine, dp):
+        off, n = engine.buckets()[-1]
+        with self._stream_ctx():
+            self._dist.all_reduce(engine.reduce_view()[off:off + n], op=self._dist.ReduceOp.SUM, group=self.group)
+        return engine.eval_finish()
+
     def on_bucket(self, b):
         t0 = time.perf_counter()
         try:  # exceptions cannot propagate through the C callback
@@ -495,6 +518,127 @@ class BucketReducer(object):
         self.masters_stale = False
 
 
+class NativeExchange(object):
+    """The exchange step run INSIDE the library (include/tfkaldi_hip.h: tfk_comm, csrc/exchange.hip): the protocol of
+    BucketReducer -- coalesced reduce-scatter / all-reduce of the gradient spans from backward's bucket announcements,
+    Adam per reduced span, all-gather of the updated parameters (bf16 shadow in mixed precision) consumed layer by layer
+    by the next forward pass -- with RCCL called from C++ on a stream the library owns.  No Python callback, no
+    torch.distributed call and no ctypes round trip per span is left in the step: one call replaces engine.apply().
+
+    torch.distributed is used once, to hand rank 0's RCCL unique id to the other ranks.  `loopback` (tests): a
+    (group handle, rank) pair instead -- N engines of one process on one GPU, each driven by its own thread."""
+
+    native = True
+
+    def __init__(self, engine, group=None, mode=None, min_bytes=None, loopback=None):
+        import ctypes
+        from . import _lib
+        self.lib = engine.lib
+        self._check = _lib.check
+        mode = mode or os.environ.get("TFK_DP_EXCHANGE", "sharded")
+        if mode not in _lib.EXCHANGE:
+            raise ValueError("exchange mode %r" % (mode,))
+        if min_bytes is None and os.environ.get("TFK_DP_BUCKET_MB"):
+            min_bytes = int(float(os.environ["TFK_DP_BUCKET_MB"]) * (1 << 20))
+        self._h = ctypes.c_void_p()
+        if loopback is not None:
+            handle, rank = loopback
+            self._check(self.lib.tfk_comm_create_loopback(engine._h, handle, int(rank), _lib.EXCHANGE[mode], int(min_bytes or 0),
+                                                          ctypes.byref(self._h)))
+        else:
+            import torch
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            uid = ctypes.create_string_buffer(128)
+            if rank == 0:
+                self._check(self.lib.tfk_comm_unique_id(uid, 128, None))
+            # the id travels as a byte tensor over the process group that is already up (its only use in this class)
+            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+            on_gpu = dist.get_backend(group) == "nccl"
+            if on_gpu:
+                t = t.cuda(engine.cfg.device)
+            dist.broadcast(t, src=0, group=group)
+            raw = bytes(t.cpu().numpy().tobytes())
+            self._check(self.lib.tfk_comm_create(engine._h, raw, 128, rank, world, _lib.EXCHANGE[mode], int(min_bytes or 0),
+                                                 ctypes.byref(self._h)))
+        r, w, m, sh = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.tfk_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(m), ctypes.byref(sh)))
+        self.rank, self.world = r.value, w.value
+        self.mode = "sharded" if m.value == 0 else "allreduce"
+        self.backend = self.lib.tfk_comm_backend(self._h).decode()
+        self.shadow = bool(sh.value)
+        self.buckets = engine.buckets()
+        if self.shadow:
+            engine.param_access_hook = self._param_access
+        engine.on_close.insert(0, self.close)  # (the comm goes before its engine)
+        self.last_launched, self.last_kinds, self.last_executed = [], [], []
+        self.host_s = {"on_bucket": 0.0, "on_layer": 0.0, "finish_and_apply": 0.0}
+        self.host_calls = {"on_bucket": 0, "on_layer": 0, "finish_and_apply": 0}
+
+    def close(self):
+        if self._h:
+            self._check(self.lib.tfk_comm_destroy(self._h))
+            self._h = None
+
+    @property
+    def masters_stale(self):
+        import ctypes
+        v = ctypes.c_int()
+        self._check(self.lib.tfk_comm_masters_stale(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
+    def _param_access(self):
+        if self._h and self.masters_stale:
+            raise RuntimeError(
+                "the fp32 master weights are sharded over the data-parallel ranks (mixed-precision sharded exchange: each "
+                "rank holds the masters of its own spans, everyone holds the bf16 shadow); call "
+                "DataParallel.gather_parameters(engine) on EVERY rank before reading or writing parameters")
+
+    def begin_step(self, engine):
+        pass  # (the comm sits behind the engine's bucket hook since it was created)
+
+    def end_step(self, engine):
+        pass
+
+    def idle(self, engine):
+        self._check(self.lib.tfk_comm_idle(self._h))
+
+    def finish_and_apply(self, engine):
+        import ctypes
+        t0 = time.perf_counter()
+        loss = ctypes.c_float()
+        self._check(self.lib.tfk_comm_apply(self._h, ctypes.byref(loss)))
+        self.host_s["finish_and_apply"] += time.perf_counter() - t0
+        self.host_calls["finish_and_apply"] += 1
+        self._last_step()
+        return float(loss.value)
+
+    def _last_step(self):
+        import ctypes
+        rs, ag, ar, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        spans = (ctypes.c_size_t * 64)()
+        self._check(self.lib.tfk_comm_last_step(self._h, ctypes.byref(rs), ctypes.byref(ag), ctypes.byref(ar), spans, 32,
+                                                ctypes.byref(n)))
+        self.last_launched = [(int(spans[2 * i]), int(spans[2 * i + 1])) for i in range(min(n.value, 32))]
+        gather = "all_gather(bf16 shadow)" if self.shadow else "all_gather"
+        self.last_executed = (["%s:reduce_scatter" % self.backend] * rs.value + ["%s:all_reduce" % self.backend] * ar.value
+                              + ["%s:%s" % (self.backend, gather)] * ag.value)
+        self.last_kinds = ["rs"] * rs.value + ["ar"] * ar.value
+
+    def eval_finish(self, engine, dp):
+        import ctypes
+        loss = ctypes.c_float()
+        self._check(self.lib.tfk_comm_eval_finish(self._h, ctypes.byref(loss)))
+        return float(loss.value)
+
+    def drain(self):
+        if self._h:
+            self._check(self.lib.tfk_comm_drain(self._h))
+
+    def gather_masters(self, engine):
+        self._check(self.lib.tfk_comm_gather_masters(self._h))
+
+
 class DataParallel(object):
     """Shards the micro-batches of one optimiser step over the ranks of a process group."""
 
@@ -533,11 +677,25 @@ class DataParallel(object):
         r = self._reducers.get(engine)
         if r is None:
             ref = weakref.ref(engine)
-            r = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(ref()), mode=self.mode)
+            if self._native(engine):
+                r = NativeExchange(engine, self.group, mode=self.mode)
+            else:
+                r = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(ref()), mode=self.mode)
             self._reducers[engine] = r
             if hasattr(engine, "on_close"):
                 engine.on_close.append(lambda: self._forget(ref()))
         return r
+
+    def _native(self, engine):
+        """RCCL from inside the library (csrc/exchange.hip) whenever the process group runs on RCCL and the engine is a real
+        one; TFK_DP_COMM=torch keeps the exchange in BucketReducer over torch.distributed (gloo groups always do)"""
+        want = os.environ.get("TFK_DP_COMM", "native")
+        if want not in ("native", "torch"):
+            raise ValueError("TFK_DP_COMM=%r (native | torch)" % want)
+        if want == "torch" or not hasattr(getattr(engine, "lib", None), "tfk_comm_create"):
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
     def _forget(self, engine):
         if engine is not None:
@@ -583,17 +741,14 @@ class DataParallel(object):
             return engine.apply()
         engine.set_later_microbatches(later)
         reducer = self.reducer(engine)
-        engine.set_bucket_callback(reducer.on_bucket)
+        reducer.begin_step(engine)
         try:
             for i, mb in enumerate(mine):
                 _accumulate(engine, mb, i == len(mine) - 1)
-            if not mine:  # more ranks than micro-batches: contribute zeros, announced in the engine's own order
-                engine.zero_accumulators()  # (every rank must launch the same collectives in the same order)
-                order = engine.bucket_order() if hasattr(engine, "bucket_order") else range(len(reducer.buckets))
-                for b in order:
-                    reducer.on_bucket(b)
+            if not mine:  # more ranks than micro-batches: this rank contributes zeros
+                reducer.idle(engine)
         finally:
-            engine.set_bucket_callback(None)
+            reducer.end_step(engine)
         if overlap is not None:
             overlap()
         loss = reducer.finish_and_apply(engine)
@@ -615,10 +770,6 @@ class DataParallel(object):
             _eval_accumulate(engine, mb)
         if not self.enabled:
             return engine.eval_finish()
-        import torch.distributed as dist
         if not mine:  # nothing on this rank: contribute physical zeros (the accumulators reset lazily)
             engine.zero_accumulators()
-        off, n = engine.buckets()[-1]
-        with self._stream_ctx(engine):
-            dist.all_reduce(engine.reduce_view()[off:off + n], op=dist.ReduceOp.SUM, group=self.group)
-        return engine.eval_finish()
+        return self.reducer(engine).eval_finish(engine, self)

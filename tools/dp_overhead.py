@@ -35,8 +35,11 @@ def child(name, mode):
     if mode != "plain":
         os.environ["TFK_FORCE_DP"] = "1"
         os.environ.setdefault("MASTER_PORT", "29533")
+        # "allreduce" / "sharded": the exchange launched by the library (csrc/exchange.hip, the default on RCCL);
+        # "torch-allreduce" / "torch-sharded": the same protocol driven from Python through torch.distributed (round 3)
+        os.environ["TFK_DP_COMM"] = "torch" if mode.startswith("torch-") else "native"
     init_from_env()
-    dp = DataParallel(mode=None if mode == "plain" else mode)
+    dp = DataParallel(mode=None if mode == "plain" else mode.replace("torch-", ""))
     eng = Engine(_lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, keep_prob=keep, max_frames=T,
                                   num_steps=1000, compute_dtype=dtype), torch_state=dp.enabled)
     eng.init_hidden_weights(np.random.default_rng(7))
@@ -45,7 +48,7 @@ def child(name, mode):
     torch.cuda.synchronize()
     red = dp.reducer(eng) if dp.enabled else None
     if red:
-        eng.set_bucket_callback(red.on_bucket)
+        red.begin_step(eng)
 
     def step():
         eng.accumulate_device(X.data_ptr(), F, y.data_ptr(), T, last=True)
@@ -72,6 +75,7 @@ def child(name, mode):
     out = {"config": name, "mode": mode, "ms_per_step": 1e3 * dt, "host_ms_per_step_in_step_call": 1e3 * t_host / K}
     if red:
         out["exchange_ran"] = red.mode
+        out["driver"] = "library" if getattr(red, "native", False) else "torch.distributed"
         out["collectives_per_step"] = list(red.last_executed)
         out["host_ms_per_step"] = {k: 1e3 * v / K for k, v in red.host_s.items()}
         out["callbacks_per_step"] = {k: v / K for k, v in red.host_calls.items()}
@@ -87,7 +91,7 @@ def main():
         return child(sys.argv[1], sys.argv[2])
     rows = []
     for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
-        for mode in ("plain", "allreduce", "sharded"):
+        for mode in ("plain", "allreduce", "sharded", "torch-allreduce", "torch-sharded"):
             env = dict(os.environ, MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                        HSA_ENABLE_IPC_MODE_LEGACY="0")
             r = subprocess.run([sys.executable, os.path.abspath(__file__), name, mode], env=env, capture_output=True,
@@ -98,14 +102,14 @@ def main():
                 continue
             rows.append(json.loads(line[0][len("DPOVERHEAD "):]))
     print("exchange machinery on ONE rank (RCCL group of size 1: wire time ~ 0; what is left is the host path + the extra launches)")
-    print("%-5s %-10s %9s %12s | host ms/step inside: %9s %9s %16s | collectives per step" % (
+    print("%-5s %-15s %9s %12s | host ms/step inside: %9s %9s %16s | collectives per step" % (
         "cfg", "mode", "ms/step", "host ms/step", "on_bucket", "on_layer", "finish_and_apply"))
     base = {}
     for r in rows:
         h = r.get("host_ms_per_step", {})
         if r["mode"] == "plain":
             base[r["config"]] = r["ms_per_step"]
-        print("%-5s %-10s %9.3f %12.3f | %30.3f %9.3f %16.3f | %s" % (
+        print("%-5s %-15s %9.3f %12.3f | %30.3f %9.3f %16.3f | %s" % (
             r["config"], r["mode"], r["ms_per_step"], r["host_ms_per_step_in_step_call"], h.get("on_bucket", 0.0),
             h.get("on_layer", 0.0), h.get("finish_and_apply", 0.0), ", ".join(
                 "%dx %s" % (r.get("collectives_per_step", []).count(c), c)

@@ -21,9 +21,10 @@ from tfkaldi_amd.engine import Engine  # noqa: E402
 
 
 def traces(steps=20, dtype="float32"):
-    F, L, H, O, T = bench.F, bench.L, bench.H, bench.O, bench.T
+    wl = bench.Workload("cfg2")
+    F, L, H, O, T = bench.F, wl.L, wl.H, wl.O, wl.T
     with tempfile.TemporaryDirectory(prefix="tfkaldi_trace_") as d:
-        batches = bench.make_batches(0, 1, min(steps, bench.MAX_RING), d)
+        batches = bench.make_batches(wl, 0, 1, min(steps, bench.MAX_RING), d)
     rng = np.random.default_rng(7)
     hidden = [(rng.standard_normal((F if l == 0 else H, H)) / np.sqrt(F if l == 0 else H)).astype(np.float32)
               for l in range(L)]
