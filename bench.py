@@ -178,12 +178,16 @@ def decode_leg(w, eng, batches):
     out = {"unit": "frames/s", "flop_per_frame": 2 * w.macs, "passes": {}}
 
     def rate(frames, reps):
+        """frames / MEDIAN pass time (a pass of a new size grows the engine's buffers and the pinned result once)"""
         Xp = X[:frames]
         eng.posteriors(Xp, log_div_prior=True)
-        t0 = time.perf_counter()
+        eng.posteriors(Xp, log_div_prior=True)
+        times = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             eng.posteriors(Xp, log_div_prior=True)
-        return reps * frames / (time.perf_counter() - t0)
+            times.append(time.perf_counter() - t0)
+        return frames / sorted(times)[len(times) // 2]
 
     for frames, reps in ((300, 20), (1000, 10), (2000, 8), (X.shape[0], 5)):
         if frames <= X.shape[0]:

@@ -159,6 +159,27 @@ int tfk_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int
 int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
                             const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn, int flags);
 
+/*
+ * Several micro-batches of ONE optimiser step in one call -- the same result as calling tfk_accumulate (tfk_accumulate_raw)
+ * once per micro-batch in order, `flags` applying to the last one -- so that the engine can STACK them: the reference runs
+ * update_gradients_op once per micro-batch (trainer.py:310-332), and at a thousand frames per micro-batch the contractions
+ * leave the matrix pipes half idle and re-read every weight matrix k times per step.  A stacked pass multiplies all k
+ * micro-batches at once (rows are independent in the affine maps; dW over the stacked rows IS G += g) and keeps per
+ * micro-batch whatever couples the rows of one: the batch-norm statistics and their moving-average updates (in order),
+ * batch-norm's backward, the dropout stream.  Equal to the sequential calls up to fp32 summation order inside the weight
+ * gradients and the loss sum.  Chains the stacked pass does not cover (no batch norm, a nonlinearity other than ReLU,
+ * L2Norm, layer-wise growth), micro-batches of more than 2048 frames and env TFK_STACK=0 run one after the other.
+ *   tfk_accumulate_stacked      X[T, ldx] (host, or device with TFK_DEVICE_PTRS) = the micro-batches back to back,
+ *                               seg_rows[k] frames each
+ *   tfk_accumulate_stacked_raw  unspliced frames of U utterances back to back (as tfk_accumulate_raw), seg_utts[k]
+ *                               utterances per micro-batch
+ */
+int tfk_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, const int32_t* seg_rows,
+                           int32_t k, int flags);
+int tfk_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
+                               const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn,
+                               const int32_t* seg_utts, int32_t k, int flags);
+
 /* CTC loss instead of the frame-level cross-entropy (BASELINE configs[4]): what the reference's
  * CTCTrainer.compute_loss means to build with tf.nn.ctc_loss (trainer.py:533-570; its code cannot run, so this is a
  * clean-room implementation of the published forward-backward algorithm with that op's conventions: the blank is

@@ -79,6 +79,9 @@ SYMBOLS = {
                                    c_int]),
     "tfk_eval_accumulate_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                         c_void_p, c_int]),
+    "tfk_accumulate_stacked": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int]),
+    "tfk_accumulate_stacked_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                           c_void_p, c_int32, c_int]),
     "tfk_accumulate_ctc": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int]),
     "tfk_eval_accumulate_ctc": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_int]),

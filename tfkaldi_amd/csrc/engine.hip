@@ -130,6 +130,8 @@ struct tfk_engine {
   float* hCmvn[2] = {nullptr, nullptr};
   size_t cmvn_cap = 0;
   int seg_cap = 0;
+  // stacked passes (tfk_accumulate_stacked*): batch mean / rstd of every SEGMENT, [kMaxStack, ldH] per hidden layer
+  std::vector<float*> seg_mean, seg_rstd;
   float* ws_stats = nullptr;  // [2, ceil(cap / 64), ldH] per-tile BN statistics from the forward GEMM epilogue
   float* ws_bwd = nullptr;  // per-layer partial column sums of backward (finalised by one kernel)
   float* ws_splitk = nullptr;  // split-K partials of narrow weight-gradient GEMMs (grown on demand)
@@ -150,6 +152,7 @@ struct tfk_engine {
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
   bool dual_gemm = true;         // env TFK_DUAL_GEMM=0: dA and dW of a layer as two launches
+  bool stack_enabled = true;     // env TFK_STACK=0: tfk_accumulate_stacked* run their micro-batches one after the other
   bool fuse_eval = true;         // env TFK_FUSE_EVAL=0: evaluation-mode layers as GEMM + bn_stats_eval + act_forward
   int post_chunk = 2048;         // env TFK_POST_CHUNK: rows per chunk of a pipelined tfk_posteriors pass (0: off)
   std::vector<hipEvent_t> post_ev;
@@ -417,7 +420,7 @@ struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient th
 };
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              int M, int N, int K, const float* bias, int epi, hipStream_t st = nullptr, float* stats = nullptr,
-             int cfg = -1, const ActEpi* act = nullptr) {
+             int cfg = -1, const ActEpi* act = nullptr, const int* row_vend = nullptr) {
   if (!st) st = e->stream;
   if (e->bf16) {
     GemmArgsB b = {};
@@ -434,6 +437,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.C_twin = act ? act->twin : nullptr; b.ldct = act ? act->ld_twin : 0;
     b.act_scale = act ? act->scale : 1.f;
     b.act_keep = act ? 1.f / act->scale : 1.f;
+    b.row_vend = row_vend;
     b.M = M; b.N = N; b.K = K; b.lda = lda8; b.ldb = ldb8; b.ldc = ldc; b.epi = epi;
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
@@ -451,6 +455,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   g.act_beta = act ? act->beta : nullptr; g.bn_eps = act ? act->eps : 0.f;
   g.act_scale = act ? act->scale : 1.f;
   g.act_keep = act ? 1.f / act->scale : 1.f;
+  g.row_vend = row_vend;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   if (layout == GEMM_TN && K >= gemm_f32_splitk_min_k() && (size_t)M * N < ((size_t)1 << 20)) {
     // narrow layer, many frames: the weight gradient may run split-K (gemm_f32.h) -- partials of up to 32 chunks
@@ -595,6 +600,8 @@ int alloc_zero_b(bf16_t** p, size_t elems) {
 int grow_zero(tfk_engine* e, float** p, size_t floats) { return dev_alloc(e, (void**)p, floats * sizeof(float), true); }
 int grow_zero_b(tfk_engine* e, bf16_t** p, size_t elems) { return dev_alloc(e, (void**)p, elems * sizeof(bf16_t), true); }
 
+inline size_t seg_ints(int cap) { return (size_t)2 * cap + cap / 64 + 8; }
+
 int reserve(tfk_engine* e, int T) {
   if (T <= e->cap) return 0;
   int cap = e->cap + e->cap / 2;
@@ -615,9 +622,10 @@ int reserve(tfk_engine* e, int T) {
     HIPCHK(hipHostMalloc((void**)&e->hY[s], (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
     // raw frames: at most F columns (context 0); one utterance per frame at worst
     CHK(grow_zero(e, &e->dRaw[s], (size_t)cap * e->ldF));
-    CHK(dev_alloc(e, (void**)&e->dSeg[s], (size_t)(cap + 1) * sizeof(int32_t), false));
+    // utterance offsets [U + 1]; stacked passes add the utterances' output rows [U] and the row_vend table [cap / 64 + 1]
+    CHK(dev_alloc(e, (void**)&e->dSeg[s], seg_ints(cap) * sizeof(int32_t), false));
     HIPCHK(hipHostMalloc((void**)&e->hRaw[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&e->hSeg[s], (size_t)(cap + 1) * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->hSeg[s], seg_ints(cap) * sizeof(int32_t), hipHostMallocDefault));
     e->slot_used[s] = false;
   }
   e->z.assign(L, nullptr); e->a.assign(L, nullptr); e->v.assign(L, nullptr); e->rowscale.assign(L, nullptr);
@@ -652,6 +660,23 @@ int reserve(tfk_engine* e, int T) {
   e->cap = cap;
   return 0;
 }
+
+// ---- stacked passes: several micro-batches of one optimiser step behind each other in ONE pass of the GEMMs ----
+// The reference runs update_gradients_op once per micro-batch (trainer.py:310-332): the contractions of a micro-batch of
+// a thousand frames leave the matrix pipes half idle (one tile per CU, weights re-read k times per step).  A stacked pass
+// multiplies all k micro-batches ("segments") at once -- rows are independent in the affine maps, and dW over the stacked
+// rows IS G += g -- while everything that couples the rows of a micro-batch stays per segment: batch-norm statistics and
+// their moving-average updates (in segment order), BN backward, the dropout stream (call index + row inside the segment).
+// Segment i starts at row r0[i], a multiple of every GEMM tile height, holds rows[i] frames and is followed by padding
+// up to span[i] rows: padding carries label -1 (zero loss, zero gradient rows) and finite activations, and is excluded
+// from the statistics by the row_vend table (gemm_f32.h).
+constexpr int kMaxStack = 32;
+struct Stack {
+  int k = 0;
+  int r0[kMaxStack], rows[kMaxStack], span[kMaxStack];
+  int T_pad = 0, T_valid = 0;
+  const int* d_vend = nullptr;  // device: row_vend table of the pass
+};
 
 // Bring one micro-batch to HBM (or adopt device pointers).  Returns the GEMM-ready X (ld in *ldx_out).
 int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int T, int flags, const float** Xd,
@@ -696,8 +721,12 @@ int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, in
 }
 
 // Bring unspliced frames + utterance offsets to HBM and splice them into dX[slot] there.
+// `st` (stacked pass): the utterances form st->k segments of seg_utts[.] utterances each; segment i's spliced rows start at
+// row st->r0[i] of the slot, the rows in between are padding (label -1), and the row_vend table of the pass is staged with
+// the utterance offsets (st->d_vend is set).
 int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int T, const int32_t* utt_len, int U,
-              int context, const float* cmvn, const float** Xd, int* ldx_out, const int32_t** yd, bool raw_on_device = false) {
+              int context, const float* cmvn, const float** Xd, int* ldx_out, const int32_t** yd, bool raw_on_device = false,
+              Stack* st = nullptr, const int32_t* seg_utts = nullptr) {
   if (context < 0) return fail(-1, "context_width %d < 0", context);
   const int win = 2 * context + 1;
   if (e->F % win != 0) return fail(-1, "input_dim %d is not a multiple of 2*context_width+1 = %d", e->F, win);
@@ -730,19 +759,44 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
     e->cmvn_cap = 2 * cmvn_floats;
   }
   if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
-  if (!raw_on_device)
-    for (int t = 0; t < T; ++t) memcpy(e->hRaw[s] + (size_t)t * D, raw + (size_t)t * ldraw, (size_t)D * sizeof(float));
+  if (!raw_on_device) {
+    if (ldraw == D) memcpy(e->hRaw[s], raw, (size_t)T * D * sizeof(float));
+    else for (int t = 0; t < T; ++t) memcpy(e->hRaw[s] + (size_t)t * D, raw + (size_t)t * ldraw, (size_t)D * sizeof(float));
+  }
   if (cmvn) memcpy(e->hCmvn[s], cmvn, cmvn_floats * sizeof(float));
   e->hSeg[s][0] = 0;
   for (int u = 0; u < U; ++u) e->hSeg[s][u + 1] = e->hSeg[s][u] + utt_len[u];
-  if (y) memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
+  size_t seg_words = (size_t)U + 1;
+  int y_rows = T;
+  if (st) {
+    int32_t* oseg = e->hSeg[s] + U + 1;
+    int32_t* vend = oseg + U;
+    int u = 0;
+    for (int i = 0; i < st->k; ++i) {
+      int row = st->r0[i];
+      for (int j = 0; j < seg_utts[i]; ++j, ++u) {
+        oseg[u] = row;
+        row += utt_len[u];
+      }
+      for (int unit = st->r0[i] / 64; unit < (st->r0[i] + st->span[i]) / 64; ++unit) vend[unit] = st->r0[i] + st->rows[i];
+    }
+    seg_words += (size_t)U + st->T_pad / 64;
+    y_rows = st->T_pad;
+    if (y) {
+      for (int t = 0; t < st->T_pad; ++t) e->hY[s][t] = -1;
+      for (int i = 0, t0 = 0; i < st->k; t0 += st->rows[i], ++i)
+        memcpy(e->hY[s] + st->r0[i], y + t0, (size_t)st->rows[i] * sizeof(int32_t));
+    }
+  } else if (y) {
+    memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
+  }
   if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
   const int ldD = (D + 3) & ~3;
   if (!raw_on_device)
     HIPCHK(hipMemcpy2DAsync(e->dRaw[s], (size_t)ldD * 4, e->hRaw[s], (size_t)D * 4, (size_t)D * 4, T,
                             hipMemcpyHostToDevice, e->copy_stream));
-  HIPCHK(hipMemcpyAsync(e->dSeg[s], e->hSeg[s], (size_t)(U + 1) * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
-  if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipMemcpyAsync(e->dSeg[s], e->hSeg[s], seg_words * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)y_rows * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
   if (cmvn)
     HIPCHK(hipMemcpyAsync(e->dCmvn[s], e->hCmvn[s], cmvn_floats * sizeof(float), hipMemcpyHostToDevice, e->copy_stream));
   HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
@@ -751,8 +805,9 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
     ProfScope ps(e, KF_MISC, 0, 4.0 * T * (D + e->F));
     // (TFK_RAW_DEVICE: the caller's matrix is spliced where it lies -- the kernel reads rows of any leading dimension)
     splice_frames(e->stream, raw_on_device ? raw : e->dRaw[s], raw_on_device ? (int)ldraw : ldD, e->dSeg[s], U, T, D, context,
-                  cmvn ? e->dCmvn[s] : nullptr, e->dX[s], e->ldF);
+                  cmvn ? e->dCmvn[s] : nullptr, e->dX[s], e->ldF, st ? e->dSeg[s] + U + 1 : nullptr);
   }
+  if (st) st->d_vend = e->dSeg[s] + 2 * U + 1;
   e->slot_used[s] = true;
   *Xd = e->dX[s];
   *ldx_out = e->ldF;
@@ -1110,6 +1165,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_FUSE_HB"))) e->fuse_hb_enabled = atoi(v) != 0;
     if ((v = getenv("TFK_POST_CHUNK"))) e->post_chunk = atoi(v) > 0 ? (int)up((size_t)atoi(v), 64) : 0;
     if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
+    if ((v = getenv("TFK_STACK"))) e->stack_enabled = atoi(v) != 0;
     if ((v = getenv("TFK_FUSE_EVAL"))) e->fuse_eval = atoi(v) != 0;
   }
   {
@@ -1342,6 +1398,308 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   return 0;
 }
 
+
+// ================= stacked passes (struct Stack above) =================
+
+// the chains a stacked pass covers: batch norm + ReLU (+ dropout), cross-entropy loss, full depth, the fused BN paths on --
+// BASELINE cfg2 / cfg3 / cfg4.  Everything else runs its micro-batches one after the other (same results).
+bool stack_eligible(const tfk_engine* e) {
+  return e->cfg.batch_norm && !e->cfg.l2_norm && e->cfg.nonlin == TFK_NONLIN_RELU && !e->cfg.layerwise_init &&
+         e->fuse_hb_enabled && e->stack_enabled;
+}
+// segments start at multiples of the tallest GEMM tile of the arithmetic (fp32: 128, bf16: 256 rows)
+int stack_align(const tfk_engine* e) { return e->bf16 ? 256 : 128; }
+// rows of a stacked pass are bounded by the chunk slots of the backward workspaces: one slab-2 slot per row split (32 rows)
+// of every segment, kMaxRowSplits in all
+constexpr int kMaxStackRows = 8192;
+// a segment this tall fills the chip on its own (and would take the merge-once statistics path): not stacked
+constexpr int kMaxSegmentRows = 2048;
+
+int seg_stats(tfk_engine* e) {
+  if (!e->seg_mean.empty()) return 0;
+  e->seg_mean.assign(e->L, nullptr);
+  e->seg_rstd.assign(e->L, nullptr);
+  for (int l = 0; l < e->L; ++l)
+    if (alloc_zero(&e->seg_mean[l], (size_t)kMaxStack * e->ldH) || alloc_zero(&e->seg_rstd[l], (size_t)kMaxStack * e->ldH))
+      return -1;
+  return 0;
+}
+
+int forward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, uint32_t call0) {
+  const int H = e->H, ldH = e->ldH, T = st.T_pad;
+  const float* in = Xd;
+  int ld_in = ldx;
+  if (e->bf16 && e->shadow_dirty) {
+    need_params(e, -1);
+    CHK(join_optimizer(e));
+    CHK(refresh_shadow(e));
+  }
+  for (int l = 0; l < e->L; ++l) {
+    const LayerLayout& y = e->lay[l];
+    need_params(e, l);
+    CHK(wait_layer_update(e, l, l == 0));
+    int cfg;
+    const int chunk = gemm_chunk_rows(e, GEMM_NN, T, H, y.d_in, &cfg);
+    if (stack_align(e) % chunk) return fail(-1, "internal: GEMM tile of %d rows does not divide the stack alignment", chunk);
+    CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->z[l], ldH, T, H, y.d_in,
+                 e->p_param() + y.b_off, EPI_BIAS | EPI_COLSTATS, nullptr, e->ws_stats, cfg, nullptr, st.d_vend));
+    const int tiles = (T + chunk - 1) / chunk;
+    for (int i = 0; i < st.k; ++i) {  // statistics, moving averages (in segment order) and the activation chain per segment
+      ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * st.rows[i] * H);
+      const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
+      Twin tw;
+      if (e->bf16) { tw.p = e->ab[l] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; }
+      bn_act_forward(e->stream, d, e->z[l] + (size_t)st.r0[i] * ldH, e->a[l] + (size_t)st.r0[i] * ldH,
+                     e->ws_stats + (size_t)(st.r0[i] / chunk) * ldH, chunk, st.rows[i], H, ldH, e->bn_eps, e->bn_decay,
+                     e->seg_mean[l] + (size_t)i * ldH, e->seg_rstd[l] + (size_t)i * ldH, e->ema_mean(l), e->ema_var(l),
+                     e->p_param() + y.beta_off, tw, st.span[i], tiles);
+    }
+    in = e->a[l];
+    ld_in = ldH;
+  }
+  const LayerLayout& o = e->lay[e->L];
+  need_params(e, e->L);
+  CHK(wait_layer_update(e, e->L, false));
+  CHK(run_gemm(e, GEMM_NN, e->a[e->L - 1], ldH, e->p_param() + o.w_off, o.ld_out, e->logits, e->ldO, T, e->O, H,
+               e->p_param() + o.b_off, EPI_BIAS));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int backward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, uint32_t call0, bool fire) {
+  const int L = e->L, H = e->H, ldH = e->ldH, T = st.T_pad;
+  const LayerLayout& o = e->lay[L];
+  float* G = e->p_grad();
+  const int acc = e->grads_fresh ? 0 : 1;
+  const int epi_w = acc ? EPI_ACCUM : 0;
+  FinalBatch fin;
+  fin.n = 0;
+  fin.accumulate = acc;
+  auto ws_of = [&](int l) { return e->ws_bwd + (size_t)l * e->ws_bwd_stride; };
+  {
+    ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
+    colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));  // (padding rows of dLogits are zero)
+    fin.it[fin.n++] = {ws_of(L), G + o.b_off, 0, row_splits(T), e->O, e->ldO};
+  }
+  int cfg_h, cfg_o;
+  const int rows_h = gemm_chunk_rows(e, GEMM_NT, T, H, H, &cfg_h), rows_o = gemm_chunk_rows(e, GEMM_NT, T, H, e->O, &cfg_o);
+  const float dscale = e->cfg.keep_prob < 1.f ? 1.f / e->cfg.keep_prob : 1.f;
+  // the EPI_DACT operands of the layer whose output gradient a GEMM produces.  ReLU chains take the normalised
+  // pre-activation from the layer output (a * keep - beta): the epilogue needs no per-segment mean / rstd.
+  auto act_of = [&](int l) {
+    ActEpi act = {e->a[l], e->z[l], e->seg_mean[l], e->seg_rstd[l], e->cfg.nonlin};
+    act.scale = dscale;
+    act.beta = e->p_param() + e->lay[l].beta_off;
+    return act;
+  };
+  int pp = 0;
+  int bm_in = rows_o;  // rows per chunk of the EPI_DACT partial sums of the GEMM that produced the current `da`
+  {
+    ActEpi act = act_of(L - 1);
+    int bm = rows_o;
+    const int rc = run_gemm_dual(e, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O, &act,
+                                 ws_of(L - 1), e->a[L - 1], ldH, G + o.w_off, o.ld_out, H, e->O, epi_w, &bm);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      bm_in = bm;
+    } else {
+      CHK(run_gemm(e, GEMM_TN, e->a[L - 1], ldH, e->logits, e->ldO, G + o.w_off, o.ld_out, H, e->O, T, nullptr, epi_w));
+      CHK(run_gemm(e, GEMM_NT, e->logits, e->ldO, e->p_param() + o.w_off, o.ld_out, e->dA[pp], ldH, T, H, e->O, nullptr,
+                   EPI_DACT, nullptr, ws_of(L - 1), cfg_o, &act));
+    }
+  }
+  if (fire && e->cb) e->cb(e->cb_user, 0);
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerLayout& y = e->lay[l];
+    float* da = e->dA[pp];
+    if (stack_align(e) % bm_in || (T + bm_in - 1) / bm_in > kMaxRowSplits)
+      return fail(-1, "internal: EPI_DACT chunks of %d rows do not fit a stacked pass of %d rows", bm_in, T);
+    int slot = 0;
+    for (int i = 0; i < st.k; ++i) {  // BN backward per segment: its own column means, its own row count
+      ProfScope ps(e, KF_HIDDEN_BWD, 0, 28.0 * st.rows[i] * H);
+      const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
+      Twin tw;
+      if (e->bf16) { tw.p = e->dAb[pp] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; }
+      const size_t r = (size_t)st.r0[i] * ldH;
+      hidden_backward(e->stream, d, 1, da + r, e->a[l] + r, e->z[l] + r, e->seg_mean[l] + (size_t)i * ldH,
+                      e->seg_rstd[l] + (size_t)i * ldH, st.rows[i], H, ldH, ws_of(l) + (size_t)(st.r0[i] / bm_in) * ldH,
+                      (st.rows[i] + bm_in - 1) / bm_in, tw, st.span[i], ws_of(l) + ((size_t)2 * kMaxRowSplits + slot) * ldH);
+      slot += row_splits(st.span[i]);
+    }
+    if (slot > kMaxRowSplits) return fail(-1, "internal: %d partial-sum slots in a stacked pass", slot);
+    // d beta = sum of du over ALL rows (the chunks of every segment; padding chunks hold zeros), d bias = sum of dz
+    fin.it[fin.n++] = {ws_of(l), G + y.beta_off, 0, (T + bm_in - 1) / bm_in, H, ldH};
+    fin.it[fin.n++] = {ws_of(l), G + y.b_off, 2, slot, H, ldH};
+    if (fin.n + 2 > kMaxFinalItems) {
+      grad_final(e->stream, fin);
+      fin.n = 0;
+    }
+    const float* in = l == 0 ? Xd : e->a[l - 1];
+    const int ld_in = l == 0 ? ldx : ldH;
+    bool fused = false;
+    if (l > 0) {
+      ActEpi act = act_of(l - 1);
+      int bm = rows_h;
+      const int rc = run_gemm_dual(e, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, &act,
+                                   ws_of(l - 1), in, ld_in, G + y.w_off, y.ld_out, y.d_in, H, epi_w, &bm);
+      if (rc < 0) return rc;
+      fused = rc == 0;
+      if (fused) bm_in = bm;
+    }
+    if (!fused) {
+      CHK(run_gemm(e, GEMM_TN, in, ld_in, da, ldH, G + y.w_off, y.ld_out, y.d_in, H, T, nullptr, epi_w));
+      if (l > 0) {
+        ActEpi act = act_of(l - 1);
+        CHK(run_gemm(e, GEMM_NT, da, ldH, e->p_param() + y.w_off, y.ld_out, e->dA[pp ^ 1], ldH, T, H, H, nullptr, EPI_DACT,
+                     nullptr, ws_of(l - 1), cfg_h, &act));
+        bm_in = rows_h;
+      }
+    }
+    if (fire && e->cb) e->cb(e->cb_user, L - l);
+    pp ^= 1;
+  }
+  {
+    ProfScope ps(e, KF_COLSUM, 0, 0);
+    grad_final(e->stream, fin);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// padded layout of `k` segments of seg_rows[.] rows
+void stack_layout(const tfk_engine* e, const int32_t* seg_rows, int k, Stack* st) {
+  const int align = stack_align(e);
+  st->k = k;
+  int row = 0, valid = 0;
+  for (int i = 0; i < k; ++i) {
+    st->r0[i] = row;
+    st->rows[i] = seg_rows[i];
+    st->span[i] = (int)up((size_t)seg_rows[i], (size_t)align);
+    row += st->span[i];
+    valid += seg_rows[i];
+  }
+  st->T_pad = row;
+  st->T_valid = valid;
+  st->d_vend = nullptr;
+}
+
+// forward + loss + backward of one stacked pass whose input is staged (Xd: [T_pad, ld], yd: labels with -1 on padding)
+int run_stacked(tfk_engine* e, const float* Xd, int ld, const int32_t* yd, const Stack& st, int flags, int slot_before) {
+  if (e->bf16) {
+    const float* x = Xd;
+    CHK(twin_input(e, &x, &ld, st.T_pad));
+    Xd = x;
+  }
+  CHK(seg_stats(e));
+  const uint32_t call0 = e->call_counter;
+  e->call_counter += (uint32_t)st.k;
+  CHK(forward_stacked(e, Xd, ld, st, call0));
+  {
+    ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * st.T_pad * e->O);
+    Twin tw;
+    if (e->bf16) { tw.p = e->logb; tw.ld = e->ldOb; }
+    softmax_xent(e->stream, e->logits, yd, st.T_pad, e->O, e->ldO, e->row_loss, 1, tw);
+  }
+  {
+    ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * st.T_pad);
+    loss_reduce(e->stream, e->row_loss, st.T_pad, e->p_scalars(), e->scalars_fresh, st.T_valid, st.k);
+    e->scalars_fresh = false;
+  }
+  const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;
+  if (fire) {
+    if (e->later_mb > 0) {
+      ProfScope ps(e, KF_MISC, 0, 8.0 * e->E);
+      scale_inplace(e->stream, e->p_ema(), e->E, (float)pow((double)e->bn_decay, (double)e->later_mb));
+    }
+    if (e->cb) e->cb(e->cb_user, e->L + 2);
+  }
+  CHK(backward_stacked(e, Xd, ld, st, call0, fire));
+  if (fire && e->cb) e->cb(e->cb_user, e->L + 1);
+  e->grads_fresh = false;
+  HIPCHK(hipGetLastError());
+  CHK(finish_slot(e, flags, slot_before));
+  e->last_T = st.T_pad; e->last_nfw = e->L; e->last_call = call0; e->last_in = Xd;
+  return 0;
+}
+
+// stage a stacked pass from a [T, F] matrix (host, or device with TFK_DEVICE_PTRS) whose segments lie back to back
+int stage_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int flags, Stack* st, const float** Xd,
+                  int* ld_out, const int32_t** yd) {
+  if (ldx < e->F) return fail(-1, "ldx %lld < input_dim %d", (long long)ldx, e->F);
+  const int s = e->slot;
+  const bool dev = (flags & TFK_DEVICE_PTRS) != 0;
+  // the row_vend table always goes through the pinned side of the slot
+  if (e->slot_used[s]) HIPCHK(hipEventSynchronize(e->copy_done[s]));
+  int32_t* vend = e->hSeg[s];
+  for (int i = 0; i < st->k; ++i)
+    for (int unit = st->r0[i] / 64; unit < (st->r0[i] + st->span[i]) / 64; ++unit) vend[unit] = st->r0[i] + st->rows[i];
+  if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  HIPCHK(hipMemcpyAsync(e->dSeg[s], vend, (size_t)(st->T_pad / 64) * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  st->d_vend = e->dSeg[s];
+  const bool dense = st->T_pad == st->T_valid;  // every segment already a multiple of the alignment: no padding rows
+  if (dev) {
+    HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
+    HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
+    if (dense && (ldx % 4) == 0 && (e->F % 4) == 0 && (((uintptr_t)X) % 16) == 0) {
+      *Xd = X; *ld_out = (int)ldx; *yd = y;  // multiplied where it lies
+    } else {
+      HIPCHK(hipMemsetAsync(e->dY[s], 0xFF, (size_t)st->T_pad * sizeof(int32_t), e->stream));  // label -1
+      for (int i = 0, t0 = 0; i < st->k; t0 += st->rows[i], ++i) {
+        HIPCHK(hipMemcpy2DAsync(e->dX[s] + (size_t)st->r0[i] * e->ldF, (size_t)e->ldF * 4, X + (size_t)t0 * ldx, (size_t)ldx * 4,
+                                (size_t)e->F * 4, st->rows[i], hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->dY[s] + st->r0[i], y + t0, (size_t)st->rows[i] * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                              e->stream));
+      }
+      *Xd = e->dX[s]; *ld_out = e->ldF; *yd = e->dY[s];
+    }
+    e->slot_used[s] = true;
+    e->slot ^= 1;
+    return 0;
+  }
+  for (int t = 0; t < st->T_pad; ++t) e->hY[s][t] = -1;
+  for (int i = 0, t0 = 0; i < st->k; t0 += st->rows[i], ++i) {
+    memcpy(e->hY[s] + st->r0[i], y + t0, (size_t)st->rows[i] * sizeof(int32_t));
+    for (int t = 0; t < st->rows[i]; ++t)
+      memcpy(e->hX[s] + (size_t)(st->r0[i] + t) * e->F, X + (size_t)(t0 + t) * ldx, (size_t)e->F * sizeof(float));
+  }
+  // (padding rows of the pinned image are whatever an earlier batch left there: finite, and multiplied by zero gradients)
+  HIPCHK(hipMemcpy2DAsync(e->dX[s], (size_t)e->ldF * 4, e->hX[s], (size_t)e->F * 4, (size_t)e->F * 4, st->T_pad,
+                          hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)st->T_pad * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
+  HIPCHK(hipEventRecord(e->copy_done[s], e->copy_stream));
+  HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[s], 0));
+  e->slot_used[s] = true;
+  *Xd = e->dX[s]; *ld_out = e->ldF; *yd = e->dY[s];
+  e->slot ^= 1;
+  return 0;
+}
+
+// Cut the k micro-batches of a call into runs: consecutive segments that fit one stacked pass, and single segments that
+// go through the ordinary path.  fn(first, count, stacked) is called for every run in order.
+template <class Fn>
+int for_each_run(const tfk_engine* e, const int32_t* seg_rows, int k, Fn fn) {
+  const bool can = stack_eligible(e);
+  const int align = stack_align(e);
+  int i = 0;
+  while (i < k) {
+    int j = i, rows = 0;
+    if (can)
+      while (j < k && j - i < kMaxStack && seg_rows[j] > 0 && seg_rows[j] <= kMaxSegmentRows &&
+             rows + (int)up((size_t)seg_rows[j], (size_t)align) <= kMaxStackRows) {
+        rows += (int)up((size_t)seg_rows[j], (size_t)align);
+        ++j;
+      }
+    if (j - i >= 2) {
+      CHK(fn(i, j - i, true));
+      i = j;
+    } else {
+      CHK(fn(i, 1, false));
+      i += 1;
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 namespace tfk {
@@ -1392,6 +1750,8 @@ int tfk_destroy(tfk_engine* e) {
   if (e->opt_stream) hipStreamDestroy(e->opt_stream);
   if (e->d_snap) hipFree(e->d_snap);
   for (auto p : e->mean) if (p) hipFree(p);
+  for (auto p : e->seg_mean) if (p) hipFree(p);
+  for (auto p : e->seg_rstd) if (p) hipFree(p);
   for (auto p : e->rstd) if (p) hipFree(p);
   if (e->prior) hipFree(e->prior);
   if (e->Wb && e->own_wb) hipFree(e->Wb);
@@ -1518,6 +1878,83 @@ int tfk_eval_accumulate_raw(tfk_engine* e, const float* raw, int64_t ldraw, cons
   const RawSpec r = {utt_len, U, context_width, cmvn};
   if (!utt_len) return fail(-1, "utt_len is NULL");
   return train_or_eval(e, raw, ldraw, y, T, flags & ~TFK_LAST_MICROBATCH, 0, &r);
+}
+
+int tfk_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, const int32_t* seg_rows,
+                           int32_t k, int flags) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (!X || !y || !seg_rows) return fail(-1, "X / y / seg_rows is NULL");
+  if (k <= 0) return fail(-1, "no micro-batch (k = %d)", k);
+  long total = 0;
+  for (int i = 0; i < k; ++i) {
+    if (seg_rows[i] <= 0) return fail(-1, "micro-batch %d of the stack is empty (%d rows)", i, seg_rows[i]);
+    total += seg_rows[i];
+  }
+  if (total != T) return fail(-1, "the micro-batches hold %ld rows, expected T = %d", total, T);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  std::vector<int> first(k + 1, 0);
+  for (int i = 0; i < k; ++i) first[i + 1] = first[i] + seg_rows[i];
+  return for_each_run(e, seg_rows, k, [&](int i0, int n, bool stacked) -> int {
+    const int last = (i0 + n == k) ? (flags & TFK_LAST_MICROBATCH) : 0;
+    const int fl = (flags & ~TFK_LAST_MICROBATCH) | last;
+    const float* Xr = X + (size_t)first[i0] * ldx;
+    const int32_t* yr = y + first[i0];
+    if (!stacked) return train_or_eval(e, Xr, ldx, yr, seg_rows[i0], fl, 1);
+    Stack st;
+    stack_layout(e, seg_rows + i0, n, &st);
+    CHK(reserve(e, st.T_pad));
+    const float* Xd; const int32_t* yd; int ld;
+    const int slot_before = e->slot;
+    CHK(stage_stacked(e, Xr, ldx, yr, fl, &st, &Xd, &ld, &yd));
+    return run_stacked(e, Xd, ld, yd, st, fl, slot_before);
+  });
+}
+
+int tfk_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
+                               const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn,
+                               const int32_t* seg_utts, int32_t k, int flags) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (!raw || !y || !utt_len || !seg_utts) return fail(-1, "raw / y / utt_len / seg_utts is NULL");
+  if (flags & (TFK_DEVICE_PTRS | TFK_RAW_DEVICE)) return fail(-1, "tfk_accumulate_stacked_raw takes host pointers");
+  if (k <= 0) return fail(-1, "no micro-batch (k = %d)", k);
+  const int win = 2 * context_width + 1;
+  if (context_width < 0 || e->F % win) return fail(-1, "input_dim %d is not a multiple of 2*context_width+1 = %d", e->F, win);
+  const int D = e->F / win;
+  std::vector<int> first_utt(k + 1, 0), first_row(k + 1, 0);
+  std::vector<int32_t> seg_rows(k, 0);
+  for (int i = 0; i < k; ++i) {
+    if (seg_utts[i] <= 0) return fail(-1, "micro-batch %d of the stack holds no utterance", i);
+    first_utt[i + 1] = first_utt[i] + seg_utts[i];
+    if (first_utt[i + 1] > U) return fail(-1, "the micro-batches hold more than U = %d utterances", U);
+    for (int u = first_utt[i]; u < first_utt[i + 1]; ++u) {
+      if (utt_len[u] < 0) return fail(-1, "negative utterance length");
+      seg_rows[i] += utt_len[u];
+    }
+    if (seg_rows[i] <= 0) return fail(-1, "micro-batch %d of the stack is empty", i);
+    first_row[i + 1] = first_row[i] + seg_rows[i];
+  }
+  if (first_utt[k] != U || first_row[k] != T)
+    return fail(-1, "the micro-batches hold %d utterances / %d frames, expected U = %d / T = %d", first_utt[k], first_row[k], U, T);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  return for_each_run(e, seg_rows.data(), k, [&](int i0, int n, bool stacked) -> int {
+    const int last = (i0 + n == k) ? (flags & TFK_LAST_MICROBATCH) : 0;
+    const float* rr = raw + (size_t)first_row[i0] * ldraw;
+    const int32_t* yr = y + first_row[i0];
+    const int32_t* ul = utt_len + first_utt[i0];
+    const float* cm = cmvn ? cmvn + (size_t)first_utt[i0] * 2 * D : nullptr;
+    const int nu = first_utt[i0 + n] - first_utt[i0], nt = first_row[i0 + n] - first_row[i0];
+    if (!stacked) {
+      const RawSpec r = {ul, nu, context_width, cm};
+      return train_or_eval(e, rr, ldraw, yr, nt, last, 1, &r);
+    }
+    Stack st;
+    stack_layout(e, seg_rows.data() + i0, n, &st);
+    CHK(reserve(e, st.T_pad));
+    const float* Xd; const int32_t* yd; int ld;
+    const int slot_before = e->slot;
+    CHK(stage_raw(e, rr, ldraw, yr, nt, ul, nu, context_width, cm, &Xd, &ld, &yd, false, &st, seg_utts + i0));
+    return run_stacked(e, Xd, ld, yd, st, last, slot_before);
+  });
 }
 
 int tfk_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,

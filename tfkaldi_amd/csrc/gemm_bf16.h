@@ -38,6 +38,7 @@ struct GemmArgsB {
   int ldct;               // its leading dimension in elements (multiple of 8)
   float act_scale;        // EPI_DACT: 1 / keep_prob for a ReLU + dropout chain (see gemm_f32.h); 0 is read as 1
   float act_keep;         // EPI_DACT: keep_prob (0 is read as 1); with act_beta set, a ReLU chain does not read act_z
+  const int* row_vend;    // EPI_COLSTATS of a stacked pass: see gemm_f32.h (nullptr: one segment)
 };
 
 // Tile configurations.  0-2: register-staged ring of round 1 (64x64 / 128x64 / 128x128 per 4-wave block).

@@ -113,7 +113,8 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
     }
     if constexpr ((EPI & EPI_COLSTATS) != 0) {
       // per-tile batch-norm statistics (mean, sum of squared deviations), two-pass over the accumulators
-      const int n_tile = min(BM, p.M - m0);
+      const int vlim = p.row_vend ? min(p.M, p.row_vend[m0 >> 6]) : p.M;  // (stacked pass: rows of this tile's segment)
+      const int n_tile = max(1, min(BM, vlim - m0));
       float cmean = 0.f;
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -123,7 +124,7 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[a][b][r];
-            if (row_of(a, r) < p.M) s += pass == 0 ? v : (v - cmean) * (v - cmean);
+            if (row_of(a, r) < vlim) s += pass == 0 ? v : (v - cmean) * (v - cmean);
           }
         s += __shfl_xor(s, 32);
         if (h == 0) red[wm * BN + cidx] = s;

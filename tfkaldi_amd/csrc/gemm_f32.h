@@ -65,6 +65,10 @@ struct GemmArgs {
   // extra blocks into partial results in `splitk_ws`, summed in chunk order by a second kernel (deterministic).
   float* splitk_ws = nullptr;
   size_t splitk_ws_floats = 0;
+  // EPI_COLSTATS of a STACKED pass (several micro-batches behind each other, each padded to a multiple of every tile
+  // height): row_vend[m / 64] = the row where the valid rows of the segment that holds row m END -- a tile's statistics
+  // count rows < row_vend[m0 / 64] only (nullptr: rows < M, one segment).
+  const int* row_vend = nullptr;
   // filled by gemm_f32() for the kernel
   int nsplit = 1, ksplit = 0;
   size_t split_stride = 0;

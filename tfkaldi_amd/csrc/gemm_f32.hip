@@ -509,7 +509,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
     // its partner lane ^ 32 the interleaved other 16; the WAVES_M waves stacked along m meet in LDS (the K loop
     // has ended behind a barrier, so the ring is free).
     float* red = smem;  // [WAVES_M][BN]
-    const int n_tile = min(T::BM, p.M - m0);
+    const int vlim = p.row_vend ? min(p.M, p.row_vend[m0 >> 6]) : p.M;  // (stacked pass: rows of this tile's segment)
+    const int n_tile = max(1, min(T::BM, vlim - m0));
     float cmean[T::FN];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -527,7 +528,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, int tiles_m, int ti
 #pragma unroll
             for (int q = 1; q < T::KS; ++q) v += acc[q][a][b][r];
             v += bv;
-            if (rbase + (r & 3) + 8 * (r >> 2) < p.M) s += pass == 0 ? v : (v - cmean[b]) * (v - cmean[b]);
+            if (rbase + (r & 3) + 8 * (r >> 2) < vlim) s += pass == 0 ? v : (v - cmean[b]) * (v - cmean[b]);
           }
         }
         s += __shfl_xor(s, 32);

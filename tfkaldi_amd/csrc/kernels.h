@@ -44,7 +44,9 @@ void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, i
 // a = dropout(nonlin((z - mean) * rstd + beta)).
 void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, const float* stats, int chunk_rows,
                     int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
-                    float* e_var, const float* beta, Twin tw = Twin());
+                    float* e_var, const float* beta, Twin tw = Twin(), int T_apply = 0, int slab_chunks = 0);
+// (a segment of a STACKED pass: T rows carry the statistics, rows [T, T_apply) behind them are padding that receives
+// finite outputs and counts for nothing; slab_chunks = chunks per statistics slab when `stats` points into a larger table)
 
 // ---- activation chain forward: z -> a (v: post-nonlin copy, rowscale: L2 mean-square; both only if l2) ----
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
@@ -62,7 +64,9 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 // `stats_chunks` > 0: slabs 0 / 1 already hold that many chunks (EPI_DACT): the statistics pass is skipped.
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
                      const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks = 0,
-                     Twin tw = Twin());
+                     Twin tw = Twin(), int T_apply = 0, float* ws_dz = nullptr);
+// (stacked pass: rows [T, T_apply) are padding -- their dz is written as zero; ws_dz = where this launch's slab-2
+// partial sums go, default slab 2 of ws)
 // per-chunk partial column sums of x[T, ld] into slab 0 of ws (bias gradient of the output layer)
 // Tall micro-batches (more than kMergeOnceChunks GEMM row tiles): merge the per-tile statistics / partial sums ONCE
 // instead of in every block of the column-tiled kernels.
@@ -91,13 +95,16 @@ void grad_final(hipStream_t s, const FinalBatch& b);
 
 // ---- softmax cross-entropy (trainer.py:526-531): row_loss[t] = logsumexp(z_t) - z_t[y_t];
 // with_grad: logits <- softmax(z) - onehot(y) in place (sum-reduced loss => no 1/T factor).
+// y[t] < 0: the row holds no frame (padding of a stacked pass): loss 0, gradient row 0.
 // (the variant that also sums the losses in the same launch -- last block by ticket -- was measured slower than the
 // second launch and is archived: tools/experiments/r03_softmax_xent_ticket.patch)
 void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, int ld, float* row_loss,
                   int with_grad, Twin tw = Twin());
 // scalars[0] += sum(row_loss), scalars[1] += T, scalars[2] += 1
 // overwrite: the accumulators were logically re-initialised since the last call (no memset needed)
-void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite);
+// frames / microbatches: what the T rows stand for (a stacked pass sums k micro-batches whose rows include padding)
+void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite, int frames = -1,
+                 int microbatches = 1);
 // decoder.py:44 softmax; prior != null: out = log(softmax / prior) (nnet.py:280-286)
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
                   const float* prior);
@@ -121,8 +128,10 @@ void fill(hipStream_t s, float* x, size_t n, float value);
 // raw[t + j - c, d] when that frame belongs to the same utterance, else 0.  Pad columns of out are zeroed.
 // cmvn (nullable) = per-utterance [U, 2, D] (mean, standard deviation): the spliced value is
 // (raw - mean) / std, IEEE-rounded like numpy's float32 subtract / divide (feature_reader.py:109-115).
+// out_seg (nullable, [U]): utterance u's spliced rows go to rows out_seg[u] .. of `out` instead of seg[u] .. (a stacked
+// pass leaves padding rows between its segments).
 void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg, int U, int T, int D, int context,
-                   const float* cmvn, float* out, int ldo);
+                   const float* cmvn, float* out, int ldo, const int32_t* out_seg = nullptr);
 // *out += sum_i p[i] * ((i & 0xffff) + 1) over n 32-bit words (unsigned 64-bit arithmetic; *out zeroed by the caller)
 void checksum_words(hipStream_t s, const uint32_t* p, size_t n, unsigned long long* out);
 // debug: regenerate the keep mask of a layer as 0/1 floats [T, ld]

@@ -331,10 +331,12 @@ __global__ void __launch_bounds__(CT_X * CT_Y)
 bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a, const float* __restrict__ st,
                       int nchunk, int chunk_rows, int T, int H, int ld, int rows_per, float eps, float decay,
                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ e_mean,
-                      float* __restrict__ e_var, const float* __restrict__ beta, Twin tw) {
+                      float* __restrict__ e_var, const float* __restrict__ beta, Twin tw, int T_apply, int slab) {
+  // T rows carry the statistics; rows [T, T_apply) are the padding behind a segment of a stacked pass: they get
+  // (finite) outputs from the segment's statistics and count for nothing.  slab = chunks per statistics slab.
   __shared__ float4 sm[CT_Y][CT_X];
   __shared__ float4 smm[CT_X];
-  const ColTile t = col_tile(T, ld, rows_per);
+  const ColTile t = col_tile(T_apply, ld, rows_per);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // Everything this block reads is requested up front -- the chunk statistics (up to KREG chunk pairs per thread
   // stay in registers) and the first batch of z rows -- so that the kernel pays ONE memory round trip before its
@@ -348,8 +350,8 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
     const int k = threadIdx.y + j * CT_Y;
     const bool ok = t.valid && k < nchunk;
     nreg[j] = ok ? (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0) : 0.f;
-    mreg[j] = ok ? ld4(st + ((size_t)0 * nchunk + k) * ld + t.col) : zero4;
-    qreg[j] = ok ? ld4(st + ((size_t)1 * nchunk + k) * ld + t.col) : zero4;
+    mreg[j] = ok ? ld4(st + ((size_t)0 * slab + k) * ld + t.col) : zero4;
+    qreg[j] = ok ? ld4(st + ((size_t)1 * slab + k) * ld + t.col) : zero4;
   }
   const int rb0 = t.r0 + threadIdx.y;
   float4 zv[RB];
@@ -369,7 +371,7 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
   if (!in_regs && t.valid)
     for (int k = threadIdx.y + KREG * CT_Y; k < nchunk; k += CT_Y) {
       const float n = (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0);
-      const float4 m = ld4(st + ((size_t)0 * nchunk + k) * ld + t.col);
+      const float4 m = ld4(st + ((size_t)0 * slab + k) * ld + t.col);
       tot.x += n * m.x; tot.y += n * m.y; tot.z += n * m.z; tot.w += n * m.w;
     }
   tot = reduce_rows(tot, sm);
@@ -390,8 +392,8 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
   if (!in_regs && t.valid)
     for (int k = threadIdx.y + KREG * CT_Y; k < nchunk; k += CT_Y) {
       const float n = (float)max(min(T, (k + 1) * chunk_rows) - k * chunk_rows, 0);
-      const float4 m = ld4(st + ((size_t)0 * nchunk + k) * ld + t.col);
-      const float4 q = ld4(st + ((size_t)1 * nchunk + k) * ld + t.col);
+      const float4 m = ld4(st + ((size_t)0 * slab + k) * ld + t.col);
+      const float4 q = ld4(st + ((size_t)1 * slab + k) * ld + t.col);
       m2.x += q.x + n * (m.x - mu.x) * (m.x - mu.x); m2.y += q.y + n * (m.y - mu.y) * (m.y - mu.y);
       m2.z += q.z + n * (m.z - mu.z) * (m.z - mu.z); m2.w += q.w + n * (m.w - mu.w) * (m.w - mu.w);
     }
@@ -567,9 +569,12 @@ hb_stats_kernel(ActDesc d, int pre_du, const float* __restrict__ da, const float
 __global__ void __launch_bounds__(CT_X * CT_Y)
 hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __restrict__ a,
                 const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd, int T,
-                int H, int ld, int rows_per, int rs_in, float* __restrict__ ws, Twin tw) {
+                int H, int ld, int rows_per, int rs_in, float* __restrict__ ws, Twin tw, int T_apply,
+                float* __restrict__ ws_dz) {
+  // rows [T, T_apply): padding behind a segment of a stacked pass -- their dz is written as ZERO (both contractions
+  // that consume dz run over the padded rows) and they count for nothing.  ws_dz: where slab 2 of this launch goes.
   __shared__ float4 sm[CT_Y][CT_X];
-  const ColTile t = col_tile(T, ld, rows_per);
+  const ColTile t = col_tile(T_apply, ld, rows_per);
   float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 zero4 = sz;
   float4 m1 = sz, m2 = sz;
@@ -637,6 +642,7 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
           dz.z = rsd.z * (dz.z - m1.z - (zv[j].z - mu.z) * rsd.z * m2.z);
           dz.w = rsd.w * (dz.w - m1.w - (zv[j].w - mu.w) * rsd.w * m2.w);
         }
+        if (r >= T) dz = zero4;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (t.col + k >= H) el(dz, k) = 0.f;
@@ -653,7 +659,7 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
     }
   }
   sz = reduce_rows(sz, sm);
-  if (threadIdx.y == 0 && t.valid) st4(ws + ((size_t)2 * kMaxRowSplits + blockIdx.y) * ld + t.col, sz);
+  if (threadIdx.y == 0 && t.valid) st4(ws_dz + (size_t)blockIdx.y * ld + t.col, sz);
 }
 
 // g[c] (+)= sum over row splits of slab `which`, for a batch of (layer, vector) items: blockIdx.y = item
@@ -730,7 +736,20 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
   float* zr = logits + (size_t)row * ld;
   const int label = y[row];
   const int nc4 = ld >> 2;
-  const float zy = (label >= 0 && label < O) ? zr[label] : 0.f;
+  if (label < 0) {
+    // a row that holds no frame (padding between the segments of a stacked pass): no loss, and a ZERO gradient row --
+    // everything backward computes from it is then zero as well
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    if (with_grad) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c4 = threadIdx.x; c4 < nc4; c4 += 256) {
+        st4(zr + (c4 << 2), z4);
+        st4_twin(tw, row, c4 << 2, z4);
+      }
+    }
+    return;
+  }
+  const float zy = label < O ? zr[label] : 0.f;
   __syncthreads();  // zr[label] is read before anyone overwrites it
   constexpr int NVR = NV > 0 ? NV : 1;
   float4 v[NVR];
@@ -796,7 +815,8 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
 }
 
 __global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restrict__ row_loss, int T,
-                                                           float* __restrict__ scalars, int overwrite) {
+                                                           float* __restrict__ scalars, int overwrite, float frames,
+                                                           float microbatches) {
   __shared__ float sm[16];
   float s = 0.f;
   for (int i = threadIdx.x; i < T; i += 1024) s += row_loss[i];
@@ -804,8 +824,8 @@ __global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restri
   if (threadIdx.x == 0) {
     // overwrite: first micro-batch since the accumulators were (logically) re-initialised -- saves the memset
     scalars[0] = overwrite ? s : scalars[0] + s;
-    scalars[1] = overwrite ? (float)T : scalars[1] + (float)T;
-    scalars[2] = overwrite ? 1.f : scalars[2] + 1.f;
+    scalars[1] = overwrite ? frames : scalars[1] + frames;
+    scalars[2] = overwrite ? microbatches : scalars[2] + microbatches;
   }
 }
 
@@ -1012,7 +1032,7 @@ __global__ void dropout_mask_kernel(ActDesc d, float* __restrict__ out, int T, i
 // one thread per output element group of 4 (scalar inside: D need not be a multiple of 4)
 __global__ void __launch_bounds__(256)
 splice_kernel(const float* __restrict__ raw, int ldr, const int32_t* __restrict__ seg, int U, int T, int D, int context,
-              const float* __restrict__ cmvn, float* __restrict__ out, int ldo) {
+              const float* __restrict__ cmvn, float* __restrict__ out, int ldo, const int32_t* __restrict__ out_seg) {
   const int nc4 = ldo >> 2;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)T * nc4) return;
@@ -1040,7 +1060,9 @@ splice_kernel(const float* __restrict__ raw, int ldr, const int32_t* __restrict_
     }
     el(o, k) = v;
   }
-  st4(out + (size_t)t * ldo + (c4 << 2), o);
+  // out_seg (stacked pass): utterance u's rows start at out_seg[u] of the output instead of seg[u]
+  const int trow = out_seg ? out_seg[lo] + (t - first) : t;
+  st4(out + (size_t)trow * ldo + (c4 << 2), o);
 }
 
 // position-weighted integer checksum of a span of 32-bit words (replica-consistency check of the data-parallel exchange:
@@ -1086,11 +1108,13 @@ void bn_stats_eval(hipStream_t s, const float* mov_mean, const float* mov_var, i
 
 void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, const float* stats, int chunk_rows,
                     int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
-                    float* e_var, const float* beta, Twin tw) {
-  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
+                    float* e_var, const float* beta, Twin tw, int T_apply, int slab_chunks) {
+  if (T_apply < T) T_apply = T;
+  const int rs = row_splits(T_apply), rows_per = (T_apply + rs - 1) / rs;
   const int nchunk = (T + chunk_rows - 1) / chunk_rows;
   hipLaunchKernelGGL(bn_act_forward_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, z, a, stats, nchunk, chunk_rows, T, H,
-                     ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta, tw);
+                     ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta, tw, T_apply,
+                     slab_chunks > 0 ? slab_chunks : nchunk);
 }
 
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
@@ -1112,13 +1136,15 @@ void act_backward_rows(hipStream_t s, const ActDesc& d, float* da, const float* 
 
 void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, const float* a, const float* z,
                      const float* mean, const float* rstd, int T, int H, int ld, float* ws, int stats_chunks,
-                     Twin tw) {
-  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
-  if (d.bn && stats_chunks <= 0)
+                     Twin tw, int T_apply, float* ws_dz) {
+  if (T_apply < T) T_apply = T;
+  const int rs = row_splits(T_apply), rows_per = (T_apply + rs - 1) / rs;
+  if (d.bn && stats_chunks <= 0)  // (never with T_apply > T: a stacked pass always brings the EPI_DACT partial sums)
     hipLaunchKernelGGL(hb_stats_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, ld,
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
-                     rows_per, stats_chunks > 0 ? stats_chunks : rs, ws, tw);
+                     rows_per, stats_chunks > 0 ? stats_chunks : rs, ws, tw, T_apply,
+                     ws_dz ? ws_dz : ws + (size_t)2 * kMaxRowSplits * ld);
 }
 
 void bn_stats_from_chunks(hipStream_t s, const float* stats, int chunk_rows, int T, int H, int ld, float eps, float decay,
@@ -1158,8 +1184,9 @@ void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, 
 #undef TFK_SMX
 }
 
-void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, row_loss, T, scalars, overwrite ? 1 : 0);
+void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite, int frames, int microbatches) {
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, row_loss, T, scalars, overwrite ? 1 : 0,
+                     (float)(frames >= 0 ? frames : T), (float)microbatches);
 }
 
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
@@ -1220,11 +1247,11 @@ void fill(hipStream_t s, float* x, size_t n, float value) {
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, value);
 }
 void splice_frames(hipStream_t s, const float* raw, int ldr, const int32_t* seg, int U, int T, int D, int context,
-                   const float* cmvn, float* out, int ldo) {
+                   const float* cmvn, float* out, int ldo, const int32_t* out_seg) {
   const size_t n = (size_t)T * (ldo / 4);
   if (n == 0) return;
   hipLaunchKernelGGL(splice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw, ldr, seg, U, T, D, context,
-                     cmvn, out, ldo);
+                     cmvn, out, ldo, out_seg);
 }
 void checksum_words(hipStream_t s, const uint32_t* p, size_t n, unsigned long long* out) {
   if (n == 0) return;

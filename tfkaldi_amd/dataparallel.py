@@ -75,6 +75,17 @@ class RawMicroBatch(object):
         self.raw, self.y, self.lens, self.context_width, self.cmvn = raw, y, lens, context_width, cmvn
 
 
+class StackedRawMicroBatches(object):
+    """SEVERAL consecutive micro-batches of one optimiser step handed to the engine in one call
+    (tfk_accumulate_stacked_raw): the unspliced frames of all their utterances back to back and the number of utterances of
+    each micro-batch.  The engine multiplies them in one pass of the GEMMs and keeps what couples the rows of a micro-batch
+    (batch-norm statistics, dropout stream) per micro-batch; the result is that of one accumulate_raw per micro-batch."""
+
+    def __init__(self, raw, y, lens, context_width, cmvn, seg_utts):
+        self.raw, self.y, self.lens, self.context_width, self.cmvn = raw, y, lens, context_width, cmvn
+        self.seg_utts = list(seg_utts)
+
+
 class CtcMicroBatch(object):
     """A micro-batch for the CTC loss: spliced frames [T, F] of U utterances, their frame counts, their label
     sequences back to back and the label counts (tfk_accumulate_ctc)."""
@@ -93,6 +104,8 @@ def _accumulate(engine, mb, last):
             engine.accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens, last=last)
     elif isinstance(mb, RawMicroBatch):
         engine.accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, last=last, cmvn=mb.cmvn)
+    elif isinstance(mb, StackedRawMicroBatches):
+        engine.accumulate_stacked_raw(mb.raw, mb.y, mb.lens, mb.context_width, mb.seg_utts, last=last, cmvn=mb.cmvn)
     else:
         engine.accumulate(mb[0], mb[1], last=last)
 

@@ -253,6 +253,35 @@ class Engine(object):
         finally:
             self._raw_release()
 
+    # ---- several micro-batches of one optimiser step in one call (stacked pass: include/tfkaldi_hip.h) ----
+    def accumulate_stacked(self, X, y, seg_rows, last=False):
+        """the micro-batches X[rows_0 + rows_1 + ..., F] back to back, seg_rows frames each: the same result as one
+        accumulate per micro-batch, the GEMMs run once over all of them"""
+        X, y = self._host_batch(X, y)
+        seg = np.ascontiguousarray(seg_rows, dtype=np.int32)
+        check(self.lib.tfk_accumulate_stacked(self._h, X.ctypes.data_as(c_void_p), X.shape[1], y.ctypes.data_as(c_void_p),
+                                              X.shape[0], seg.ctypes.data_as(c_void_p), seg.size,
+                                              _lib.LAST_MICROBATCH if last else 0))
+
+    def accumulate_stacked_device(self, x_ptr, ldx, y_ptr, T, seg_rows, last=False):
+        seg = np.ascontiguousarray(seg_rows, dtype=np.int32)
+        flags = _lib.DEVICE_PTRS | (_lib.LAST_MICROBATCH if last else 0)
+        check(self.lib.tfk_accumulate_stacked(self._h, c_void_p(x_ptr), ldx, c_void_p(y_ptr), T, seg.ctypes.data_as(c_void_p),
+                                              seg.size, flags))
+
+    def accumulate_stacked_raw(self, raw, y, lens, context_width, seg_utts, last=False, cmvn=None):
+        """unspliced frames of all utterances back to back, seg_utts utterances per micro-batch (CMVN + splice on the device)"""
+        raw, lens = self._raw_batch(raw, lens)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        seg = np.ascontiguousarray(seg_utts, dtype=np.int32)
+        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
+        if y.shape != (raw.shape[0],):
+            raise ValueError("targets %s do not match %d frames" % (y.shape, raw.shape[0]))
+        check(self.lib.tfk_accumulate_stacked_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1], y.ctypes.data_as(c_void_p),
+                                                  raw.shape[0], lens.ctypes.data_as(c_void_p), lens.size, int(context_width),
+                                                  cmvn_ptr, seg.ctypes.data_as(c_void_p), seg.size,
+                                                  _lib.LAST_MICROBATCH if last else 0))
+
     def eval_accumulate_raw(self, raw, y, lens, context_width, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
         y = np.ascontiguousarray(y, dtype=np.int32)

@@ -20,7 +20,8 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .. import _lib
-from ..dataparallel import CtcMicroBatch, DataParallel, RawMicroBatch, partition, rank_seed
+from ..dataparallel import (CtcMicroBatch, DataParallel, RawMicroBatch, StackedRawMicroBatches, partition,
+                            rank_seed)
 from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
 
@@ -247,13 +248,18 @@ class Trainer(object, metaclass=ABCMeta):
             self._selector = MicrobatchSelector(self.numutterances_per_minibatch, self.dp.rank, self.dp.world)
         return self._selector
 
-    def _packed_microbatches(self, batch):
+    def _packed_microbatches(self, batch, stack=False):
+        """the micro-batches of a PackedBatch as the engine takes them; stack: ONE object for all of them (training with
+        the cross-enthropy loss: the engine runs consecutive micro-batches as one pass of the GEMMs when it can)"""
         out = []
         ce = self.loss_kind != "ctc"
         if ce and not np.array_equal(batch.lens, batch.target_lens):
             bad = int(np.flatnonzero(batch.lens != batch.target_lens)[0])
             raise ValueError("utterance %s: %d input frames but %d targets (the cross-enthropy trainer needs equal "
                              "lengths)" % (batch.utt_ids[bad], batch.lens[bad], batch.target_lens[bad]))
+        if stack and ce and len(batch.groups) > 1 and hasattr(self.engine, "accumulate_stacked_raw"):
+            return [StackedRawMicroBatches(batch.frames, batch.targets, batch.lens, batch.context_width, batch.cmvn,
+                                           [u1 - u0 for u0, u1, _, _, _, _ in batch.groups])]
         for u0, u1, r0, r1, t0, t1 in batch.groups:
             cmvn = None if batch.cmvn is None else batch.cmvn[u0:u1]
             if ce:
@@ -271,7 +277,7 @@ class Trainer(object, metaclass=ABCMeta):
         if total == 0:
             raise ValueError("Trainer.update: the batch holds no frames (no micro-batch could be built from %d "
                              "utterance(s))" % batch.batch_utts)
-        loss = self.dp.train_own(self.engine, self._packed_microbatches(batch), total - end, overlap)
+        loss = self.dp.train_own(self.engine, self._packed_microbatches(batch, stack=True), total - end, overlap)
         self._summarise(loss)
         return loss
 
