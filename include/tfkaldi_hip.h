@@ -330,6 +330,10 @@ int tfk_comm_info(tfk_comm* c, int* rank, int* world, int* mode, int* gathers_sh
 const char* tfk_comm_backend(tfk_comm* c);  /* "rccl" | "loopback" */
 int tfk_comm_apply(tfk_comm* c, float* average_loss);
 int tfk_comm_eval_finish(tfk_comm* c, float* average_loss);
+/* (tests / diagnostics) launch what is still coalescing and make the engine stream wait for every collective of the step,
+ * WITHOUT the optimiser: the reduce region then holds the summed gradients -- of a reduce-scattered span only this rank's
+ * 1/world.  tfk_comm_apply may follow. */
+int tfk_comm_finish_reduce(tfk_comm* c);
 int tfk_comm_idle(tfk_comm* c);
 /* make the engine stream wait for parameter gathers still in flight (before the state is read behind the engine's back) */
 int tfk_comm_drain(tfk_comm* c);
@@ -337,7 +341,8 @@ int tfk_comm_drain(tfk_comm* c);
  * home (all-gather of every sharded span) before a checkpoint or a tensor get / set */
 int tfk_comm_masters_stale(tfk_comm* c, int* stale);
 int tfk_comm_gather_masters(tfk_comm* c);
-/* collectives of the last completed step: counts by kind and the (offset, floats) spans in launch order */
+/* collectives of the last completed step: counts by kind and, in launch order, the gradient spans as triples
+ * (offset in floats, floats, 1 = reduce-scattered / 0 = all-reduced); spans holds 3 * capacity values */
 int tfk_comm_last_step(tfk_comm* c, int* reduce_scatters, int* all_gathers, int* all_reduces, size_t* spans, int capacity,
                        int* num_spans);
 /* Tests: a group of `world` engines of ONE process on ONE device; each rank is driven by its own host thread and the

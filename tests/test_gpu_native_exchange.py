@@ -221,3 +221,56 @@ def test_mismatched_collectives_fail_loudly(gpu):
     for eng in engines:
         eng.close()
     _lib.check(lib.tfk_loopback_destroy(handle))
+
+
+def _region(eng):
+    """the reduce region [G | scalars | BN increments] on the host"""
+    import torch
+    ptr, n = eng.reduce_region()
+    out = np.empty(n, dtype=np.float32)
+    eng.synchronize()
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    rc = hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(4 * n), 2)
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world):
+    """BEFORE Adam (which amplifies round-off): after the collectives of a step, rank r's 1/world of every reduce-scattered
+    span and the whole of every all-reduced span hold the gradient sums of the serial run.  One micro-batch per rank: the
+    ranks' sums are added in rank order = the order the serial run accumulates micro-batches in, so the sums are
+    bit-identical (the scalar tail's BN increments excepted: their closed form is another arithmetic)."""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    mbs = _data(world, 0)
+    serial = _engine(torch_state=False)
+    for i, (X, y) in enumerate(mbs):
+        serial.accumulate(X, y, last=(i == world - 1))
+    want = _region(serial)
+    num_params = serial.buckets()[-1][0]
+    serial.close()
+    group = _Group(world, "sharded")
+
+    def program(rank, eng, dp):
+        red = dp.reducer(eng)
+        eng.set_later_microbatches(world - 1 - rank)
+        eng.accumulate(*mbs[rank], last=True)
+        red.finish_reduce()
+        got = _region(eng)
+        red.finish_and_apply(eng)
+        return got, list(red.last_launched), list(red.last_span_kinds)
+
+    try:
+        results = group.run(program)
+    finally:
+        group.close()
+    for rank, (got, spans, kinds) in enumerate(results):
+        assert kinds.count("rs") >= 2 and kinds.count("ar") == 2, kinds
+        for (off, n), kind in zip(spans, kinds):
+            if off >= num_params:  # loss, frames, #micro-batches (exact) + BN increments (closed form: close)
+                np.testing.assert_array_equal(got[off + 1:off + 3], want[off + 1:off + 3])
+                assert np.allclose(got[off:off + n], want[off:off + n], rtol=1e-5, atol=1e-7)
+                continue
+            part = slice(off + rank * (n // world), off + (rank + 1) * (n // world)) if kind == "rs" else slice(off, off + n)
+            np.testing.assert_array_equal(got[part], want[part], err_msg="rank %d %s span %s" % (rank, kind, (off, n)))

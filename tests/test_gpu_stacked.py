@@ -38,8 +38,12 @@ def test_stacked_matches_oracle_and_sequential(gpu, rows, dtype, keep):
             for Xs, ys in parts:
                 oracle.accumulate(Xs, ys)
         g_stk, g_seq = engine_grads(eng), engine_grads(seq)
-        for k in g_seq:  # same kernels, same per-segment statistics: only the summation order inside dW / the loss differs
-            scale = np.abs(g_seq[k]).max() + 1e-30
+        # same kernels, same per-segment statistics: only the summation order inside dW / the loss differs.  Scale: the
+        # largest gradient of the LAYER (the bias gradient in front of a batch norm is a sum of dz that is zero in exact
+        # arithmetic: pure round-off, to be judged on the scale of the layer's weight gradient)
+        for k in g_seq:
+            layer = "".join(ch for ch in k if ch.isdigit())
+            scale = max(np.abs(v).max() for kk, v in g_seq.items() if kk.endswith(layer)) + 1e-30
             tol = 2e-6 if dtype == "float32" else 2e-2
             assert np.abs(g_stk[k] - g_seq[k]).max() <= tol * scale, (step, k, np.abs(g_stk[k] - g_seq[k]).max() / scale)
         if keep >= 1.0 and dtype == "float32":
@@ -106,8 +110,9 @@ def test_stacked_raw_equals_sequential_raw(gpu):
         seq.accumulate_raw(raw[r:r + rows], y[r:r + rows], lens[u:u + n], C, last=(i == len(seg_utts) - 1), cmvn=cmvn[u:u + n])
         u, r = u + n, r + rows
     g_stk, g_seq = engine_grads(eng), engine_grads(seq)
+    scale = max(np.abs(v).max() for v in g_seq.values())
     for k in g_seq:
-        assert np.abs(g_stk[k] - g_seq[k]).max() <= 2e-6 * (np.abs(g_seq[k]).max() + 1e-30), k
+        assert np.abs(g_stk[k] - g_seq[k]).max() <= 2e-6 * scale, k
     assert abs(eng.apply() - seq.apply()) <= 2e-6
     eng.close(); seq.close()
 

@@ -122,6 +122,7 @@ SYMBOLS = {
     "tfk_comm_apply": (c_int, [c_void_p, POINTER(c_float)]),
     "tfk_comm_eval_finish": (c_int, [c_void_p, POINTER(c_float)]),
     "tfk_comm_idle": (c_int, [c_void_p]),
+    "tfk_comm_finish_reduce": (c_int, [c_void_p]),
     "tfk_comm_drain": (c_int, [c_void_p]),
     "tfk_comm_masters_stale": (c_int, [c_void_p, POINTER(c_int)]),
     "tfk_comm_gather_masters": (c_int, [c_void_p]),

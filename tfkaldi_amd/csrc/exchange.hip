@@ -338,6 +338,7 @@ struct tfk_comm {
   // what ran in the last completed step (tfk_comm_last_step)
   int last_rs = 0, last_ag = 0, last_ar = 0, cur_rs = 0, cur_ag = 0, cur_ar = 0;
   std::vector<std::pair<size_t, size_t>> last_spans;
+  std::vector<int> last_span_rs;
 };
 
 namespace {
@@ -708,7 +709,11 @@ int tfk_comm_apply(tfk_comm* c, float* average_loss) {
     }
   }
   c->last_spans.clear();
-  for (size_t i = 0; i < c->num_spans; ++i) c->last_spans.push_back({c->spans[i].off, c->spans[i].n});
+  c->last_span_rs.clear();
+  for (size_t i = 0; i < c->num_spans; ++i) {
+    c->last_spans.push_back({c->spans[i].off, c->spans[i].n});
+    c->last_span_rs.push_back(c->spans[i].rs ? 1 : 0);
+  }
   c->last_rs = c->cur_rs; c->last_ag = c->cur_ag; c->last_ar = c->cur_ar;
   c->cur_rs = c->cur_ag = c->cur_ar = 0;
   c->num_spans = 0;
@@ -717,6 +722,15 @@ int tfk_comm_apply(tfk_comm* c, float* average_loss) {
     c->verify_left -= 1;
     XCHK(verify_replicas(c, via_shadow));
   }
+  return 0;
+}
+
+int tfk_comm_finish_reduce(tfk_comm* c) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  XCHK(flush_range(c));
+  for (size_t i = 0; i < c->num_spans; ++i) XCHK(wait_span(c, c->spans[i]));
   return 0;
 }
 
@@ -771,8 +785,9 @@ int tfk_comm_last_step(tfk_comm* c, int* reduce_scatters, int* all_gathers, int*
   if (num_spans) *num_spans = (int)c->last_spans.size();
   if (spans)
     for (int i = 0; i < capacity && i < (int)c->last_spans.size(); ++i) {
-      spans[2 * i] = c->last_spans[i].first;
-      spans[2 * i + 1] = c->last_spans[i].second;
+      spans[3 * i] = c->last_spans[i].first;
+      spans[3 * i + 1] = c->last_spans[i].second;
+      spans[3 * i + 2] = (size_t)c->last_span_rs[i];
     }
   return 0;
 }

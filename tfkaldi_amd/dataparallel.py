@@ -616,6 +616,10 @@ class NativeExchange(object):
     def idle(self, engine):
         self._check(self.lib.tfk_comm_idle(self._h))
 
+    def finish_reduce(self):
+        """(tests) every collective of the step launched and awaited on the engine stream, the optimiser not yet run"""
+        self._check(self.lib.tfk_comm_finish_reduce(self._h))
+
     def finish_and_apply(self, engine):
         import ctypes
         t0 = time.perf_counter()
@@ -629,10 +633,11 @@ class NativeExchange(object):
     def _last_step(self):
         import ctypes
         rs, ag, ar, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        spans = (ctypes.c_size_t * 64)()
+        spans = (ctypes.c_size_t * 96)()
         self._check(self.lib.tfk_comm_last_step(self._h, ctypes.byref(rs), ctypes.byref(ag), ctypes.byref(ar), spans, 32,
                                                 ctypes.byref(n)))
-        self.last_launched = [(int(spans[2 * i]), int(spans[2 * i + 1])) for i in range(min(n.value, 32))]
+        self.last_launched = [(int(spans[3 * i]), int(spans[3 * i + 1])) for i in range(min(n.value, 32))]
+        self.last_span_kinds = ["rs" if spans[3 * i + 2] else "ar" for i in range(min(n.value, 32))]
         gather = "all_gather(bf16 shadow)" if self.shadow else "all_gather"
         self.last_executed = (["%s:reduce_scatter" % self.backend] * rs.value + ["%s:all_reduce" % self.backend] * ar.value
                               + ["%s:%s" % (self.backend, gather)] * ag.value)
