@@ -372,7 +372,10 @@ int tfk_profile_end(tfk_engine* e, tfk_kernel_stat* stats, int capacity, int* co
 enum { /* debug tensors of the LAST accumulate / eval / posteriors call */
   TFK_DBG_LOGITS = 0,      /* [T, O] logits; after tfk_accumulate: dLogits = softmax - onehot */
   TFK_DBG_HIDDEN = 1,      /* [T, H] output of hidden layer `layer` */
-  TFK_DBG_DROPOUT_MASK = 2 /* [T, H] 0/1 keep mask of hidden layer `layer` (regenerated) */
+  TFK_DBG_DROPOUT_MASK = 2,/* [T, H] 0/1 keep mask of hidden layer `layer` (regenerated) */
+  TFK_DBG_PREACT = 3,      /* [T, H] affine output z of hidden layer `layer` (what batch norm normalises) */
+  TFK_DBG_BN_MEAN = 4,     /* row 0 of [T, H]: batch mean of z's columns as the backward pass reads it (training calls) */
+  TFK_DBG_BN_RSTD = 5      /* row 0 of [T, H]: 1 / sqrt(batch variance + eps) */
 };
 int tfk_debug_fetch(tfk_engine* e, int what, int layer, float* host, size_t count);
 

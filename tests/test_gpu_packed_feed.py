@@ -45,9 +45,12 @@ def _train(tmp_path, paths, name, capsys, **over):
 
 @pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}, {"compute_dtype": "bfloat16"},
                                   {"add_layer_period": "5", "valid_adapt": "False"}])
-def test_packed_feed_equals_list_feed(gpu, tmp_path, capsys, over):
+def test_packed_feed_equals_list_feed(gpu, tmp_path, capsys, over, monkeypatch):
     """6 utterances per batch in micro-batches of 4 (the reference's quirk: the last two are one micro-batch), a
-    held-out set of 2 batches, validation every 3 steps with rollback -- every printed line and the final model"""
+    held-out set of 2 batches, validation every 3 steps with rollback -- every printed line and the final model.
+    (TFK_STACK=0: the micro-batches of a step run one after the other, as the list feed runs them; with stacked passes
+    the two feeds differ in fp32 summation order: test_packed_feed_with_stacked_passes_tracks_the_list_feed)"""
+    monkeypatch.setenv("TFK_STACK", "0")
     paths = _corpus(tmp_path)
     out_p, model_p, bytes_p = _train(tmp_path, paths, "packed", capsys, packed_feed="True", **over)
     out_l, model_l, bytes_l = _train(tmp_path, paths, "lists", capsys, packed_feed="False", **over)
@@ -60,9 +63,10 @@ def test_packed_feed_equals_list_feed(gpu, tmp_path, capsys, over):
     assert bytes_p <= bytes_l + (1 + rollbacks) * 6 * 30 * F_RAW * 4  # (a rollback puts an unused prefetched batch back)
 
 
-def test_rollback_with_a_prefetched_batch(gpu, tmp_path, capsys):
+def test_rollback_with_a_prefetched_batch(gpu, tmp_path, capsys, monkeypatch):
     """a learning rate large enough that validation gets worse: the schedule rewinds the dispenser while a prefetched
     batch is waiting; the packed run must still print what the list-fed run prints"""
+    monkeypatch.setenv("TFK_STACK", "0")
     paths = _corpus(tmp_path)
     over = dict(initial_learning_rate="0.5", valid_frequency="2", valid_retries="3", num_epochs="3")
     out_p, model_p, _ = _train(tmp_path, paths, "packed", capsys, packed_feed="True", **over)
@@ -71,3 +75,25 @@ def test_rollback_with_a_prefetched_batch(gpu, tmp_path, capsys):
     assert out_p == out_l
     for k in model_p:
         assert model_p[k].tobytes() == model_l[k].tobytes(), k
+
+
+def _losses(out):
+    import re
+    return [float(x) for x in re.findall(r"loss(?: at step \d+)?: ([-0-9.e]+)", out)]
+
+
+@pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}])
+def test_packed_feed_with_stacked_passes_tracks_the_list_feed(gpu, tmp_path, capsys, over):
+    """the default: the packed feed hands all micro-batches of a step to the engine at once and the engine stacks them into
+    one pass of the GEMMs -- same statistics per micro-batch, same dropout stream, another summation order inside dW and the
+    loss: every printed loss within 1e-4 (relative) of the list feed's over the first steps, same schedule decisions"""
+    paths = _corpus(tmp_path)
+    kw = dict(valid_adapt="False", num_epochs="1", initial_learning_rate="0.001")
+    out_p, model_p, _ = _train(tmp_path, paths, "packed", capsys, packed_feed="True", **dict(kw, **over))
+    out_l, model_l, _ = _train(tmp_path, paths, "lists", capsys, packed_feed="False", **dict(kw, **over))
+    lp, ll = _losses(out_p), _losses(out_l)
+    assert len(lp) == len(ll) >= 8
+    assert np.allclose(lp, ll, rtol=1e-4, atol=0), (lp, ll)
+    assert [l for l in out_p.splitlines() if "loss" not in l] == [l for l in out_l.splitlines() if "loss" not in l]
+    for k in model_p:
+        assert np.abs(model_p[k].astype(np.float64) - model_l[k]).max() <= 2e-2, k

@@ -159,9 +159,26 @@ def _rccl_worker(rank, world, port, num_mb, out_dir, mode):
     from util import make_pair
     from test_gpu_dp_two_ranks import KW
     eng, _ = make_pair(np.random.default_rng(3), torch_state=True, device=local, **KW)
+    # one step by hand BEFORE Adam amplifies anything: after the collectives the reduce region must hold the serial run's
+    # gradient sums -- the whole of an all-reduced span, this rank's 1/world of a reduce-scattered one
+    from tfkaldi_amd.dataparallel import partition
+    red = dp.reducer(eng)
+    assert red.native and red.backend == "rccl"
+    mbs = _data(num_mb, 100)
+    start, end = partition(len(mbs), world)[rank]
+    eng.set_later_microbatches(len(mbs) - end)
+    for i, (X, y) in enumerate(mbs[start:end]):
+        eng.accumulate(X, y, last=(i == end - start - 1))
+    red.finish_reduce()
+    eng.synchronize()
+    region = eng.reduce_view().cpu().numpy().copy()
+    loss100 = red.finish_and_apply(eng)
+    spans = np.array([[off, n, kind == "rs"] for (off, n), kind in zip(red.last_launched, red.last_span_kinds)])
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **_collect(eng, losses))
+    dp.gather_parameters(eng)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), region=region, spans=spans, loss100=np.array(loss100),
+             **_collect(eng, losses))
     eng.close()
     dist.destroy_process_group()
 
@@ -176,7 +193,14 @@ def test_two_real_rccl_ranks_match_serial(gpu, tmp_path, mode):
     import torch.multiprocessing as mp
     num_mb = 4
     mp.spawn(_rccl_worker, args=(2, _free_port(), num_mb, str(tmp_path), mode), nprocs=2, join=True)
-    eng = _engine(torch_state=False)
+    eng = _engine(torch_state=True)
+    mbs = _data(num_mb, 100)
+    for i, (X, y) in enumerate(mbs):
+        eng.accumulate(X, y, last=(i == len(mbs) - 1))
+    eng.synchronize()
+    region = eng.reduce_view().cpu().numpy().copy()
+    num_params = eng.buckets()[-1][0]
+    loss100 = eng.apply()
     want = []
     for step in range(3):
         mbs = _data(num_mb, step)
@@ -191,6 +215,19 @@ def test_two_real_rccl_ranks_match_serial(gpu, tmp_path, mode):
     lr = 1e-3
     for rank in range(2):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        # the summed gradients before the optimiser: same addends as the serial accumulation, another order (two micro-batches
+        # per rank, then rank 0 + rank 1) -- 1e-5 on the scale of the span, as the all-reduce variant of
+        # tests/test_gpu_dp_two_ranks.py
+        assert abs(float(got["loss100"]) - loss100) <= 3e-6 * abs(loss100)
+        kinds = [bool(k) for _, _, k in got["spans"]]
+        assert any(kinds) == (mode == "sharded")
+        for off, n, rs in got["spans"]:
+            off, n = int(off), int(n)
+            if off >= num_params:
+                continue
+            part = slice(off + rank * (n // 2), off + (rank + 1) * (n // 2)) if rs else slice(off, off + n)
+            scale = np.abs(region[off:off + n]).max() + 1e-30
+            assert np.abs(got["region"][part] - region[part]).max() <= 1e-5 * scale, (mode, rank, off, n, bool(rs))
         assert np.allclose(got["losses"], ref["losses"], rtol=2e-6, atol=0), (got["losses"], ref["losses"])
         for k in ref:
             if k == "losses":

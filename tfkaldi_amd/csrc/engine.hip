@@ -2443,6 +2443,16 @@ int tfk_debug_fetch(tfk_engine* e, int what, int layer, float* host, size_t coun
     HIPCHK(hipMemcpy2D(host, (size_t)e->H * 4, e->a[layer], (size_t)e->ldH * 4, (size_t)e->H * 4, T, hipMemcpyDeviceToHost));
     return 0;
   }
+  if (what == TFK_DBG_PREACT || what == TFK_DBG_BN_MEAN || what == TFK_DBG_BN_RSTD) {
+    // the other tensors batch-norm's backward reads: the affine output z of the layer / its batch mean / rstd (row 0)
+    if (what == TFK_DBG_PREACT) {
+      HIPCHK(hipMemcpy2D(host, (size_t)e->H * 4, e->z[layer], (size_t)e->ldH * 4, (size_t)e->H * 4, T, hipMemcpyDeviceToHost));
+    } else {
+      memset(host, 0, count * sizeof(float));
+      HIPCHK(hipMemcpy(host, what == TFK_DBG_BN_MEAN ? e->mean[layer] : e->rstd[layer], (size_t)e->H * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+  }
   if (what == TFK_DBG_DROPOUT_MASK) {
     const ActDesc d = act_desc(e, layer, 1, e->last_call);
     if (d.keep >= 1.f) {

@@ -882,8 +882,18 @@ int gemm_f32_pick_config(GemmLayout layout, int M, int N, int K) {
     if ((e = getenv("TFK_GEMM_DMA"))) g_dma = atoi(e);
   }
   if (g_forced_cfg >= 0) return g_forced_cfg;
+  {  // (debugging) TFK_GEMM_CFG_NN / _NT / _TN: force the configuration of one layout only
+    static int per_layout[3] = {-2, -2, -2};
+    if (per_layout[0] == -2) {
+      const char* names[3] = {"TFK_GEMM_CFG_NN", "TFK_GEMM_CFG_NT", "TFK_GEMM_CFG_TN"};
+      for (int l = 0; l < 3; ++l) {
+        const char* e = getenv(names[l]);
+        per_layout[l] = e ? atoi(e) : -1;
+      }
+    }
+    if (per_layout[(int)layout] >= 0) return per_layout[(int)layout];
+  }
   (void)K;
-  (void)layout;
   // Measured on MI355X (profiles/r01_gemm_sweep_v3.txt): the 128x128 tile (4 waves of 64x64: half the LDS
   // staging per MFMA of a 64x64 tile) wins once it yields two blocks per CU; below that the 64x64 tile with
   // its 3-slot ring and 2-tile prefetch (two or more independent blocks per CU) is fastest for all layouts.
