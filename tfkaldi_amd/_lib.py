@@ -20,7 +20,7 @@ SLOT_PARAM, SLOT_GRAD, SLOT_ADAM_M, SLOT_ADAM_V = range(4)
 (GLOBAL_STEP, LEARNING_RATE_FACT, INITIALISED_LAYERS, ADAM_STEPS, BATCH_LOSS, NUM_FRAMES,
  LEARNING_RATE) = range(7)
 DEVICE_PTRS, LAST_MICROBATCH, LOG_DIV_PRIOR, RAW_LOGITS, RAW_DEVICE = 1, 2, 4, 8, 16
-DBG_LOGITS, DBG_HIDDEN, DBG_DROPOUT_MASK = range(3)
+DBG_LOGITS, DBG_HIDDEN, DBG_DROPOUT_MASK, DBG_PREACT, DBG_BN_MEAN, DBG_BN_RSTD = range(6)
 GEMM_NN, GEMM_NT, GEMM_TN = range(3)
 EPI_BIAS, EPI_ACCUM, EPI_RELU = 1, 2, 4
 EXCHANGE = {"sharded": 0, "allreduce": 1}  # TFK_EXCHANGE_*
