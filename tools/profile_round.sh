@@ -6,7 +6,8 @@ tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 # (the clock pre-warm GEMMs of bench.py are switched off under the profiler: they would fill the kernel statistics)
 export TFK_BENCH_PREWARM_MS=0
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+# (the decode and Nnet.train legs of the bench line are measured un-profiled below: they would fill the kernel statistics)
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-decode --no-api-fed"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B --steps 50 --warmup 5 > $out.trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B --steps 10 --warmup 3 > $out.fetch.log 2>&1
@@ -20,4 +21,6 @@ for c in cfg2 cfg3 cfg4; do timeout 200 python tools/step_line.py $c $out.step_$
 unset TFK_BENCH_PREWARM_MS
 timeout 300 python bench.py --steps 100 --warmup 10 > $out.bench.json 2> $out.bench.err
 timeout 300 python bench.py --steps 100 --warmup 10 --dtype bfloat16 --no-cpu-baseline > $out.bench_bf16.json 2> $out.bench_bf16.err
+timeout 300 python bench.py --config cfg3 --steps 100 --warmup 10 > $out.bench_cfg3.json 2> $out.bench_cfg3.err
+timeout 300 python bench.py --config cfg4 --steps 50 --warmup 10 --no-cpu-baseline > $out.bench_cfg4.json 2> $out.bench_cfg4.err
 ls $out* | head -40
