@@ -32,7 +32,13 @@ typedef struct tfk_engine tfk_engine;
  * TFK_DTYPE_BF16 is mixed precision (BASELINE cfg3 / cfg4): GEMM operands -- layer inputs, weights, dZ -- are
  * rounded to bfloat16 (round to nearest even), products accumulate in fp32; master parameters, batch-norm
  * statistics, the loss, gradient sums and the Adam update stay fp32. */
-enum { TFK_DTYPE_F32 = 0, TFK_DTYPE_BF16 = 1 };
+/* TFK_DTYPE_F32X3: fp32 arithmetic EMULATED on the bf16 matrix pipe.  Every GEMM operand is split, exactly, into three
+ * bfloat16 pieces (8 + 8 + 8 significand bits) and the six piece products of order <= 2^-16 are accumulated in fp32: products of
+ * bf16 values are exact in fp32 and the dropped pairs are below 2^-24 of a product, so a contraction differs from the exact
+ * fp32 dot product only by fp32 accumulation error -- against float64 it is at least as close as the fp32 MFMA chain of
+ * TFK_DTYPE_F32 (tools/bf16x3_probe.py) -- at 6/16 of that mode's matrix-pipe time.  Parameters, statistics, loss, gradient
+ * sums and the optimiser are fp32 as in every mode; held to the same parity bounds as TFK_DTYPE_F32. */
+enum { TFK_DTYPE_F32 = 0, TFK_DTYPE_BF16 = 1, TFK_DTYPE_F32X3 = 2 };
 
 /* nonlinearity of the hidden layers: neuralNetworks/nnet.py:48-65 */
 enum { TFK_NONLIN_RELU = 0, TFK_NONLIN_SIGMOID = 1, TFK_NONLIN_TANH = 2, TFK_NONLIN_LINEAR = 3 };
@@ -386,6 +392,12 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
  * leading dimensions (in elements) that are multiples of 8 and zero padding (gemm_bf16.h). */
 int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   int M, int N, int K, const float* bias, int epi);
+/* Stand-alone fp32-emulating GEMM (TFK_DTYPE_F32X3's contraction; gemm_bf16.h: gemm_bf16x3) on device pointers: A and B are given
+ * as three bf16 planes each, `a_plane` / `b_plane` elements apart (same leading dimension, a multiple of 8); tfk_split3 makes such
+ * planes from an fp32 matrix [rows, lds]: src == plane 0 + plane 1 + plane 2 exactly.  Tests and tools. */
+int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int64_t plane, int rows, int cols);
+int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, int64_t a_plane, const uint16_t* B, int ldb,
+                    int64_t b_plane, float* C, int ldc, int M, int N, int K, const float* bias, int epi);
 /* The backward pair of one layer in ONE launch (gemm_bf16.h: gemm_bf16_dual): C_nt[M_nt, N_nt] = A_nt . B_nt^T and
  * C_tn[M_tn, N_tn] (+)= A_tn^T . B_tn (epi_tn: 0 or 2 = accumulate).  Fails when the pair of shapes is not eligible
  * (tfk_gemm_bf16_dual_config == 0).  Block geometry: env TFK_BF16_DUAL_CFG (3: 128x64, 4: 128x128, 5: 256x128,

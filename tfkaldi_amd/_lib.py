@@ -14,7 +14,7 @@ ABI_VERSION = 6
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
-DTYPES = {"float32": 0, "bfloat16": 1}  # TFK_DTYPE_*: arithmetic of the GEMMs (bfloat16 = mixed precision)
+DTYPES = {"float32": 0, "bfloat16": 1, "float32x3": 2}  # TFK_DTYPE_*: arithmetic of the GEMMs (bfloat16 = mixed precision)
 WEIGHTS, BIASES, BN_BETA, BN_MOVING_MEAN, BN_MOVING_VAR = range(5)
 SLOT_PARAM, SLOT_GRAD, SLOT_ADAM_M, SLOT_ADAM_V = range(4)
 (GLOBAL_STEP, LEARNING_RATE_FACT, INITIALISED_LAYERS, ADAM_STEPS, BATCH_LOSS, NUM_FRAMES,
@@ -140,6 +140,9 @@ SYMBOLS = {
                              c_int, c_void_p, c_int, c_int]),
     "tfk_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int]),
+    "tfk_split3": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int]),
+    "tfk_gemm_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int,
+                                c_int, c_void_p, c_int]),
     "tfk_gemm_bf16_dual": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "tfk_gemm_bf16_dual_config": (c_int, [c_int, c_int, c_int, c_int]),

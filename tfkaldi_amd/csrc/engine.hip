@@ -173,7 +173,11 @@ struct tfk_engine {
 
   // mixed precision (cfg.compute_dtype == TFK_DTYPE_BF16): every fp32 buffer that is a GEMM operand has a bf16
   // twin written by its producer; master parameters, statistics, gradients and the optimiser stay fp32
-  bool bf16 = false;
+  bool bf16 = false;                 // GEMM operands have bf16 twins (compute_dtype bf16 or f32x3)
+  bool x3 = false;                   // TFK_DTYPE_F32X3: every twin is THREE bf16 planes summing to the fp32 value (gemm_bf16x3)
+  long wb_plane = 0;                 // elements between the planes of the weight shadow (x3)
+  // elements between the planes of an activation twin with leading dimension ld (all twins hold `cap` rows)
+  long act_plane(int ld) const { return x3 ? (long)cap * ld : 0; }
   int ldFb = 0, ldHb = 0, ldOb = 0;  // leading dimensions of the twins (multiples of 8 elements)
   bf16_t* Xb[2] = {nullptr, nullptr};
   std::vector<bf16_t*> ab;
@@ -245,7 +249,7 @@ int validate(const tfk_config* c) {
     return fail(-1, "bad dimensions F=%d L=%d H=%d O=%d", c->input_dim, c->num_layers, c->num_units, c->output_dim);
   if (c->nonlin < 0 || c->nonlin > 3) return fail(-1, "unkown nonlinearity %d", c->nonlin);
   if (!(c->keep_prob > 0.f)) return fail(-1, "dropout keep probability must be in (0, 1], got %g", c->keep_prob);
-  if (c->compute_dtype != TFK_DTYPE_F32 && c->compute_dtype != TFK_DTYPE_BF16)
+  if (c->compute_dtype != TFK_DTYPE_F32 && c->compute_dtype != TFK_DTYPE_BF16 && c->compute_dtype != TFK_DTYPE_F32X3)
     return fail(-1, "unknown compute_dtype %d", c->compute_dtype);
   return 0;
 }
@@ -287,6 +291,11 @@ constexpr size_t kScalarFloats = 64;
 // fp32 arena element for element and lives at the END of the state arena (w_end bf16 values = w_end / 2 floats), so a
 // host that owns the arena (torch.distributed) can all-gather SHARDS OF THE SHADOW ITSELF -- half the bytes of the
 // fp32 parameters, and the next forward pass waits for them layer by layer.  Otherwise it is packed in its own allocation.
+bool x3_aligned(const std::vector<LayerLayout>& lay) {
+  for (const LayerLayout& y : lay)
+    if (y.ld_out % 8) return false;
+  return true;
+}
 bool shadow_mirrors(const tfk_config* c, const std::vector<LayerLayout>& lay) {
   if (c->compute_dtype != TFK_DTYPE_BF16) return false;
   for (const LayerLayout& y : lay)
@@ -378,20 +387,24 @@ inline void need_params(tfk_engine* e, int layer) {
 }
 
 // bf16 twin of an fp32 GEMM operand buffer (mixed-precision mode)
-const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
+// (*plane: elements between the three planes of the twin in x3 mode, 0 otherwise)
+const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld, long* plane = nullptr) {
+  long dummy;
+  if (!plane) plane = &dummy;
   for (int s = 0; s < 2; ++s) {
-    if (p == e->dX[s]) { *ld = e->ldFb; return e->Xb[s]; }
-    if (p == e->dA[s]) { *ld = e->ldHb; return e->dAb[s]; }
+    if (p == e->dX[s]) { *ld = e->ldFb; *plane = e->act_plane(e->ldFb); return e->Xb[s]; }
+    if (p == e->dA[s]) { *ld = e->ldHb; *plane = e->act_plane(e->ldHb); return e->dAb[s]; }
   }
-  if (p == e->logits) { *ld = e->ldOb; return e->logb; }
+  if (p == e->logits) { *ld = e->ldOb; *plane = e->act_plane(e->ldOb); return e->logb; }
   for (size_t l = 0; l < e->a.size(); ++l)
-    if (p == e->a[l]) { *ld = e->ldHb; return e->ab[l]; }
+    if (p == e->a[l]) { *ld = e->ldHb; *plane = e->act_plane(e->ldHb); return e->ab[l]; }
   for (int l = 0; l <= e->L; ++l)
-    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; return e->Wb + e->wb_off[l]; }
+    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; *plane = e->wb_plane; return e->Wb + e->wb_off[l]; }
   return nullptr;
 }
 // rows a GEMM's per-tile statistics (EPI_COLSTATS / EPI_DACT) are chunked by
 int gemm_chunk_rows(tfk_engine* e, GemmLayout layout, int M, int N, int K, int* cfg) {
+  if (e->x3) { *cfg = -1; return kGemmBf16x3TileRows; }
   if (e->bf16) { *cfg = -1; return gemm_bf16_tile_rows(M, N); }
   *cfg = gemm_f32_pick_config(layout, M, N, K);
   return gemm_f32_config_bm(*cfg);
@@ -401,7 +414,7 @@ int refresh_shadow(tfk_engine* e) {
   if (!e->bf16 || !e->shadow_dirty) return 0;
   for (int l = 0; l <= e->L; ++l) {
     const LayerLayout& y = e->lay[l];
-    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->wb_off[l], e->wb_ld[l], y.d_in, y.d_out);
+    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->wb_off[l], e->wb_ld[l], y.d_in, y.d_out, e->wb_plane);
   }
   HIPCHK(hipGetLastError());
   e->shadow_dirty = false;
@@ -416,6 +429,7 @@ struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient th
   float eps = 0.f;
   bf16_t* twin = nullptr;  // mixed precision: bf16 copy of the result
   int ld_twin = 0;
+  long twin_plane = 0;     // x3: elements between its three planes
   float scale = 1.f;       // EPI_DACT: 1 / keep_prob of a ReLU + dropout chain
 };
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -425,8 +439,8 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   if (e->bf16) {
     GemmArgsB b = {};
     int lda8 = 0, ldb8 = 0;
-    b.A = twin_of(e, A, &lda8);
-    b.B = twin_of(e, B, &ldb8);
+    b.A = twin_of(e, A, &lda8, &b.a_plane);
+    b.B = twin_of(e, B, &ldb8, &b.b_plane);
     if (!b.A || !b.B) return fail(-1, "internal: GEMM operand without a bf16 twin");
     b.C = C; b.bias = bias; b.stats = stats;
     b.act_a = act ? act->a : nullptr; b.act_z = act ? act->z : nullptr;
@@ -435,6 +449,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.stats_stride = kMaxRowSplits;
     b.act_beta = act ? act->beta : nullptr; b.bn_eps = act ? act->eps : 0.f;
     b.C_twin = act ? act->twin : nullptr; b.ldct = act ? act->ld_twin : 0;
+    b.ct_plane = act ? act->twin_plane : 0;
     b.act_scale = act ? act->scale : 1.f;
     b.act_keep = act ? 1.f / act->scale : 1.f;
     b.row_vend = row_vend;
@@ -442,8 +457,8 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
                  2.0 * ((double)M * K + (double)K * N) + 4.0 * (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1), st);
-    const int rc = gemm_bf16(layout, b, st);
-    if (rc != 0) return fail(rc, "gemm_bf16 launch failed: %s", hipGetErrorString((hipError_t)rc));
+    const int rc = e->x3 ? gemm_bf16x3(layout, b, st) : gemm_bf16(layout, b, st);
+    if (rc != 0) return fail(rc, "gemm_bf16%s launch failed: %s", e->x3 ? "x3" : "", hipGetErrorString((hipError_t)rc));
     return 0;
   }
   GemmArgs g;
@@ -482,7 +497,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
 int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int ldw, float* da_out, int ld_da, int T,
                   int N_da, int K_da, const ActEpi* act, float* stats, const float* in, int ld_in, float* Gw, int ld_g,
                   int d_in, int d_out, int epi_w, int* chunk_rows) {
-  if (!e->dual_gemm) return 1;
+  if (!e->dual_gemm || e->x3) return 1;  // (the three-plane kernel has no dual form: dA and dW run one after the other)
   const double flops = 2.0 * T * N_da * K_da + 2.0 * d_in * d_out * T;
   if (e->bf16) {
     const int dcfg = gemm_bf16_dual_config(T, N_da, d_in, d_out);
@@ -638,13 +653,14 @@ int reserve(tfk_engine* e, int T) {
     }
   }
   if (e->bf16) {
+    const size_t np = e->x3 ? 3 : 1;  // planes per twin (plane stride = cap * ld: act_plane)
     for (int s = 0; s < 2; ++s) {
-      CHK(grow_zero_b(e, &e->Xb[s], (size_t)cap * e->ldFb));
-      CHK(grow_zero_b(e, &e->dAb[s], (size_t)cap * e->ldHb));
+      CHK(grow_zero_b(e, &e->Xb[s], np * cap * e->ldFb));
+      CHK(grow_zero_b(e, &e->dAb[s], np * cap * e->ldHb));
     }
     e->ab.assign(L, nullptr);
-    for (int l = 0; l < L; ++l) CHK(grow_zero_b(e, &e->ab[l], (size_t)cap * e->ldHb));
-    CHK(grow_zero_b(e, &e->logb, (size_t)cap * e->ldOb));
+    for (int l = 0; l < L; ++l) CHK(grow_zero_b(e, &e->ab[l], np * cap * e->ldHb));
+    CHK(grow_zero_b(e, &e->logb, np * cap * e->ldOb));
   }
   CHK(grow_zero(e, &e->logits, (size_t)cap * e->ldO));
   CHK(grow_zero(e, &e->post, (size_t)cap * e->ldO));
@@ -828,7 +844,7 @@ int twin_input(tfk_engine* e, const float** Xd, int* ld, int T) {
     *Xd = e->dX[s];
     *ld = e->ldF;
   }
-  to_bf16_rows(e->stream, src, ld_src, e->Xb[s], e->ldFb, T, e->F);
+  to_bf16_rows(e->stream, src, ld_src, e->Xb[s], e->ldFb, T, e->F, e->act_plane(e->ldFb));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -857,7 +873,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
     CHK(join_optimizer(e));
     CHK(refresh_shadow(e));
   }
-  auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; } return t; };
+  auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; t.plane = e->act_plane(e->ldHb); } return t; };
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
     need_params(e, l);
@@ -896,7 +912,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
                    e->cfg.batch_norm ? e->mov_var(l) : nullptr, e->cfg.nonlin};
       ev.beta = e->cfg.batch_norm ? e->p_param() + y.beta_off : nullptr;
       ev.eps = e->bn_eps;
-      if (e->bf16) { ev.twin = e->ab[l]; ev.ld_twin = e->ldHb; }
+      if (e->bf16) { ev.twin = e->ab[l]; ev.ld_twin = e->ldHb; ev.twin_plane = e->act_plane(e->ldHb); }
       CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->a[l], ldH, T, H, y.d_in,
                    e->p_param() + y.b_off, EPI_BIAS | EPI_EVAL_ACT, nullptr, nullptr, -1, &ev));
       in = e->a[l];
@@ -1019,7 +1035,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
       Twin tw;
-      if (e->bf16) { tw.p = e->dAb[pp]; tw.ld = e->ldHb; }
+      if (e->bf16) { tw.p = e->dAb[pp]; tw.ld = e->ldHb; tw.plane = e->act_plane(e->ldHb); }
       int chunks_eff = fuse_hb ? chunks_in : 0;
       if (chunks_eff > kMergeOnceChunks) {  // tall micro-batch: reduce the EPI_DACT partial sums once
         chunk_totals(e->stream, ws_of(l), chunks_eff, ldH);
@@ -1127,7 +1143,8 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   e->cfg = *cfg;
   e->F = cfg->input_dim; e->L = cfg->num_layers; e->H = cfg->num_units; e->O = cfg->output_dim;
   e->ldF = (int)up(e->F, 4); e->ldH = (int)up(e->H, 4); e->ldO = (int)up(e->O, 4);
-  e->bf16 = cfg->compute_dtype == TFK_DTYPE_BF16;
+  e->bf16 = cfg->compute_dtype != TFK_DTYPE_F32;
+  e->x3 = cfg->compute_dtype == TFK_DTYPE_F32X3;
   e->ldFb = (int)up(e->F, 8); e->ldHb = (int)up(e->H, 8); e->ldOb = (int)up(e->O, 8);
   e->bn_decay = cfg->bn_decay > 0.f ? cfg->bn_decay : 0.999f;
   e->bn_eps = cfg->bn_epsilon > 0.f ? cfg->bn_epsilon : 1e-3f;
@@ -1213,7 +1230,10 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   if (e->bf16) {
     // shadow: mirrors the fp32 arena element for element inside the state arena when every leading dimension is a
     // multiple of 8 (the optimiser then writes it with the update and the sharded exchange gathers it), else packed
-    e->wb_aligned = shadow_mirrors(cfg, e->lay);
+    // (x3: three planes in an allocation of their own, at the arena's element offsets when every leading dimension is a
+    // multiple of 8 so that the optimiser writes them with the update; a data-parallel exchange gathers the fp32
+    // parameters in that mode and the planes are rebuilt from them)
+    e->wb_aligned = e->x3 ? x3_aligned(e->lay) : shadow_mirrors(cfg, e->lay);
     e->wb_off.assign(e->L + 1, 0);
     e->wb_ld.assign(e->L + 1, 0);
     size_t off = 0;
@@ -1223,7 +1243,11 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
       e->wb_off[l] = e->wb_aligned ? y.w_off : off;
       off += up((size_t)y.d_in * e->wb_ld[l], 64);
     }
-    if (e->wb_aligned) {
+    if (e->x3) {
+      e->wb_plane = (long)up(e->wb_aligned ? e->lay[0].b_off : off, 128);
+      if (alloc_zero_b(&e->Wb, (size_t)3 * e->wb_plane)) return bail(-1);
+      e->own_wb = true;
+    } else if (e->wb_aligned) {
       e->Wb = reinterpret_cast<bf16_t*>(e->state + e->off_shadow);  // (zeroed with the arena)
     } else {
       if (alloc_zero_b(&e->Wb, off)) return bail(-1);
@@ -1322,7 +1346,7 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * T * e->O + 16.0 * T * sext);
     Twin tw;
-    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
+    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; tw.plane = e->act_plane(e->ldOb); }
     ctc_loss_grad(e->stream, b, e->logits, train, tw);
   }
   {
@@ -1365,7 +1389,7 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
     {
       ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
       Twin tw;
-      if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; }
+      if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; tw.plane = e->act_plane(e->ldOb); }
       softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw);
     }
     {
@@ -1408,7 +1432,7 @@ bool stack_eligible(const tfk_engine* e) {
          e->fuse_hb_enabled && e->stack_enabled;
 }
 // segments start at multiples of the tallest GEMM tile of the arithmetic (fp32: 128, bf16: 256 rows)
-int stack_align(const tfk_engine* e) { return e->bf16 ? 256 : 128; }
+int stack_align(const tfk_engine* e) { return (e->bf16 && !e->x3) ? 256 : 128; }
 // rows of a stacked pass are bounded by the chunk slots of the backward workspaces: one slab-2 slot per row split (32 rows)
 // of every segment, kMaxRowSplits in all
 constexpr int kMaxStackRows = 8192;
@@ -1448,7 +1472,7 @@ int forward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, ui
       ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * st.rows[i] * H);
       const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
       Twin tw;
-      if (e->bf16) { tw.p = e->ab[l] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; }
+      if (e->bf16) { tw.p = e->ab[l] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; tw.plane = e->act_plane(e->ldHb); }
       bn_act_forward(e->stream, d, e->z[l] + (size_t)st.r0[i] * ldH, e->a[l] + (size_t)st.r0[i] * ldH,
                      e->ws_stats + (size_t)(st.r0[i] / chunk) * ldH, chunk, st.rows[i], H, ldH, e->bn_eps, e->bn_decay,
                      e->seg_mean[l] + (size_t)i * ldH, e->seg_rstd[l] + (size_t)i * ldH, e->ema_mean(l), e->ema_var(l),
@@ -1519,7 +1543,7 @@ int backward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, u
       ProfScope ps(e, KF_HIDDEN_BWD, 0, 28.0 * st.rows[i] * H);
       const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
       Twin tw;
-      if (e->bf16) { tw.p = e->dAb[pp] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; }
+      if (e->bf16) { tw.p = e->dAb[pp] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; tw.plane = e->act_plane(e->ldHb); }
       const size_t r = (size_t)st.r0[i] * ldH;
       hidden_backward(e->stream, d, 1, da + r, e->a[l] + r, e->z[l] + r, e->seg_mean[l] + (size_t)i * ldH,
                       e->seg_rstd[l] + (size_t)i * ldH, st.rows[i], H, ldH, ws_of(l) + (size_t)(st.r0[i] / bm_in) * ldH,
@@ -1597,7 +1621,7 @@ int run_stacked(tfk_engine* e, const float* Xd, int ld, const int32_t* yd, const
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * st.T_pad * e->O);
     Twin tw;
-    if (e->bf16) { tw.p = e->logb; tw.ld = e->ldOb; }
+    if (e->bf16) { tw.p = e->logb; tw.ld = e->ldOb; tw.plane = e->act_plane(e->ldOb); }
     softmax_xent(e->stream, e->logits, yd, st.T_pad, e->O, e->ldO, e->row_loss, 1, tw);
   }
   {
@@ -2029,7 +2053,8 @@ int apply_span(tfk_engine* e, size_t off, size_t n, hipStream_t st = nullptr) {
   // from the snapshot step_finish took
   ProfScope ps(e, KF_ADAM, 0, 28.0 * n, st);
   adam_apply(st ? st : e->stream, e->p_param() + off, e->p_grad() + off, e->p_m() + off, e->p_v() + off, n,
-             st ? e->d_snap : e->p_scalars(), e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0, n_wb ? e->Wb + off : nullptr, n_wb);
+             st ? e->d_snap : e->p_scalars(), e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0, n_wb ? e->Wb + off : nullptr, n_wb,
+             e->wb_plane);
   return 0;
 }
 // the whole optimiser step of tfk_apply, layer by layer on the optimiser stream (vectors first: every layer reads them)
@@ -2124,7 +2149,8 @@ int tfk_init_last_layer(tfk_engine* e) {
   if (e->bf16 && e->wb_aligned && !e->shadow_dirty) {
     // a current arena-mirroring shadow stays current: zero its output-layer span too instead of rebuilding it from
     // every fp32 master (under the sharded exchange the masters of other ranks' spans are not valid here)
-    HIPCHK(hipMemsetAsync(e->Wb + o.w_off, 0, o.w_sz * sizeof(bf16_t), e->stream));
+    for (int pl = 0; pl < (e->x3 ? 3 : 1); ++pl)
+      HIPCHK(hipMemsetAsync(e->Wb + (size_t)pl * e->wb_plane + o.w_off, 0, o.w_sz * sizeof(bf16_t), e->stream));
   } else {
     e->shadow_dirty = true;
   }
@@ -2332,9 +2358,11 @@ int tfk_params_touched(tfk_engine* e) {
 }
 int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* mirrors_arena) {
   if (!e || !device_ptr || !num_elems || !mirrors_arena) return fail(-1, "NULL argument");
-  *device_ptr = e->bf16 ? (void*)e->Wb : nullptr;
-  *num_elems = (e->bf16 && e->wb_aligned) ? e->lay[0].b_off : 0;
-  *mirrors_arena = (e->bf16 && e->wb_aligned) ? 1 : 0;
+  // (x3: the shadow is three planes outside the arena -- nothing a sharded exchange could gather in place of the parameters)
+  const bool mirrors = e->bf16 && !e->x3 && e->wb_aligned;
+  *device_ptr = (e->bf16 && !e->x3) ? (void*)e->Wb : nullptr;
+  *num_elems = mirrors ? e->lay[0].b_off : 0;
+  *mirrors_arena = mirrors ? 1 : 0;
   return 0;
 }
 int tfk_apply_writes_shadow(tfk_engine* e, int* direct) {
@@ -2352,7 +2380,7 @@ int tfk_param_checksum(tfk_engine* e, int which, uint64_t* value) {
     p = reinterpret_cast<const uint32_t*>(e->p_param());
     words = e->P;
   } else if (which == 1) {
-    if (!e->bf16 || !e->wb_aligned) return fail(-1, "no arena-mirroring bf16 shadow to checksum");
+    if (!e->bf16 || e->x3 || !e->wb_aligned) return fail(-1, "no arena-mirroring bf16 shadow to checksum");
     p = reinterpret_cast<const uint32_t*>(e->Wb);
     words = e->lay[0].b_off / 2;
   } else if (which == 2) {
@@ -2487,6 +2515,27 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   const int rc = gemm_bf16((GemmLayout)layout, g, (hipStream_t)stream);
   if (rc != 0) return fail(rc, "gemm_bf16 failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
+
+int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int64_t plane, int rows, int cols) {
+  if (!src || !dst) return fail(-1, "NULL argument");
+  if ((ldd & 7) || plane <= 0 || (plane & 7) || plane < (int64_t)rows * ldd)
+    return fail(-1, "tfk_split3: ldd %d / plane %lld (multiples of 8, plane >= rows * ldd)", ldd, (long long)plane);
+  to_bf16_rows((hipStream_t)stream, src, lds, dst, ldd, rows, cols, (long)plane);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, int64_t a_plane, const uint16_t* B, int ldb,
+                    int64_t b_plane, float* C, int ldc, int M, int N, int K, const float* bias, int epi) {
+  if (layout < 0 || layout > 2) return fail(-1, "bad layout %d", layout);
+  GemmArgsB g = {};
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.a_plane = (long)a_plane; g.b_plane = (long)b_plane;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  const int rc = gemm_bf16x3((GemmLayout)layout, g, (hipStream_t)stream);
+  if (rc != 0) return fail(rc, "gemm_bf16x3 failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;
 }
 

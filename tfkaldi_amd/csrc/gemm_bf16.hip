@@ -216,7 +216,19 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
         if (col_ok && row < p.M) {
           p.C[(size_t)row * p.ldc + col] = v;
           if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
-            if (p.C_twin) p.C_twin[(size_t)row * p.ldct + col] = f2bf(v);
+            if (p.C_twin) {
+              if (p.ct_plane) {  // three planes whose sum is v exactly (truncation split, 8 significand bits each)
+                float r = v;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                  const uint32_t bits = __builtin_bit_cast(uint32_t, r) & 0xffff0000u;
+                  p.C_twin[(size_t)pl * p.ct_plane + (size_t)row * p.ldct + col] = (bf16_t)(bits >> 16);
+                  r -= __builtin_bit_cast(float, bits);
+                }
+              } else {
+                p.C_twin[(size_t)row * p.ldct + col] = f2bf(v);
+              }
+            }
           }
         }
       }
@@ -236,9 +248,12 @@ __device__ __forceinline__ int ks_swz(int r) {
 
 // One operand's share of a stage: EXT rows of BKT k (k-contiguous; BKT = 64 only) or BKT k-rows of EXT elements;
 // EXT * BKT * 2 bytes either way.
+// (k-contiguous images: 128-byte rows at 64 k per slot, chunk c of row r at c ^ ((r >> 1) & 7); 64-byte rows at 32 k per slot
+// -- the three-plane stages of the fp32-emulating kernel -- chunk c of row r at c ^ ((r >> 2) & 3): the 16 lanes of a
+// ds_read_b128 service group then touch 16 distinct 16-byte slots of a 256-byte bank row in both cases)
 template <bool KC, int EXT, int NTH, int BKT = 64>
 struct DmaOperand {
-  static_assert(!KC || BKT == 64, "k-contiguous images have 128-byte rows");
+  static_assert(BKT == 64 || BKT == 32, "ring slot of 64 or 32 k");
   static constexpr int NP = EXT * BKT / 8 / NTH;  // 16-byte pieces per thread per tile
   static_assert((EXT * BKT / 8) % NTH == 0 && NP >= 1, "pieces per thread");
   i32x4 rsrc;
@@ -247,12 +262,14 @@ struct DmaOperand {
   int kstride;   // bytes per unit of k
   int k_lim;
 
+  // extra_bytes: further planes of the operand behind the first one (the resource must cover them: issue() reaches
+  // plane q through the scalar offset)
   __device__ __forceinline__ void init(const bf16_t* base, int ld, int rows, int ext0, int ext_lim, int k_lim_,
-                                       int tid) {
+                                       int tid, long extra_bytes = 0) {
     const unsigned long long a = (unsigned long long)base;
     rsrc[0] = (int)(unsigned)a;
     rsrc[1] = (int)((unsigned)(a >> 32) & 0xffffu);
-    rsrc[2] = rows * ld * 2;
+    rsrc[2] = (int)(rows * ld * 2 + extra_bytes);
     rsrc[3] = 0x00020000;
     k_lim = k_lim_;
     kstride = KC ? 2 : ld * 2;
@@ -260,8 +277,10 @@ struct DmaOperand {
     for (int j = 0; j < NP; ++j) {
       const int idx = tid + j * NTH;  // chunk position inside the LDS image
       if (KC) {
-        const int r = idx >> 3;
-        const int k = ((idx & 7) ^ ((r >> 1) & 7)) << 3;
+        constexpr int CPR = BKT / 8;  // 16-byte chunks per row
+        const int r = idx / CPR;
+        const int sw = BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3);
+        const int k = ((idx % CPR) ^ sw) << 3;
         const int e = ext0 + r;
         voff[j] = e < ext_lim ? (e * ld + k) * 2 : kOOB;
         kidx[j] = k;
@@ -276,10 +295,10 @@ struct DmaOperand {
     }
   }
   // piece j of the tile at k0 -> image at LDS byte address `image` (out-of-range pieces land as zeros)
-  __device__ __forceinline__ void issue(int j, unsigned image, int k0, int wave) const {
+  __device__ __forceinline__ void issue(int j, unsigned image, int k0, int wave, int plane_bytes = 0) const {
     const int off = (k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
     const unsigned dst = image + (unsigned)(wave * 64 + j * NTH) * 16u;
-    const int soff = k0 * kstride;
+    const int soff = k0 * kstride + plane_bytes;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(dst), "v"(off), "s"(rsrc), "s"(soff)
@@ -288,14 +307,14 @@ struct DmaOperand {
 };
 
 // MFMA operand fetch from the DMA image.  NF fragments of 32 rows (columns) starting at fragment index frag0.
-template <bool KC, int EXT, int NF>
+template <bool KC, int EXT, int NF, int BKT = 64>
 struct Frag {
   int off[KC ? 4 : NF];
   __device__ __forceinline__ void init(int lane, int frag0) {
     if constexpr (KC) {
-      const int i = lane & 31, kb = lane >> 5, sw = (i >> 1) & 7;
+      const int i = lane & 31, kb = lane >> 5, sw = BKT == 64 ? ((i >> 1) & 7) : ((i >> 2) & 3);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) off[ks] = (frag0 * 32 + i) * 128 + ((((2 * ks + kb) ^ sw)) << 4);
+      for (int ks = 0; ks < BKT / 16; ++ks) off[ks] = (frag0 * 32 + i) * (BKT * 2) + ((((2 * ks + kb) ^ sw)) << 4);
     } else {
       constexpr int ROWB = EXT * 2;
       const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
@@ -308,7 +327,7 @@ struct Frag {
   // fragment f, 16-k step ks of the operand image at `img`
   __device__ __forceinline__ bf16x8 read(const char* img, int f, int ks) const {
     if constexpr (KC) {
-      return *reinterpret_cast<const bf16x8*>(img + off[ks] + f * 32 * 128);
+      return *reinterpret_cast<const bf16x8*>(img + off[ks] + f * 32 * (BKT * 2));
     } else {
       constexpr int ROWB = EXT * 2;
       typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -334,18 +353,23 @@ struct Frag {
 // SCHED 2 = "ping-pong" (8-wave blocks): the two waves that share a SIMD run half a tile apart -- while one multiplies a whole
 // ring slot out of registers (nothing but MFMAs), its partner fetches every fragment of its next slot and issues its LDS-DMA
 // pieces; a block-wide barrier separates the half-steps and the two swap roles.  See the loop.
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0>
+// NPL = 3: the fp32-EMULATING contraction ("bf16x3", gemm_bf16.h): every operand comes as three bf16 planes whose sum is the
+// fp32 value exactly; a ring slot holds all six plane tiles of a 32-k step, and each 16-k MFMA step multiplies the six plane
+// pairs of order <= 2^-16 -- (3,1) (2,2) (1,3) (2,1) (1,2) (1,1), smallest first -- into the SAME fp32 accumulators.
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
+          int NPL = 1>
 __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
   typedef DmaOperand<A_KC, BM, NTH, BKT> OA;
   typedef DmaOperand<B_KC, BN, NTH, BKT> OB;
-  constexpr int A_BYTES = BM * BKT * 2, STAGE = (BM + BN) * BKT * 2;
-  constexpr int NPA = OA::NP, NP = OA::NP + OB::NP;
+  constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE = NPL * (A_BYTES + B_BYTES);
+  constexpr int NPA = OA::NP, NPB = OB::NP, NP = NPL * (OA::NP + OB::NP);
   constexpr int KSPT = BKT / 16;  // 16-k MFMA steps per ring slot
   static_assert(KSPT == 4 || KSPT == 2, "ring slot of 64 or 32 k");
   static_assert(NS >= 3 && (NS - 2) * NP <= 63, "ring depth / vmcnt range");
   static_assert(FM * FN >= 2, "two independent accumulator chains per wave");
+  static_assert(NPL == 1 || (NPL == 3 && SCHED == 0 && TFKB_ABL == 0), "planes");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -363,12 +387,13 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   OB lb;
   // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
   // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
-  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid);
-  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid);
-  Frag<A_KC, BM, FM> qa;
-  Frag<B_KC, BN, FN> qb;
+  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid, (NPL - 1) * p.a_plane * 2);
+  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid, (NPL - 1) * p.b_plane * 2);
+  Frag<A_KC, BM, FM, BKT> qa;
+  Frag<B_KC, BN, FN, BKT> qb;
   qa.init(lane, wm * FM);
   qb.init(lane, wn * FN);
+  const int a_plane_b = __builtin_amdgcn_readfirstlane((int)(p.a_plane * 2)), b_plane_b = __builtin_amdgcn_readfirstlane((int)(p.b_plane * 2));
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -380,8 +405,13 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 
   auto piece = [&](int j, int slot, int kt) {
     if (TFKB_ABL & 2) return;
-    if (j < NPA) la.issue(j, lds0 + (unsigned)(slot * STAGE), kt * BKT, wave);
-    else lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + A_BYTES), kt * BKT, wave);
+    if (j < NPL * NPA) {
+      const int pl = j / NPA;
+      la.issue(j % NPA, lds0 + (unsigned)(slot * STAGE + pl * A_BYTES), kt * BKT, wave, pl * a_plane_b);
+    } else {
+      const int jb = j - NPL * NPA, pl = jb / NPB;
+      lb.issue(jb % NPB, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES + pl * B_BYTES), kt * BKT, wave, pl * b_plane_b);
+    }
   };
   // prologue: tiles 0 .. NS-2 (tiles beyond K land as zeros without touching memory)
 #pragma unroll
@@ -390,13 +420,16 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     for (int j = 0; j < NP; ++j) piece(j, t, t);
   TFKB_WAIT_BARRIER((NS - 2) * NP);
 
-  bf16x8 fa[2][FM], fb[2][FN];
+  bf16x8 fa[2][NPL][FM], fb[2][NPL][FN];
   auto read_frags = [&](int buf, const char* st, int ks) {
     if (TFKB_ABL & 4) return;
 #pragma unroll
-    for (int a = 0; a < FM; ++a) fa[buf][a] = qa.read(st, a, ks);
+    for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-    for (int b = 0; b < FN; ++b) fb[buf][b] = qb.read(st + A_BYTES, b, ks);
+      for (int a = 0; a < FM; ++a) fa[buf][pl][a] = qa.read(st + pl * A_BYTES, a, ks);
+#pragma unroll
+      for (int b = 0; b < FN; ++b) fb[buf][pl][b] = qb.read(st + NPL * A_BYTES + pl * B_BYTES, b, ks);
+    }
   };
   if (TFKB_ABL & 4) {
 #pragma unroll
@@ -404,25 +437,35 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fa[q][a][e] = (__bf16)(float)(lane + e);
+        for (int e = 0; e < 8; ++e) fa[q][0][a][e] = (__bf16)(float)(lane + e);
 #pragma unroll
       for (int b = 0; b < FN; ++b)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fb[q][b][e] = (__bf16)(float)(lane - e);
+        for (int e = 0; e < 8; ++e) fb[q][0][b][e] = (__bf16)(float)(lane - e);
     }
   }
   auto mfma_step = [&](int cur) {
     if (TFKB_ABL & 1) {  // keep the fragment reads alive without the MFMAs
 #pragma unroll
-      for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][a]));
+      for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][0][a]));
 #pragma unroll
-      for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][b]));
-    } else {
+      for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][0][b]));
+    } else if constexpr (NPL == 1) {
 #pragma unroll
       for (int a = 0; a < FM; ++a)
 #pragma unroll
         for (int b = 0; b < FN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][a], fb[cur][b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][a], fb[cur][0][b], acc[a][b], 0, 0, 0);
+    } else {
+      // plane pairs (pa, pb), smallest products first; consecutive MFMAs go to different accumulators (FM * FN >= 2)
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+          for (int b = 0; b < FN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[c]][a], fb[cur][PB[c]][b], acc[a][b], 0, 0, 0);
     }
   };
   // The K loop is ROTATED by one 16-k step (round 3): the per-tile barrier sits between the third and the fourth step of a
@@ -508,11 +551,12 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0>
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
+          int NPL = 1>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
+  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
 }
 
 // Two INDEPENDENT contractions in one launch -- backward: dA = dZ . W^T (NT, optionally EPI_DACT) of a layer and the
@@ -759,14 +803,30 @@ int launch_reg(const GemmArgsB& p, hipStream_t stream) {
   static bool attr_done = false;
   return launch_grid(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>, p, BM, BN, NT, lds, stream, &attr_done);
 }
-template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0>
+template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
+          int NPL = 1>
 int launch_dma(const GemmArgsB& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
-  const size_t lds = (size_t)NS * (BM + BN) * BKT * 2;
-  static_assert((size_t)NS * (BM + BN) * BKT * 2 <= 160 * 1024, "LDS");
+  const size_t lds = (size_t)NS * NPL * (BM + BN) * BKT * 2;
+  static_assert((size_t)NS * NPL * (BM + BN) * BKT * 2 <= 160 * 1024, "LDS");
   static bool attr_done = false;
-  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED>, p, BM, BN,
+  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL>, p, BM, BN,
                      WAVES_M * WAVES_N * 64, lds, stream, &attr_done);
+}
+
+// fp32-emulating contraction on three bf16 planes per operand: 128x128 blocks (three 48 KB slots) when the result has a
+// tile of it for nearly every CU, else 128x64 (four 36 KB slots); 32 k per slot, four waves
+int g_x3_cfg = -2;  // env TFK_BF16X3_CFG (experiments): 0 = 128x64, 1 = 128x128, -1 heuristic
+template <bool A_KC, bool B_KC, int EPI>
+int launch_x3(const GemmArgsB& p, hipStream_t stream) {
+  if (g_x3_cfg == -2) {
+    const char* q = getenv("TFK_BF16X3_CFG");
+    g_x3_cfg = q ? atoi(q) : -1;
+  }
+  const long m128 = (p.M + 127) / 128, n128 = (p.N + 127) / 128;
+  const bool big = g_x3_cfg >= 0 ? g_x3_cfg == 1 : m128 * n128 >= 200;
+  if (big) return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
+  return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3>(p, stream);
 }
 
 template <bool A_KC, bool B_KC, int EPI>
@@ -891,6 +951,37 @@ int gemm_bf16_pick_config(int M, int N) {
 }
 
 int gemm_bf16_tile_rows(int M, int N) { return kCfgB[gemm_bf16_pick_config(M, N)].bm; }
+
+int gemm_bf16x3(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
+  if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || p.a_plane <= 0 || p.b_plane <= 0 || (p.a_plane & 7) || (p.b_plane & 7))
+    return (int)hipErrorInvalidValue;
+  {  // the three planes of an operand are addressed through ONE buffer resource with 32-bit byte offsets
+    const long a_rows = layout == GEMM_TN ? p.K : p.M;
+    const long b_rows = layout == GEMM_NT ? p.N : p.K;
+    if ((2 * p.a_plane + a_rows * p.lda) * 2 >= (1L << 31) || (2 * p.b_plane + b_rows * p.ldb) * 2 >= (1L << 31))
+      return (int)hipErrorInvalidValue;
+  }
+  switch (layout) {
+    case GEMM_NN:
+      switch (p.epi) {
+        case 0: return launch_x3<true, false, 0>(p, stream);
+        case EPI_BIAS: return launch_x3<true, false, EPI_BIAS>(p, stream);
+        case EPI_BIAS | EPI_COLSTATS: return launch_x3<true, false, EPI_BIAS | EPI_COLSTATS>(p, stream);
+        case EPI_BIAS | EPI_EVAL_ACT: return launch_x3<true, false, EPI_BIAS | EPI_EVAL_ACT>(p, stream);
+      }
+      break;
+    case GEMM_NT:
+      if (p.epi == 0) return launch_x3<true, true, 0>(p, stream);
+      if (p.epi == EPI_DACT) return launch_x3<true, true, EPI_DACT>(p, stream);
+      break;
+    case GEMM_TN:
+      if (p.epi == 0) return launch_x3<false, false, 0>(p, stream);
+      if (p.epi == EPI_ACCUM) return launch_x3<false, false, EPI_ACCUM>(p, stream);
+      break;
+  }
+  return (int)hipErrorInvalidValue;
+}
 
 int gemm_bf16(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;

@@ -23,10 +23,33 @@ constexpr int kMaxRowSplits = 256;
 
 // Mixed-precision mode: kernels that produce a GEMM operand also store its bf16 twin (p == nullptr: fp32 mode).
 // ld in bf16 elements, a multiple of 8; padding columns of the twin stay zero from its allocation.
+// plane > 0 ("bf16x3", gemm_bf16.h): the twin is THREE bf16 planes, `plane` elements apart, whose sum is the fp32 value
+// exactly (twin_split3 below); plane == 0: one plane, round to nearest even.
 struct Twin {
   uint16_t* p = nullptr;
   int ld = 0;
+  long plane = 0;
 };
+// x = p1 + p2 + p3 exactly, each a bf16: truncation of the fp32 significand, 8 bits per piece (the remainder after two
+// pieces has at most 8 significant bits left)
+__device__ __forceinline__ void twin_split3(float x, uint16_t& p1, uint16_t& p2, uint16_t& p3) {
+  const uint32_t b1 = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+  const float r1 = x - __builtin_bit_cast(float, b1);
+  const uint32_t b2 = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+  const float r2 = r1 - __builtin_bit_cast(float, b2);
+  p1 = (uint16_t)(b1 >> 16);
+  p2 = (uint16_t)(b2 >> 16);
+  p3 = (uint16_t)(__builtin_bit_cast(uint32_t, r2) >> 16);
+}
+__device__ __forceinline__ void twin_put(const Twin& t, size_t idx, float v) {
+  if (t.plane) {
+    uint16_t a, b, c;
+    twin_split3(v, a, b, c);
+    t.p[idx] = a; t.p[idx + t.plane] = b; t.p[idx + 2 * t.plane] = c;
+  } else {
+    t.p[idx] = __builtin_bit_cast(uint16_t, (__bf16)v);
+  }
+}
 
 // ---- batch norm statistics ----
 // train: per-column mean / biased variance of z[T,H] (two-level, Chan-merged), rstd = rsqrt(var+eps);
@@ -112,10 +135,10 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 // ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam (G is left as is) ----
 // grid_cap > 0 limits the number of blocks (grid-stride loop does the rest)
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0);
-// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update
-// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns
-void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols);
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0, long wb_plane = 0);
+// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update (wb_plane > 0: three planes)
+// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns (plane > 0: three planes whose sum is the value exactly)
+void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, long plane = 0);
 // end of a step in one launch: moving <- decay^{num_microbatches} * moving + E, E <- 0, and
 // host[0..3] <- scalars[0..3] (host = device address of mapped pinned memory)
 // snap (nullable): device copy of scalars[0..3] that stays valid until the next step_finish
