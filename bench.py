@@ -66,7 +66,9 @@ class Workload(object):
         self.macs = F * self.H + (self.L - 1) * self.H * self.H + self.H * self.O
         # fwd 2M, dW 2M, dA 2M minus the unneeded layer-0 dA
         self.flop_per_frame = 6 * self.macs - 2 * F * self.H
-        self.peak = PEAK_FP32_MFMA_TFLOPS if self.dtype == "float32" else PEAK_BF16_MFMA_TFLOPS
+        # (float32x3: six bf16 MFMAs per fp32 product -- the ceiling of the emulation in fp32-equivalent flops)
+        self.peak = {"float32": PEAK_FP32_MFMA_TFLOPS, "bfloat16": PEAK_BF16_MFMA_TFLOPS,
+                     "float32x3": PEAK_BF16_MFMA_TFLOPS / 6.0}[self.dtype]
 
 
 def self_launch(args):
@@ -168,6 +170,59 @@ def measured_traffic(kernel_name):
         % (meta.get("csrc_sha16"), meta.get("measured", "?")))
 
 
+def emulated_leg(w, batches, hidden, steps, warmup, device, ref_trace):
+    """The same workload with the fp32 contractions EMULATED on the bf16 matrix pipe (compute_dtype float32x3: every operand
+    split exactly into three bf16 planes, six plane products accumulated in fp32 -- include/tfkaldi_hip.h).  Reported beside the
+    headline, never as it: `value` above is the exact-fp32 MFMA path.  Same weights, same micro-batch sequence; its loss trace
+    is held against the same float64 referee."""
+    import torch
+    from tfkaldi_amd import _lib
+    from tfkaldi_amd.engine import Engine
+    cfg = _lib.make_config(F, w.L, w.H, w.O, nonlin="relu", batch_norm=True, keep_prob=w.keep, init_learning_rate=1e-3,
+                           num_steps=3 * (steps + warmup), max_frames=w.T, device=device, compute_dtype="float32x3")
+    eng = Engine(cfg)
+    for l, weights in enumerate(hidden):
+        eng.set(_lib.WEIGHTS, l, weights)
+    dev = [(torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda()) for X, y in batches]
+    torch.cuda.synchronize()
+    n = [0]
+
+    def step():
+        dX, dy = dev[n[0] % len(dev)]
+        n[0] += 1
+        eng.accumulate_device(dX.data_ptr(), F, dy.data_ptr(), w.T, last=True)
+        return eng.apply()
+
+    losses = [step() for _ in range(warmup)]
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(step())
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.profile_begin()
+    for _ in range(min(steps, 20)):
+        step()
+    eng.synchronize()
+    stats = eng.profile_end()
+    eng.close()
+    gemms = [s for s in stats if s["name"].startswith("gemm_")]
+    out = {"value": w.T / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt,
+           "arithmetic": "fp32 emulated on the bf16 MFMA pipe: operands split exactly into 3 bf16 planes, 6 plane products, fp32 "
+                         "accumulate; parameters / statistics / loss / gradient sums / Adam in fp32 (TFK_DTYPE_F32X3)",
+           "all_gemm_tflops_fp32_equivalent": sum(s["flops"] for s in gemms) / sum(s["total_ms"] for s in gemms) / 1e9,
+           "bf16_pipe_frac": 6.0 * sum(s["flops"] for s in gemms) / sum(s["total_ms"] for s in gemms) / 1e9 / PEAK_BF16_MFMA_TFLOPS,
+           "step_tflops_fp32_equivalent": w.T / dt * w.flop_per_frame / 1e12,
+           "loss_trace": losses[:TRACE_STEPS],
+           "kernel_ms_per_step": {s["name"].replace("gemm_f32", "gemm_bf16x3"): s["total_ms"] / min(steps, 20) for s in stats}}
+    if ref_trace:
+        from oracle.loss_trace import distances
+        rel, _ = distances(losses, ref_trace)
+        out["loss_trace_f64_max_rel_diff"] = max(rel) if rel else None
+        out["loss_trace_f64_rel_diff_per_step"] = rel
+    return out
+
+
 def decode_leg(w, eng, batches):
     """The decode half of the path (reference neuralNetworks/decoder.py:49-71, nnet.py:270-286): evaluation-mode forward
     + softmax / prior + log -> log-likelihoods on the HOST, for one batched pass of 8 micro-batches and for
@@ -217,7 +272,7 @@ def decode_leg(w, eng, batches):
 
 def kernel_label(w, family):
     """the engine names its kernel families after the fp32 kernels; say which arithmetic actually ran"""
-    return family if w.dtype == "float32" else family.replace("gemm_f32", "gemm_bf16")
+    return family if w.dtype == "float32" else family.replace("gemm_f32", "gemm_bf16x3" if w.dtype == "float32x3" else "gemm_bf16")
 
 
 def api_fed_leg(w, world, steps):
@@ -255,8 +310,11 @@ def main():
                     help="BASELINE.json configuration as one GPU sees it: cfg2 (default; configs[1], the one the metric is "
                          "quoted on, fp32), cfg3 / cfg4 (configs[2] / [3]: the 8-GPU bf16 runs, --gpus 8).  Also "
                          "TFK_BENCH_CONFIG")
-    ap.add_argument("--dtype", choices=["float32", "bfloat16"], default=None,
-                    help="arithmetic of the GEMMs; default = the configuration's own (cfg2 float32, cfg3 / cfg4 bfloat16)")
+    ap.add_argument("--dtype", choices=["float32", "bfloat16", "float32x3"], default=None,
+                    help="arithmetic of the GEMMs; default = the configuration's own (cfg2 float32, cfg3 / cfg4 bfloat16); "
+                         "float32x3 = fp32 emulated on the bf16 pipe (three bf16 planes per operand, include/tfkaldi_hip.h)")
+    ap.add_argument("--no-emulated", action="store_true",
+                    help="skip the `emulated_fp32` sub-record (cfg2 / float32 runs on one GPU only)")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (N = 1 only)")
     ap.add_argument("--no-api-fed", action="store_true",
                     help="skip the Nnet.train leg (api_fed_value; also TFK_BENCH_API_FED=0)")
@@ -410,13 +468,15 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_with_event_profiling": 1e3 * elapsed_profiled / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "float32" else "bf16 operands, f32 accumulate / master / optimiser",
+            "dtype": {"float32": "f32", "bfloat16": "bf16 operands, f32 accumulate / master / optimiser",
+                      "float32x3": "f32 emulated: operands split exactly into 3 bf16 planes, 6 plane products, f32 accumulate"}[args.dtype],
             "data": "synthetic ark/scp/alignment files (SURVEY 8d) read through the feature reader + dispenser, %d "
                     "distinct micro-batches per rank cycled (a different one every step); random-init weights "
                     "N(0,1/sqrt(d_in)), zero output layer" % ring,
             "lib_build_id": eng.lib.tfk_build_id().decode(),
             "config": {"workload": "%s, %d frames/GPU/step, %s, Adam" % (
-                           w.text, T, "fp32 MFMA" if args.dtype == "float32" else "bf16 MFMA (mixed precision)"),
+                           w.text, T, {"float32": "fp32 MFMA", "bfloat16": "bf16 MFMA (mixed precision)",
+                                       "float32x3": "fp32 emulated on the bf16 MFMA pipe (bf16x3)"}[args.dtype]),
                        "name": w.name, "frames_per_gpu": T, "global_frames": world * T,
                        "parallelism": "dp%d" % world, "flop_per_frame": w.flop_per_frame},
             "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend,
@@ -471,6 +531,8 @@ def main():
             out["posterior_max_err"] = posterior_error(w, eng, batches[0][0][:w.utt_len])
         if world == 1 and not args.no_decode:
             out["decode"] = decode_leg(w, eng, batches)
+        if world == 1 and args.dtype == "float32" and not args.no_emulated:
+            out["emulated_fp32"] = emulated_leg(w, batches, hidden, args.steps, args.warmup, local_rank, out.get("loss_trace_f64"))
     eng.close()
     if not args.no_api_fed and os.environ.get("TFK_BENCH_API_FED", "1") != "0":
         try:

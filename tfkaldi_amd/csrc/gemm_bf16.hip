@@ -396,12 +396,21 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   const int a_plane_b = __builtin_amdgcn_readfirstlane((int)(p.a_plane * 2)), b_plane_b = __builtin_amdgcn_readfirstlane((int)(p.b_plane * 2));
 
   f32x16 acc[FM][FN];
+  f32x16 acc2[NPL == 3 ? FM : 1][NPL == 3 ? FN : 1];  // (NPL == 3: the correction products, see mfma_step)
 #pragma unroll
   for (int a = 0; a < FM; ++a)
 #pragma unroll
     for (int b = 0; b < FN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  if constexpr (NPL == 3) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+  }
 
   auto piece = [&](int j, int slot, int kt) {
     if (TFKB_ABL & 2) return;
@@ -457,15 +466,23 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
         for (int b = 0; b < FN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][a], fb[cur][0][b], acc[a][b], 0, 0, 0);
     } else {
-      // plane pairs (pa, pb), smallest products first; consecutive MFMAs go to different accumulators (FM * FN >= 2)
+      // plane pairs (pa, pb), smallest products first.  The five CORRECTION products (order 2^-8 and 2^-16 of a1 b1) have an
+      // accumulator of their own, added to the main one in front of the epilogue: added to the large running sum one by one
+      // they would each be rounded at ITS scale (measured: rms error 1.7x the fp32 MFMA chain's; with their own accumulator
+      // below it).  Consecutive MFMAs go to different accumulators.
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int c = 0; c < 6; ++c)
+      for (int c = 0; c < 5; ++c)
 #pragma unroll
         for (int a = 0; a < FM; ++a)
 #pragma unroll
           for (int b = 0; b < FN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[c]][a], fb[cur][PB[c]][b], acc[a][b], 0, 0, 0);
+            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[c]][a], fb[cur][PB[c]][b], acc2[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][a], fb[cur][0][b], acc[a][b], 0, 0, 0);
     }
   };
   // The K loop is ROTATED by one 16-k step (round 3): the per-tile barrier sits between the third and the fourth step of a
@@ -548,6 +565,14 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   }
   }
   TFKB_WAIT_BARRIER(0);  // the epilogue reuses the ring as scratch: nothing may still be landing in it
+  if constexpr (NPL == 3) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += acc2[a][b][r];
+  }
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 

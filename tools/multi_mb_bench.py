@@ -21,6 +21,7 @@ from tfkaldi_amd.engine import Engine  # noqa: E402
 CONFIGS = {  # frames per micro-batch, F, L, H, O, keep_prob, dtype
     "cfg2": (1024, 440, 6, 2048, 2000, 1.0, "float32"),
     "cfg2-bf16": (1024, 440, 6, 2048, 2000, 1.0, "bfloat16"),
+    "cfg2-x3": (1024, 440, 6, 2048, 2000, 1.0, "float32x3"),  # fp32 emulated on the bf16 pipe
     "cfg3": (1024, 440, 6, 2048, 4000, 1.0, "bfloat16"),
     "cfg4": (2048, 440, 8, 4096, 8000, 0.5, "bfloat16"),
 }

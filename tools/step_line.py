@@ -17,10 +17,11 @@ from tfkaldi_amd.engine import Engine  # noqa: E402
 
 CONFIGS = {  # T per GPU, F, L, H, O, keep_prob, dtype
     "cfg2": (1024, 440, 6, 2048, 2000, 1.0, "float32"),
+    "cfg2x3": (1024, 440, 6, 2048, 2000, 1.0, "float32x3"),  # fp32 emulated on the bf16 pipe
     "cfg3": (1024, 440, 6, 2048, 4000, 1.0, "bfloat16"),
     "cfg4": (2048, 440, 8, 4096, 8000, 0.5, "bfloat16"),
 }
-PEAK = {"float32": 157.3, "bfloat16": 2500.0}
+PEAK = {"float32": 157.3, "bfloat16": 2500.0, "float32x3": 2500.0 / 6}
 
 
 def main():
@@ -61,7 +62,8 @@ def main():
     line = {
         "config": name, "workload": "%dx%d ReLU+BN%s, 440 in, %d pdf, %d frames per GPU per step, %s" % (
             L, H, " + dropout %.1f" % keep if keep < 1 else "", O, T,
-            "fp32 MFMA" if dtype == "float32" else "bf16 MFMA (fp32 accumulate / master / optimiser)"),
+            {"float32": "fp32 MFMA", "bfloat16": "bf16 MFMA (fp32 accumulate / master / optimiser)",
+             "float32x3": "fp32 emulated on the bf16 MFMA pipe (3 bf16 planes per operand, 6 plane products)"}[dtype]),
         "ms_per_step": 1e3 * dt, "frames_per_s_per_gpu": T / dt, "parameters": P,
         "step_tflops": T / dt * flop_per_frame / 1e12, "step_frac_of_mfma_peak": T / dt * flop_per_frame / 1e12 / PEAK[dtype],
         "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s",
