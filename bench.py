@@ -42,6 +42,7 @@ F = F_RAW * (2 * CONTEXT + 1)
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0           # v_mfma_f32_32x32x16_bf16, dense
 TRACE_STEPS = 20                         # per-step average_loss of the first 20 steps
+CPU_WARMUP = 10                          # warm-up steps kept out of the cpu_baseline rate
 MAX_RING = 16                            # distinct micro-batches resident per rank
 
 
@@ -117,20 +118,26 @@ def cpu_baseline(w, batches, hidden_weights, budget_s=20.0):
     t = TorchCpuTrainer(F, w.L, w.H, w.O, nonlin="relu", batch_norm=True, threads=cores)
     T = w.T
     t.set_hidden_weights(hidden_weights)
-    trace, steps, t0 = [], 0, time.perf_counter()
+    # the first CPU_WARMUP steps (thread pool start, allocator, first-touch pages) belong to the loss trace but not to the rate
+    trace, steps, t0, t_warm = [], 0, time.perf_counter(), None
     while True:
         X, y = batches[steps % len(batches)]
         t.accumulate(X, y)
         trace.append(t.apply())
         steps += 1
-        dt = time.perf_counter() - t0
+        now = time.perf_counter()
+        if steps == CPU_WARMUP:
+            t_warm = now
+        dt = now - t0
         if (dt > budget_s and steps >= TRACE_STEPS) or steps >= 60 or dt > 3 * budget_s:
             break
-    return {"value": steps * T / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    timed = steps - CPU_WARMUP if t_warm is not None and steps > CPU_WARMUP else steps
+    span = now - t_warm if timed != steps else dt
+    return {"value": timed * T / span, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d optimiser steps from the same initial weights over the same micro-batch sequence (%d frames "
-                      "each), no warm-up, PyTorch-CPU fp32 restatement of CrossEnthropyTrainer.update (a stand-in: "
+                      "each), the first %d untimed, PyTorch-CPU fp32 restatement of CrossEnthropyTrainer.update (a stand-in: "
                       "TensorFlow, the reference's CPU path, is absent)%s" % (
-                          steps, T, "" if w.keep >= 1 else "; the stand-in has no dropout layer (the masks cost it "
+                          steps, T, steps - timed, "" if w.keep >= 1 else "; the stand-in has no dropout layer (the masks cost it "
                           "nothing measurable)")}, trace[:TRACE_STEPS]
 
 
@@ -484,7 +491,9 @@ def main():
             # the torch.distributed calls of the last timed step, in launch order
             "exchange": reducer.mode if reducer else None,
             "exchange_driver": (("library (csrc/exchange.hip, %s)" % reducer.backend) if getattr(reducer, "native", False)
-                                else "torch.distributed (dataparallel.BucketReducer)") if reducer else None,
+                                else "torch.distributed (dataparallel.BucketReducer)%s" % (
+                                    "; in-library exchange FAILED: %s" % reducer.fallback_reason
+                                    if getattr(reducer, "fallback_reason", None) else "")) if reducer else None,
             "exchange_requested": (args.exchange or os.environ.get("TFK_DP_EXCHANGE", "sharded")) if reducer else None,
             "collectives_last_step": list(reducer.last_executed) if reducer else None,
             "collective_spans_last_step": [list(x) for x in reducer.last_launched] if reducer else None,

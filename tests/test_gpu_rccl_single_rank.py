@@ -26,7 +26,10 @@ def _free_port():
 
 def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64", TFK_DP_COMM=comm)
+                      TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64",
+                      TFK_DP_COMM="native" if comm == "unloadable" else comm)
+    if comm == "unloadable":  # the library cannot bind RCCL: every rank agrees to run the exchange through torch.distributed
+        os.environ["TFK_RCCL_LIB"] = "/nonexistent/librccl.so"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
@@ -38,6 +41,9 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
     # who launched the collectives: the library itself (csrc/exchange.hip) or BucketReducer through torch.distributed
     assert dp.reducer(eng).native == (comm == "native")
+    assert (dp.native_failure is not None) == (comm == "unloadable"), dp.native_failure
+    if comm == "unloadable":
+        assert "could not be loaded" in dp.reducer(eng).fallback_reason
     if mode == "sharded":  # RCCL's reduce-scatter / all-gather really carried the step
         assert "rs" in dp.last_kinds, dp.last_kinds
         assert any("reduce_scatter" in name for name in dp.last_executed), dp.last_executed
@@ -49,7 +55,7 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("comm", ["native", "torch"])
+@pytest.mark.parametrize("comm", ["native", "torch", "unloadable"])
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
 def test_single_rank_rccl_is_identity(gpu, tmp_path, mode, comm):
     import torch.multiprocessing as mp

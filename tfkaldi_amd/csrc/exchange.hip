@@ -76,12 +76,18 @@ Rccl* rccl() {
   static std::once_flag once;
   std::call_once(once, [] {
     // by SONAME: a process that already holds a copy (PyTorch ships its own next to its HIP runtime) gets THAT one
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.handle) break;
+    // (env TFK_RCCL_LIB names another file: a site's own build of RCCL -- or a missing one, to rehearse the failure)
+    if (const char* named = getenv("TFK_RCCL_LIB")) {
+      r.handle = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+      }
     }
     if (!r.handle) {
-      r.error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+      const char* why = dlerror();
+      r.error = std::string("RCCL could not be loaded: ") + (why ? why : "?");
       return;
     }
 #define BIND(field, sym)                                                    \

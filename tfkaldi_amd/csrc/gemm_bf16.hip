@@ -369,7 +369,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   static_assert(KSPT == 4 || KSPT == 2, "ring slot of 64 or 32 k");
   static_assert(NS >= 3 && (NS - 2) * NP <= 63, "ring depth / vmcnt range");
   static_assert(FM * FN >= 2, "two independent accumulator chains per wave");
-  static_assert(NPL == 1 || (NPL == 3 && SCHED == 0 && TFKB_ABL == 0), "planes");
+  static_assert(NPL == 1 || (NPL == 3 && SCHED == 0), "planes");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -444,21 +444,27 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
-      for (int a = 0; a < FM; ++a)
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fa[q][0][a][e] = (__bf16)(float)(lane + e);
+        for (int a = 0; a < FM; ++a)
 #pragma unroll
-      for (int b = 0; b < FN; ++b)
+          for (int e = 0; e < 8; ++e) fa[q][pl][a][e] = (__bf16)(float)(lane + e + pl);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fb[q][0][b][e] = (__bf16)(float)(lane - e);
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fb[q][pl][b][e] = (__bf16)(float)(lane - e - pl);
+      }
     }
   }
   auto mfma_step = [&](int cur) {
     if (TFKB_ABL & 1) {  // keep the fragment reads alive without the MFMAs
 #pragma unroll
-      for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][0][a]));
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-      for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][0][b]));
+        for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][pl][a]));
+#pragma unroll
+        for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][pl][b]));
+      }
     } else if constexpr (NPL == 1) {
 #pragma unroll
       for (int a = 0; a < FM; ++a)

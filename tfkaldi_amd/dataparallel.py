@@ -562,16 +562,25 @@ class NativeExchange(object):
             import torch
             import torch.distributed as dist
             rank, world = dist.get_rank(group), dist.get_world_size(group)
-            uid = ctypes.create_string_buffer(128)
+            uid, failed = ctypes.create_string_buffer(128), None
             if rank == 0:
-                self._check(self.lib.tfk_comm_unique_id(uid, 128, None))
-            # the id travels as a byte tensor over the process group that is already up (its only use in this class)
-            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+                try:
+                    self._check(self.lib.tfk_comm_unique_id(uid, 128, None))
+                except Exception as e:  # noqa: BLE001 (the others are about to wait for the id: they must hear of it first)
+                    failed = e
+            # the id travels as a byte tensor over the process group that is already up (its only use in this class);
+            # byte 0 says whether rank 0 has one at all
+            t = torch.frombuffer(bytearray((b"\0" if failed else b"\1") + uid.raw), dtype=torch.uint8).clone()
             on_gpu = dist.get_backend(group) == "nccl"
             if on_gpu:
                 t = t.cuda(engine.cfg.device)
             dist.broadcast(t, src=0, group=group)
+            if failed is not None:
+                raise failed
             raw = bytes(t.cpu().numpy().tobytes())
+            if raw[0] != 1:
+                raise RuntimeError("rank 0 could not obtain an RCCL unique id")
+            raw = raw[1:]
             self._check(self.lib.tfk_comm_create(engine._h, raw, 128, rank, world, _lib.EXCHANGE[mode], int(min_bytes or 0),
                                                  ctypes.byref(self._h)))
         r, w, m, sh = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -695,10 +704,10 @@ class DataParallel(object):
         r = self._reducers.get(engine)
         if r is None:
             ref = weakref.ref(engine)
-            if self._native(engine):
-                r = NativeExchange(engine, self.group, mode=self.mode)
-            else:
+            r = self._native_exchange(engine) if self._native(engine) else None
+            if r is None:
                 r = BucketReducer(engine, self.group, stream_ctx=lambda: self._stream_ctx(ref()), mode=self.mode)
+                r.fallback_reason = self.native_failure
             self._reducers[engine] = r
             if hasattr(engine, "on_close"):
                 engine.on_close.append(lambda: self._forget(ref()))
@@ -708,12 +717,44 @@ class DataParallel(object):
         """RCCL from inside the library (csrc/exchange.hip) whenever the process group runs on RCCL and the engine is a real
         one; TFK_DP_COMM=torch keeps the exchange in BucketReducer over torch.distributed (gloo groups always do)"""
         want = os.environ.get("TFK_DP_COMM", "native")
-        if want not in ("native", "torch"):
-            raise ValueError("TFK_DP_COMM=%r (native | torch)" % want)
+        if want not in ("native", "native-only", "torch"):
+            raise ValueError("TFK_DP_COMM=%r (native | native-only | torch)" % want)
         if want == "torch" or not hasattr(getattr(engine, "lib", None), "tfk_comm_create"):
             return False
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
+    native_failure = None  # why the in-library exchange was given up (None: it was not)
+
+    def _native_exchange(self, engine):
+        """NativeExchange, or None when ANY rank could not bring it up (RCCL not loadable from the library, communicator
+        refused): the ranks agree through one all-reduce of a flag, everyone then runs BucketReducer over torch.distributed,
+        and the reason goes to stderr and into bench.py's `exchange_driver` -- a job that would otherwise die at its first
+        step keeps running on the slower driver, and says so.  TFK_DP_COMM=native-only makes the failure fatal instead."""
+        import torch
+        import torch.distributed as dist
+        r, err = None, None
+        try:
+            r = NativeExchange(engine, self.group, mode=self.mode)
+        except Exception as e:  # noqa: BLE001 (whatever it was, the other ranks must hear of it)
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([1 if r is not None else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) == "nccl":
+            ok = ok.cuda(engine.cfg.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 1:
+            return r
+        if r is not None:
+            engine.on_close.remove(r.close)
+            engine.param_access_hook = None
+            r.close()
+        self.native_failure = err or "another rank could not create its communicator"
+        if os.environ.get("TFK_DP_COMM") == "native-only":
+            raise RuntimeError("in-library exchange unavailable: %s" % self.native_failure)
+        import sys
+        sys.stderr.write("tfkaldi_amd: WARNING in-library RCCL exchange unavailable on rank %d (%s); this job runs the exchange "
+                         "through torch.distributed (dataparallel.BucketReducer)\n" % (self.rank, self.native_failure))
+        return None
 
     def _forget(self, engine):
         if engine is not None:
