@@ -67,8 +67,38 @@ def test_contraction_within_the_fp32_kernels_bound(gpu, layout):
     shape per block geometry (128x64, 128x128), the epilogues the layout carries"""
     epi = {0: 1, 1: 0, 2: 2}[layout]
     for n, (M, N, K) in enumerate([(197, 203, 75), (70, 330, 33), (1, 1, 1), (1, 70, 5), (65, 1, 31), (129, 257, 1027),
-                                   (2, 3, 700), (1024, 2048, 440), (1024, 2000, 2048), (2048, 2048, 1024), (2048, 4096, 512)]):
+                                   (2, 3, 700), (1024, 2048, 440), (1024, 2000, 2048), (2048, 2048, 1024), (2048, 4096, 512),
+                                   # two blocks per tile over half of K each (NN / NT): K halves of 17 + 16 and 31 + 31 ring tiles,
+                                   # a ragged last tile row
+                                   (1024, 2048, 1040), (1000, 2048, 1976)]):
         _run(gpu, layout, M, N, K, epi=epi if n % 2 == 0 else 0, seed=n)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_split_k_does_not_depend_on_who_finishes_first(gpu, layout):
+    """the 1024-frame contractions run two blocks per tile (gemm_bf16.h: gemm_bf16x3_splitk_floats); the second to finish adds
+    the first one's partial sums to its own -- a + b = b + a, so forty launches give forty identical results"""
+    import torch
+    from tfkaldi_amd import _lib
+    lib = gpu
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 1024, 2048, 2048
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(*((N, K) if layout == 1 else (K, N)), device="cuda", generator=g)
+    Ap, lda, pa = _planes(lib, torch, A)
+    Bp, ldb, pb = _planes(lib, torch, B)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for _ in range(40):
+        C = torch.empty(M, N, device="cuda")
+        _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, pa, ctypes.c_void_p(Bp.data_ptr()), ldb, pb,
+                                       ctypes.c_void_p(C.data_ptr()), N, M, N, K, None, 0))
+        outs.append(C)
+    torch.cuda.synchronize()
+    for C in outs[1:]:
+        assert torch.equal(C, outs[0])
+    ref = A.double() @ (B.double().T if layout == 1 else B.double())
+    assert float((outs[0].double() - ref).abs().max()) < 1e-3
 
 
 def test_transpose_detecting(gpu):

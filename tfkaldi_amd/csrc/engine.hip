@@ -454,6 +454,21 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.act_keep = act ? 1.f / act->scale : 1.f;
     b.row_vend = row_vend;
     b.M = M; b.N = N; b.K = K; b.lda = lda8; b.ldb = ldb8; b.ldc = ldc; b.epi = epi;
+    if (e->x3) {
+      // the split-K form of the 1024-frame contractions (gemm_bf16.h); its flag words start out as zeros and every launch
+      // leaves them so.  (The workspace is shared with the fp32 split-K form, which an x3 engine never runs.)
+      const size_t need = gemm_bf16x3_splitk_floats(layout, M, N, K);
+      if (need > e->ws_splitk_floats) {  // stream-ordered: behind the GEMMs that still use the old workspace
+        dev_free(e, e->ws_splitk, true);
+        e->ws_splitk = nullptr;
+        e->ws_splitk_floats = 0;
+        CHK(dev_alloc(e, (void**)&e->ws_splitk, need * sizeof(float), false));
+        e->ws_splitk_floats = need;
+        HIPCHK(hipMemsetAsync(e->ws_splitk, 0, need * sizeof(float), st));
+      }
+      b.splitk_ws = e->ws_splitk;
+      b.splitk_ws_floats = e->ws_splitk_floats;
+    }
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
                  2.0 * ((double)M * K + (double)K * N) + 4.0 * (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1), st);
@@ -2534,6 +2549,24 @@ int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, int64_
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.a_plane = (long)a_plane; g.b_plane = (long)b_plane;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
+  {  // (a process-wide split-K workspace for this tool entry: calls are expected on one stream at a time)
+    static float* ws = nullptr;
+    static size_t ws_floats = 0;
+    const size_t need = gemm_bf16x3_splitk_floats((GemmLayout)layout, M, N, K);
+    if (need > ws_floats) {
+      if (ws) {
+        hipDeviceSynchronize();
+        hipFree(ws);
+      }
+      ws = nullptr;
+      ws_floats = 0;
+      if (hipMalloc((void**)&ws, need * sizeof(float)) != hipSuccess) return fail(-1, "split-K workspace of %zu floats", need);
+      hipMemset(ws, 0, need * sizeof(float));
+      ws_floats = need;
+    }
+    g.splitk_ws = ws;
+    g.splitk_ws_floats = ws_floats;
+  }
   const int rc = gemm_bf16x3((GemmLayout)layout, g, (hipStream_t)stream);
   if (rc != 0) return fail(rc, "gemm_bf16x3 failed: %s", hipGetErrorString((hipError_t)rc));
   return 0;

@@ -42,6 +42,10 @@ struct GemmArgsB {
   // gemm_bf16x3: elements between the three bf16 planes of A / B (plane q of an operand starts q * plane elements behind
   // plane 0, same leading dimension); ct_plane: the same for C_twin (EPI_EVAL_ACT writes three planes of its result)
   long a_plane, b_plane, ct_plane;
+  // gemm_bf16x3, optional: workspace of the two-way split-K form (see gemm_bf16x3_splitk_floats); ZERO before its first use,
+  // left zero in its flag words by every launch.  nullptr: never split
+  float* splitk_ws;
+  size_t splitk_ws_floats;
 };
 
 // Tile configurations.  0-2: register-staged ring of round 1 (64x64 / 128x64 / 128x128 per 4-wave block).
@@ -77,6 +81,12 @@ int gemm_bf16_dual_tile_rows(int cfg);
 // gemm_bf16; blocks of 128 rows (= rows per EPI_COLSTATS / EPI_DACT chunk).
 int gemm_bf16x3(GemmLayout layout, const GemmArgsB& args, hipStream_t stream);
 constexpr int kGemmBf16x3TileRows = 128;
+// Split-K.  A [1024, 2048] result has 128 tiles of 128x128 for 256 CUs; 128x64 blocks fill every CU but stage 4/3 of the bytes
+// per flop, and at 1024 frames the contraction is bound by exactly that (L2 -> LDS fill).  With a workspace the NN / NT
+// layouts run 128x128 blocks on HALF of K each, two blocks per tile: the first to finish leaves its partial sums in the
+// workspace, the second adds them to its own (a + b = b + a: the result does not depend on who was first) and runs the
+// epilogue.  Floats of workspace an [M, N] x K contraction needs for that (0: it would not split).
+size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K);
 
 // rows of the block tile gemm_bf16 uses for an [M, N] result (= rows per EPI_COLSTATS / EPI_DACT chunk)
 int gemm_bf16_tile_rows(int M, int N);

@@ -356,8 +356,10 @@ struct Frag {
 // NPL = 3: the fp32-EMULATING contraction ("bf16x3", gemm_bf16.h): every operand comes as three bf16 planes whose sum is the
 // fp32 value exactly; a ring slot holds all six plane tiles of a 32-k step, and each 16-k MFMA step multiplies the six plane
 // pairs of order <= 2^-16 -- (3,1) (2,2) (1,3) (2,1) (1,2) (1,1), smallest first -- into the SAME fp32 accumulators.
+// KSPLIT = 2 (NPL == 3 only): two blocks per tile, each over half of K; see gemm_bf16x3_splitk_floats (gemm_bf16.h)
+constexpr int kSplitFlagWords = 2048;  // head of the split-K workspace: {ticket, ready} per tile, then the partial sums
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
-          int NPL = 1>
+          int NPL = 1, int KSPLIT = 1>
 __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
@@ -367,9 +369,10 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   constexpr int NPA = OA::NP, NPB = OB::NP, NP = NPL * (OA::NP + OB::NP);
   constexpr int KSPT = BKT / 16;  // 16-k MFMA steps per ring slot
   static_assert(KSPT == 4 || KSPT == 2, "ring slot of 64 or 32 k");
-  static_assert(NS >= 3 && (NS - 2) * NP <= 63, "ring depth / vmcnt range");
+  static_assert(NS >= 3 && (NS - 2) * NP + (NPL == 3 ? NP / 2 : 0) <= 63, "ring depth / vmcnt range");
   static_assert(FM * FN >= 2, "two independent accumulator chains per wave");
   static_assert(NPL == 1 || (NPL == 3 && SCHED == 0), "planes");
+  static_assert(KSPLIT == 1 || (KSPLIT == 2 && NPL == 3), "split-K: the fp32-emulating contraction only");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -377,18 +380,25 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   int tm, tn;
-  tile_of_block(tiles_m, tiles_n, group_rows, bid, tm, tn);
+  // split-K: the two halves of a tile are neighbours in the block sequence of ONE XCD (blocks b and b + 8), so they run at the
+  // same time and meet in that XCD's L2; the tile sequence is the unsplit one (tiles_m * tiles_n is a multiple of 8 here)
+  const int khalf = KSPLIT == 2 ? (bid / NUM_XCD) & 1 : 0;
+  const int tile_bid = KSPLIT == 2 ? (bid / NUM_XCD >> 1) * NUM_XCD + bid % NUM_XCD : bid;
+  tile_of_block(tiles_m, tiles_n, group_rows, tile_bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int K8 = (p.K + 7) & ~7;
-  const int nk = (p.K + BKT - 1) / BKT;
+  const int nk_all = (p.K + BKT - 1) / BKT;
+  const int kbase = khalf ? (nk_all + 1) / 2 : 0;                               // first ring tile of this block ...
+  const int nk = KSPLIT == 2 ? (khalf ? nk_all - kbase : (nk_all + 1) / 2) : nk_all;  // ... and how many it multiplies
+  const int k_end = (kbase + nk) * BKT;  // (tiles behind the block's share land as zeros, like the ones behind K)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
   OA la;
   OB lb;
   // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
   // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
-  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), A_KC ? K8 : p.K, tid, (NPL - 1) * p.a_plane * 2);
-  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), B_KC ? K8 : p.K, tid, (NPL - 1) * p.b_plane * 2);
+  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), min(A_KC ? K8 : p.K, k_end), tid, (NPL - 1) * p.a_plane * 2);
+  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), min(B_KC ? K8 : p.K, k_end), tid, (NPL - 1) * p.b_plane * 2);
   Frag<A_KC, BM, FM, BKT> qa;
   Frag<B_KC, BN, FN, BKT> qb;
   qa.init(lane, wm * FM);
@@ -416,10 +426,10 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     if (TFKB_ABL & 2) return;
     if (j < NPL * NPA) {
       const int pl = j / NPA;
-      la.issue(j % NPA, lds0 + (unsigned)(slot * STAGE + pl * A_BYTES), kt * BKT, wave, pl * a_plane_b);
+      la.issue(j % NPA, lds0 + (unsigned)(slot * STAGE + pl * A_BYTES), (kt + kbase) * BKT, wave, pl * a_plane_b);
     } else {
       const int jb = j - NPL * NPA, pl = jb / NPB;
-      lb.issue(jb % NPB, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES + pl * B_BYTES), kt * BKT, wave, pl * b_plane_b);
+      lb.issue(jb % NPB, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES + pl * B_BYTES), (kt + kbase) * BKT, wave, pl * b_plane_b);
     }
   };
   // prologue: tiles 0 .. NS-2 (tiles beyond K land as zeros without touching memory)
@@ -427,7 +437,11 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   for (int t = 0; t < NS - 1; ++t)
 #pragma unroll
     for (int j = 0; j < NP; ++j) piece(j, t, t);
-  TFKB_WAIT_BARRIER((NS - 2) * NP);
+  // (NPL == 3 spreads a tile's pieces over TWO half-steps, see its loop: the first half of tile NS-1 goes out here)
+  constexpr int NPH = NPL == 3 ? NP / 2 : 0;
+#pragma unroll
+  for (int j = 0; j < NPH; ++j) piece(j, NS - 1, NS - 1);
+  TFKB_WAIT_BARRIER((NS - 2) * NP + NPH);
 
   bf16x8 fa[2][NPL][FM], fb[2][NPL][FN];
   auto read_frags = [&](int buf, const char* st, int ks) {
@@ -544,6 +558,57 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
       asm volatile("s_barrier" : : : "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
+  } else if constexpr (NPL == 3) {
+    // One wave per SIMD, and per 16-k step 6 * FM * FN MFMAs for 3 * (FM + FN) fragment reads and a handful of LDS-DMA pieces:
+    // issued in bursts (every read, then every piece, then the MFMAs -- the bf16 loop below) the wave sits in the LDS / vector
+    // memory issue queues while the matrix pipe runs dry (tools/gemm_f32x3_ablate.hip: MFMAs alone 31 us, with the pieces 50,
+    // with everything 61 at 1024 x 2048 x 2048).  Here every step is SIX groups, one per plane product: a share of the next
+    // step's fragment reads (in the order of their first use; the last three groups read nothing, so the reads have three
+    // groups of MFMAs to land), a share of the pieces, then the product's FM * FN MFMAs.  A tile's pieces are spread over BOTH
+    // half-steps between two barriers: the half-step after barrier kt sends the first half of tile kt+NS into the slot tile
+    // kt just left, the half-step in front of the next barrier the second half.
+    static_assert(KSPT == 2, "fp32-emulating contraction: 32 k per ring slot");
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    auto step3 = [&](int cur, bool fetch, const char* nst, int nks, int j0, int j1, int slot, int tile) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        if (c < 3 && fetch && !(TFKB_ABL & 4)) {
+#pragma unroll
+          for (int a = 0; a < FM; ++a) fa[cur ^ 1][PA[c]][a] = qa.read(nst + PA[c] * A_BYTES, a, nks);
+#pragma unroll
+          for (int b = 0; b < FN; ++b) fb[cur ^ 1][PB[c]][b] = qb.read(nst + NPL * A_BYTES + PB[c] * B_BYTES, b, nks);
+        }
+#pragma unroll
+        for (int j = j0 + c * (j1 - j0) / 6; j < j0 + (c + 1) * (j1 - j0) / 6; ++j) piece(j, slot, tile);
+        if (TFKB_ABL & 1) {
+#pragma unroll
+          for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][PA[c]][a]));
+#pragma unroll
+          for (int b = 0; b < FN; ++b) asm volatile("" : : "v"(fb[cur][PB[c]][b]));
+        } else {
+#pragma unroll
+          for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+              if (c < 5)
+                acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[c]][a], fb[cur][PB[c]][b], acc2[a][b], 0, 0, 0);
+              else
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[c]][a], fb[cur][PB[c]][b], acc[a][b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    read_frags(0, smem, 0);
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* st = smem + rs * STAGE;
+      step3(0, true, st, 1, NPH, NP, ws, kt + NS - 1);
+      TFKB_WAIT_BARRIER((NS - 2) * NP);
+      rs = rs + 1 == NS ? 0 : rs + 1;
+      ws = ws + 1 == NS ? 0 : ws + 1;
+      step3(1, kt + 1 < nk, smem + rs * STAGE, 0, 0, NPH, ws, kt + NS);
+    }
   } else {
   read_frags(0, smem, 0);
 #pragma unroll 1
@@ -579,15 +644,75 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] += acc2[a][b][r];
   }
+  if constexpr (KSPLIT == 2) {
+    // The two halves of the tile meet: whoever takes the ticket first stores its partial sums (lane-linear 16-byte pieces) and
+    // raises `ready`; the other waits for that, adds them to its own and goes on to the epilogue.  The first block has its
+    // ticket before the second one can wait for it and never waits itself: no deadlock whatever order the blocks start in.
+    // Coherence by hand: the partial sums travel with sc0 sc1 (written through / read past every cache), the flag words by
+    // agent-scope atomics, and the stores are acknowledged (vmcnt 0, then the block's barrier) before `ready` goes up.  The
+    // fences of the memory model (`buffer_wbl2` / `buffer_inv sc1`) would write back and drop a whole L2 per wave instead --
+    // measured: 87 us instead of 52 for the contraction.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    unsigned* flags = reinterpret_cast<unsigned*>(p.splitk_ws);
+    const int tile = tm * tiles_n + tn;
+    constexpr int kSys = 1 | (1 << 4);  // sc0 sc1
+    __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.splitk_ws + kSplitFlagWords + (size_t)tile * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+    unsigned* sh = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) sh[0] = __hip_atomic_fetch_add(&flags[2 * tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool first = sh[0] == 0;
+    if (first) {
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(u32x4, f32x4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]}),
+                part, ((((wave * FM + a) * FN + b) * 4 + q) * 64 + lane) * 16, 0, kSys);
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&flags[2 * tile + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      // (the bound -- about a second -- only keeps a broken workspace from hanging the device: the partner holds its
+      // ticket, so it is running and a few microseconds from its store)
+      for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(&flags[2 * tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+           ++spin)
+        __builtin_amdgcn_s_sleep(2);
+      // (both words back to zero for the next launch: the other block is past them)
+      __hip_atomic_store(&flags[2 * tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&flags[2 * tile + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+      for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(part, ((((wave * FM + a) * FN + b) * 4 + q) * 64 + lane) * 16, 0, kSys));
+          acc[a][b][4 * q] += o.x;
+          acc[a][b][4 * q + 1] += o.y;
+          acc[a][b][4 * q + 2] += o.z;
+          acc[a][b][4 * q + 3] += o.w;
+        }
+    __syncthreads();  // (the epilogue reuses smem)
+  }
   epilogue<EPI, WAVES_M, WAVES_N, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
-          int NPL = 1>
+          int NPL = 1, int KSPLIT = 1>
 __global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
 gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL>(p, tiles_m, tiles_n, group_rows, blockIdx.x, smem);
+  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL, KSPLIT>(p, tiles_m, tiles_n, group_rows, blockIdx.x,
+                                                                                   smem);
 }
 
 // Two INDEPENDENT contractions in one launch -- backward: dA = dZ . W^T (NT, optionally EPI_DACT) of a layer and the
@@ -807,7 +932,8 @@ int g_forced_b = -2;  // -2: env not read yet; -1: heuristic
 int g_group_rows = 0;  // env TFK_BF16_GROUP_ROWS (experiments): tile rows per XCD patch; 0 = balanced, large = column-major
 
 template <class Kern>
-int launch_grid(Kern kern, const GemmArgsB& p, int bm, int bn, int threads, size_t lds, hipStream_t stream, bool* attr_done) {
+int launch_grid(Kern kern, const GemmArgsB& p, int bm, int bn, int threads, size_t lds, hipStream_t stream, bool* attr_done,
+                int blocks_per_tile = 1) {
   const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;
   if (!*attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -823,7 +949,7 @@ int launch_grid(Kern kern, const GemmArgsB& p, int bm, int bn, int threads, size
   }
   if (group_rows < 1) group_rows = 1;
   if (group_rows > tiles_m) group_rows = tiles_m;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(threads), lds, stream, p, tiles_m, tiles_n, group_rows);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n * blocks_per_tile), dim3(threads), lds, stream, p, tiles_m, tiles_n, group_rows);
   return (int)hipGetLastError();
 }
 
@@ -835,27 +961,42 @@ int launch_reg(const GemmArgsB& p, hipStream_t stream) {
   return launch_grid(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>, p, BM, BN, NT, lds, stream, &attr_done);
 }
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
-          int NPL = 1>
+          int NPL = 1, int KSPLIT = 1>
 int launch_dma(const GemmArgsB& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
   const size_t lds = (size_t)NS * NPL * (BM + BN) * BKT * 2;
   static_assert((size_t)NS * NPL * (BM + BN) * BKT * 2 <= 160 * 1024, "LDS");
   static bool attr_done = false;
-  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL>, p, BM, BN,
-                     WAVES_M * WAVES_N * 64, lds, stream, &attr_done);
+  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL, KSPLIT>, p, BM, BN,
+                     WAVES_M * WAVES_N * 64, lds, stream, &attr_done, KSPLIT);
 }
 
 // fp32-emulating contraction on three bf16 planes per operand: 128x128 blocks (three 48 KB slots) when the result has a
 // tile of it for nearly every CU, else 128x64 (four 36 KB slots); 32 k per slot, four waves
-int g_x3_cfg = -2;  // env TFK_BF16X3_CFG (experiments): 0 = 128x64, 1 = 128x128, -1 heuristic
-template <bool A_KC, bool B_KC, int EPI>
-int launch_x3(const GemmArgsB& p, hipStream_t stream) {
+int g_x3_cfg = -2;  // env TFK_BF16X3_CFG (experiments): 0 = 128x64, 1 = 128x128, 2 = 128x128 split-K where eligible, -1 heuristic
+int x3_cfg() {
   if (g_x3_cfg == -2) {
     const char* q = getenv("TFK_BF16X3_CFG");
     g_x3_cfg = q ? atoi(q) : -1;
   }
+  return g_x3_cfg;
+}
+// two 128x128 blocks per tile, each over half of K: between a quarter and three quarters of a tile per CU (beyond that the
+// unsplit 128x128 grid fills the chip), whole XCD chunks, and at least 8 ring tiles per half
+bool x3_split_shape(bool tn, int M, int N, int K) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  return !tn && tiles >= 64 && tiles < 200 && tiles % NUM_XCD == 0 && 2 * tiles <= kSplitFlagWords && K >= 512;
+}
+template <bool A_KC, bool B_KC, int EPI>
+int launch_x3(const GemmArgsB& p, hipStream_t stream) {
+  const int forced = x3_cfg();
   const long m128 = (p.M + 127) / 128, n128 = (p.N + 127) / 128;
-  const bool big = g_x3_cfg >= 0 ? g_x3_cfg == 1 : m128 * n128 >= 200;
+  if constexpr (A_KC) {
+    if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape(false, p.M, p.N, p.K) &&
+        p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * n128 * 128 * 128)
+      return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
+  }
+  const bool big = forced >= 0 ? forced == 1 : m128 * n128 >= 200;
   if (big) return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
   return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3>(p, stream);
 }
@@ -982,6 +1123,12 @@ int gemm_bf16_pick_config(int M, int N) {
 }
 
 int gemm_bf16_tile_rows(int M, int N) { return kCfgB[gemm_bf16_pick_config(M, N)].bm; }
+
+size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K) {
+  const int forced = x3_cfg();
+  if (!(forced == 2 || forced < 0) || !x3_split_shape(layout == GEMM_TN, M, N, K)) return 0;
+  return (size_t)kSplitFlagWords + (size_t)((M + 127) / 128) * ((N + 127) / 128) * 128 * 128;
+}
 
 int gemm_bf16x3(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;

@@ -28,6 +28,12 @@ int main(int argc, char** argv) {
   tfk::GemmArgsB g = {};
   g.A = dA; g.B = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.a_plane = pa; g.b_plane = pb;
+  // the split-K form where the shape is eligible (TFK_BF16X3_CFG=0 / 1: never)
+  if (const size_t need = tfk::gemm_bf16x3_splitk_floats((tfk::GemmLayout)layout, M, N, K)) {
+    hipMalloc(&g.splitk_ws, need * 4);
+    hipMemset(g.splitk_ws, 0, need * 4);
+    g.splitk_ws_floats = need;
+  }
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 5; ++i) tfk::gemm_bf16x3((tfk::GemmLayout)layout, g, 0);
@@ -39,6 +45,6 @@ int main(int argc, char** argv) {
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= iters;
-  printf("ABL=%d layout %d %dx%dx%d: %7.1f us  %7.1f TF fp32-equivalent\n", TFKB_ABL, layout, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+  printf("ABL=%d %s layout %d %dx%dx%d: %7.1f us  %7.1f TF fp32-equivalent\n", TFKB_ABL, g.splitk_ws ? "split-K" : "       ", layout, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
   return 0;
 }
