@@ -323,7 +323,7 @@ int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
  *                           tfk_comm_gather_masters) -- consumed layer by layer by the next forward pass;
  *   TFK_EXCHANGE_ALLREDUCE  SUM all-reduce of every span, full Adam on every rank.
  * bucket_bytes: adjacent gradient buckets are coalesced until a collective carries at least this much (0: default,
- * 24 MiB sharded / 48 MiB all-reduce -- xGMI is point-to-point: few large collectives beat one per layer).
+ * 64 MiB -- xGMI is point-to-point: few large collectives beat one per layer, and each costs the step a fixed 10-13 us).
  * Bootstrap: rank 0 calls tfk_comm_unique_id, the host distributes the bytes any way it likes (torch.distributed, MPI, a
  * file), every rank calls tfk_comm_create with them (collective: ncclCommInitRank). */
 enum { TFK_EXCHANGE_SHARDED = 0, TFK_EXCHANGE_ALLREDUCE = 1 };

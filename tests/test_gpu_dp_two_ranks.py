@@ -198,7 +198,7 @@ CFG2 = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=2000, nonlin
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
-    """BASELINE cfg2's network on eight ranks: the real span sizes (3.6 / 16.8 / 16.4 MB), 24 MB coalescing, shards of
+    """BASELINE cfg2's network on eight ranks: the real span sizes (3.6 / 16.8 / 16.4 MB), 64 MiB coalescing, shards of
     n / 8, an idle rank (seven micro-batches), real engines, the sharded protocol end to end"""
     import torch.multiprocessing as mp
     world, num_mb = 8, 7
@@ -212,4 +212,6 @@ def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
     # elements beyond a fifth of the distance five full steps cover, none beyond twice that distance
     _compare(tmp_path, world, ref, CFG2["init_learning_rate"], 5, loss_rtol=1e-4 if dtype == "float32" else 2e-3,
              flip_threshold=0.2,  # (BN moving statistics follow the drifting parameters; bf16 operands drift further)
-             stat_tol=(1e-3, 1e-5) if dtype == "float32" else (2e-2, 5e-4))
+             # (the order in which gloo's ring adds the eight partial sums depends on how a span is chunked: with the 64 MiB
+             # spans one moving mean of 2048 x 6 came out 1.2e-5 from the serial run's, with round 3's 24 MB spans none did)
+             stat_tol=(1e-3, 3e-5) if dtype == "float32" else (2e-2, 5e-4))

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -220,7 +221,11 @@ struct LoopBackend : Backend {
       }
       return 0;
     }
-    for (int r = 0; r < W; ++r)  // nobody starts before every rank's operand is ready
+    // one communicator's operations run one after the other whatever streams they were posted on (RCCL orders them itself; the
+    // comm posts the tail of a step on the engine stream, the rest on its comm stream): behind the previous operation's end ...
+    for (int r = 0; r < W; ++r)
+      for (int q = 0; q < W; ++q) XHIP(hipStreamWaitEvent(g->slot[r].st, g->slot[q].finish, 0));
+    for (int r = 0; r < W; ++r)  // ... and nobody starts before every rank's operand is ready
       for (int q = 0; q < W; ++q) XHIP(hipStreamWaitEvent(g->slot[r].st, g->slot[q].arrive, 0));
     const size_t n = s0.count;
     if (s0.kind == 0) {
@@ -306,6 +311,7 @@ struct Span {
   size_t off = 0, n = 0;
   bool rs = false;
   hipEvent_t ready = nullptr, done = nullptr;
+  hipEvent_t wait_on = nullptr;  // what the engine stream waits for: `done` of the last piece of the range this span was cut from
   bool waited = false;
 };
 struct Gather {
@@ -332,6 +338,7 @@ struct tfk_comm {
   size_t lo = 0, hi = 0;
   std::vector<Span> spans;  // collectives of the current step, launch order
   size_t num_spans = 0;
+  size_t waited_upto = 0;       // spans [0, waited_upto) of this step are complete as far as the engine stream is concerned
   std::vector<Gather> pending;  // parameter gathers nobody has waited for yet (ascending offsets = forward order)
   std::vector<hipEvent_t> gather_events;
   size_t gathers_used = 0;
@@ -360,43 +367,64 @@ bool shardable(const tfk_comm* c, size_t lo, size_t hi) {
          n >= c->min_shard_floats;
 }
 
-int launch_range(tfk_comm* c, size_t lo, size_t hi) {
-  if (c->mode == TFK_EXCHANGE_SHARDED) {
-    // a coalesced range that runs from the weight matrices into the bias / beta vectors, or from the gradient arena into
-    // the scalar + BN tail, is cut there: only weight matrices are sharded (the vectors are a few thousand values,
-    // all-reduced and updated on every rank, so that no layer ever waits for THEIR gather)
+// One coalesced range of gradients is ready on the engine stream: its collective(s) go to the comm stream.
+// In the sharded mode a range that runs from the weight matrices into the bias / beta vectors, or from the gradient arena into
+// the scalar + BN tail, is cut there: only weight matrices are sharded (the vectors are a few thousand values, all-reduced and
+// updated on every rank, so that no layer ever waits for THEIR gather).  The pieces of one range share ONE `ready` record on the
+// engine stream and ONE `done` record behind the last of them: an event record between two kernels costs the engine stream
+// ~6 us of idle time and every record / wait pair on the comm stream ~9 us of latency before the optimiser may start
+// (profiles/r04_dp_trace.txt) -- the range launched by tfk_comm_apply, after the last backward kernel, has three pieces.
+// inline_on_engine: nothing is left to overlap with (the range launched by tfk_comm_apply behind the last backward kernel, the
+// evaluation sums): the collectives go to the ENGINE stream itself and no event is needed at all -- the record -> comm stream
+// -> record -> engine stream round trip measured ~26 us of idle time in front of the optimiser.  (One communicator on two
+// streams is legal for RCCL: it orders its operations itself.)
+bool inline_tail() {
+  static const bool on = !getenv("TFK_DP_INLINE_TAIL") || atoi(getenv("TFK_DP_INLINE_TAIL")) != 0;
+  return on;
+}
+int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = false) {
+  size_t cuts[4] = {lo, 0, 0, 0};
+  int pieces = 1;
+  if (c->mode == TFK_EXCHANGE_SHARDED)
     for (size_t cut : {c->vec_off, c->num_params})
-      if (lo < cut && cut < hi) {
-        XCHK(launch_range(c, lo, cut));
-        return launch_range(c, cut, hi);
-      }
+      if (lo < cut && cut < hi) cuts[pieces++] = cut;
+  cuts[pieces] = hi;
+  const size_t first = c->num_spans;
+  for (int k = 0; k < pieces; ++k) {
+    if (c->num_spans == c->spans.size()) {
+      Span s;
+      XCHK(new_event(&s.ready));
+      XCHK(new_event(&s.done));
+      c->spans.push_back(s);
+    }
+    Span& s = c->spans[c->num_spans++];
+    s.off = cuts[k]; s.n = cuts[k + 1] - cuts[k]; s.waited = false;
+    s.rs = shardable(c, s.off, s.off + s.n);
   }
-  if (c->num_spans == c->spans.size()) {
-    Span s;
-    XCHK(new_event(&s.ready));
-    XCHK(new_event(&s.done));
-    c->spans.push_back(s);
+  hipStream_t st = inline_on_engine ? c->engine_stream : c->comm_stream;
+  if (!inline_on_engine) {
+    XHIP(hipEventRecord(c->spans[first].ready, c->engine_stream));
+    XHIP(hipStreamWaitEvent(c->comm_stream, c->spans[first].ready, 0));
   }
-  Span& s = c->spans[c->num_spans++];
-  s.off = lo; s.n = hi - lo; s.waited = false;
-  s.rs = shardable(c, lo, hi);
-  XHIP(hipEventRecord(s.ready, c->engine_stream));
-  XHIP(hipStreamWaitEvent(c->comm_stream, s.ready, 0));
-  if (s.rs) {
-    XCHK(c->be->reduce_scatter(c->grad + lo, s.n / c->be->world, c->comm_stream));
-    c->cur_rs += 1;
-  } else {
-    XCHK(c->be->all_reduce(c->grad + lo, s.n, c->comm_stream));
-    c->cur_ar += 1;
+  for (size_t k = first; k < c->num_spans; ++k) {
+    Span& s = c->spans[k];
+    if (s.rs) {
+      XCHK(c->be->reduce_scatter(c->grad + s.off, s.n / c->be->world, st));
+      c->cur_rs += 1;
+    } else {
+      XCHK(c->be->all_reduce(c->grad + s.off, s.n, st));
+      c->cur_ar += 1;
+    }
+    s.wait_on = inline_on_engine ? nullptr : c->spans[c->num_spans - 1].done;
   }
-  XHIP(hipEventRecord(s.done, c->comm_stream));
+  if (!inline_on_engine) XHIP(hipEventRecord(c->spans[c->num_spans - 1].done, c->comm_stream));
   return 0;
 }
 
-int flush_range(tfk_comm* c) {
+int flush_range(tfk_comm* c, bool inline_on_engine = false) {
   if (!c->have_range) return 0;
   c->have_range = false;
-  return launch_range(c, c->lo, c->hi);
+  return launch_range(c, c->lo, c->hi, inline_on_engine);
 }
 
 int announce(tfk_comm* c, int b) {
@@ -429,9 +457,17 @@ int raise_remembered(tfk_comm* c) {
   return failx(rc, "%s", c->error_text.c_str());
 }
 
+double g_bucket_us = 0;  // (TFK_DP_HOST_PHASES) host time inside the bucket callback, i.e. the collectives launched under backward
 void on_bucket(void* user, int b) {
   tfk_comm* c = static_cast<tfk_comm*>(user);
+  static const bool timed = getenv("TFK_DP_HOST_PHASES") != nullptr;
+  if (!timed) {
+    remember(c, announce(c, b));
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
   remember(c, announce(c, b));
+  g_bucket_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
 
 int drain(tfk_comm* c) {
@@ -460,11 +496,18 @@ void on_layer(void* user, int layer) {
   remember(c, wait_layer(c, layer));
 }
 
+// The engine stream waits for span s's collective.  The comm stream runs its collectives in launch order (= span index), so a
+// wait for span j covers every span before it: a stream wait costs the engine stream ~6 us of idle time even when its event
+// fired long ago (a barrier packet between two kernels; profiles/r04_dp_trace.txt), and tfk_comm_apply's first wait -- for the
+// span that carries the loss and the frame count, the LAST one launched -- used to be followed by one per span.
 int wait_span(tfk_comm* c, Span& s) {
-  if (!s.waited) {
-    XHIP(hipStreamWaitEvent(c->engine_stream, s.done, 0));
-    s.waited = true;
+  const size_t index = (size_t)(&s - c->spans.data());
+  static const bool collapse = !getenv("TFK_DP_COLLAPSE_WAITS") || atoi(getenv("TFK_DP_COLLAPSE_WAITS")) != 0;  // (experiments)
+  if (!s.waited && (index >= c->waited_upto || !collapse)) {
+    if (s.wait_on) XHIP(hipStreamWaitEvent(c->engine_stream, s.wait_on, 0));  // (nullptr: it ran on the engine stream itself)
+    if (s.wait_on) c->waited_upto = index + 1;
   }
+  s.waited = true;
   return 0;
 }
 
@@ -494,7 +537,10 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   };
   if (mode != TFK_EXCHANGE_SHARDED && mode != TFK_EXCHANGE_ALLREDUCE) return bail(failx(-1, "unknown exchange mode %d", mode));
   c->mode = mode;
-  if (bucket_bytes == 0) bucket_bytes = (size_t)(mode == TFK_EXCHANGE_SHARDED ? 24 : 48) << 20;
+  // default: 64 MiB per collective.  Few, large collectives suit point-to-point xGMI links, and every collective costs the
+  // step a fixed ~10-13 us (an event record between two backward kernels, RCCL's own stream work) whatever it carries: at
+  // BASELINE cfg3 one RCCL rank measures +11.5 % with 24 MiB spans and +6.4 % with 64 (profiles/r04_dp_overhead*.txt)
+  if (bucket_bytes == 0) bucket_bytes = (size_t)64 << 20;
   c->min_floats = std::max<size_t>(1, bucket_bytes / 4);
   if (const char* v = getenv("TFK_DP_MIN_SHARD")) c->min_shard_floats = (size_t)atol(v);
   if (const char* v = getenv("TFK_DP_VERIFY_STEPS")) c->verify_left = atoi(v);
@@ -653,18 +699,44 @@ int tfk_comm_idle(tfk_comm* c) {
   return 0;
 }
 
+// env TFK_DP_HOST_PHASES=1 (tools): host microseconds tfk_comm_apply spends per phase, averaged, printed when the comm goes
+struct Phases {
+  bool on = getenv("TFK_DP_HOST_PHASES") != nullptr;
+  double sum[8] = {0};
+  long calls = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() { if (on) t = std::chrono::steady_clock::now(); }
+  void mark(int k) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    sum[k] += std::chrono::duration<double, std::micro>(n - t).count();
+    t = n;
+  }
+  ~Phases() {
+    if (on && calls)
+      fprintf(stderr, "tfk_comm_apply host us/call: flush %.1f | head wait %.1f | apply_begin %.1f | adam launches %.1f | gathers %.1f | "
+              "apply_end (waits for the loss) %.1f | bucket callbacks under backward %.1f   [%ld calls]\n", sum[0] / calls,
+              sum[1] / calls, sum[2] / calls, sum[3] / calls, sum[4] / calls, sum[5] / calls, g_bucket_us / calls, calls);
+  }
+};
+Phases g_phases;
+
 int tfk_comm_apply(tfk_comm* c, float* average_loss) {
   if (!c) return failx(-1, "comm is NULL");
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
-  XCHK(flush_range(c));
+  g_phases.start();
+  XCHK(flush_range(c, inline_tail()));
+  g_phases.mark(0);
   const size_t head_off = c->buckets.back().first, head_n = c->buckets.back().second;
   for (size_t i = 0; i < c->num_spans; ++i) {
     Span& s = c->spans[i];
     if (s.off < head_off + head_n && s.off + s.n > head_off) XCHK(wait_span(c, s));
   }
   XCHK(drain(c));  // (gathers of the previous step that no forward pass has consumed: none in a training loop)
+  g_phases.mark(1);
   XCHK(tfk_apply_begin(c->e));
+  g_phases.mark(2);
   bool via_shadow = c->shadow != nullptr;
   if (via_shadow) {
     int direct = 0;
@@ -672,27 +744,51 @@ int tfk_comm_apply(tfk_comm* c, float* average_loss) {
     if (!direct) return failx(-1, "mixed-precision engine with an arena-mirroring shadow that the optimiser does not write");
   }
   const int W = c->be->world, R = c->be->rank;
-  std::vector<std::pair<size_t, size_t>> sharded;
+  // every span is complete by now (the head wait above covered them all, see wait_span); what this rank updates -- its 1/W of
+  // a reduce-scattered span, the whole of an all-reduced one -- goes to the optimiser in ascending order with neighbours
+  // merged: the all-reduce mode is back to ONE Adam launch over the arena, the sharded mode to one per shard
+  std::vector<std::pair<size_t, size_t>> sharded, mine;
   for (size_t i = 0; i < c->num_spans; ++i) {
     Span& s = c->spans[i];
     XCHK(wait_span(c, s));
     if (s.rs) {
       const size_t per = s.n / W;
-      XCHK(tfk_apply_span(c->e, s.off + (size_t)R * per, per));
+      mine.push_back({s.off + (size_t)R * per, per});
       sharded.push_back({s.off, s.n});
     } else {
-      XCHK(tfk_apply_span(c->e, s.off, s.n));  // (spans beyond the parameter arena are clipped by the engine)
+      mine.push_back({s.off, s.n});  // (spans beyond the parameter arena are clipped by the engine)
     }
   }
+  std::sort(mine.begin(), mine.end());
+  for (size_t i = 0; i < mine.size();) {
+    size_t off = mine[i].first, n = mine[i].second, j = i + 1;
+    static const bool merge = !getenv("TFK_DP_MERGE_ADAM") || atoi(getenv("TFK_DP_MERGE_ADAM")) != 0;  // (experiments)
+    while (merge && j < mine.size() && mine[j].first == off + n) n += mine[j++].second;
+    XCHK(tfk_apply_span(c->e, off, n));
+    i = j;
+  }
+  g_phases.mark(3);
   if (!sharded.empty()) {
     if (c->masters_stale && !via_shadow) return failx(-1, "sharded fp32 masters and a step that does not write the shadow");
     std::sort(sharded.begin(), sharded.end());  // lowest offsets (layer 0) first: the order the next forward pass reads in
-    XHIP(hipEventRecord(c->ev_adam, c->engine_stream));
-    XHIP(hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
     char* target = static_cast<char*>(via_shadow ? c->shadow : (void*)c->param);
     const size_t elem = via_shadow ? 2 : 4;
     c->gathers_used = 0;
-    for (const auto& s : sharded) {
+    size_t first_on_comm = 0;
+    if (inline_tail()) {
+      // the span the next forward pass reads FIRST is gathered on the engine stream itself, right behind the optimiser: that
+      // pass could not start before it anyway, and the hop to the comm stream and back is saved; the others follow on the
+      // comm stream, under the first layers
+      XCHK(c->be->all_gather(target + sharded[0].first * elem, sharded[0].second / W * elem, c->engine_stream));
+      c->cur_ag += 1;
+      first_on_comm = 1;
+    }
+    if (first_on_comm < sharded.size()) {
+      XHIP(hipEventRecord(c->ev_adam, c->engine_stream));
+      XHIP(hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
+    }
+    for (size_t k = first_on_comm; k < sharded.size(); ++k) {
+      const auto& s = sharded[k];
       if (c->gathers_used == c->gather_events.size()) {
         hipEvent_t ev;
         XCHK(new_event(&ev));
@@ -723,7 +819,11 @@ int tfk_comm_apply(tfk_comm* c, float* average_loss) {
   c->last_rs = c->cur_rs; c->last_ag = c->cur_ag; c->last_ar = c->cur_ar;
   c->cur_rs = c->cur_ag = c->cur_ar = 0;
   c->num_spans = 0;
+  c->waited_upto = 0;
+  g_phases.mark(4);
   XCHK(tfk_apply_end(c->e, average_loss));
+  g_phases.mark(5);
+  g_phases.calls += 1;
   if (c->verify_left > 0 && !sharded.empty()) {
     c->verify_left -= 1;
     XCHK(verify_replicas(c, via_shadow));
@@ -735,7 +835,7 @@ int tfk_comm_finish_reduce(tfk_comm* c) {
   if (!c) return failx(-1, "comm is NULL");
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
-  XCHK(flush_range(c));
+  XCHK(flush_range(c, inline_tail()));
   for (size_t i = 0; i < c->num_spans; ++i) XCHK(wait_span(c, c->spans[i]));
   return 0;
 }
@@ -746,9 +846,10 @@ int tfk_comm_eval_finish(tfk_comm* c, float* average_loss) {
   XCHK(raise_remembered(c));
   const size_t off = c->buckets.back().first, n = c->buckets.back().second;
   if (c->num_spans || c->have_range) return failx(-1, "tfk_comm_eval_finish in the middle of a training step");
-  XCHK(launch_range(c, off, off + n));
+  XCHK(launch_range(c, off, off + n, inline_tail()));
   XCHK(wait_span(c, c->spans[0]));
   c->num_spans = 0;
+  c->waited_upto = 0;
   c->cur_ar = 0;
   return tfk_eval_finish(c->e, average_loss);
 }

@@ -192,10 +192,10 @@ class BucketReducer(object):
                 mode = "allreduce"
         self.mode = mode
         if min_bytes is None:
-            # sharded: the parameter gathers are consumed layer by layer by the next forward pass, so finer spans
-            # overlap better (two 16 MB layers per collective at BASELINE cfg2); both values are untuned guesses --
-            # no multi-GPU node was available to this build
-            default_mb = "24" if mode == "sharded" else "48"
+            # 64 MiB per collective (csrc/exchange.hip has the same default and the measurements behind it): few, large
+            # collectives for point-to-point xGMI, and a fixed cost per collective that one RCCL rank measures at
+            # 10-13 us.  Not tuned on a multi-GPU node: none was available to this build
+            default_mb = "64"
             min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", default_mb)) * (1 << 20))
         self.min_floats = max(1, min_bytes // 4)
         self.num_params = self.buckets[-1][0]  # the scalar + BN tail starts where the gradient arena ends

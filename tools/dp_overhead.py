@@ -41,7 +41,8 @@ def child(name, mode):
     init_from_env()
     dp = DataParallel(mode=None if mode == "plain" else mode.replace("torch-", ""))
     eng = Engine(_lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, keep_prob=keep, max_frames=T,
-                                  num_steps=1000, compute_dtype=dtype), torch_state=dp.enabled)
+                                  num_steps=1000, compute_dtype=dtype),
+                 torch_state=dp.enabled or bool(os.environ.get("TFK_PLAIN_TORCH_STATE")))  # (experiment: plain step on a torch stream)
     eng.init_hidden_weights(np.random.default_rng(7))
     X = torch.randn(T, F, device="cuda")
     y = torch.randint(0, O, (T,), device="cuda", dtype=torch.int32)
