@@ -213,5 +213,5 @@ def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
     _compare(tmp_path, world, ref, CFG2["init_learning_rate"], 5, loss_rtol=1e-4 if dtype == "float32" else 2e-3,
              flip_threshold=0.2,  # (BN moving statistics follow the drifting parameters; bf16 operands drift further)
              # (the order in which gloo's ring adds the eight partial sums depends on how a span is chunked: with the 64 MiB
-             # spans one moving mean of 2048 x 6 came out 1.2e-5 from the serial run's, with round 3's 24 MB spans none did)
+             # spans a moving mean missed round 3's absolute bound of 1e-5, with the 24 MB spans none did)
              stat_tol=(1e-3, 3e-5) if dtype == "float32" else (2e-2, 5e-4))
