@@ -497,13 +497,12 @@ void on_layer(void* user, int layer) {
 }
 
 // The engine stream waits for span s's collective.  The comm stream runs its collectives in launch order (= span index), so a
-// wait for span j covers every span before it: a stream wait costs the engine stream ~6 us of idle time even when its event
-// fired long ago (a barrier packet between two kernels; profiles/r04_dp_trace.txt), and tfk_comm_apply's first wait -- for the
-// span that carries the loss and the frame count, the LAST one launched -- used to be followed by one per span.
+// wait for span j covers every span before it: one is only issued for a span beyond the last one waited for.  (A stream wait
+// whose event fired long ago costs the engine stream nothing measurable; what costs are event RECORDS and round trips through
+// the other stream -- profiles/r04_dp_trace.txt.)
 int wait_span(tfk_comm* c, Span& s) {
   const size_t index = (size_t)(&s - c->spans.data());
-  static const bool collapse = !getenv("TFK_DP_COLLAPSE_WAITS") || atoi(getenv("TFK_DP_COLLAPSE_WAITS")) != 0;  // (experiments)
-  if (!s.waited && (index >= c->waited_upto || !collapse)) {
+  if (!s.waited && index >= c->waited_upto) {
     if (s.wait_on) XHIP(hipStreamWaitEvent(c->engine_stream, s.wait_on, 0));  // (nullptr: it ran on the engine stream itself)
     if (s.wait_on) c->waited_upto = index + 1;
   }
@@ -762,8 +761,7 @@ int tfk_comm_apply(tfk_comm* c, float* average_loss) {
   std::sort(mine.begin(), mine.end());
   for (size_t i = 0; i < mine.size();) {
     size_t off = mine[i].first, n = mine[i].second, j = i + 1;
-    static const bool merge = !getenv("TFK_DP_MERGE_ADAM") || atoi(getenv("TFK_DP_MERGE_ADAM")) != 0;  // (experiments)
-    while (merge && j < mine.size() && mine[j].first == off + n) n += mine[j++].second;
+    while (j < mine.size() && mine[j].first == off + n) n += mine[j++].second;
     XCHK(tfk_apply_span(c->e, off, n));
     i = j;
   }
