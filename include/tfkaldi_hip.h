@@ -322,6 +322,11 @@ int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
  *                           bf16 shadow (2 B per parameter; the fp32 masters of a span then live on its owner until
  *                           tfk_comm_gather_masters) -- consumed layer by layer by the next forward pass;
  *   TFK_EXCHANGE_ALLREDUCE  SUM all-reduce of every span, full Adam on every rank.
+ * Streams: collectives launched while backward still runs, and the parameter gathers the next forward pass consumes layer
+ * by layer, go to a comm stream the tfk_comm owns (ordered against the engine stream by events); the collectives launched
+ * behind the LAST backward kernel and the gather the next forward pass reads first go to the engine stream itself
+ * (nothing is left to overlap with, and a round trip through another stream costs ~26 us; env TFK_DP_INLINE_TAIL=0:
+ * everything on the comm stream).  RCCL orders the operations of one communicator itself.
  * bucket_bytes: adjacent gradient buckets are coalesced until a collective carries at least this much (0: default,
  * 64 MiB -- xGMI is point-to-point: few large collectives beat one per layer, and each costs the step a fixed 10-13 us).
  * Bootstrap: rank 0 calls tfk_comm_unique_id, the host distributes the bytes any way it likes (torch.distributed, MPI, a
