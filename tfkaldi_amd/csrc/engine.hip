@@ -512,18 +512,18 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
 int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int ldw, float* da_out, int ld_da, int T,
                   int N_da, int K_da, const ActEpi* act, float* stats, const float* in, int ld_in, float* Gw, int ld_g,
                   int d_in, int d_out, int epi_w, int* chunk_rows) {
-  if (!e->dual_gemm || e->x3) return 1;  // (the three-plane kernel has no dual form: dA and dW run one after the other)
+  if (!e->dual_gemm) return 1;
   const double flops = 2.0 * T * N_da * K_da + 2.0 * d_in * d_out * T;
   if (e->bf16) {
-    const int dcfg = gemm_bf16_dual_config(T, N_da, d_in, d_out);
-    const int bm = gemm_bf16_dual_tile_rows(dcfg);
+    const int dcfg = e->x3 ? -1 : gemm_bf16_dual_config(T, N_da, d_in, d_out);
+    const int bm = e->x3 ? kGemmBf16x3TileRows : gemm_bf16_dual_tile_rows(dcfg);
     if (!dcfg || (act && (T + bm - 1) / bm > kMaxRowSplits)) return 1;
     GemmArgsB a = {}, w = {};
     int ld_a = 0, ld_b = 0, ld_c = 0, ld_d = 0;
-    a.A = twin_of(e, dz, &ld_a);
-    a.B = twin_of(e, W, &ld_b);
-    w.A = twin_of(e, in, &ld_c);
-    w.B = twin_of(e, dz, &ld_d);
+    a.A = twin_of(e, dz, &ld_a, &a.a_plane);
+    a.B = twin_of(e, W, &ld_b, &a.b_plane);
+    w.A = twin_of(e, in, &ld_c, &w.a_plane);
+    w.B = twin_of(e, dz, &ld_d, &w.b_plane);
     if (!a.A || !a.B || !w.A || !w.B) return fail(-1, "internal: GEMM operand without a bf16 twin");
     a.C = da_out; a.stats = stats;
     a.act_a = act ? act->a : nullptr; a.act_z = act ? act->z : nullptr;
@@ -543,9 +543,9 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
       pa = get_event(e); pb = get_event(e);
       hipEventRecord(pa, e->stream);
     }
-    const int rc = gemm_bf16_dual(a, w, e->stream);
+    const int rc = e->x3 ? gemm_bf16x3_dual(a, w, e->stream) : gemm_bf16_dual(a, w, e->stream);
     if (rc == -1) return 1;
-    if (rc != 0) return fail(rc, "gemm_bf16_dual launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (rc != 0) return fail(rc, "gemm_bf16%s_dual launch failed: %s", e->x3 ? "x3" : "", hipGetErrorString((hipError_t)rc));
     if (e->profiling) {
       hipEventRecord(pb, e->stream);
       ProfRec r;

@@ -87,6 +87,9 @@ constexpr int kGemmBf16x3TileRows = 128;
 // workspace, the second adds them to its own (a + b = b + a: the result does not depend on who was first) and runs the
 // epilogue.  Floats of workspace an [M, N] x K contraction needs for that (0: it would not split).
 size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K);
+// The NT (epi 0 / EPI_DACT) and TN (epi 0 / EPI_ACCUM) contractions of a layer's backward pass in ONE launch of 128x128 blocks
+// (as gemm_bf16_dual; -1: not eligible -- fewer than a tile per CU between them).  Rows per EPI_DACT chunk: kGemmBf16x3TileRows.
+int gemm_bf16x3_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t stream);
 
 // rows of the block tile gemm_bf16 uses for an [M, N] result (= rows per EPI_COLSTATS / EPI_DACT chunk)
 int gemm_bf16_tile_rows(int M, int N);

@@ -922,6 +922,25 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   epilogue<EPI, 2, 2, FM, FN>(p, acc, tiles_m, tm, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(smem));
 }
 
+// The dual launch of the fp32-emulating contraction: dA (NT) and dW (TN) of a layer on 128x128 blocks in ONE launch.  At 1024
+// frames dA alone has 128 tiles for 256 CUs (which is why gemm_bf16x3 splits its K in two) and dW 256; together every CU runs one
+// dA tile (64 ring tiles) or two dW tiles (32 each): no partial-sum exchange, one ramp and one tail instead of two.
+template <int EPI_NT, int EPI_TN>
+__global__ void __launch_bounds__(256)
+gemm_bf16x3_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, int group1, int tiles_m2, int tiles_n2, int group2,
+                        int tn_first) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // the tiles with the longer K go first in block order (dA at 1024 frames: K = d_out against K = frames; dW in a stacked pass
+  // of 8192 rows): the short ones fill the tail
+  const int n1 = tiles_m1 * tiles_n1, n2 = tiles_m2 * tiles_n2;
+  const int b = blockIdx.x;
+  const bool nt = tn_first ? b >= n2 : b < n1;
+  if (nt)
+    dma_tile<true, true, EPI_NT, 2, 2, 2, 2, 3, 32, 0, 3>(p1, tiles_m1, tiles_n1, group1, tn_first ? b - n2 : b, smem);
+  else
+    dma_tile<false, false, EPI_TN, 2, 2, 2, 2, 3, 32, 0, 3>(p2, tiles_m2, tiles_n2, group2, tn_first ? b : b - n1, smem);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 struct CfgB {
   int bm, bn;
@@ -1128,6 +1147,45 @@ size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K) {
   const int forced = x3_cfg();
   if (!(forced == 2 || forced < 0) || !x3_split_shape(layout == GEMM_TN, M, N, K)) return 0;
   return (size_t)kSplitFlagWords + (size_t)((M + 127) / 128) * ((N + 127) / 128) * 128 * 128;
+}
+
+namespace {
+template <int EPI_NT, int EPI_TN>
+int launch_x3_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
+  constexpr size_t lds = (size_t)3 * 3 * (128 + 128) * 32 * 2;
+  auto kern = &gemm_bf16x3_dual_kernel<EPI_NT, EPI_TN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int tma = (a.M + 127) / 128, tna = (a.N + 127) / 128, tmw = (w.M + 127) / 128, tnw = (w.N + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(256), lds, stream, a, w, tma, tna, pick_group_rows(tma, tna, 128, 128),
+                     tmw, tnw, pick_group_rows(tmw, tnw, 128, 128), w.K > a.K ? 1 : 0);
+  return (int)hipGetLastError();
+}
+bool x3_operands_ok(const GemmArgsB& p, long a_rows, long b_rows) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || p.a_plane <= 0 || p.b_plane <= 0 ||
+      (p.a_plane & 7) || (p.b_plane & 7))
+    return false;
+  return (2 * p.a_plane + a_rows * p.lda) * 2 < (1L << 31) && (2 * p.b_plane + b_rows * p.ldb) * 2 < (1L << 31);
+}
+}  // namespace
+
+int gemm_bf16x3_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t stream) {
+  if (!x3_operands_ok(nt, nt.M, nt.N) || !x3_operands_ok(tn, tn.K, tn.K)) return (int)hipErrorInvalidValue;
+  if ((nt.epi != 0 && nt.epi != EPI_DACT) || (tn.epi != 0 && tn.epi != EPI_ACCUM)) return -1;
+  static const bool on = !getenv("TFK_BF16X3_DUAL") || atoi(getenv("TFK_BF16X3_DUAL")) != 0;
+  const long tiles = (long)((nt.M + 127) / 128) * ((nt.N + 127) / 128) + (long)((tn.M + 127) / 128) * ((tn.N + 127) / 128);
+  if (!on || tiles < 256) return -1;
+  const int key = (nt.epi == EPI_DACT ? 2 : 0) + (tn.epi == EPI_ACCUM ? 1 : 0);
+  switch (key) {
+    case 0: return launch_x3_dual<0, 0>(nt, tn, stream);
+    case 1: return launch_x3_dual<0, EPI_ACCUM>(nt, tn, stream);
+    case 2: return launch_x3_dual<EPI_DACT, 0>(nt, tn, stream);
+    default: return launch_x3_dual<EPI_DACT, EPI_ACCUM>(nt, tn, stream);
+  }
 }
 
 int gemm_bf16x3(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
