@@ -655,7 +655,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     unsigned* flags = reinterpret_cast<unsigned*>(p.splitk_ws);
     const int tile = tm * tiles_n + tn;
-    constexpr int kSys = 1 | (1 << 4);  // sc0 sc1
+    constexpr int kSys = 1 | (1 << 4);  // sc0 sc1 (agent scope -- sc1 alone -- measured the same)
     __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.splitk_ws + kSplitFlagWords + (size_t)tile * (BM * BN)), 0, BM * BN * 4, 0x00020000);
     unsigned* sh = reinterpret_cast<unsigned*>(smem);
