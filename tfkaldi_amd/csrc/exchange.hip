@@ -70,6 +70,8 @@ struct Rccl {
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   std::string error;
 };
 Rccl* rccl() {
@@ -101,6 +103,8 @@ Rccl* rccl() {
     BIND(ReduceScatter, "ncclReduceScatter");
     BIND(AllGather, "ncclAllGather");
     BIND(GetErrorString, "ncclGetErrorString");
+    BIND(GroupStart, "ncclGroupStart");
+    BIND(GroupEnd, "ncclGroupEnd");
 #undef BIND
   });
   return &r;
@@ -122,6 +126,9 @@ struct Backend {
   virtual int all_reduce(float* buf, size_t count, hipStream_t st) = 0;
   // host-level: v[0] = min over ranks, v[1] = max over ranks of the value passed in v[0] (blocks the calling thread)
   virtual int min_max(unsigned long long* v, hipStream_t st) = 0;
+  // the collectives posted between the two calls (all on ONE stream) may be launched as one operation
+  virtual int group_begin() { return 0; }
+  virtual int group_end() { return 0; }
   virtual const char* name() const = 0;
 };
 
@@ -153,6 +160,15 @@ struct RcclBackend : Backend {
     XNCCL(rccl()->AllReduce(d_pair + 1, d_pair + 1, 1, ncclUint64, ncclMax, comm, st));
     XHIP(hipMemcpyAsync(v, d_pair, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     XHIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  // (an RCCL call costs its stream 10-13 us of event work whatever it moves -- profiles/r04_dp_trace.txt; a group pays it once)
+  int group_begin() override {
+    XNCCL(rccl()->GroupStart());
+    return 0;
+  }
+  int group_end() override {
+    XNCCL(rccl()->GroupEnd());
     return 0;
   }
   const char* name() const override { return "rccl"; }
@@ -406,6 +422,16 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
     XHIP(hipEventRecord(c->spans[first].ready, c->engine_stream));
     XHIP(hipStreamWaitEvent(c->comm_stream, c->spans[first].ready, 0));
   }
+  const bool grouped = c->num_spans - first > 1;
+  struct Group {  // (closed on every way out: a failed collective must not leave RCCL inside a group)
+    Backend* be;
+    bool open;
+    ~Group() { if (open) (void)be->group_end(); }
+  } group = {c->be, false};
+  if (grouped) {
+    XCHK(c->be->group_begin());
+    group.open = true;
+  }
   for (size_t k = first; k < c->num_spans; ++k) {
     Span& s = c->spans[k];
     if (s.rs) {
@@ -416,6 +442,10 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
       c->cur_ar += 1;
     }
     s.wait_on = inline_on_engine ? nullptr : c->spans[c->num_spans - 1].done;
+  }
+  if (grouped) {
+    group.open = false;
+    XCHK(c->be->group_end());
   }
   if (!inline_on_engine) XHIP(hipEventRecord(c->spans[c->num_spans - 1].done, c->comm_stream));
   return 0;
