@@ -389,7 +389,8 @@ bool shardable(const tfk_comm* c, size_t lo, size_t hi) {
 // updated on every rank, so that no layer ever waits for THEIR gather).  The pieces of one range share ONE `ready` record on the
 // engine stream and ONE `done` record behind the last of them: an event record between two kernels costs the engine stream
 // ~6 us of idle time and every record / wait pair on the comm stream ~9 us of latency before the optimiser may start
-// (profiles/r04_dp_trace.txt) -- the range launched by tfk_comm_apply, after the last backward kernel, has three pieces.
+// (profiles/r04_dp_trace.txt) -- the range launched by tfk_comm_apply, after the last backward kernel, has two or three pieces;
+// they also go to RCCL as one group (one launch).
 // inline_on_engine: nothing is left to overlap with (the range launched by tfk_comm_apply behind the last backward kernel, the
 // evaluation sums): the collectives go to the ENGINE stream itself and no event is needed at all -- the record -> comm stream
 // -> record -> engine stream round trip measured ~26 us of idle time in front of the optimiser.  (One communicator on two
