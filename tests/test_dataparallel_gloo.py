@@ -88,3 +88,55 @@ def test_two_ranks_equal_serial(tmp_path, num_mb, mode):
             assert np.allclose(got[k], v, rtol=1e-9, atol=1e-12), k
         assert np.allclose(got["mov_mean"], np.stack(serial.mov_mean), rtol=1e-10, atol=1e-14)
         assert np.allclose(got["mov_var"], np.stack(serial.mov_var), rtol=1e-10, atol=1e-14)
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tfkaldi_amd.dataparallel import DataParallel, init_from_env
+    import tfkaldi_amd.dataparallel as dpmod
+    init_from_env()
+    closed = []
+
+    class Flaky(object):  # stands in for NativeExchange: comes up on rank 0 only
+        native = True
+
+        def __init__(self, engine, group, mode=None):
+            if dist.get_rank() == 1:
+                raise RuntimeError("RCCL could not be loaded: no such file")
+            engine.on_close.insert(0, self.close)
+            engine.param_access_hook = lambda: None
+
+        def close(self):
+            closed.append(True)
+
+    class Eng(object):
+        def __init__(self):
+            self.on_close, self.param_access_hook = [], None
+
+    dpmod.NativeExchange = Flaky
+    dp = DataParallel(mode="sharded")
+    eng = Eng()
+    got = dp._native_exchange(eng)
+    # every rank agrees: nobody keeps the in-library exchange, the rank that had one gives it back, everyone knows why
+    assert got is None and dp.native_failure
+    assert eng.on_close == [] and eng.param_access_hook is None
+    assert closed == ([True] if rank == 0 else [])
+    assert ("could not be loaded" in dp.native_failure) == (rank == 1)
+    os.environ["TFK_DP_COMM"] = "native-only"
+    try:
+        dp._native_exchange(Eng())
+    except RuntimeError as e:
+        assert "in-library exchange unavailable" in str(e)
+    else:
+        raise AssertionError("native-only must make the failure fatal")
+    open(os.path.join(out_dir, "ok%d" % rank), "w").close()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_to_leave_the_in_library_exchange(tmp_path):
+    """one rank cannot bring the in-library RCCL exchange up: ALL ranks run the torch.distributed reducer (a flag all-reduced
+    with MIN), the rank that did create one closes it, and TFK_DP_COMM=native-only turns the agreement into an error"""
+    mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))
