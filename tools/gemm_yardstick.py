@@ -70,20 +70,39 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     print("this library vs torch.mm (vendor GEMM), us per launch and TFLOP/s; 1x MI355X")
     print("== BASELINE cfg2, fp32 (peak 157.3)")
-    print("%-5s %-2s %5s %5s %5s | %16s | %16s" % ("op", "ly", "M", "N", "K", "tfk_gemm_f32", "torch.mm fp32"))
+    print("%-5s %-2s %5s %5s %5s | %16s | %16s | %22s" % ("op", "ly", "M", "N", "K", "tfk_gemm_f32", "torch.mm fp32",
+                                                          "tfk_gemm_bf16x3 (f32x3)"))
     torch.backends.cuda.matmul.allow_tf32 = False
+
+    def planes(x, cols):
+        """the exact three-plane bf16 split of x[:, :cols] (tfk_split3): what the fp32-emulating contraction reads"""
+        rows, ld = x.shape[0], p8(cols)
+        plane = (rows * ld + 127) & ~127
+        out = torch.zeros(3 * plane, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.tfk_split3(st, ctypes.c_void_p(x.data_ptr()), x.stride(0), ctypes.c_void_p(out.data_ptr()), ld, plane,
+                                  rows, cols))
+        return out, ld, plane
+
     for name, layout, M, N, K in shapes(1024, 440, 2048, 2000):
         a, b, sa, sb = operands(layout, M, N, K, torch.float32, lambda n: (n + 3) & ~3)
         c = torch.zeros(M, (N + 3) & ~3, device="cuda")
         args = (st, layout, ctypes.c_void_p(a.data_ptr()), a.shape[1], ctypes.c_void_p(b.data_ptr()), b.shape[1],
                 ctypes.c_void_p(c.data_ptr()), c.shape[1], M, N, K, None, 0, -1)
+        ap, lda, pa = planes(a, sa[1])
+        bp, ldb, pb = planes(b, sb[1])
+        c3 = torch.zeros_like(c)
+        args3 = (st, layout, ctypes.c_void_p(ap.data_ptr()), lda, pa, ctypes.c_void_p(bp.data_ptr()), ldb, pb,
+                 ctypes.c_void_p(c3.data_ptr()), c3.shape[1], M, N, K, None, 0)
 
         def ours():
             assert lib.tfk_gemm_f32(*args) == 0
-        t0, t1 = timed([ours, vendor(layout, a, b, sa, sb)])
+
+        def ours3():
+            assert lib.tfk_gemm_bf16x3(*args3) == 0
+        t0, t1, t3 = timed([ours, vendor(layout, a, b, sa, sb), ours3])
         fl = 2.0 * M * N * K
-        print("%-5s %-2s %5d %5d %5d | %7.1fus %6.1fTF | %7.1fus %6.1fTF" % (name, LAY[layout], M, N, K, t0, fl / t0 / 1e6,
-                                                                             t1, fl / t1 / 1e6), flush=True)
+        print("%-5s %-2s %5d %5d %5d | %7.1fus %6.1fTF | %7.1fus %6.1fTF | %7.1fus %6.1fTF-equivalent" % (
+            name, LAY[layout], M, N, K, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, t3, fl / t3 / 1e6), flush=True)
     for tag, dims in (("cfg3/gpu", (1024, 440, 2048, 4000)), ("cfg4/gpu", (2048, 440, 4096, 8000))):
         print("== BASELINE %s, bf16 operands (peak 2500)" % tag)
         print("%-5s %-2s %5s %5s %5s | %16s | %16s | %16s" % ("op", "ly", "M", "N", "K", "tfk_gemm_bf16->f32", "torch.mm ->bf16",
