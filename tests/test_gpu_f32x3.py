@@ -70,7 +70,9 @@ def test_contraction_within_the_fp32_kernels_bound(gpu, layout):
                                    (2, 3, 700), (1024, 2048, 440), (1024, 2000, 2048), (2048, 2048, 1024), (2048, 4096, 512),
                                    # two blocks per tile over half of K each (NN / NT): K halves of 17 + 16 and 31 + 31 ring tiles,
                                    # a ragged last tile row
-                                   (1024, 2048, 1040), (1000, 2048, 1976)]):
+                                   (1024, 2048, 1040), (1000, 2048, 1976),
+                                   # the narrow layer's weight gradient (TN): 128x64 blocks, two per tile
+                                   (440, 2048, 1024), (500, 2000, 1100)]):
         _run(gpu, layout, M, N, K, epi=epi if n % 2 == 0 else 0, seed=n)
 
 

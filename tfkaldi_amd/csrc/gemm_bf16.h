@@ -85,7 +85,8 @@ constexpr int kGemmBf16x3TileRows = 128;
 // per flop, and at 1024 frames the contraction is bound by exactly that (L2 -> LDS fill).  With a workspace the NN / NT
 // layouts run 128x128 blocks on HALF of K each, two blocks per tile: the first to finish leaves its partial sums in the
 // workspace, the second adds them to its own (a + b = b + a: the result does not depend on who was first) and runs the
-// epilogue.  Floats of workspace an [M, N] x K contraction needs for that (0: it would not split).
+// epilogue.  The TN layout splits where even 128x64 blocks leave half the chip idle (the weight gradient of a narrow layer:
+// 440 x 2048 over 1024 frames).  Floats of workspace an [M, N] x K contraction needs for that (0: it would not split).
 size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K);
 // The NT (epi 0 / EPI_DACT) and TN (epi 0 / EPI_ACCUM) contractions of a layer's backward pass in ONE launch of 128x128 blocks
 // (as gemm_bf16_dual; -1: not eligible -- fewer than a tile per CU between them).  Rows per EPI_DACT chunk: kGemmBf16x3TileRows.

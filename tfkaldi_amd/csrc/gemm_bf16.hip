@@ -1006,6 +1006,12 @@ bool x3_split_shape(bool tn, int M, int N, int K) {
   const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   return !tn && tiles >= 64 && tiles < 200 && tiles % NUM_XCD == 0 && 2 * tiles <= kSplitFlagWords && K >= 512;
 }
+// the weight gradient of a NARROW layer (layer 0: 440 x 2048 x 1024 frames): too few tiles even for 128x64 blocks -- 128 of
+// them for 256 CUs -- so each runs as two blocks over half of K (the frames)
+bool x3_split_shape_tn(int M, int N, int K) {
+  const long m128 = (M + 127) / 128, tiles128 = m128 * ((N + 127) / 128), tiles64 = m128 * ((N + 63) / 64);
+  return tiles128 < 100 && tiles64 >= 64 && tiles64 < 200 && tiles64 % NUM_XCD == 0 && 2 * tiles64 <= kSplitFlagWords && K >= 512;
+}
 template <bool A_KC, bool B_KC, int EPI>
 int launch_x3(const GemmArgsB& p, hipStream_t stream) {
   const int forced = x3_cfg();
@@ -1014,6 +1020,10 @@ int launch_x3(const GemmArgsB& p, hipStream_t stream) {
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape(false, p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * n128 * 128 * 128)
       return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
+  } else {
+    if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape_tn(p.M, p.N, p.K) &&
+        p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * ((p.N + 63) / 64) * 128 * 64)
+      return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3, 2>(p, stream);
   }
   const bool big = forced >= 0 ? forced == 1 : m128 * n128 >= 200;
   if (big) return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
@@ -1145,7 +1155,10 @@ int gemm_bf16_tile_rows(int M, int N) { return kCfgB[gemm_bf16_pick_config(M, N)
 
 size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K) {
   const int forced = x3_cfg();
-  if (!(forced == 2 || forced < 0) || !x3_split_shape(layout == GEMM_TN, M, N, K)) return 0;
+  if (!(forced == 2 || forced < 0)) return 0;
+  if (layout == GEMM_TN)
+    return x3_split_shape_tn(M, N, K) ? (size_t)kSplitFlagWords + (size_t)((M + 127) / 128) * ((N + 63) / 64) * 128 * 64 : 0;
+  if (!x3_split_shape(false, M, N, K)) return 0;
   return (size_t)kSplitFlagWords + (size_t)((M + 127) / 128) * ((N + 127) / 128) * 128 * 128;
 }
 
