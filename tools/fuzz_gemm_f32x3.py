@@ -63,7 +63,9 @@ def main():
         assert bool((outs[0][:, N:] == C0[:, N:]).all())
         worst = max(worst, ratio)
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        split += int(layout != 2 and 64 <= tiles < 200 and tiles % 8 == 0 and K >= 512)
+        tiles64 = ((M + 127) // 128) * ((N + 63) // 64)
+        split += int(K >= 512 and ((layout != 2 and 64 <= tiles < 200 and tiles % 8 == 0) or
+                                   (layout == 2 and tiles < 100 and 64 <= tiles64 < 200 and tiles64 % 8 == 0)))
     print("== gemm_bf16x3: %d cases OK (%d of them split-K shapes); worst error %.3f of the fp32 kernels' bound "
           "(4e-7 * sum|ab| + 1e-6)" % (cases, split, worst))
 
