@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 6
+#define TFK_ABI_VERSION 7
 
 typedef struct tfk_engine tfk_engine;
 
@@ -329,10 +329,14 @@ int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
  * everything on the comm stream).  RCCL orders the operations of one communicator itself.
  * bucket_bytes: adjacent gradient buckets are coalesced until a collective carries at least this much (0: default,
  * 64 MiB -- xGMI is point-to-point: few large collectives beat one per layer, and each costs the step a fixed 10-13 us).
- * Bootstrap: rank 0 calls tfk_comm_unique_id, the host distributes the bytes any way it likes (torch.distributed, MPI, a
- * file), every rank calls tfk_comm_create with them (collective: ncclCommInitRank). */
+ * Bootstrap: EVERY rank first calls tfk_comm_available (local, no collective: RCCL loadable, engine and mode acceptable) and
+ * the host agrees on the answers (one MIN all-reduce over whatever process group it already has) -- tfk_comm_create is
+ * collective (ncclCommInitRank), so a rank that could not even load RCCL must be known BEFORE the others enter it and
+ * block.  Then rank 0 calls tfk_comm_unique_id, the host distributes the bytes any way it likes (torch.distributed, MPI, a
+ * file), and every rank calls tfk_comm_create with them. */
 enum { TFK_EXCHANGE_SHARDED = 0, TFK_EXCHANGE_ALLREDUCE = 1 };
 typedef struct tfk_comm tfk_comm;
+int tfk_comm_available(tfk_engine* e, int mode);
 int tfk_comm_unique_id(void* id, size_t capacity, size_t* size);  /* 128 bytes */
 int tfk_comm_create(tfk_engine* e, const void* id, size_t id_size, int rank, int world, int mode, size_t bucket_bytes,
                     tfk_comm** out);
@@ -398,11 +402,17 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
 int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   int M, int N, int K, const float* bias, int epi);
 /* Stand-alone fp32-emulating GEMM (TFK_DTYPE_F32X3's contraction; gemm_bf16.h: gemm_bf16x3) on device pointers: A and B are given
- * as three bf16 planes each, `a_plane` / `b_plane` elements apart (same leading dimension, a multiple of 8); tfk_split3 makes such
- * planes from an fp32 matrix [rows, lds]: src == plane 0 + plane 1 + plane 2 exactly.  Tests and tools. */
-int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int64_t plane, int rows, int cols);
-int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, int64_t a_plane, const uint16_t* B, int ldb,
-                    int64_t b_plane, float* C, int ldc, int M, int N, int K, const float* bias, int epi);
+ * as three bf16 planes each, INTERLEAVED per 32 elements of the flat index i = row * ld + col (ld a multiple of 8; element i of
+ * plane q at (i / 32) * 96 + 32 q + i % 32: csrc/x3_layout.h), 3 * ceil(rows * ld / 32) * 32 elements in all; tfk_split3 makes such
+ * an array from an fp32 matrix [rows, lds]: src == plane 0 + plane 1 + plane 2 exactly, padding columns zero.
+ * tfk_gemm_bf16x3_dual: the backward pair of a layer in one launch (as tfk_gemm_bf16_dual).  Tests and tools.  (ABI 7: the
+ * separate-plane form of ABI 6 -- `a_plane` / `b_plane` arguments -- is gone.) */
+int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols);
+int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M,
+                    int N, int K, const float* bias, int epi);
+int tfk_gemm_bf16x3_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uint16_t* B_nt, int ldb_nt, float* C_nt,
+                         int ldc_nt, int M_nt, int N_nt, int K_nt, const uint16_t* A_tn, int lda_tn, const uint16_t* B_tn,
+                         int ldb_tn, float* C_tn, int ldc_tn, int M_tn, int N_tn, int K_tn, int epi_tn);
 /* The backward pair of one layer in ONE launch (gemm_bf16.h: gemm_bf16_dual): C_nt[M_nt, N_nt] = A_nt . B_nt^T and
  * C_tn[M_tn, N_tn] (+)= A_tn^T . B_tn (epi_tn: 0 or 2 = accumulate).  Fails when the pair of shapes is not eligible
  * (tfk_gemm_bf16_dual_config == 0).  Block geometry: env TFK_BF16_DUAL_CFG (3: 128x64, 4: 128x128, 5: 256x128,

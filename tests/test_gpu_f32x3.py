@@ -18,20 +18,25 @@ p8 = lambda n: (n + 7) & ~7  # noqa: E731
 p4 = lambda n: (n + 3) & ~3  # noqa: E731
 
 
-def _planes(lib, torch, x):
+def _planes(lib, torch, x, ld=None):
+    """the interleaved three-plane array of x (csrc/x3_layout.h) and its leading dimension"""
+    from tfkaldi_amd import x3
+    return x3.split(lib, x, ld)
+
+
+def _gemm(lib, torch, layout, Ap, lda, Bp, ldb, C, ldc, M, N, K, bias=None, epi=0):
     from tfkaldi_amd import _lib
-    rows, cols = x.shape
-    ld = p8(cols)
-    plane = (rows * ld + 127) & ~127
-    out = torch.zeros(3 * plane, dtype=torch.bfloat16, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.tfk_split3(st, ctypes.c_void_p(x.data_ptr()), x.stride(0), ctypes.c_void_p(out.data_ptr()), ld, plane, rows, cols))
-    return out, ld, plane
+    _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, ctypes.c_void_p(Bp.data_ptr()), ldb,
+                                   ctypes.c_void_p(C.data_ptr()), ldc, M, N, K,
+                                   ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, epi))
 
 
-def _run(lib, layout, M, N, K, epi=0, seed=0):
+def _run(lib, layout, M, N, K, epi=0, seed=0, ld8=False):
+    """ld8: leading dimensions that are multiples of 8 only (rows then start in the middle of an interleave block: the layout
+    is a function of the flat index) instead of multiples of 32"""
     import torch
-    from tfkaldi_amd import _lib
+    from tfkaldi_amd import x3
     g = torch.Generator(device="cuda").manual_seed(seed)
     shape_a = (K, M) if layout == 2 else (M, K)
     shape_b = (N, K) if layout == 1 else (K, N)
@@ -40,19 +45,19 @@ def _run(lib, layout, M, N, K, epi=0, seed=0):
     Ad, Bd = A.double(), B.double()
     ref = (Ad.T if layout == 2 else Ad) @ (Bd.T if layout == 1 else Bd)
     sab = (Ad.abs().T if layout == 2 else Ad.abs()) @ (Bd.abs().T if layout == 1 else Bd.abs())
-    Ap, lda, pa = _planes(lib, torch, A)
-    Bp, ldb, pb = _planes(lib, torch, B)
-    for X, Xp, ld, pl in ((A, Ap, lda, pa), (B, Bp, ldb, pb)):  # the split is exact, plane by plane a bf16
+    Ap, lda = _planes(lib, torch, A, p8(A.shape[1]) if ld8 else None)
+    Bp, ldb = _planes(lib, torch, B, p8(B.shape[1]) if ld8 else None)
+    for X, Xp, ld in ((A, Ap, lda), (B, Bp, ldb)):  # the split is exact, plane by plane a bf16
         r, c = X.shape
-        total = sum(Xp[q * pl:q * pl + r * ld].view(r, ld)[:, :c].float() for q in range(3))
-        assert torch.equal(total, X)
+        if (r * ld) % 32 == 0:
+            pl = x3.planes(Xp, r, ld)
+            assert torch.equal(sum(q[:, :c].float() for q in pl), X)
+            assert all(bool((q[:, c:] == 0).all()) for q in pl)  # padding columns are zeros
     ldc = p4(N)
     C0 = torch.randn(M, ldc, device="cuda", generator=g)
     C = C0.clone()
     bias = torch.randn(N, device="cuda", generator=g)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, pa, ctypes.c_void_p(Bp.data_ptr()), ldb, pb,
-                                   ctypes.c_void_p(C.data_ptr()), ldc, M, N, K, ctypes.c_void_p(bias.data_ptr()), epi))
+    _gemm(lib, torch, layout, Ap, lda, Bp, ldb, C, ldc, M, N, K, bias, epi)
     torch.cuda.synchronize()
     want = ref + (bias.double() if epi & 1 else 0) + (C0[:, :N].double() if epi & 2 else 0)
     err = (C[:, :N].double() - want).abs()
@@ -74,6 +79,9 @@ def test_contraction_within_the_fp32_kernels_bound(gpu, layout):
                                    # the narrow layer's weight gradient (TN): 128x64 blocks, two per tile
                                    (440, 2048, 1024), (500, 2000, 1100)]):
         _run(gpu, layout, M, N, K, epi=epi if n % 2 == 0 else 0, seed=n)
+    # leading dimensions of 8 q, not 32 q: 2000 pdfs (the arena-mirroring shadow of cfg2's output layer), 440 inputs, ragged
+    for n, (M, N, K) in enumerate([(1024, 2000, 2048), (1024, 2048, 2000), (440, 2000, 1024), (130, 72, 200), (70, 330, 33)]):
+        _run(gpu, layout, M, N, K, epi=0, seed=100 + n, ld8=True)
 
 
 @pytest.mark.parametrize("layout", [0, 1])
@@ -87,14 +95,12 @@ def test_split_k_does_not_depend_on_who_finishes_first(gpu, layout):
     M, N, K = 1024, 2048, 2048
     A = torch.randn(M, K, device="cuda", generator=g)
     B = torch.randn(*((N, K) if layout == 1 else (K, N)), device="cuda", generator=g)
-    Ap, lda, pa = _planes(lib, torch, A)
-    Bp, ldb, pb = _planes(lib, torch, B)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Ap, lda = _planes(lib, torch, A)
+    Bp, ldb = _planes(lib, torch, B)
     outs = []
     for _ in range(40):
         C = torch.empty(M, N, device="cuda")
-        _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, pa, ctypes.c_void_p(Bp.data_ptr()), ldb, pb,
-                                       ctypes.c_void_p(C.data_ptr()), N, M, N, K, None, 0))
+        _gemm(lib, torch, layout, Ap, lda, Bp, ldb, C, N, M, N, K)
         outs.append(C)
     torch.cuda.synchronize()
     for C in outs[1:]:
@@ -107,16 +113,13 @@ def test_transpose_detecting(gpu):
     """A = I with an asymmetric B (integers up to 2^17: they need all three planes): a swapped row / column or a dropped
     plane cannot pass"""
     import torch
-    from tfkaldi_amd import _lib
     n = 96
     A = torch.eye(n, device="cuda")
     B = (torch.arange(n, device="cuda")[:, None] * 1000 + torch.arange(n, device="cuda")[None, :]).float() + 0.5
-    Ap, lda, pa = _planes(gpu, torch, A)
-    Bp, ldb, pb = _planes(gpu, torch, B)
+    Ap, lda = _planes(gpu, torch, A)
+    Bp, ldb = _planes(gpu, torch, B)
     C = torch.zeros(n, n, device="cuda")
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(gpu.tfk_gemm_bf16x3(st, 0, ctypes.c_void_p(Ap.data_ptr()), lda, pa, ctypes.c_void_p(Bp.data_ptr()), ldb, pb,
-                                   ctypes.c_void_p(C.data_ptr()), n, n, n, n, None, 0))
+    _gemm(gpu, torch, 0, Ap, lda, Bp, ldb, C, n, n, n, n)
     torch.cuda.synchronize()
     assert torch.equal(C, B)
 

@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_flo
 
 from .build import lib_path, source_id
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
@@ -114,6 +114,7 @@ SYMBOLS = {
     "tfk_apply_writes_shadow": (c_int, [_E, POINTER(c_int)]),
     "tfk_param_checksum": (c_int, [_E, c_int, POINTER(c_uint64)]),
     "tfk_param_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t)]),
+    "tfk_comm_available": (c_int, [_E, c_int]),
     "tfk_comm_unique_id": (c_int, [c_void_p, c_size_t, POINTER(c_size_t)]),
     "tfk_comm_create": (c_int, [_E, c_void_p, c_size_t, c_int, c_int, c_int, c_size_t, POINTER(c_void_p)]),
     "tfk_comm_destroy": (c_int, [c_void_p]),
@@ -140,9 +141,11 @@ SYMBOLS = {
                              c_int, c_void_p, c_int, c_int]),
     "tfk_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int]),
-    "tfk_split3": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int]),
-    "tfk_gemm_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int,
-                                c_int, c_void_p, c_int]),
+    "tfk_split3": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
+    "tfk_gemm_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                c_int]),
+    "tfk_gemm_bf16x3_dual": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "tfk_gemm_bf16_dual": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "tfk_gemm_bf16_dual_config": (c_int, [c_int, c_int, c_int, c_int]),

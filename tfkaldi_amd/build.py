@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libtfkaldi_hip.so"
 SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "kernels.hip", "ctc.hip", "engine.hip", "features.hip", "exchange.hip"]
-HEADERS = ["gemm_f32.h", "gemm_bf16.h", "kernels.h", "ctc.h", os.path.join("..", "..", "include", "tfkaldi_hip.h")]
+HEADERS = ["gemm_f32.h", "gemm_bf16.h", "kernels.h", "ctc.h", "x3_layout.h", os.path.join("..", "..", "include", "tfkaldi_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -174,11 +174,11 @@ struct tfk_engine {
   // mixed precision (cfg.compute_dtype == TFK_DTYPE_BF16): every fp32 buffer that is a GEMM operand has a bf16
   // twin written by its producer; master parameters, statistics, gradients and the optimiser stay fp32
   bool bf16 = false;                 // GEMM operands have bf16 twins (compute_dtype bf16 or f32x3)
-  bool x3 = false;                   // TFK_DTYPE_F32X3: every twin is THREE bf16 planes summing to the fp32 value (gemm_bf16x3)
-  long wb_plane = 0;                 // elements between the planes of the weight shadow (x3)
-  // elements between the planes of an activation twin with leading dimension ld (all twins hold `cap` rows)
-  long act_plane(int ld) const { return x3 ? (long)cap * ld : 0; }
-  int ldFb = 0, ldHb = 0, ldOb = 0;  // leading dimensions of the twins (multiples of 8 elements)
+  bool x3 = false;                   // TFK_DTYPE_F32X3: every twin is THREE bf16 planes summing to the fp32 value, interleaved
+                                     // per 32 elements of the flat index (x3_layout.h; gemm_bf16x3)
+  // elements a twin of n fp32 elements occupies / the offset of fp32 element n (a multiple of 32) inside a twin
+  size_t tw_el(size_t n) const { return x3 ? 3 * n : n; }
+  int ldFb = 0, ldHb = 0, ldOb = 0;  // leading dimensions of the twins (multiples of 8 elements; of 32 in x3 mode)
   bf16_t* Xb[2] = {nullptr, nullptr};
   std::vector<bf16_t*> ab;
   bf16_t* logb = nullptr;
@@ -387,19 +387,17 @@ inline void need_params(tfk_engine* e, int layer) {
 }
 
 // bf16 twin of an fp32 GEMM operand buffer (mixed-precision mode)
-// (*plane: elements between the three planes of the twin in x3 mode, 0 otherwise)
-const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld, long* plane = nullptr) {
-  long dummy;
-  if (!plane) plane = &dummy;
+// (x3 mode: the twin is the plane-interleaved array of x3_layout.h, 3 * rows * ld elements)
+const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
   for (int s = 0; s < 2; ++s) {
-    if (p == e->dX[s]) { *ld = e->ldFb; *plane = e->act_plane(e->ldFb); return e->Xb[s]; }
-    if (p == e->dA[s]) { *ld = e->ldHb; *plane = e->act_plane(e->ldHb); return e->dAb[s]; }
+    if (p == e->dX[s]) { *ld = e->ldFb; return e->Xb[s]; }
+    if (p == e->dA[s]) { *ld = e->ldHb; return e->dAb[s]; }
   }
-  if (p == e->logits) { *ld = e->ldOb; *plane = e->act_plane(e->ldOb); return e->logb; }
+  if (p == e->logits) { *ld = e->ldOb; return e->logb; }
   for (size_t l = 0; l < e->a.size(); ++l)
-    if (p == e->a[l]) { *ld = e->ldHb; *plane = e->act_plane(e->ldHb); return e->ab[l]; }
+    if (p == e->a[l]) { *ld = e->ldHb; return e->ab[l]; }
   for (int l = 0; l <= e->L; ++l)
-    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; *plane = e->wb_plane; return e->Wb + e->wb_off[l]; }
+    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; return e->Wb + e->tw_el(e->wb_off[l]); }
   return nullptr;
 }
 // rows a GEMM's per-tile statistics (EPI_COLSTATS / EPI_DACT) are chunked by
@@ -414,7 +412,7 @@ int refresh_shadow(tfk_engine* e) {
   if (!e->bf16 || !e->shadow_dirty) return 0;
   for (int l = 0; l <= e->L; ++l) {
     const LayerLayout& y = e->lay[l];
-    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->wb_off[l], e->wb_ld[l], y.d_in, y.d_out, e->wb_plane);
+    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->tw_el(e->wb_off[l]), e->wb_ld[l], y.d_in, y.d_out, e->x3);
   }
   HIPCHK(hipGetLastError());
   e->shadow_dirty = false;
@@ -429,7 +427,6 @@ struct ActEpi {  // EPI_DACT operands: the hidden layer whose output gradient th
   float eps = 0.f;
   bf16_t* twin = nullptr;  // mixed precision: bf16 copy of the result
   int ld_twin = 0;
-  long twin_plane = 0;     // x3: elements between its three planes
   float scale = 1.f;       // EPI_DACT: 1 / keep_prob of a ReLU + dropout chain
 };
 int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -439,8 +436,8 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
   if (e->bf16) {
     GemmArgsB b = {};
     int lda8 = 0, ldb8 = 0;
-    b.A = twin_of(e, A, &lda8, &b.a_plane);
-    b.B = twin_of(e, B, &ldb8, &b.b_plane);
+    b.A = twin_of(e, A, &lda8);
+    b.B = twin_of(e, B, &ldb8);
     if (!b.A || !b.B) return fail(-1, "internal: GEMM operand without a bf16 twin");
     b.C = C; b.bias = bias; b.stats = stats;
     b.act_a = act ? act->a : nullptr; b.act_z = act ? act->z : nullptr;
@@ -449,7 +446,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     b.stats_stride = kMaxRowSplits;
     b.act_beta = act ? act->beta : nullptr; b.bn_eps = act ? act->eps : 0.f;
     b.C_twin = act ? act->twin : nullptr; b.ldct = act ? act->ld_twin : 0;
-    b.ct_plane = act ? act->twin_plane : 0;
+    b.ct_x3 = e->x3;
     b.act_scale = act ? act->scale : 1.f;
     b.act_keep = act ? 1.f / act->scale : 1.f;
     b.row_vend = row_vend;
@@ -520,10 +517,10 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
     if (!dcfg || (act && (T + bm - 1) / bm > kMaxRowSplits)) return 1;
     GemmArgsB a = {}, w = {};
     int ld_a = 0, ld_b = 0, ld_c = 0, ld_d = 0;
-    a.A = twin_of(e, dz, &ld_a, &a.a_plane);
-    a.B = twin_of(e, W, &ld_b, &a.b_plane);
-    w.A = twin_of(e, in, &ld_c, &w.a_plane);
-    w.B = twin_of(e, dz, &ld_d, &w.b_plane);
+    a.A = twin_of(e, dz, &ld_a);
+    a.B = twin_of(e, W, &ld_b);
+    w.A = twin_of(e, in, &ld_c);
+    w.B = twin_of(e, dz, &ld_d);
     if (!a.A || !a.B || !w.A || !w.B) return fail(-1, "internal: GEMM operand without a bf16 twin");
     a.C = da_out; a.stats = stats;
     a.act_a = act ? act->a : nullptr; a.act_z = act ? act->z : nullptr;
@@ -668,7 +665,7 @@ int reserve(tfk_engine* e, int T) {
     }
   }
   if (e->bf16) {
-    const size_t np = e->x3 ? 3 : 1;  // planes per twin (plane stride = cap * ld: act_plane)
+    const size_t np = e->x3 ? 3 : 1;  // planes per twin
     for (int s = 0; s < 2; ++s) {
       CHK(grow_zero_b(e, &e->Xb[s], np * cap * e->ldFb));
       CHK(grow_zero_b(e, &e->dAb[s], np * cap * e->ldHb));
@@ -859,7 +856,7 @@ int twin_input(tfk_engine* e, const float** Xd, int* ld, int T) {
     *Xd = e->dX[s];
     *ld = e->ldF;
   }
-  to_bf16_rows(e->stream, src, ld_src, e->Xb[s], e->ldFb, T, e->F, e->act_plane(e->ldFb));
+  to_bf16_rows(e->stream, src, ld_src, e->Xb[s], e->ldFb, T, e->F, e->x3);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -888,7 +885,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
     CHK(join_optimizer(e));
     CHK(refresh_shadow(e));
   }
-  auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; t.plane = e->act_plane(e->ldHb); } return t; };
+  auto twin_a = [&](int l) { Twin t; if (e->bf16) { t.p = e->ab[l]; t.ld = e->ldHb; t.x3 = e->x3; } return t; };
   for (int l = 0; l < nfw; ++l) {
     const LayerLayout& y = e->lay[l];
     need_params(e, l);
@@ -927,7 +924,7 @@ int forward(tfk_engine* e, const float* Xd, int ldx, int T, int train, int nact,
                    e->cfg.batch_norm ? e->mov_var(l) : nullptr, e->cfg.nonlin};
       ev.beta = e->cfg.batch_norm ? e->p_param() + y.beta_off : nullptr;
       ev.eps = e->bn_eps;
-      if (e->bf16) { ev.twin = e->ab[l]; ev.ld_twin = e->ldHb; ev.twin_plane = e->act_plane(e->ldHb); }
+      if (e->bf16) { ev.twin = e->ab[l]; ev.ld_twin = e->ldHb; }
       CHK(run_gemm(e, GEMM_NN, in, ld_in, e->p_param() + y.w_off, y.ld_out, e->a[l], ldH, T, H, y.d_in,
                    e->p_param() + y.b_off, EPI_BIAS | EPI_EVAL_ACT, nullptr, nullptr, -1, &ev));
       in = e->a[l];
@@ -1050,7 +1047,7 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
     {
       ProfScope ps(e, KF_HIDDEN_BWD, 0, (e->cfg.batch_norm ? 28.0 : 12.0) * T * H);
       Twin tw;
-      if (e->bf16) { tw.p = e->dAb[pp]; tw.ld = e->ldHb; tw.plane = e->act_plane(e->ldHb); }
+      if (e->bf16) { tw.p = e->dAb[pp]; tw.ld = e->ldHb; tw.x3 = e->x3; }
       int chunks_eff = fuse_hb ? chunks_in : 0;
       if (chunks_eff > kMergeOnceChunks) {  // tall micro-batch: reduce the EPI_DACT partial sums once
         chunk_totals(e->stream, ws_of(l), chunks_eff, ldH);
@@ -1160,7 +1157,10 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   e->ldF = (int)up(e->F, 4); e->ldH = (int)up(e->H, 4); e->ldO = (int)up(e->O, 4);
   e->bf16 = cfg->compute_dtype != TFK_DTYPE_F32;
   e->x3 = cfg->compute_dtype == TFK_DTYPE_F32X3;
-  e->ldFb = (int)up(e->F, 8); e->ldHb = (int)up(e->H, 8); e->ldOb = (int)up(e->O, 8);
+  // (x3: rows of whole 32-element interleave blocks -- a ring slot's row segment is then one 192-byte run, and a row offset
+  //  into a twin, as the stacked passes take, is a whole number of blocks)
+  const size_t ldq = e->x3 ? 32 : 8;
+  e->ldFb = (int)up(e->F, ldq); e->ldHb = (int)up(e->H, ldq); e->ldOb = (int)up(e->O, ldq);
   e->bn_decay = cfg->bn_decay > 0.f ? cfg->bn_decay : 0.999f;
   e->bn_eps = cfg->bn_epsilon > 0.f ? cfg->bn_epsilon : 1e-3f;
   e->b1 = cfg->adam_beta1 > 0.f ? cfg->adam_beta1 : 0.9f;
@@ -1245,22 +1245,22 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   if (e->bf16) {
     // shadow: mirrors the fp32 arena element for element inside the state arena when every leading dimension is a
     // multiple of 8 (the optimiser then writes it with the update and the sharded exchange gathers it), else packed
-    // (x3: three planes in an allocation of their own, at the arena's element offsets when every leading dimension is a
-    // multiple of 8 so that the optimiser writes them with the update; a data-parallel exchange gathers the fp32
-    // parameters in that mode and the planes are rebuilt from them)
+    // (x3: the three interleaved planes -- x3_layout.h -- in an allocation of their own: the image of the arena's weight
+    // region [0, b_off) when every leading dimension is a multiple of 8, so that the optimiser writes it with the update
+    // straight from the arena offset; a data-parallel exchange gathers the fp32 parameters in that mode and the planes are
+    // rebuilt from them)
     e->wb_aligned = e->x3 ? x3_aligned(e->lay) : shadow_mirrors(cfg, e->lay);
     e->wb_off.assign(e->L + 1, 0);
     e->wb_ld.assign(e->L + 1, 0);
     size_t off = 0;
     for (int l = 0; l <= e->L; ++l) {
       const LayerLayout& y = e->lay[l];
-      e->wb_ld[l] = (int)up(y.d_out, 8);
+      e->wb_ld[l] = (int)up(y.d_out, (e->x3 && !e->wb_aligned) ? 32 : 8);
       e->wb_off[l] = e->wb_aligned ? y.w_off : off;
       off += up((size_t)y.d_in * e->wb_ld[l], 64);
     }
     if (e->x3) {
-      e->wb_plane = (long)up(e->wb_aligned ? e->lay[0].b_off : off, 128);
-      if (alloc_zero_b(&e->Wb, (size_t)3 * e->wb_plane)) return bail(-1);
+      if (alloc_zero_b(&e->Wb, (size_t)3 * up(e->wb_aligned ? e->lay[0].b_off : off, 128))) return bail(-1);
       e->own_wb = true;
     } else if (e->wb_aligned) {
       e->Wb = reinterpret_cast<bf16_t*>(e->state + e->off_shadow);  // (zeroed with the arena)
@@ -1361,7 +1361,7 @@ int ctc_loss(tfk_engine* e, const CtcSpec& c, int T, int train) {
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * T * e->O + 16.0 * T * sext);
     Twin tw;
-    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; tw.plane = e->act_plane(e->ldOb); }
+    if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; tw.x3 = e->x3; }
     ctc_loss_grad(e->stream, b, e->logits, train, tw);
   }
   {
@@ -1404,7 +1404,7 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
     {
       ProfScope ps(e, KF_SOFTMAX_XENT, 0, (train ? 8.0 : 4.0) * T * e->O);
       Twin tw;
-      if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; tw.plane = e->act_plane(e->ldOb); }
+      if (e->bf16 && train) { tw.p = e->logb; tw.ld = e->ldOb; tw.x3 = e->x3; }
       softmax_xent(e->stream, e->logits, yd, T, e->O, e->ldO, e->row_loss, train, tw);
     }
     {
@@ -1487,7 +1487,7 @@ int forward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, ui
       ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * st.rows[i] * H);
       const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
       Twin tw;
-      if (e->bf16) { tw.p = e->ab[l] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; tw.plane = e->act_plane(e->ldHb); }
+      if (e->bf16) { tw.p = e->ab[l] + e->tw_el((size_t)st.r0[i] * e->ldHb); tw.ld = e->ldHb; tw.x3 = e->x3; }
       bn_act_forward(e->stream, d, e->z[l] + (size_t)st.r0[i] * ldH, e->a[l] + (size_t)st.r0[i] * ldH,
                      e->ws_stats + (size_t)(st.r0[i] / chunk) * ldH, chunk, st.rows[i], H, ldH, e->bn_eps, e->bn_decay,
                      e->seg_mean[l] + (size_t)i * ldH, e->seg_rstd[l] + (size_t)i * ldH, e->ema_mean(l), e->ema_var(l),
@@ -1558,7 +1558,7 @@ int backward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, u
       ProfScope ps(e, KF_HIDDEN_BWD, 0, 28.0 * st.rows[i] * H);
       const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
       Twin tw;
-      if (e->bf16) { tw.p = e->dAb[pp] + (size_t)st.r0[i] * e->ldHb; tw.ld = e->ldHb; tw.plane = e->act_plane(e->ldHb); }
+      if (e->bf16) { tw.p = e->dAb[pp] + e->tw_el((size_t)st.r0[i] * e->ldHb); tw.ld = e->ldHb; tw.x3 = e->x3; }
       const size_t r = (size_t)st.r0[i] * ldH;
       hidden_backward(e->stream, d, 1, da + r, e->a[l] + r, e->z[l] + r, e->seg_mean[l] + (size_t)i * ldH,
                       e->seg_rstd[l] + (size_t)i * ldH, st.rows[i], H, ldH, ws_of(l) + (size_t)(st.r0[i] / bm_in) * ldH,
@@ -1636,7 +1636,7 @@ int run_stacked(tfk_engine* e, const float* Xd, int ld, const int32_t* yd, const
   {
     ProfScope ps(e, KF_SOFTMAX_XENT, 0, 8.0 * st.T_pad * e->O);
     Twin tw;
-    if (e->bf16) { tw.p = e->logb; tw.ld = e->ldOb; tw.plane = e->act_plane(e->ldOb); }
+    if (e->bf16) { tw.p = e->logb; tw.ld = e->ldOb; tw.x3 = e->x3; }
     softmax_xent(e->stream, e->logits, yd, st.T_pad, e->O, e->ldO, e->row_loss, 1, tw);
   }
   {
@@ -2068,8 +2068,8 @@ int apply_span(tfk_engine* e, size_t off, size_t n, hipStream_t st = nullptr) {
   // from the snapshot step_finish took
   ProfScope ps(e, KF_ADAM, 0, 28.0 * n, st);
   adam_apply(st ? st : e->stream, e->p_param() + off, e->p_grad() + off, e->p_m() + off, e->p_v() + off, n,
-             st ? e->d_snap : e->p_scalars(), e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0, n_wb ? e->Wb + off : nullptr, n_wb,
-             e->wb_plane);
+             st ? e->d_snap : e->p_scalars(), e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0,
+             n_wb ? (e->x3 ? e->Wb : e->Wb + off) : nullptr, n_wb, e->x3, e->x3 ? off : 0);
   return 0;
 }
 // the whole optimiser step of tfk_apply, layer by layer on the optimiser stream (vectors first: every layer reads them)
@@ -2164,8 +2164,7 @@ int tfk_init_last_layer(tfk_engine* e) {
   if (e->bf16 && e->wb_aligned && !e->shadow_dirty) {
     // a current arena-mirroring shadow stays current: zero its output-layer span too instead of rebuilding it from
     // every fp32 master (under the sharded exchange the masters of other ranks' spans are not valid here)
-    for (int pl = 0; pl < (e->x3 ? 3 : 1); ++pl)
-      HIPCHK(hipMemsetAsync(e->Wb + (size_t)pl * e->wb_plane + o.w_off, 0, o.w_sz * sizeof(bf16_t), e->stream));
+    HIPCHK(hipMemsetAsync(e->Wb + e->tw_el(o.w_off), 0, e->tw_el(o.w_sz) * sizeof(bf16_t), e->stream));
   } else {
     e->shadow_dirty = true;
   }
@@ -2533,21 +2532,19 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
   return 0;
 }
 
-int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int64_t plane, int rows, int cols) {
+int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols) {
   if (!src || !dst) return fail(-1, "NULL argument");
-  if ((ldd & 7) || plane <= 0 || (plane & 7) || plane < (int64_t)rows * ldd)
-    return fail(-1, "tfk_split3: ldd %d / plane %lld (multiples of 8, plane >= rows * ldd)", ldd, (long long)plane);
-  to_bf16_rows((hipStream_t)stream, src, lds, dst, ldd, rows, cols, (long)plane);
+  if ((ldd & 7) || ldd < cols) return fail(-1, "tfk_split3: ldd %d (a multiple of 8, >= cols)", ldd);
+  to_bf16_rows((hipStream_t)stream, src, lds, dst, ldd, rows, cols, 1);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, int64_t a_plane, const uint16_t* B, int ldb,
-                    int64_t b_plane, float* C, int ldc, int M, int N, int K, const float* bias, int epi) {
+int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M,
+                    int N, int K, const float* bias, int epi) {
   if (layout < 0 || layout > 2) return fail(-1, "bad layout %d", layout);
   GemmArgsB g = {};
   g.A = A; g.B = B; g.C = C; g.bias = bias;
-  g.a_plane = (long)a_plane; g.b_plane = (long)b_plane;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epi = epi;
   {  // (a process-wide split-K workspace for this tool entry: calls are expected on one stream at a time)
     static float* ws = nullptr;
@@ -2585,6 +2582,18 @@ int tfk_gemm_bf16_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uin
   return 0;
 }
 int tfk_gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn) { return gemm_bf16_dual_config(M_nt, N_nt, M_tn, N_tn); }
+int tfk_gemm_bf16x3_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uint16_t* B_nt, int ldb_nt, float* C_nt,
+                         int ldc_nt, int M_nt, int N_nt, int K_nt, const uint16_t* A_tn, int lda_tn, const uint16_t* B_tn,
+                         int ldb_tn, float* C_tn, int ldc_tn, int M_tn, int N_tn, int K_tn, int epi_tn) {
+  GemmArgsB a = {}, w = {};
+  a.A = A_nt; a.B = B_nt; a.C = C_nt; a.M = M_nt; a.N = N_nt; a.K = K_nt; a.lda = lda_nt; a.ldb = ldb_nt; a.ldc = ldc_nt;
+  w.A = A_tn; w.B = B_tn; w.C = C_tn; w.M = M_tn; w.N = N_tn; w.K = K_tn; w.lda = lda_tn; w.ldb = ldb_tn; w.ldc = ldc_tn;
+  w.epi = epi_tn;
+  const int rc = gemm_bf16x3_dual(a, w, (hipStream_t)stream);
+  if (rc == -1) return fail(-1, "gemm_bf16x3_dual: this pair of shapes is not eligible for the dual launch");
+  if (rc != 0) return fail(rc, "gemm_bf16x3_dual failed: %s", hipGetErrorString((hipError_t)rc));
+  return 0;
+}
 
 int tfk_gemm_bf16_force_config(int cfg) {
   gemm_bf16_force_config(cfg);

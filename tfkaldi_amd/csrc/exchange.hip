@@ -617,6 +617,27 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
 
 extern "C" {
 
+int tfk_comm_available(tfk_engine* e, int mode) {
+  // everything tfk_comm_create can refuse WITHOUT talking to another rank: RCCL loadable with every symbol bound, a known
+  // exchange mode, an engine whose regions and stream can be queried on a device this process can select
+  if (!e) return failx(-1, "NULL argument");
+  if (mode != TFK_EXCHANGE_SHARDED && mode != TFK_EXCHANGE_ALLREDUCE) return failx(-1, "unknown exchange mode %d", mode);
+  Rccl* r = rccl();
+  if (!r->error.empty()) return failx(-1, "%s", r->error.c_str());
+  void* p = nullptr;
+  size_t n = 0;
+  int nb = 0;
+  XCHK(tfk_stream(e, &p));
+  XCHK(tfk_reduce_region(e, &p, &n));
+  hipPointerAttribute_t attr;
+  XHIP(hipPointerGetAttributes(&attr, p));
+  XHIP(hipSetDevice(attr.device));
+  XCHK(tfk_param_region(e, &p, &n));
+  XCHK(tfk_num_buckets(e, &nb));
+  if (nb < 3) return failx(-1, "engine announces %d buckets", nb);
+  return 0;
+}
+
 int tfk_comm_unique_id(void* id, size_t capacity, size_t* size) {
   if (!id || capacity < sizeof(ncclUniqueId)) return failx(-1, "tfk_comm_unique_id needs %zu bytes", sizeof(ncclUniqueId));
   Rccl* r = rccl();

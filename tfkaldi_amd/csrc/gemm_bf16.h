@@ -39,9 +39,9 @@ struct GemmArgsB {
   float act_scale;        // EPI_DACT: 1 / keep_prob for a ReLU + dropout chain (see gemm_f32.h); 0 is read as 1
   float act_keep;         // EPI_DACT: keep_prob (0 is read as 1); with act_beta set, a ReLU chain does not read act_z
   const int* row_vend;    // EPI_COLSTATS of a stacked pass: see gemm_f32.h (nullptr: one segment)
-  // gemm_bf16x3: elements between the three bf16 planes of A / B (plane q of an operand starts q * plane elements behind
-  // plane 0, same leading dimension); ct_plane: the same for C_twin (EPI_EVAL_ACT writes three planes of its result)
-  long a_plane, b_plane, ct_plane;
+  // gemm_bf16x3: A, B (and C_twin when ct_x3 is set: EPI_EVAL_ACT then writes three planes of its result) are THREE bf16 planes
+  // interleaved per 32 elements of the flat index row * ld + col (x3_layout.h): 3 * rows * ld elements each
+  int ct_x3;
   // gemm_bf16x3, optional: workspace of the two-way split-K form (see gemm_bf16x3_splitk_floats); ZERO before its first use,
   // left zero in its flag words by every launch.  nullptr: never split
   float* splitk_ws;
@@ -73,7 +73,8 @@ int gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn);
 int gemm_bf16_dual_tile_rows(int cfg);
 
 // An fp32 contraction EMULATED on the bf16 matrix pipe ("bf16x3").  Every operand is given as THREE bf16 planes p1, p2, p3
-// with x = p1 + p2 + p3 exactly (truncation split of the fp32 significand, 8 bits per plane: split3 in kernels.h); the
+// with x = p1 + p2 + p3 exactly (truncation split of the fp32 significand, 8 bits per plane: split3 in kernels.h), interleaved
+// per 32 elements (x3_layout.h: a ring slot's row segment is 192 contiguous bytes); the
 // kernel accumulates the six plane products of order <= 2^-16 -- a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1 -- in fp32.  Products
 // of bf16 values are exact in fp32 and the dropped pairs are below 2^-24 of a product, so the result differs from the exact
 // fp32 dot product only by fp32 accumulation error: measured against float64 it is CLOSER than the fp32 MFMA chain of

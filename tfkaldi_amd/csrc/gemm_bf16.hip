@@ -30,9 +30,12 @@
 //         operands are k-strided, so a slot may be any multiple of 16 k deep) on a PING-PONG schedule: see SCHED 2.
 // (2) register-staged ring of round 1 (configs 0-2; kept for A/B runs: tools/gemm_bf16_sweep.py).
 #include "gemm_bf16.h"
+#include "x3_layout.h"
 
 #include <math.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 namespace tfk {
 namespace {
@@ -217,12 +220,13 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
           p.C[(size_t)row * p.ldc + col] = v;
           if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
             if (p.C_twin) {
-              if (p.ct_plane) {  // three planes whose sum is v exactly (truncation split, 8 significand bits each)
+              if (p.ct_x3) {  // three interleaved planes whose sum is v exactly (truncation split; x3_layout.h)
                 float r = v;
+                const size_t at = x3::il((size_t)row * p.ldct + col);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                   const uint32_t bits = __builtin_bit_cast(uint32_t, r) & 0xffff0000u;
-                  p.C_twin[(size_t)pl * p.ct_plane + (size_t)row * p.ldct + col] = (bf16_t)(bits >> 16);
+                  p.C_twin[at + pl * 32] = (bf16_t)(bits >> 16);
                   r -= __builtin_bit_cast(float, bits);
                 }
               } else {
@@ -339,6 +343,91 @@ struct Frag {
   }
 };
 
+// ---- the fp32-emulating contraction: plane-interleaved operands (x3_layout.h) --------------------------------------------
+// One operand's share of a ring slot: 32 k of ALL THREE planes of EXT rows (k-contiguous) or EXT columns (k-strided);
+// EXT * 192 bytes either way.  A lane's source is computed from the flat element index of its chunk, so any leading dimension
+// that is a multiple of 8 works (a multiple of 32 keeps a row's slot segment in one 192-byte block).
+template <bool KC, int EXT, int NTH>
+struct DmaOperand3 {
+  static constexpr int NP = EXT * 12 / NTH;  // 16-byte pieces per thread per tile (three planes)
+  static_assert((EXT * 12) % NTH == 0 && NP >= 1, "pieces per thread");
+  i32x4 rsrc;
+  int voff[NP];  // byte offset of the piece's source inside the interleaved array, k-tile term excluded; kOOB outside along ext
+  int kidx[NP];  // its first k inside a tile
+  int kstride;   // bytes per unit of k (k in steps of 32)
+  int k_lim;
+
+  __device__ __forceinline__ void init(const bf16_t* base, int ld, int rows, int ext0, int ext_lim, int k_lim_, int tid) {
+    const unsigned long long a = (unsigned long long)base;
+    rsrc[0] = (int)(unsigned)a;
+    rsrc[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+    rsrc[2] = (int)((((size_t)rows * ld + 31) >> 5) * 192);
+    rsrc[3] = 0x00020000;
+    k_lim = k_lim_;
+    kstride = KC ? 6 : ld * 6;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int n = tid + j * NTH;  // chunk position inside the LDS image
+      if (KC) {
+        int r, q, c;
+        x3::kc_decode(n, r, q, c);
+        const int e = ext0 + r;
+        voff[j] = e < ext_lim ? (int)(x3::il((size_t)e * ld + c * 8) + q * 32) * 2 : kOOB;
+        kidx[j] = c * 8;
+      } else {
+        int r, b, q, e8;
+        x3::ks_decode<EXT>(n, r, b, q, e8);
+        const int e = ext0 + b * 32 + e8 * 8;
+        voff[j] = e < ext_lim ? (int)(x3::il((size_t)r * ld + e) + q * 32) * 2 : kOOB;
+        kidx[j] = r;
+      }
+    }
+  }
+  // piece j of the tile at k0 (a multiple of 32) -> image at LDS byte address `image`
+  __device__ __forceinline__ void issue(int j, unsigned image, int k0, int wave) const {
+    const int off = (k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
+    const unsigned dst = image + (unsigned)(wave * 64 + j * NTH) * 16u;
+    const int soff = k0 * kstride;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(dst), "v"(off), "s"(rsrc), "s"(soff)
+                 : "memory");
+  }
+};
+
+// MFMA operand fetch from an interleaved image: plane q of NF fragments of 32 rows (columns) starting at fragment frag0.
+template <bool KC, int EXT, int NF>
+struct Frag3 {
+  int off[KC ? 2 : 3 * NF];
+  __device__ __forceinline__ void init(int lane, int frag0) {
+    if constexpr (KC) {
+      const int i = lane & 31, kb = lane >> 5;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) off[ks] = x3::kc_addr(frag0 * 32 + i, 0, 2 * ks + kb);
+    } else {
+      const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          off[3 * f + pl] = x3::ks_addr<EXT>(8 * kb + j, frag0 + f, pl, 2 * half + (q >> 1)) + ((q & 1) << 3);
+    }
+  }
+  // fragment f, plane pl, 16-k step ks of the operand image at `img`
+  __device__ __forceinline__ bf16x8 read(const char* img, int f, int ks, int pl) const {
+    if constexpr (KC) {
+      return *reinterpret_cast<const bf16x8*>(img + off[ks] + f * (32 * 192) + pl * 64);
+    } else {
+      constexpr int ROWB = EXT * 6;
+      typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+      const char* q = img + off[3 * f + pl] + ks * 16 * ROWB;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * ROWB));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+};
+
 // TFKB_ABL (tools/gemm_bf16_ablate.hip only): timing-only variants of the DMA kernel with pieces of the K loop removed
 // -- 1 MFMAs, 2 LDS-DMA pieces, 4 fragment reads.  Results are wrong by construction.
 #ifndef TFKB_ABL
@@ -363,10 +452,11 @@ template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int F
 __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
-  typedef DmaOperand<A_KC, BM, NTH, BKT> OA;
-  typedef DmaOperand<B_KC, BN, NTH, BKT> OB;
+  // (NPL == 3: one image per operand holds its three planes, x3_layout.h)
+  typedef typename std::conditional<NPL == 3, DmaOperand3<A_KC, BM, NTH>, DmaOperand<A_KC, BM, NTH, BKT>>::type OA;
+  typedef typename std::conditional<NPL == 3, DmaOperand3<B_KC, BN, NTH>, DmaOperand<B_KC, BN, NTH, BKT>>::type OB;
   constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE = NPL * (A_BYTES + B_BYTES);
-  constexpr int NPA = OA::NP, NPB = OB::NP, NP = NPL * (OA::NP + OB::NP);
+  constexpr int NPA = OA::NP, NPB = OB::NP, NP = OA::NP + OB::NP;
   constexpr int KSPT = BKT / 16;  // 16-k MFMA steps per ring slot
   static_assert(KSPT == 4 || KSPT == 2, "ring slot of 64 or 32 k");
   static_assert(NS >= 3 && (NS - 2) * NP + (NPL == 3 ? NP / 2 : 0) <= 63, "ring depth / vmcnt range");
@@ -397,13 +487,12 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   OB lb;
   // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
   // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
-  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), min(A_KC ? K8 : p.K, k_end), tid, (NPL - 1) * p.a_plane * 2);
-  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), min(B_KC ? K8 : p.K, k_end), tid, (NPL - 1) * p.b_plane * 2);
-  Frag<A_KC, BM, FM, BKT> qa;
-  Frag<B_KC, BN, FN, BKT> qb;
+  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), min(A_KC ? K8 : p.K, k_end), tid);
+  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), min(B_KC ? K8 : p.K, k_end), tid);
+  typename std::conditional<NPL == 3, Frag3<A_KC, BM, FM>, Frag<A_KC, BM, FM, BKT>>::type qa;
+  typename std::conditional<NPL == 3, Frag3<B_KC, BN, FN>, Frag<B_KC, BN, FN, BKT>>::type qb;
   qa.init(lane, wm * FM);
   qb.init(lane, wn * FN);
-  const int a_plane_b = __builtin_amdgcn_readfirstlane((int)(p.a_plane * 2)), b_plane_b = __builtin_amdgcn_readfirstlane((int)(p.b_plane * 2));
 
   f32x16 acc[FM][FN];
   f32x16 acc2[NPL == 3 ? FM : 1][NPL == 3 ? FN : 1];  // (NPL == 3: the correction products, see mfma_step)
@@ -424,13 +513,10 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 
   auto piece = [&](int j, int slot, int kt) {
     if (TFKB_ABL & 2) return;
-    if (j < NPL * NPA) {
-      const int pl = j / NPA;
-      la.issue(j % NPA, lds0 + (unsigned)(slot * STAGE + pl * A_BYTES), (kt + kbase) * BKT, wave, pl * a_plane_b);
-    } else {
-      const int jb = j - NPL * NPA, pl = jb / NPB;
-      lb.issue(jb % NPB, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES + pl * B_BYTES), (kt + kbase) * BKT, wave, pl * b_plane_b);
-    }
+    if (j < NPA)
+      la.issue(j, lds0 + (unsigned)(slot * STAGE), (kt + kbase) * BKT, wave);
+    else
+      lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES), (kt + kbase) * BKT, wave);
   };
   // prologue: tiles 0 .. NS-2 (tiles beyond K land as zeros without touching memory)
 #pragma unroll
@@ -448,10 +534,17 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     if (TFKB_ABL & 4) return;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
+      if constexpr (NPL == 3) {
 #pragma unroll
-      for (int a = 0; a < FM; ++a) fa[buf][pl][a] = qa.read(st + pl * A_BYTES, a, ks);
+        for (int a = 0; a < FM; ++a) fa[buf][pl][a] = qa.read(st, a, ks, pl);
 #pragma unroll
-      for (int b = 0; b < FN; ++b) fb[buf][pl][b] = qb.read(st + NPL * A_BYTES + pl * B_BYTES, b, ks);
+        for (int b = 0; b < FN; ++b) fb[buf][pl][b] = qb.read(st + NPL * A_BYTES, b, ks, pl);
+      } else {
+#pragma unroll
+        for (int a = 0; a < FM; ++a) fa[buf][pl][a] = qa.read(st, a, ks);
+#pragma unroll
+        for (int b = 0; b < FN; ++b) fb[buf][pl][b] = qb.read(st + A_BYTES, b, ks);
+      }
     }
   };
   if (TFKB_ABL & 4) {
@@ -574,9 +667,9 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
       for (int c = 0; c < 6; ++c) {
         if (c < 3 && fetch && !(TFKB_ABL & 4)) {
 #pragma unroll
-          for (int a = 0; a < FM; ++a) fa[cur ^ 1][PA[c]][a] = qa.read(nst + PA[c] * A_BYTES, a, nks);
+          for (int a = 0; a < FM; ++a) fa[cur ^ 1][PA[c]][a] = qa.read(nst, a, nks, PA[c]);
 #pragma unroll
-          for (int b = 0; b < FN; ++b) fb[cur ^ 1][PB[c]][b] = qb.read(nst + NPL * A_BYTES + PB[c] * B_BYTES, b, nks);
+          for (int b = 0; b < FN; ++b) fb[cur ^ 1][PB[c]][b] = qb.read(nst + NPL * A_BYTES, b, nks, PB[c]);
         }
 #pragma unroll
         for (int j = j0 + c * (j1 - j0) / 6; j < j0 + (c + 1) * (j1 - j0) / 6; ++j) piece(j, slot, tile);
@@ -925,8 +1018,9 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 // The dual launch of the fp32-emulating contraction: dA (NT) and dW (TN) of a layer on 128x128 blocks in ONE launch.  At 1024
 // frames dA alone has 128 tiles for 256 CUs (which is why gemm_bf16x3 splits its K in two) and dW 256; together every CU runs one
 // dA tile (64 ring tiles) or two dW tiles (32 each): no partial-sum exchange, one ramp and one tail instead of two.
-template <int EPI_NT, int EPI_TN>
-__global__ void __launch_bounds__(256)
+// WN: waves along n -- 2 (four waves of 64x64) or 4 (EIGHT waves of 64x32, two per SIMD: see launch_x3)
+template <int EPI_NT, int EPI_TN, int WN>
+__global__ void __launch_bounds__(WN * 128)
 gemm_bf16x3_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, int group1, int tiles_m2, int tiles_n2, int group2,
                         int tn_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -936,9 +1030,9 @@ gemm_bf16x3_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, 
   const int b = blockIdx.x;
   const bool nt = tn_first ? b >= n2 : b < n1;
   if (nt)
-    dma_tile<true, true, EPI_NT, 2, 2, 2, 2, 3, 32, 0, 3>(p1, tiles_m1, tiles_n1, group1, tn_first ? b - n2 : b, smem);
+    dma_tile<true, true, EPI_NT, 2, WN, 2, 4 / WN, 3, 32, 0, 3>(p1, tiles_m1, tiles_n1, group1, tn_first ? b - n2 : b, smem);
   else
-    dma_tile<false, false, EPI_TN, 2, 2, 2, 2, 3, 32, 0, 3>(p2, tiles_m2, tiles_n2, group2, tn_first ? b : b - n1, smem);
+    dma_tile<false, false, EPI_TN, 2, WN, 2, 4 / WN, 3, 32, 0, 3>(p2, tiles_m2, tiles_n2, group2, tn_first ? b : b - n1, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -1012,21 +1106,34 @@ bool x3_split_shape_tn(int M, int N, int K) {
   const long m128 = (M + 127) / 128, tiles128 = m128 * ((N + 127) / 128), tiles64 = m128 * ((N + 63) / 64);
   return tiles128 < 100 && tiles64 >= 64 && tiles64 < 200 && tiles64 % NUM_XCD == 0 && 2 * tiles64 <= kSplitFlagWords && K >= 512;
 }
+// Waves per 128x128 block.  Four waves (64x64 each, one per SIMD) read the fewest fragment bytes per MFMA, but a wave issues in
+// order: every LDS-DMA piece it issues (60-185 cycles in the vector-memory queue) and every wait for a fragment is a bubble in
+// its SIMD's matrix pipe, and nothing else is there to fill it (round 4: MFMAs alone 37 us, fill alone 32, together 50).  Eight
+// waves (64x32 each) put TWO instruction streams on every SIMD -- while one sits in an issue queue the other multiplies -- for
+// 1.5x the fragment reads per MFMA.  env TFK_BF16X3_WAVES = 4 | 8
+int x3_waves() {
+  static const int w = [] { const char* q = getenv("TFK_BF16X3_WAVES"); return q && atoi(q) == 4 ? 4 : 8; }();
+  return w;
+}
 template <bool A_KC, bool B_KC, int EPI>
 int launch_x3(const GemmArgsB& p, hipStream_t stream) {
   const int forced = x3_cfg();
   const long m128 = (p.M + 127) / 128, n128 = (p.N + 127) / 128;
+  const bool w8 = x3_waves() == 8;
   if constexpr (A_KC) {
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape(false, p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * n128 * 128 * 128)
-      return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
+      return w8 ? launch_dma<A_KC, B_KC, EPI, 2, 4, 2, 1, 3, 32, 0, 3, 2>(p, stream)
+                : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
   } else {
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape_tn(p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * ((p.N + 63) / 64) * 128 * 64)
       return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3, 2>(p, stream);
   }
   const bool big = forced >= 0 ? forced == 1 : m128 * n128 >= 200;
-  if (big) return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
+  if (big)
+    return w8 ? launch_dma<A_KC, B_KC, EPI, 2, 4, 2, 1, 3, 32, 0, 3>(p, stream)
+              : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
   return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3>(p, stream);
 }
 
@@ -1163,10 +1270,10 @@ size_t gemm_bf16x3_splitk_floats(GemmLayout layout, int M, int N, int K) {
 }
 
 namespace {
-template <int EPI_NT, int EPI_TN>
+template <int EPI_NT, int EPI_TN, int WN>
 int launch_x3_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
   constexpr size_t lds = (size_t)3 * 3 * (128 + 128) * 32 * 2;
-  auto kern = &gemm_bf16x3_dual_kernel<EPI_NT, EPI_TN>;
+  auto kern = &gemm_bf16x3_dual_kernel<EPI_NT, EPI_TN, WN>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1174,15 +1281,14 @@ int launch_x3_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
     attr_done = true;
   }
   const int tma = (a.M + 127) / 128, tna = (a.N + 127) / 128, tmw = (w.M + 127) / 128, tnw = (w.N + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(256), lds, stream, a, w, tma, tna, pick_group_rows(tma, tna, 128, 128),
+  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(WN * 128), lds, stream, a, w, tma, tna, pick_group_rows(tma, tna, 128, 128),
                      tmw, tnw, pick_group_rows(tmw, tnw, 128, 128), w.K > a.K ? 1 : 0);
   return (int)hipGetLastError();
 }
 bool x3_operands_ok(const GemmArgsB& p, long a_rows, long b_rows) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || p.a_plane <= 0 || p.b_plane <= 0 ||
-      (p.a_plane & 7) || (p.b_plane & 7))
-    return false;
-  return (2 * p.a_plane + a_rows * p.lda) * 2 < (1L << 31) && (2 * p.b_plane + b_rows * p.ldb) * 2 < (1L << 31);
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3)) return false;
+  // (the three interleaved planes of an operand are addressed through ONE buffer resource with 32-bit byte offsets)
+  return a_rows * p.lda * 6 + 192 < (1L << 31) && b_rows * p.ldb * 6 + 192 < (1L << 31);
 }
 }  // namespace
 
@@ -1194,23 +1300,18 @@ int gemm_bf16x3_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t strea
   if (!on || tiles < 256) return -1;
   const int key = (nt.epi == EPI_DACT ? 2 : 0) + (tn.epi == EPI_ACCUM ? 1 : 0);
   switch (key) {
-    case 0: return launch_x3_dual<0, 0>(nt, tn, stream);
-    case 1: return launch_x3_dual<0, EPI_ACCUM>(nt, tn, stream);
-    case 2: return launch_x3_dual<EPI_DACT, 0>(nt, tn, stream);
-    default: return launch_x3_dual<EPI_DACT, EPI_ACCUM>(nt, tn, stream);
+    case 0: return x3_waves() == 8 ? launch_x3_dual<0, 0, 4>(nt, tn, stream) : launch_x3_dual<0, 0, 2>(nt, tn, stream);
+    case 1: return x3_waves() == 8 ? launch_x3_dual<0, EPI_ACCUM, 4>(nt, tn, stream) : launch_x3_dual<0, EPI_ACCUM, 2>(nt, tn, stream);
+    case 2: return x3_waves() == 8 ? launch_x3_dual<EPI_DACT, 0, 4>(nt, tn, stream) : launch_x3_dual<EPI_DACT, 0, 2>(nt, tn, stream);
+    default:
+      return x3_waves() == 8 ? launch_x3_dual<EPI_DACT, EPI_ACCUM, 4>(nt, tn, stream)
+                             : launch_x3_dual<EPI_DACT, EPI_ACCUM, 2>(nt, tn, stream);
   }
 }
 
 int gemm_bf16x3(GemmLayout layout, const GemmArgsB& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
-  if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 3) || p.a_plane <= 0 || p.b_plane <= 0 || (p.a_plane & 7) || (p.b_plane & 7))
-    return (int)hipErrorInvalidValue;
-  {  // the three planes of an operand are addressed through ONE buffer resource with 32-bit byte offsets
-    const long a_rows = layout == GEMM_TN ? p.K : p.M;
-    const long b_rows = layout == GEMM_NT ? p.N : p.K;
-    if ((2 * p.a_plane + a_rows * p.lda) * 2 >= (1L << 31) || (2 * p.b_plane + b_rows * p.ldb) * 2 >= (1L << 31))
-      return (int)hipErrorInvalidValue;
-  }
+  if (!x3_operands_ok(p, layout == GEMM_TN ? p.K : p.M, layout == GEMM_NT ? p.N : p.K)) return (int)hipErrorInvalidValue;
   switch (layout) {
     case GEMM_NN:
       switch (p.epi) {

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "x3_layout.h"
+
 namespace tfk {
 
 // The activation chain of one hidden layer (neuralNetworks/classifiers/activation.py:22-42 order:
@@ -23,12 +25,13 @@ constexpr int kMaxRowSplits = 256;
 
 // Mixed-precision mode: kernels that produce a GEMM operand also store its bf16 twin (p == nullptr: fp32 mode).
 // ld in bf16 elements, a multiple of 8; padding columns of the twin stay zero from its allocation.
-// plane > 0 ("bf16x3", gemm_bf16.h): the twin is THREE bf16 planes, `plane` elements apart, whose sum is the fp32 value
-// exactly (twin_split3 below); plane == 0: one plane, round to nearest even.
+// x3 != 0 ("bf16x3", gemm_bf16.h): the twin is THREE bf16 planes whose sum is the fp32 value exactly (twin_split3 below),
+// interleaved per 32 elements of the flat index row * ld + col (x3_layout.h: element i of plane q at (i >> 5) * 96 + 32 q +
+// (i & 31) -- 3 * rows * ld elements in all); x3 == 0: one plane, round to nearest even.
 struct Twin {
   uint16_t* p = nullptr;
   int ld = 0;
-  long plane = 0;
+  int x3 = 0;
 };
 // x = p1 + p2 + p3 exactly, each a bf16: truncation of the fp32 significand, 8 bits per piece (the remainder after two
 // pieces has at most 8 significant bits left)
@@ -42,10 +45,11 @@ __device__ __forceinline__ void twin_split3(float x, uint16_t& p1, uint16_t& p2,
   p3 = (uint16_t)(__builtin_bit_cast(uint32_t, r2) >> 16);
 }
 __device__ __forceinline__ void twin_put(const Twin& t, size_t idx, float v) {
-  if (t.plane) {
+  if (t.x3) {
     uint16_t a, b, c;
     twin_split3(v, a, b, c);
-    t.p[idx] = a; t.p[idx + t.plane] = b; t.p[idx + 2 * t.plane] = c;
+    const size_t at = x3::il(idx);
+    t.p[at] = a; t.p[at + 32] = b; t.p[at + 64] = c;
   } else {
     t.p[idx] = __builtin_bit_cast(uint16_t, (__bf16)v);
   }
@@ -135,10 +139,12 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 // ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam (G is left as is) ----
 // grid_cap > 0 limits the number of blocks (grid-stride loop does the rest)
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0, long wb_plane = 0);
-// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update (wb_plane > 0: three planes)
-// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns (plane > 0: three planes whose sum is the value exactly)
-void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, long plane = 0);
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0, int wb_x3 = 0,
+                size_t wb_first = 0);
+// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update.  wb_x3: three interleaved
+// planes -- `wb` is then the base of the interleaved array and w[0] its flat element wb_first
+// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns (x3: three interleaved planes whose sum is the value exactly)
+void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, int x3 = 0);
 // end of a step in one launch: moving <- decay^{num_microbatches} * moving + E, E <- 0, and
 // host[0..3] <- scalars[0..3] (host = device address of mapped pinned memory)
 // snap (nullable): device copy of scalars[0..3] that stays valid until the next step_finish

@@ -101,7 +101,7 @@ typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
 __device__ __forceinline__ void st4_twin(const Twin& t, size_t row, int col, float4 v) {
   if (!t.p) return;
-  if (t.plane) {  // three planes whose sum is the value exactly
+  if (t.x3) {  // three interleaved planes whose sum is the value exactly
     uint16_t a[4], b[4], c[4];
     twin_split3(v.x, a[0], b[0], c[0]); twin_split3(v.y, a[1], b[1], c[1]);
     twin_split3(v.z, a[2], b[2], c[2]); twin_split3(v.w, a[3], b[3], c[3]);
@@ -109,10 +109,10 @@ __device__ __forceinline__ void st4_twin(const Twin& t, size_t row, int col, flo
     q1.x = a[0]; q1.y = a[1]; q1.z = a[2]; q1.w = a[3];
     q2.x = b[0]; q2.y = b[1]; q2.z = b[2]; q2.w = b[3];
     q3.x = c[0]; q3.y = c[1]; q3.z = c[2]; q3.w = c[3];
-    uint16_t* d = t.p + row * t.ld + col;
+    uint16_t* d = t.p + x3::il(row * t.ld + col);  // (col is a multiple of 4: the four values share a block)
     *reinterpret_cast<u16x4*>(d) = q1;
-    *reinterpret_cast<u16x4*>(d + t.plane) = q2;
-    *reinterpret_cast<u16x4*>(d + 2 * t.plane) = q3;
+    *reinterpret_cast<u16x4*>(d + 32) = q2;
+    *reinterpret_cast<u16x4*>(d + 64) = q3;
     return;
   }
   u16x4 q;
@@ -946,7 +946,7 @@ template <bool NT, int UN>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
             const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps, uint16_t* __restrict__ wb,
-            size_t n4_wb, long wb_plane) {
+            size_t n4_wb, int wb_x3, size_t wb_first) {
   // a step without frames (G / 0): the reference would write NaN into every parameter; here the parameters are
   // left alone and tfk_apply_end reports the error
   if (!(scalars[1] > 0.f)) return;
@@ -982,8 +982,8 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
       st4(w + 4 * i, wv[u]);
       if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices (same element offsets as the fp32 arena)
         Twin sh;
-        sh.p = wb; sh.ld = 0; sh.plane = wb_plane;
-        st4_twin(sh, 0, (int)(4 * i), wv[u]);
+        sh.p = wb; sh.ld = 1; sh.x3 = wb_x3;
+        st4_twin(sh, wb_first + 4 * i, 0, wv[u]);  // (leading dimension 1: the "row" is the flat index)
       }
       // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
     }
@@ -1010,7 +1010,7 @@ __global__ void step_finish_kernel(float* __restrict__ mov, float* __restrict__ 
 // fp32 [rows, lds] -> bf16 [rows, ldd] (ldd multiple of 8): one thread per 8-column chunk, padding columns zero
 __global__ void __launch_bounds__(256)
 to_bf16_rows_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict__ dst, int ldd, int rows, int cols,
-                    long plane) {
+                    int x3) {
   const int nc8 = ldd >> 3;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)rows * nc8) return;
@@ -1022,14 +1022,14 @@ to_bf16_rows_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict
     q.z = o[4] | ((uint32_t)o[5] << 16); q.w = o[6] | ((uint32_t)o[7] << 16);
     return q;
   };
-  if (plane) {
+  if (x3) {
     uint16_t o1[8], o2[8], o3[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) twin_split3((c + k < cols) ? src[(size_t)r * lds + c + k] : 0.f, o1[k], o2[k], o3[k]);
-    uint16_t* d = dst + (size_t)r * ldd + c;
+    uint16_t* d = dst + x3::il((size_t)r * ldd + c);
     *reinterpret_cast<u32x4*>(d) = pack(o1);
-    *reinterpret_cast<u32x4*>(d + plane) = pack(o2);
-    *reinterpret_cast<u32x4*>(d + 2 * plane) = pack(o3);
+    *reinterpret_cast<u32x4*>(d + 32) = pack(o2);
+    *reinterpret_cast<u32x4*>(d + 64) = pack(o3);
     return;
   }
   uint16_t o[8];
@@ -1230,7 +1230,7 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 }
 
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb, long wb_plane) {
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb, int wb_x3, size_t wb_first) {
   const size_t n4 = n / 4;
   static const int un_div = [] { const char* q = getenv("TFK_ADAM_UNROLL"); const int u = q ? atoi(q) : 2; return u == 4 ? 4 : u == 2 ? 2 : 1; }();
   size_t blocks = ((n4 + un_div - 1) / un_div + 255) / 256;
@@ -1246,7 +1246,7 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
   static const int un = [] { const char* q = getenv("TFK_ADAM_UNROLL"); return q ? atoi(q) : 2; }();
 #define TFK_ADAM_LAUNCH(NTV, UNV)                                                                                  \
   hipLaunchKernelGGL((adam_kernel<NTV, UNV>), dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, \
-                     beta1, beta2, eps, wb, n_wb / 4, wb_plane)
+                     beta1, beta2, eps, wb, n_wb / 4, wb_x3, wb_first)
   if (nt) {
     if (un == 4) TFK_ADAM_LAUNCH(true, 4); else if (un == 2) TFK_ADAM_LAUNCH(true, 2); else TFK_ADAM_LAUNCH(true, 1);
   } else {
@@ -1260,11 +1260,11 @@ void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* 
   const size_t blocks = n ? (n + 255) / 256 : 1;
   hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host, snap);
 }
-void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, long plane) {
+void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, int x3) {
   const size_t n = (size_t)rows * (ldd / 8);
   if (n == 0) return;
   hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, lds, dst, ldd, rows,
-                     cols, plane);
+                     cols, x3);
 }
 void scale_inplace(hipStream_t s, float* x, size_t n, float factor) {
   if (n == 0) return;

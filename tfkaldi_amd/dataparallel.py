@@ -727,28 +727,48 @@ class DataParallel(object):
     native_failure = None  # why the in-library exchange was given up (None: it was not)
 
     def _native_exchange(self, engine):
-        """NativeExchange, or None when ANY rank could not bring it up (RCCL not loadable from the library, communicator
-        refused): the ranks agree through one all-reduce of a flag, everyone then runs BucketReducer over torch.distributed,
-        and the reason goes to stderr and into bench.py's `exchange_driver` -- a job that would otherwise die at its first
-        step keeps running on the slower driver, and says so.  TFK_DP_COMM=native-only makes the failure fatal instead."""
+        """NativeExchange, or None when ANY rank cannot bring it up (RCCL not loadable from the library, engine or mode
+        refused, communicator refused): everyone then runs BucketReducer over torch.distributed, and the reason goes to stderr
+        and into bench.py's `exchange_driver` -- a job that would otherwise die at its first step keeps running on the slower
+        driver, and says so.  TFK_DP_COMM=native-only makes the failure fatal instead.
+
+        Two agreements over the process group that is already up, in this order: (1) BEFORE anything collective of RCCL's --
+        every rank probes locally (`tfk_comm_available`: no other rank is involved) and the answers are MIN-reduced; only if
+        every rank can go on does rank 0 make the unique id and everyone enter `tfk_comm_create` (ncclCommInitRank blocks
+        until all ranks have arrived: a rank that failed earlier would leave the others waiting there for ever -- round 4
+        announced rank 0's failures only); (2) after it, the outcome of the creation itself."""
         import torch
         import torch.distributed as dist
+        from . import _lib
+        on_gpu = dist.get_backend(self.group) == "nccl"
+
+        def agree(flag):
+            ok = torch.tensor([1 if flag else 0], dtype=torch.int32)
+            if on_gpu:
+                ok = ok.cuda(engine.cfg.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            return int(ok.item()) == 1
+
         r, err = None, None
+        mode = self.mode or os.environ.get("TFK_DP_EXCHANGE", "sharded")
         try:
-            r = NativeExchange(engine, self.group, mode=self.mode)
+            if mode not in _lib.EXCHANGE:
+                raise ValueError("exchange mode %r" % (mode,))
+            _lib.check(engine.lib.tfk_comm_available(engine._h, _lib.EXCHANGE[mode]))
         except Exception as e:  # noqa: BLE001 (whatever it was, the other ranks must hear of it)
             err = "%s: %s" % (type(e).__name__, e)
-        ok = torch.tensor([1 if r is not None else 0], dtype=torch.int32)
-        if dist.get_backend(self.group) == "nccl":
-            ok = ok.cuda(engine.cfg.device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        if int(ok.item()) == 1:
-            return r
+        if agree(err is None):
+            try:
+                r = NativeExchange(engine, self.group, mode=self.mode)
+            except Exception as e:  # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+            if agree(r is not None):
+                return r
         if r is not None:
             engine.on_close.remove(r.close)
             engine.param_access_hook = None
             r.close()
-        self.native_failure = err or "another rank could not create its communicator"
+        self.native_failure = err or "another rank could not bring the in-library exchange up"
         if os.environ.get("TFK_DP_COMM") == "native-only":
             raise RuntimeError("in-library exchange unavailable: %s" % self.native_failure)
         import sys

@@ -43,16 +43,17 @@ def main():
         Ad, Bd = A.double(), B.double()
         ref = (Ad.T if layout == 2 else Ad) @ (Bd.T if layout == 1 else Bd)
         sab = (Ad.abs().T if layout == 2 else Ad.abs()) @ (Bd.abs().T if layout == 1 else Bd.abs())
-        Ap, lda, pa = _planes(lib, torch, A)
-        Bp, ldb, pb = _planes(lib, torch, B)
+        ld8 = bool(rng.integers(0, 2))  # leading dimensions of 8 q (rows start inside an interleave block) or 32 q
+        Ap, lda = _planes(lib, torch, A, ((A.shape[1] + 7) & ~7) if ld8 else None)
+        Bp, ldb = _planes(lib, torch, B, ((B.shape[1] + 7) & ~7) if ld8 else None)
         ldc = p4(N)
         C0 = torch.randn(M, ldc, device="cuda", generator=g)
         bias = torch.randn(N, device="cuda", generator=g)
         outs = []
         for _ in range(3):
             C = C0.clone()
-            _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, pa, ctypes.c_void_p(Bp.data_ptr()), ldb,
-                                           pb, ctypes.c_void_p(C.data_ptr()), ldc, M, N, K, ctypes.c_void_p(bias.data_ptr()), epi))
+            _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, ctypes.c_void_p(Bp.data_ptr()), ldb,
+                                           ctypes.c_void_p(C.data_ptr()), ldc, M, N, K, ctypes.c_void_p(bias.data_ptr()), epi))
             outs.append(C)
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "case %d: launches differ" % case

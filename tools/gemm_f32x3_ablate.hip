@@ -2,20 +2,60 @@
 // of the K loop removed (-DTFKB_ABL: 1 no MFMAs, 2 no LDS-DMA pieces, 4 no fragment reads; sums combine) and times a shape.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTFKB_ABL=<n> -I tfkaldi_amd/csrc tools/gemm_f32x3_ablate.hip -o tools/bin/x3abl<n>
 //   tools/bin/x3abl<n> <layout> <M> <N> <K>         (block geometry: env TFK_BF16X3_CFG)
+//   tools/bin/x3abl<n> 3 <frames> <d_in> <d_out>    the backward pair of a layer in one launch (gemm_bf16x3_dual):
+//                                                   dA[frames, d_in] = dZ . W^T  and  dW[d_in, d_out] = in^T . dZ
 #include "../tfkaldi_amd/csrc/gemm_bf16.hip"
 
 #include <stdio.h>
 #include <vector>
 
+static uint16_t* random_planes(size_t elems, unsigned seed) {
+  std::vector<uint16_t> h(3 * elems);
+  unsigned s = seed;
+  for (auto& x : h) { s = s * 1664525u + 1013904223u; x = (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) + ((s >> 8) & 0x8000u)); }
+  uint16_t* d;
+  hipMalloc(&d, h.size() * 2);
+  hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  return d;
+}
+
+static int dual(int T, int din, int dout) {
+  auto p32 = [](int n) { return (n + 31) & ~31; };
+  const int ld_in = p32(din), ld_out = p32(dout);
+  uint16_t* dz = random_planes((size_t)T * ld_out, 1u);   // [T, d_out]
+  uint16_t* w = random_planes((size_t)din * ld_out, 2u);  // [d_in, d_out]
+  uint16_t* in = random_planes((size_t)T * ld_in, 3u);    // [T, d_in]
+  float *dA, *dW;
+  hipMalloc(&dA, (size_t)T * ld_in * 4); hipMalloc(&dW, (size_t)din * ld_out * 4);
+  tfk::GemmArgsB a = {}, g = {};
+  a.A = dz; a.B = w; a.C = dA; a.M = T; a.N = din; a.K = dout; a.lda = ld_out; a.ldb = ld_out; a.ldc = ld_in;
+  g.A = in; g.B = dz; g.C = dW; g.M = din; g.N = dout; g.K = T; g.lda = ld_in; g.ldb = ld_out; g.ldc = ld_out;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i)
+    if (tfk::gemm_bf16x3_dual(a, g, 0) != 0) { printf("dual launch not eligible\n"); return 1; }
+  const int iters = 30;
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) tfk::gemm_bf16x3_dual(a, g, 0);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= iters;
+  printf("ABL=%d dual (dA + dW) frames %d, %d x %d: %7.1f us  %7.1f TF fp32-equivalent\n", TFKB_ABL, T, din, dout, ms * 1e3,
+         4.0 * T * din * dout / ms / 1e9);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 5) return 1;
   const int layout = atoi(argv[1]), M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]);
-  auto p8 = [](int n) { return (n + 7) & ~7; };
+  if (layout == 3) return dual(M, N, K);
+  auto p8 = [](int n) { return (n + 31) & ~31; };  // (rows of whole interleave blocks, as the engine's twins)
   const int a_rows = layout == 2 ? K : M, a_cols = layout == 2 ? M : K;
   const int b_rows = layout == 1 ? N : K, b_cols = layout == 1 ? K : N;
   const int lda = p8(a_cols), ldb = p8(b_cols), ldc = (N + 3) & ~3;
-  const long pa = ((long)a_rows * lda + 127) & ~127L, pb = ((long)b_rows * ldb + 127) & ~127L;
-  std::vector<uint16_t> ha((size_t)3 * pa), hb((size_t)3 * pb);
+  std::vector<uint16_t> ha((size_t)3 * a_rows * lda), hb((size_t)3 * b_rows * ldb);
   unsigned s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) + ((s >> 8) & 0x8000u)); };
   for (auto& x : ha) x = rnd();
@@ -27,7 +67,6 @@ int main(int argc, char** argv) {
   hipMemcpy(dB, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
   tfk::GemmArgsB g = {};
   g.A = dA; g.B = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.a_plane = pa; g.b_plane = pb;
   // the split-K form where the shape is eligible (TFK_BF16X3_CFG=0 / 1: never)
   if (const size_t need = tfk::gemm_bf16x3_splitk_floats((tfk::GemmLayout)layout, M, N, K)) {
     hipMalloc(&g.splitk_ws, need * 4);

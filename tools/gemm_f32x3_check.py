@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tfkaldi_amd import _lib  # noqa: E402
+from tfkaldi_amd import _lib, x3 as x3l  # noqa: E402
 
 lib = _lib.load()
 p8 = lambda n: (n + 7) & ~7
@@ -20,14 +20,8 @@ p4 = lambda n: (n + 3) & ~3
 
 
 def planes(x):
-    """fp32 [rows, cols] on the device -> (three bf16 planes [3, rows, ld8], ld8, plane elements)"""
-    rows, cols = x.shape
-    ld = p8(cols)
-    plane = (rows * ld + 127) & ~127
-    out = torch.zeros(3 * plane, dtype=torch.bfloat16, device="cuda")
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.tfk_split3(st, ctypes.c_void_p(x.data_ptr()), x.stride(0), ctypes.c_void_p(out.data_ptr()), ld, plane, rows, cols))
-    return out, ld, plane
+    """fp32 [rows, cols] on the device -> (interleaved three-plane bf16 array, its leading dimension): csrc/x3_layout.h"""
+    return x3l.split(lib, x)
 
 
 def timed(fn, iters):
@@ -53,12 +47,12 @@ def run(layout, M, N, K, epi=0, iters=20, seed=0):
     else:
         A = torch.randn(K, M, device="cuda", generator=g); B = torch.randn(K, N, device="cuda", generator=g)
         ref = A.double().T @ B.double(); sab = A.double().abs().T @ B.double().abs()
-    Ap, lda, pa = planes(A)
-    Bp, ldb, pb = planes(B)
+    Ap, lda = planes(A)
+    Bp, ldb = planes(B)
     # the split is exact
-    for X, Xp, ld, pl in ((A, Ap, lda, pa), (B, Bp, ldb, pb)):
+    for X, Xp, ld in ((A, Ap, lda), (B, Bp, ldb)):
         r, c = X.shape
-        s = sum(Xp[q * pl:q * pl + r * ld].view(r, ld)[:, :c].float() for q in range(3))
+        s = sum(q[:, :c].float() for q in x3l.planes(Xp, r, ld))
         assert torch.equal(s, X), "split3 is not exact"
     ldc = p4(N)
     C0 = torch.randn(M, ldc, device="cuda", generator=g) if epi & 2 else torch.zeros(M, ldc, device="cuda")
@@ -69,7 +63,7 @@ def run(layout, M, N, K, epi=0, iters=20, seed=0):
     B4 = torch.zeros(B.shape[0], p4(B.shape[1]), device="cuda"); B4[:, :B.shape[1]] = B
 
     def x3():
-        _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, pa, ctypes.c_void_p(Bp.data_ptr()), ldb, pb,
+        _lib.check(lib.tfk_gemm_bf16x3(st, layout, ctypes.c_void_p(Ap.data_ptr()), lda, ctypes.c_void_p(Bp.data_ptr()), ldb,
                                        ctypes.c_void_p(C.data_ptr()), ldc, M, N, K, ctypes.c_void_p(bias.data_ptr()), epi))
 
     def f32():

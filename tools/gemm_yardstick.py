@@ -75,23 +75,20 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
 
     def planes(x, cols):
-        """the exact three-plane bf16 split of x[:, :cols] (tfk_split3): what the fp32-emulating contraction reads"""
-        rows, ld = x.shape[0], p8(cols)
-        plane = (rows * ld + 127) & ~127
-        out = torch.zeros(3 * plane, dtype=torch.bfloat16, device="cuda")
-        _lib.check(lib.tfk_split3(st, ctypes.c_void_p(x.data_ptr()), x.stride(0), ctypes.c_void_p(out.data_ptr()), ld, plane,
-                                  rows, cols))
-        return out, ld, plane
+        """the exact three-plane bf16 split of x[:, :cols] (tfk_split3, interleaved: csrc/x3_layout.h): what the fp32-emulating
+        contraction reads"""
+        from tfkaldi_amd import x3
+        return x3.split(lib, x[:, :cols])
 
     for name, layout, M, N, K in shapes(1024, 440, 2048, 2000):
         a, b, sa, sb = operands(layout, M, N, K, torch.float32, lambda n: (n + 3) & ~3)
         c = torch.zeros(M, (N + 3) & ~3, device="cuda")
         args = (st, layout, ctypes.c_void_p(a.data_ptr()), a.shape[1], ctypes.c_void_p(b.data_ptr()), b.shape[1],
                 ctypes.c_void_p(c.data_ptr()), c.shape[1], M, N, K, None, 0, -1)
-        ap, lda, pa = planes(a, sa[1])
-        bp, ldb, pb = planes(b, sb[1])
+        ap, lda = planes(a, sa[1])
+        bp, ldb = planes(b, sb[1])
         c3 = torch.zeros_like(c)
-        args3 = (st, layout, ctypes.c_void_p(ap.data_ptr()), lda, pa, ctypes.c_void_p(bp.data_ptr()), ldb, pb,
+        args3 = (st, layout, ctypes.c_void_p(ap.data_ptr()), lda, ctypes.c_void_p(bp.data_ptr()), ldb,
                  ctypes.c_void_p(c3.data_ptr()), c3.shape[1], M, N, K, None, 0)
 
         def ours():
