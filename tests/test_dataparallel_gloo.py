@@ -99,31 +99,55 @@ def _fallback_worker(rank, world, port, out_dir):
     init_from_env()
     closed = []
 
+    entered = []
+
     class Flaky(object):  # stands in for NativeExchange: comes up on rank 0 only
         native = True
 
         def __init__(self, engine, group, mode=None):
+            entered.append(True)
             if dist.get_rank() == 1:
-                raise RuntimeError("RCCL could not be loaded: no such file")
+                raise RuntimeError("ncclCommInitRank failed: unhandled system error")
             engine.on_close.insert(0, self.close)
             engine.param_access_hook = lambda: None
 
         def close(self):
             closed.append(True)
 
+    class Lib(object):  # the one library call the agreement makes before anything collective
+        def __init__(self, loadable):
+            self.loadable = loadable
+
+        def tfk_comm_available(self, handle, mode):
+            if not self.loadable:
+                raise RuntimeError("RCCL could not be loaded: no such file")
+            return 0
+
+    class Cfg(object):
+        device = 0
+
     class Eng(object):
-        def __init__(self):
+        def __init__(self, loadable=True):
             self.on_close, self.param_access_hook = [], None
+            self.lib, self._h, self.cfg = Lib(loadable), None, Cfg()
 
     dpmod.NativeExchange = Flaky
+    # (a) rank 1 cannot even load RCCL: the ranks hear of it BEFORE anyone enters the collective bootstrap (the real
+    # NativeExchange would block in ncclCommInitRank waiting for rank 1) -- nobody constructs one
+    dp = DataParallel(mode="sharded")
+    eng = Eng(loadable=rank != 1)
+    got = dp._native_exchange(eng)
+    assert got is None and dp.native_failure and entered == [] and closed == []
+    assert ("could not be loaded" in dp.native_failure) == (rank == 1)
+    # (b) every rank can load it, rank 1's communicator is refused: every rank agrees, nobody keeps the in-library exchange,
+    # the rank that had one gives it back, everyone knows why
     dp = DataParallel(mode="sharded")
     eng = Eng()
     got = dp._native_exchange(eng)
-    # every rank agrees: nobody keeps the in-library exchange, the rank that had one gives it back, everyone knows why
-    assert got is None and dp.native_failure
+    assert got is None and dp.native_failure and entered == [True]
     assert eng.on_close == [] and eng.param_access_hook is None
     assert closed == ([True] if rank == 0 else [])
-    assert ("could not be loaded" in dp.native_failure) == (rank == 1)
+    assert ("ncclCommInitRank failed" in dp.native_failure) == (rank == 1)
     os.environ["TFK_DP_COMM"] = "native-only"
     try:
         dp._native_exchange(Eng())
@@ -136,7 +160,9 @@ def _fallback_worker(rank, world, port, out_dir):
 
 
 def test_ranks_agree_to_leave_the_in_library_exchange(tmp_path):
-    """one rank cannot bring the in-library RCCL exchange up: ALL ranks run the torch.distributed reducer (a flag all-reduced
-    with MIN), the rank that did create one closes it, and TFK_DP_COMM=native-only turns the agreement into an error"""
+    """one rank cannot bring the in-library RCCL exchange up: ALL ranks run the torch.distributed reducer.  Two agreements
+    (flags all-reduced with MIN): a local probe BEFORE the collective bootstrap -- a rank that cannot load RCCL must not leave
+    the others blocked inside ncclCommInitRank -- and the outcome of the creation itself, after which the rank that did create
+    one closes it; TFK_DP_COMM=native-only turns the agreement into an error"""
     mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))

@@ -19,7 +19,7 @@ p4 = lambda n: (n + 3) & ~3  # noqa: E731
 
 
 def _planes(lib, torch, x, ld=None):
-    """the interleaved three-plane array of x (csrc/x3_layout.h) and its leading dimension"""
+    """the tiled three-plane twin of x (csrc/x3_layout.h) and its leading dimension"""
     from tfkaldi_amd import x3
     return x3.split(lib, x, ld)
 
@@ -32,9 +32,8 @@ def _gemm(lib, torch, layout, Ap, lda, Bp, ldb, C, ldc, M, N, K, bias=None, epi=
                                    ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, epi))
 
 
-def _run(lib, layout, M, N, K, epi=0, seed=0, ld8=False):
-    """ld8: leading dimensions that are multiples of 8 only (rows then start in the middle of an interleave block: the layout
-    is a function of the flat index) instead of multiples of 32"""
+def _run(lib, layout, M, N, K, epi=0, seed=0, wide=False):
+    """wide: leading dimensions one unit (32 columns) longer than the matrix needs"""
     import torch
     from tfkaldi_amd import x3
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -45,14 +44,13 @@ def _run(lib, layout, M, N, K, epi=0, seed=0, ld8=False):
     Ad, Bd = A.double(), B.double()
     ref = (Ad.T if layout == 2 else Ad) @ (Bd.T if layout == 1 else Bd)
     sab = (Ad.abs().T if layout == 2 else Ad.abs()) @ (Bd.abs().T if layout == 1 else Bd.abs())
-    Ap, lda = _planes(lib, torch, A, p8(A.shape[1]) if ld8 else None)
-    Bp, ldb = _planes(lib, torch, B, p8(B.shape[1]) if ld8 else None)
+    Ap, lda = _planes(lib, torch, A, x3.padded_ld(A.shape[1]) + 32 if wide else None)
+    Bp, ldb = _planes(lib, torch, B, x3.padded_ld(B.shape[1]) + 32 if wide else None)
     for X, Xp, ld in ((A, Ap, lda), (B, Bp, ldb)):  # the split is exact, plane by plane a bf16
         r, c = X.shape
-        if (r * ld) % 32 == 0:
-            pl = x3.planes(Xp, r, ld)
-            assert torch.equal(sum(q[:, :c].float() for q in pl), X)
-            assert all(bool((q[:, c:] == 0).all()) for q in pl)  # padding columns are zeros
+        pl = x3.planes(Xp, r, ld)
+        assert torch.equal(sum(q[:, :c].float() for q in pl), X)
+        assert all(bool((q[:, c:] == 0).all()) for q in pl)  # padding columns are zeros
     ldc = p4(N)
     C0 = torch.randn(M, ldc, device="cuda", generator=g)
     C = C0.clone()
@@ -79,9 +77,9 @@ def test_contraction_within_the_fp32_kernels_bound(gpu, layout):
                                    # the narrow layer's weight gradient (TN): 128x64 blocks, two per tile
                                    (440, 2048, 1024), (500, 2000, 1100)]):
         _run(gpu, layout, M, N, K, epi=epi if n % 2 == 0 else 0, seed=n)
-    # leading dimensions of 8 q, not 32 q: 2000 pdfs (the arena-mirroring shadow of cfg2's output layer), 440 inputs, ragged
-    for n, (M, N, K) in enumerate([(1024, 2000, 2048), (1024, 2048, 2000), (440, 2000, 1024), (130, 72, 200), (70, 330, 33)]):
-        _run(gpu, layout, M, N, K, epi=0, seed=100 + n, ld8=True)
+    # odd row counts (the last row pair half empty), 2000 pdfs / 440 inputs (the last unit of a row part padding), wide twins
+    for n, (M, N, K) in enumerate([(1023, 2000, 2047), (1024, 2048, 2000), (441, 2000, 1023), (129, 71, 199), (71, 331, 33)]):
+        _run(gpu, layout, M, N, K, epi=0, seed=100 + n, wide=n % 2 == 0)
 
 
 @pytest.mark.parametrize("layout", [0, 1])

@@ -310,7 +310,7 @@ ctc_grad_kernel(CtcBatch b, float* __restrict__ dlogits, Twin tw) {
   float* dr = dlogits + (size_t)t * b.ld;
   for (int c = lane; c < b.ld; c += 64) dr[c] = row[c];
   if (tw.p)
-    for (int c = lane; c < b.ld; c += 64) twin_put(tw, (size_t)t * tw.ld + c, row[c]);
+    for (int c = lane; c < b.ld; c += 64) twin_put(tw, (size_t)t, c, row[c]);
 }
 
 __global__ void __launch_bounds__(256)

@@ -174,10 +174,13 @@ struct tfk_engine {
   // mixed precision (cfg.compute_dtype == TFK_DTYPE_BF16): every fp32 buffer that is a GEMM operand has a bf16
   // twin written by its producer; master parameters, statistics, gradients and the optimiser stay fp32
   bool bf16 = false;                 // GEMM operands have bf16 twins (compute_dtype bf16 or f32x3)
-  bool x3 = false;                   // TFK_DTYPE_F32X3: every twin is THREE bf16 planes summing to the fp32 value, interleaved
-                                     // per 32 elements of the flat index (x3_layout.h; gemm_bf16x3)
-  // elements a twin of n fp32 elements occupies / the offset of fp32 element n (a multiple of 32) inside a twin
-  size_t tw_el(size_t n) const { return x3 ? 3 * n : n; }
+  bool x3 = false;                   // TFK_DTYPE_F32X3: every twin is THREE bf16 planes summing to the fp32 value, in the tiled
+                                     // layout of x3_layout.h (gemm_bf16x3)
+  // elements the twin of an [rows, ld] matrix occupies / the offset of its row r (even in x3 mode) inside it
+  size_t tw_elems(size_t rows, int ld) const { return x3 ? x3::elems(rows, ld) : rows * ld; }
+  size_t tw_row(size_t r, int ld) const { return x3 ? x3::at(r, 0, ld) : r * ld; }
+  ShadowMap wb_map;                  // x3: where the optimiser finds the twin of every weight matrix (n == 0: it cannot --
+                                     // more than kShadowMapMax matrices -- and the twins are rebuilt after the update)
   int ldFb = 0, ldHb = 0, ldOb = 0;  // leading dimensions of the twins (multiples of 8 elements; of 32 in x3 mode)
   bf16_t* Xb[2] = {nullptr, nullptr};
   std::vector<bf16_t*> ab;
@@ -291,11 +294,6 @@ constexpr size_t kScalarFloats = 64;
 // fp32 arena element for element and lives at the END of the state arena (w_end bf16 values = w_end / 2 floats), so a
 // host that owns the arena (torch.distributed) can all-gather SHARDS OF THE SHADOW ITSELF -- half the bytes of the
 // fp32 parameters, and the next forward pass waits for them layer by layer.  Otherwise it is packed in its own allocation.
-bool x3_aligned(const std::vector<LayerLayout>& lay) {
-  for (const LayerLayout& y : lay)
-    if (y.ld_out % 8) return false;
-  return true;
-}
 bool shadow_mirrors(const tfk_config* c, const std::vector<LayerLayout>& lay) {
   if (c->compute_dtype != TFK_DTYPE_BF16) return false;
   for (const LayerLayout& y : lay)
@@ -387,7 +385,7 @@ inline void need_params(tfk_engine* e, int layer) {
 }
 
 // bf16 twin of an fp32 GEMM operand buffer (mixed-precision mode)
-// (x3 mode: the twin is the plane-interleaved array of x3_layout.h, 3 * rows * ld elements)
+// (x3 mode: the twin is the tiled three-plane array of x3_layout.h, x3::elems(rows, ld) elements)
 const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
   for (int s = 0; s < 2; ++s) {
     if (p == e->dX[s]) { *ld = e->ldFb; return e->Xb[s]; }
@@ -397,7 +395,7 @@ const bf16_t* twin_of(tfk_engine* e, const float* p, int* ld) {
   for (size_t l = 0; l < e->a.size(); ++l)
     if (p == e->a[l]) { *ld = e->ldHb; return e->ab[l]; }
   for (int l = 0; l <= e->L; ++l)
-    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; return e->Wb + e->tw_el(e->wb_off[l]); }
+    if (p == e->p_param() + e->lay[l].w_off) { *ld = e->wb_ld[l]; return e->Wb + e->wb_off[l]; }
   return nullptr;
 }
 // rows a GEMM's per-tile statistics (EPI_COLSTATS / EPI_DACT) are chunked by
@@ -412,7 +410,7 @@ int refresh_shadow(tfk_engine* e) {
   if (!e->bf16 || !e->shadow_dirty) return 0;
   for (int l = 0; l <= e->L; ++l) {
     const LayerLayout& y = e->lay[l];
-    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->tw_el(e->wb_off[l]), e->wb_ld[l], y.d_in, y.d_out, e->x3);
+    to_bf16_rows(e->stream, e->p_param() + y.w_off, y.ld_out, e->Wb + e->wb_off[l], e->wb_ld[l], y.d_in, y.d_out, e->x3);
   }
   HIPCHK(hipGetLastError());
   e->shadow_dirty = false;
@@ -665,14 +663,13 @@ int reserve(tfk_engine* e, int T) {
     }
   }
   if (e->bf16) {
-    const size_t np = e->x3 ? 3 : 1;  // planes per twin
     for (int s = 0; s < 2; ++s) {
-      CHK(grow_zero_b(e, &e->Xb[s], np * cap * e->ldFb));
-      CHK(grow_zero_b(e, &e->dAb[s], np * cap * e->ldHb));
+      CHK(grow_zero_b(e, &e->Xb[s], e->tw_elems(cap, e->ldFb)));
+      CHK(grow_zero_b(e, &e->dAb[s], e->tw_elems(cap, e->ldHb)));
     }
     e->ab.assign(L, nullptr);
-    for (int l = 0; l < L; ++l) CHK(grow_zero_b(e, &e->ab[l], np * cap * e->ldHb));
-    CHK(grow_zero_b(e, &e->logb, np * cap * e->ldOb));
+    for (int l = 0; l < L; ++l) CHK(grow_zero_b(e, &e->ab[l], e->tw_elems(cap, e->ldHb)));
+    CHK(grow_zero_b(e, &e->logb, e->tw_elems(cap, e->ldOb)));
   }
   CHK(grow_zero(e, &e->logits, (size_t)cap * e->ldO));
   CHK(grow_zero(e, &e->post, (size_t)cap * e->ldO));
@@ -1157,8 +1154,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   e->ldF = (int)up(e->F, 4); e->ldH = (int)up(e->H, 4); e->ldO = (int)up(e->O, 4);
   e->bf16 = cfg->compute_dtype != TFK_DTYPE_F32;
   e->x3 = cfg->compute_dtype == TFK_DTYPE_F32X3;
-  // (x3: rows of whole 32-element interleave blocks -- a ring slot's row segment is then one 192-byte run, and a row offset
-  //  into a twin, as the stacked passes take, is a whole number of blocks)
+  // (x3: the tiled twins consist of 2-row x 32-column units, x3_layout.h)
   const size_t ldq = e->x3 ? 32 : 8;
   e->ldFb = (int)up(e->F, ldq); e->ldHb = (int)up(e->H, ldq); e->ldOb = (int)up(e->O, ldq);
   e->bn_decay = cfg->bn_decay > 0.f ? cfg->bn_decay : 0.999f;
@@ -1245,22 +1241,28 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   if (e->bf16) {
     // shadow: mirrors the fp32 arena element for element inside the state arena when every leading dimension is a
     // multiple of 8 (the optimiser then writes it with the update and the sharded exchange gathers it), else packed
-    // (x3: the three interleaved planes -- x3_layout.h -- in an allocation of their own: the image of the arena's weight
-    // region [0, b_off) when every leading dimension is a multiple of 8, so that the optimiser writes it with the update
-    // straight from the arena offset; a data-parallel exchange gathers the fp32 parameters in that mode and the planes are
-    // rebuilt from them)
-    e->wb_aligned = e->x3 ? x3_aligned(e->lay) : shadow_mirrors(cfg, e->lay);
+    // (x3: one tiled three-plane twin per weight matrix -- x3_layout.h -- in an allocation of their own; the optimiser writes
+    // them with the update through a map of the arena, `wb_map`; a data-parallel exchange gathers the fp32 parameters in that
+    // mode and the twins are rebuilt from them)
+    e->wb_aligned = e->x3 ? (e->L + 1 <= kShadowMapMax) : shadow_mirrors(cfg, e->lay);
     e->wb_off.assign(e->L + 1, 0);
     e->wb_ld.assign(e->L + 1, 0);
+    e->wb_map.n = 0;
     size_t off = 0;
     for (int l = 0; l <= e->L; ++l) {
       const LayerLayout& y = e->lay[l];
-      e->wb_ld[l] = (int)up(y.d_out, (e->x3 && !e->wb_aligned) ? 32 : 8);
-      e->wb_off[l] = e->wb_aligned ? y.w_off : off;
-      off += up((size_t)y.d_in * e->wb_ld[l], 64);
+      e->wb_ld[l] = (int)up(y.d_out, e->x3 ? 32 : 8);
+      e->wb_off[l] = (e->wb_aligned && !e->x3) ? y.w_off : off;
+      off += e->x3 ? up(x3::elems(y.d_in, e->wb_ld[l]), 64) : up((size_t)y.d_in * e->wb_ld[l], 64);
+      if (e->x3 && e->wb_aligned) {
+        ShadowMap& m = e->wb_map;
+        m.begin[l] = (uint32_t)y.w_off; m.rows[l] = (uint32_t)y.d_in; m.ld[l] = (uint32_t)y.ld_out;
+        m.ld_twin[l] = (uint32_t)e->wb_ld[l]; m.twin[l] = e->wb_off[l];
+        m.n = l + 1;
+      }
     }
     if (e->x3) {
-      if (alloc_zero_b(&e->Wb, (size_t)3 * up(e->wb_aligned ? e->lay[0].b_off : off, 128))) return bail(-1);
+      if (alloc_zero_b(&e->Wb, up(off, 128))) return bail(-1);
       e->own_wb = true;
     } else if (e->wb_aligned) {
       e->Wb = reinterpret_cast<bf16_t*>(e->state + e->off_shadow);  // (zeroed with the arena)
@@ -1487,7 +1489,7 @@ int forward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, ui
       ProfScope ps(e, KF_ACT_FWD, 0, 8.0 * st.rows[i] * H);
       const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
       Twin tw;
-      if (e->bf16) { tw.p = e->ab[l] + e->tw_el((size_t)st.r0[i] * e->ldHb); tw.ld = e->ldHb; tw.x3 = e->x3; }
+      if (e->bf16) { tw.p = e->ab[l] + e->tw_row((size_t)st.r0[i], e->ldHb); tw.ld = e->ldHb; tw.x3 = e->x3; }
       bn_act_forward(e->stream, d, e->z[l] + (size_t)st.r0[i] * ldH, e->a[l] + (size_t)st.r0[i] * ldH,
                      e->ws_stats + (size_t)(st.r0[i] / chunk) * ldH, chunk, st.rows[i], H, ldH, e->bn_eps, e->bn_decay,
                      e->seg_mean[l] + (size_t)i * ldH, e->seg_rstd[l] + (size_t)i * ldH, e->ema_mean(l), e->ema_var(l),
@@ -1558,7 +1560,7 @@ int backward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, u
       ProfScope ps(e, KF_HIDDEN_BWD, 0, 28.0 * st.rows[i] * H);
       const ActDesc d = act_desc(e, l, 1, call0 + (uint32_t)i);
       Twin tw;
-      if (e->bf16) { tw.p = e->dAb[pp] + e->tw_el((size_t)st.r0[i] * e->ldHb); tw.ld = e->ldHb; tw.x3 = e->x3; }
+      if (e->bf16) { tw.p = e->dAb[pp] + e->tw_row((size_t)st.r0[i], e->ldHb); tw.ld = e->ldHb; tw.x3 = e->x3; }
       const size_t r = (size_t)st.r0[i] * ldH;
       hidden_backward(e->stream, d, 1, da + r, e->a[l] + r, e->z[l] + r, e->seg_mean[l] + (size_t)i * ldH,
                       e->seg_rstd[l] + (size_t)i * ldH, st.rows[i], H, ldH, ws_of(l) + (size_t)(st.r0[i] / bm_in) * ldH,
@@ -2069,7 +2071,7 @@ int apply_span(tfk_engine* e, size_t off, size_t n, hipStream_t st = nullptr) {
   ProfScope ps(e, KF_ADAM, 0, 28.0 * n, st);
   adam_apply(st ? st : e->stream, e->p_param() + off, e->p_grad() + off, e->p_m() + off, e->p_v() + off, n,
              st ? e->d_snap : e->p_scalars(), e->cur_lr_t, e->b1, e->b2, e->adam_eps, 0,
-             n_wb ? (e->x3 ? e->Wb : e->Wb + off) : nullptr, n_wb, e->x3, e->x3 ? off : 0);
+             n_wb ? (e->x3 ? e->Wb : e->Wb + off) : nullptr, n_wb, e->x3 ? &e->wb_map : nullptr, off);
   return 0;
 }
 // the whole optimiser step of tfk_apply, layer by layer on the optimiser stream (vectors first: every layer reads them)
@@ -2164,7 +2166,8 @@ int tfk_init_last_layer(tfk_engine* e) {
   if (e->bf16 && e->wb_aligned && !e->shadow_dirty) {
     // a current arena-mirroring shadow stays current: zero its output-layer span too instead of rebuilding it from
     // every fp32 master (under the sharded exchange the masters of other ranks' spans are not valid here)
-    HIPCHK(hipMemsetAsync(e->Wb + e->tw_el(o.w_off), 0, e->tw_el(o.w_sz) * sizeof(bf16_t), e->stream));
+    HIPCHK(hipMemsetAsync(e->Wb + e->wb_off[e->L], 0,
+                          (e->x3 ? x3::elems(o.d_in, e->wb_ld[e->L]) : o.w_sz) * sizeof(bf16_t), e->stream));
   } else {
     e->shadow_dirty = true;
   }
@@ -2534,7 +2537,7 @@ int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const ui
 
 int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols) {
   if (!src || !dst) return fail(-1, "NULL argument");
-  if ((ldd & 7) || ldd < cols) return fail(-1, "tfk_split3: ldd %d (a multiple of 8, >= cols)", ldd);
+  if ((ldd & 31) || ldd < cols) return fail(-1, "tfk_split3: ldd %d (a multiple of 32, >= cols)", ldd);
   to_bf16_rows((hipStream_t)stream, src, lds, dst, ldd, rows, cols, 1);
   HIPCHK(hipGetLastError());
   return 0;

@@ -222,11 +222,11 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
             if (p.C_twin) {
               if (p.ct_x3) {  // three interleaved planes whose sum is v exactly (truncation split; x3_layout.h)
                 float r = v;
-                const size_t at = x3::il((size_t)row * p.ldct + col);
+                const size_t at = x3::at((size_t)row, col, p.ldct);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                   const uint32_t bits = __builtin_bit_cast(uint32_t, r) & 0xffff0000u;
-                  p.C_twin[at + pl * 32] = (bf16_t)(bits >> 16);
+                  p.C_twin[at + pl * 64] = (bf16_t)(bits >> 16);
                   r -= __builtin_bit_cast(float, bits);
                 }
               } else {
@@ -343,16 +343,15 @@ struct Frag {
   }
 };
 
-// ---- the fp32-emulating contraction: plane-interleaved operands (x3_layout.h) --------------------------------------------
+// ---- the fp32-emulating contraction: tiled three-plane operands (x3_layout.h) -----------------------------------------------
 // One operand's share of a ring slot: 32 k of ALL THREE planes of EXT rows (k-contiguous) or EXT columns (k-strided);
-// EXT * 192 bytes either way.  A lane's source is computed from the flat element index of its chunk, so any leading dimension
-// that is a multiple of 8 works (a multiple of 32 keeps a row's slot segment in one 192-byte block).
+// EXT * 192 bytes either way, whole 128-byte lines of the tiled array in both cases.
 template <bool KC, int EXT, int NTH>
 struct DmaOperand3 {
   static constexpr int NP = EXT * 12 / NTH;  // 16-byte pieces per thread per tile (three planes)
   static_assert((EXT * 12) % NTH == 0 && NP >= 1, "pieces per thread");
   i32x4 rsrc;
-  int voff[NP];  // byte offset of the piece's source inside the interleaved array, k-tile term excluded; kOOB outside along ext
+  int voff[NP];  // byte offset of the piece's source inside the tiled array, k-tile term excluded; kOOB outside along ext
   int kidx[NP];  // its first k inside a tile
   int kstride;   // bytes per unit of k (k in steps of 32)
   int k_lim;
@@ -361,10 +360,10 @@ struct DmaOperand3 {
     const unsigned long long a = (unsigned long long)base;
     rsrc[0] = (int)(unsigned)a;
     rsrc[1] = (int)((unsigned)(a >> 32) & 0xffffu);
-    rsrc[2] = (int)((((size_t)rows * ld + 31) >> 5) * 192);
+    rsrc[2] = (int)(x3::elems((size_t)rows, ld) * 2);
     rsrc[3] = 0x00020000;
     k_lim = k_lim_;
-    kstride = KC ? 6 : ld * 6;
+    kstride = KC ? 12 : ld * 6;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int n = tid + j * NTH;  // chunk position inside the LDS image
@@ -372,20 +371,24 @@ struct DmaOperand3 {
         int r, q, c;
         x3::kc_decode(n, r, q, c);
         const int e = ext0 + r;
-        voff[j] = e < ext_lim ? (int)(x3::il((size_t)e * ld + c * 8) + q * 32) * 2 : kOOB;
+        voff[j] = e < ext_lim ? (int)(x3::at((size_t)e, c * 8, ld) + q * 64) * 2 : kOOB;
         kidx[j] = c * 8;
       } else {
         int r, b, q, e8;
         x3::ks_decode<EXT>(n, r, b, q, e8);
         const int e = ext0 + b * 32 + e8 * 8;
-        voff[j] = e < ext_lim ? (int)(x3::il((size_t)r * ld + e) + q * 32) * 2 : kOOB;
+        voff[j] = e < ext_lim ? (int)(x3::at((size_t)r, e, ld) + q * 64) * 2 : kOOB;
         kidx[j] = r;
       }
     }
   }
   // piece j of the tile at k0 (a multiple of 32) -> image at LDS byte address `image`
+  // GUARD = false: the caller knows that the whole tile lies below k_lim (every tile but the last few of a block: the K loop
+  // is peeled, see dma_tile -- twelve compare + select pairs per slot would otherwise sit between the MFMAs of a wave that
+  // issues in order)
+  template <bool GUARD>
   __device__ __forceinline__ void issue(int j, unsigned image, int k0, int wave) const {
-    const int off = (k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
+    const int off = (!GUARD || k0 + kidx[j] < k_lim) ? voff[j] : kOOB;
     const unsigned dst = image + (unsigned)(wave * 64 + j * NTH) * 16u;
     const int soff = k0 * kstride;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -395,34 +398,35 @@ struct DmaOperand3 {
   }
 };
 
-// MFMA operand fetch from an interleaved image: plane q of NF fragments of 32 rows (columns) starting at fragment frag0.
+// MFMA operand fetch from a tiled image: plane q of NF fragments of 32 rows (columns) starting at fragment frag0.
+// Two per-lane byte offsets serve every fragment, plane and 16-k step: the rest of an address is an immediate.
+//   k-contiguous: off[ks] (the two k-chunks a lane reads in the two steps of a slot sit at different swizzled positions);
+//   k-strided:    off[parity of X], X = 3 * fragment + plane: the quadrant of (fragment, plane) for a lane whose k-row pair
+//                 is odd is X ^ 1 (x3_layout.h) = X + 1 for even X, X - 1 for odd X.
 template <bool KC, int EXT, int NF>
 struct Frag3 {
-  int off[KC ? 2 : 3 * NF];
+  int off[2];
   __device__ __forceinline__ void init(int lane, int frag0) {
-    if constexpr (KC) {
-      const int i = lane & 31, kb = lane >> 5;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) off[ks] = x3::kc_addr(frag0 * 32 + i, 0, 2 * ks + kb);
-    } else {
-      const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          off[3 * f + pl] = x3::ks_addr<EXT>(8 * kb + j, frag0 + f, pl, 2 * half + (q >> 1)) + ((q & 1) << 3);
-    }
+    for (int v = 0; v < 2; ++v) off[v] = KC ? x3::kc_lane_off(lane, frag0, v) : x3::ks_lane_off<EXT>(lane, frag0, v);
+  }
+  // the same offsets shifted by a constant (a ring slot's base): the reads then need no address arithmetic at all
+  __device__ __forceinline__ Frag3 at(int bytes) const {
+    Frag3 r;
+    r.off[0] = off[0] + bytes;
+    r.off[1] = off[1] + bytes;
+    return r;
   }
   // fragment f, plane pl, 16-k step ks of the operand image at `img`
   __device__ __forceinline__ bf16x8 read(const char* img, int f, int ks, int pl) const {
     if constexpr (KC) {
-      return *reinterpret_cast<const bf16x8*>(img + off[ks] + f * (32 * 192) + pl * 64);
+      return *reinterpret_cast<const bf16x8*>(img + off[ks] + x3::kc_imm(f, pl));
     } else {
-      constexpr int ROWB = EXT * 6;
       typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-      const char* q = img + off[3 * f + pl] + ks * 16 * ROWB;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)q);
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * ROWB));
+      const int X = 3 * f + pl;
+      const char* q = img + off[X & 1];
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + x3::ks_imm<EXT>(X, ks, 0)));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + x3::ks_imm<EXT>(X, ks, 1)));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
   }
@@ -447,9 +451,19 @@ struct Frag3 {
 // pairs of order <= 2^-16 -- (3,1) (2,2) (1,3) (2,1) (1,2) (1,1), smallest first -- into the SAME fp32 accumulators.
 // KSPLIT = 2 (NPL == 3 only): two blocks per tile, each over half of K; see gemm_bf16x3_splitk_floats (gemm_bf16.h)
 constexpr int kSplitFlagWords = 2048;  // head of the split-K workspace: {ticket, ready} per tile, then the partial sums
+// LOADERS (NPL == 3 only; 0 or WAVES_M * WAVES_N): that many EXTRA waves behind the multiplying ones do nothing but issue the
+// LDS-DMA pieces ("wave specialisation").  A wave issues in order, and `buffer_load ... lds` sits in the vector-memory issue
+// queue for as long as the fill path is busy (it is: the fill of a slot takes about as long as its MFMAs) -- in a wave that also
+// multiplies, every one of the twelve pieces per slot is a bubble in the matrix pipe: MFMAs + fragment reads alone 34 us, with
+// the pieces 47 (profiles/r04_gemm_f32x3_ablation.txt), i.e. fill and MFMA time ADD UP although neither saturates the CU.  With
+// a loader wave next to every multiplying wave on its SIMD the stalls hit a wave that has nothing else to do; the multiplying
+// waves' stream is fragment reads and MFMAs only.  Loaders and multipliers meet at the per-slot barrier (the loader arrives
+// once its own pieces of the NEXT tile have landed); after the K loop the loaders end -- a barrier counts surviving waves only,
+// so the epilogue's barriers are the multipliers' own.
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
-          int NPL = 1, int KSPLIT = 1>
+          int NPL = 1, int KSPLIT = 1, int LOADERS = 0>
 __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int tiles_n, int group_rows, int bid, char* smem) {
+  static_assert(LOADERS == 0 || (NPL == 3 && LOADERS == WAVES_M * WAVES_N), "loader waves: one per multiplying wave, x3 only");
   constexpr int NTH = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
   // (NPL == 3: one image per operand holds its three planes, x3_layout.h)
@@ -487,8 +501,44 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   OB lb;
   // k-contiguous: rows = ext, chunks valid while k < K8 (zero padding inside the row)
   // k-strided:    rows = k (valid while k < K), chunks valid while ext < ext rounded up to 8
-  la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), min(A_KC ? K8 : p.K, k_end), tid);
-  lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), min(B_KC ? K8 : p.K, k_end), tid);
+  const int a_klim = min(A_KC ? K8 : p.K, k_end), b_klim = min(B_KC ? K8 : p.K, k_end);
+  // tiles [0, nk_full) of this block lie wholly below both operands' k limits
+  const int nk_full = min(a_klim, b_klim) / BKT - kbase;
+  if constexpr (LOADERS > 0) {
+    if (wave >= WAVES_M * WAVES_N) {
+      // ---- a loader wave: tile t + NS - 1 goes out right behind barrier t - 1 (its slot's last reader has every fragment of
+      // tile t - 1 in registers by then), and barrier t is entered once this wave's pieces of tile t + 1 have landed ----
+      const int lwave = wave - WAVES_M * WAVES_N;
+      la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), a_klim, tid - NTH);
+      lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), b_klim, tid - NTH);
+      auto tile = [&](auto guard, int slot, int kt) {
+        if (TFKB_ABL & 2) return;
+#pragma unroll
+        for (int j = 0; j < NPA; ++j)
+          la.template issue<decltype(guard)::value>(j, lds0 + (unsigned)(slot * STAGE), (kt + kbase) * BKT, lwave);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j)
+          lb.template issue<decltype(guard)::value>(j, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES), (kt + kbase) * BKT, lwave);
+      };
+#pragma unroll
+      for (int t = 0; t < NS - 1; ++t) tile(std::true_type(), t, t);
+      TFKB_WAIT_BARRIER((NS - 2) * NP);
+      int ws = NS - 1;
+      const int n_fast = max(0, min(nk, nk_full - (NS - 1)));
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt < n_fast) tile(std::false_type(), ws, kt + NS - 1);
+        else tile(std::true_type(), ws, kt + NS - 1);
+        TFKB_WAIT_BARRIER((NS - 2) * NP);
+        ws = ws + 1 == NS ? 0 : ws + 1;
+      }
+      TFKB_WAIT_BARRIER(0);
+      return;
+    }
+  } else {
+    la.init(p.A, p.lda, A_KC ? p.M : p.K, m0, A_KC ? p.M : ((p.M + 7) & ~7), a_klim, tid);
+    lb.init(p.B, p.ldb, B_KC ? p.N : p.K, n0, B_KC ? p.N : ((p.N + 7) & ~7), b_klim, tid);
+  }
   typename std::conditional<NPL == 3, Frag3<A_KC, BM, FM>, Frag<A_KC, BM, FM, BKT>>::type qa;
   typename std::conditional<NPL == 3, Frag3<B_KC, BN, FN>, Frag<B_KC, BN, FN, BKT>>::type qb;
   qa.init(lane, wm * FM);
@@ -511,13 +561,25 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
         for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
   }
 
-  auto piece = [&](int j, int slot, int kt) {
+  // (guard: std::true_type -- a piece beyond the operand's k range lands as zeros; std::false_type, NPL == 3 only: the caller
+  //  knows the tile lies inside it, see DmaOperand3::issue)
+  auto piece_g = [&](auto guard, int j, int slot, int kt) {
     if (TFKB_ABL & 2) return;
-    if (j < NPA)
-      la.issue(j, lds0 + (unsigned)(slot * STAGE), (kt + kbase) * BKT, wave);
-    else
-      lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES), (kt + kbase) * BKT, wave);
+    if constexpr (LOADERS > 0) {
+      return;  // (the loader waves issue every piece)
+    } else if constexpr (NPL == 3) {
+      if (j < NPA)
+        la.template issue<decltype(guard)::value>(j, lds0 + (unsigned)(slot * STAGE), (kt + kbase) * BKT, wave);
+      else
+        lb.template issue<decltype(guard)::value>(j - NPA, lds0 + (unsigned)(slot * STAGE + NPL * A_BYTES), (kt + kbase) * BKT, wave);
+    } else {
+      if (j < NPA)
+        la.issue(j, lds0 + (unsigned)(slot * STAGE), (kt + kbase) * BKT, wave);
+      else
+        lb.issue(j - NPA, lds0 + (unsigned)(slot * STAGE + A_BYTES), (kt + kbase) * BKT, wave);
+    }
   };
+  auto piece = [&](int j, int slot, int kt) { piece_g(std::true_type(), j, slot, kt); };
   // prologue: tiles 0 .. NS-2 (tiles beyond K land as zeros without touching memory)
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
@@ -662,17 +724,21 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     // kt just left, the half-step in front of the next barrier the second half.
     static_assert(KSPT == 2, "fp32-emulating contraction: 32 k per ring slot");
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-    auto step3 = [&](int cur, bool fetch, const char* nst, int nks, int j0, int j1, int slot, int tile) {
+    // Addresses: the fragment offsets of the slot being read are advanced ONCE per slot (four additions); every read is then
+    // `offset register + immediate`.  The k-range guard of the pieces is peeled: all iterations but the last NS + 1 of a block
+    // issue tiles that lie wholly inside K.
+    auto step3 = [&](auto guard, int cur, bool fetch, const decltype(qa)& ra, const decltype(qb)& rb, int nks, int j0, int j1,
+                     int slot, int tile) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         if (c < 3 && fetch && !(TFKB_ABL & 4)) {
 #pragma unroll
-          for (int a = 0; a < FM; ++a) fa[cur ^ 1][PA[c]][a] = qa.read(nst, a, nks, PA[c]);
+          for (int a = 0; a < FM; ++a) fa[cur ^ 1][PA[c]][a] = ra.read(smem, a, nks, PA[c]);
 #pragma unroll
-          for (int b = 0; b < FN; ++b) fb[cur ^ 1][PB[c]][b] = qb.read(nst + NPL * A_BYTES, b, nks, PB[c]);
+          for (int b = 0; b < FN; ++b) fb[cur ^ 1][PB[c]][b] = rb.read(smem, b, nks, PB[c]);
         }
 #pragma unroll
-        for (int j = j0 + c * (j1 - j0) / 6; j < j0 + (c + 1) * (j1 - j0) / 6; ++j) piece(j, slot, tile);
+        for (int j = j0 + c * (j1 - j0) / 6; j < j0 + (c + 1) * (j1 - j0) / 6; ++j) piece_g(guard, j, slot, tile);
         if (TFKB_ABL & 1) {
 #pragma unroll
           for (int a = 0; a < FM; ++a) asm volatile("" : : "v"(fa[cur][PA[c]][a]));
@@ -693,15 +759,22 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
       }
     };
     read_frags(0, smem, 0);
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* st = smem + rs * STAGE;
-      step3(0, true, st, 1, NPH, NP, ws, kt + NS - 1);
+    const int n_fast = max(0, min(nk, nk_full - NS));
+    auto iteration = [&](auto guard, int kt) {
+      const auto ra = qa.at(rs * STAGE);
+      const auto rb = qb.at(rs * STAGE + NPL * A_BYTES);
+      step3(guard, 0, true, ra, rb, 1, NPH, NP, ws, kt + NS - 1);
       TFKB_WAIT_BARRIER((NS - 2) * NP);
       rs = rs + 1 == NS ? 0 : rs + 1;
       ws = ws + 1 == NS ? 0 : ws + 1;
-      step3(1, kt + 1 < nk, smem + rs * STAGE, 0, 0, NPH, ws, kt + NS);
-    }
+      const auto na = qa.at(rs * STAGE);
+      const auto nb = qb.at(rs * STAGE + NPL * A_BYTES);
+      step3(guard, 1, kt + 1 < nk, na, nb, 0, 0, NPH, ws, kt + NS);
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < n_fast; ++kt) iteration(std::false_type(), kt);
+#pragma unroll 1
+    for (int kt = n_fast; kt < nk; ++kt) iteration(std::true_type(), kt);
   } else {
   read_frags(0, smem, 0);
 #pragma unroll 1
@@ -800,12 +873,12 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 }
 
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
-          int NPL = 1, int KSPLIT = 1>
-__global__ void __launch_bounds__(WAVES_M * WAVES_N * 64)
+          int NPL = 1, int KSPLIT = 1, int LOADERS = 0>
+__global__ void __launch_bounds__((WAVES_M * WAVES_N + LOADERS) * 64)
 gemm_bf16_dma_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL, KSPLIT>(p, tiles_m, tiles_n, group_rows, blockIdx.x,
-                                                                                   smem);
+  dma_tile<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL, KSPLIT, LOADERS>(p, tiles_m, tiles_n, group_rows,
+                                                                                            blockIdx.x, smem);
 }
 
 // Two INDEPENDENT contractions in one launch -- backward: dA = dZ . W^T (NT, optionally EPI_DACT) of a layer and the
@@ -1018,9 +1091,10 @@ gemm_bf16_kernel(GemmArgsB p, int tiles_m, int tiles_n, int group_rows) {
 // The dual launch of the fp32-emulating contraction: dA (NT) and dW (TN) of a layer on 128x128 blocks in ONE launch.  At 1024
 // frames dA alone has 128 tiles for 256 CUs (which is why gemm_bf16x3 splits its K in two) and dW 256; together every CU runs one
 // dA tile (64 ring tiles) or two dW tiles (32 each): no partial-sum exchange, one ramp and one tail instead of two.
-// WN: waves along n -- 2 (four waves of 64x64) or 4 (EIGHT waves of 64x32, two per SIMD: see launch_x3)
+// WN: waves along n -- 2 (four waves of 64x64), 4 (EIGHT waves of 64x32, two per SIMD) or 0 (four waves of 64x64 + four loader
+// waves): see launch_x3
 template <int EPI_NT, int EPI_TN, int WN>
-__global__ void __launch_bounds__(WN * 128)
+__global__ void __launch_bounds__(WN == 2 ? 256 : 512)
 gemm_bf16x3_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, int group1, int tiles_m2, int tiles_n2, int group2,
                         int tn_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1030,9 +1104,11 @@ gemm_bf16x3_dual_kernel(GemmArgsB p1, GemmArgsB p2, int tiles_m1, int tiles_n1, 
   const int b = blockIdx.x;
   const bool nt = tn_first ? b >= n2 : b < n1;
   if (nt)
-    dma_tile<true, true, EPI_NT, 2, WN, 2, 4 / WN, 3, 32, 0, 3>(p1, tiles_m1, tiles_n1, group1, tn_first ? b - n2 : b, smem);
+    dma_tile<true, true, EPI_NT, 2, WN ? WN : 2, 2, WN ? 4 / WN : 2, 3, 32, 0, 3, 1, WN ? 0 : 4>(p1, tiles_m1, tiles_n1, group1,
+                                                                                              tn_first ? b - n2 : b, smem);
   else
-    dma_tile<false, false, EPI_TN, 2, WN, 2, 4 / WN, 3, 32, 0, 3>(p2, tiles_m2, tiles_n2, group2, tn_first ? b : b - n1, smem);
+    dma_tile<false, false, EPI_TN, 2, WN ? WN : 2, 2, WN ? 4 / WN : 2, 3, 32, 0, 3, 1, WN ? 0 : 4>(p2, tiles_m2, tiles_n2, group2,
+                                                                                                tn_first ? b : b - n1, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -1074,14 +1150,14 @@ int launch_reg(const GemmArgsB& p, hipStream_t stream) {
   return launch_grid(&gemm_bf16_kernel<A_KC, B_KC, EPI, FM, FN>, p, BM, BN, NT, lds, stream, &attr_done);
 }
 template <bool A_KC, bool B_KC, int EPI, int WAVES_M, int WAVES_N, int FM, int FN, int NS, int BKT = 64, int SCHED = 0,
-          int NPL = 1, int KSPLIT = 1>
+          int NPL = 1, int KSPLIT = 1, int LOADERS = 0>
 int launch_dma(const GemmArgsB& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * FM * 32, BN = WAVES_N * FN * 32;
   const size_t lds = (size_t)NS * NPL * (BM + BN) * BKT * 2;
   static_assert((size_t)NS * NPL * (BM + BN) * BKT * 2 <= 160 * 1024, "LDS");
   static bool attr_done = false;
-  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL, KSPLIT>, p, BM, BN,
-                     WAVES_M * WAVES_N * 64, lds, stream, &attr_done, KSPLIT);
+  return launch_grid(&gemm_bf16_dma_kernel<A_KC, B_KC, EPI, WAVES_M, WAVES_N, FM, FN, NS, BKT, SCHED, NPL, KSPLIT, LOADERS>, p,
+                     BM, BN, (WAVES_M * WAVES_N + LOADERS) * 64, lds, stream, &attr_done, KSPLIT);
 }
 
 // fp32-emulating contraction on three bf16 planes per operand: 128x128 blocks (three 48 KB slots) when the result has a
@@ -1106,25 +1182,35 @@ bool x3_split_shape_tn(int M, int N, int K) {
   const long m128 = (M + 127) / 128, tiles128 = m128 * ((N + 127) / 128), tiles64 = m128 * ((N + 63) / 64);
   return tiles128 < 100 && tiles64 >= 64 && tiles64 < 200 && tiles64 % NUM_XCD == 0 && 2 * tiles64 <= kSplitFlagWords && K >= 512;
 }
-// Waves per 128x128 block.  Four waves (64x64 each, one per SIMD) read the fewest fragment bytes per MFMA, but a wave issues in
-// order: every LDS-DMA piece it issues (60-185 cycles in the vector-memory queue) and every wait for a fragment is a bubble in
-// its SIMD's matrix pipe, and nothing else is there to fill it (round 4: MFMAs alone 37 us, fill alone 32, together 50).  Eight
-// waves (64x32 each) put TWO instruction streams on every SIMD -- while one sits in an issue queue the other multiplies -- for
-// 1.5x the fragment reads per MFMA.  env TFK_BF16X3_WAVES = 4 | 8
+// Waves per 128x128 block (env TFK_BF16X3_WAVES = 8 | 4 | 44; profiles/r05_gemm_f32x3_power.txt):
+//    8  eight multiplying waves of 64x32, two instruction streams per SIMD (default);
+//    4  four multiplying waves of 64x64, one per SIMD: the fewest fragment bytes per MFMA, but every LDS-DMA piece the wave
+//       issues and every wait for a fragment is a bubble in its SIMD's matrix pipe;
+//   44  four multiplying waves + four loader waves (dma_tile: LOADERS).
+// Round 5 built all three expecting the schedule to be the limiter (MFMAs alone 36 us, fill alone 27, together 47 at
+// 1024 x 2048 x 2048) -- and they finish within 2 % of each other, because the contraction is POWER-bound: over operands of
+// zeros the same launches take 39.7 us (the pair of a layer 71 us instead of 99, 8192 frames 252 us instead of 372 = the time
+// of the MFMAs alone), i.e. fill and MFMAs DO overlap and what random significands cost is clock.  In the training step (half
+// of the activations are ReLU zeros) the eight-wave form is ahead: 1.11 ms against 1.14 (4) and 1.16 (44) at BASELINE cfg2.
 int x3_waves() {
-  static const int w = [] { const char* q = getenv("TFK_BF16X3_WAVES"); return q && atoi(q) == 4 ? 4 : 8; }();
+  static const int w = [] {
+    const char* q = getenv("TFK_BF16X3_WAVES");
+    const int v = q ? atoi(q) : 8;
+    return v == 4 || v == 44 ? v : 8;
+  }();
   return w;
 }
 template <bool A_KC, bool B_KC, int EPI>
 int launch_x3(const GemmArgsB& p, hipStream_t stream) {
   const int forced = x3_cfg();
   const long m128 = (p.M + 127) / 128, n128 = (p.N + 127) / 128;
-  const bool w8 = x3_waves() == 8;
+  const int wv = x3_waves();
   if constexpr (A_KC) {
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape(false, p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * n128 * 128 * 128)
-      return w8 ? launch_dma<A_KC, B_KC, EPI, 2, 4, 2, 1, 3, 32, 0, 3, 2>(p, stream)
-                : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
+      return wv == 8    ? launch_dma<A_KC, B_KC, EPI, 2, 4, 2, 1, 3, 32, 0, 3, 2>(p, stream)
+             : wv == 44 ? launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2, 4>(p, stream)
+                        : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
   } else {
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape_tn(p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * ((p.N + 63) / 64) * 128 * 64)
@@ -1132,8 +1218,9 @@ int launch_x3(const GemmArgsB& p, hipStream_t stream) {
   }
   const bool big = forced >= 0 ? forced == 1 : m128 * n128 >= 200;
   if (big)
-    return w8 ? launch_dma<A_KC, B_KC, EPI, 2, 4, 2, 1, 3, 32, 0, 3>(p, stream)
-              : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
+    return wv == 8    ? launch_dma<A_KC, B_KC, EPI, 2, 4, 2, 1, 3, 32, 0, 3>(p, stream)
+           : wv == 44 ? launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 1, 4>(p, stream)
+                      : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3>(p, stream);
   return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3>(p, stream);
 }
 
@@ -1281,14 +1368,14 @@ int launch_x3_dual(const GemmArgsB& a, const GemmArgsB& w, hipStream_t stream) {
     attr_done = true;
   }
   const int tma = (a.M + 127) / 128, tna = (a.N + 127) / 128, tmw = (w.M + 127) / 128, tnw = (w.N + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(WN * 128), lds, stream, a, w, tma, tna, pick_group_rows(tma, tna, 128, 128),
+  hipLaunchKernelGGL(kern, dim3(tma * tna + tmw * tnw), dim3(WN == 2 ? 256 : 512), lds, stream, a, w, tma, tna, pick_group_rows(tma, tna, 128, 128),
                      tmw, tnw, pick_group_rows(tmw, tnw, 128, 128), w.K > a.K ? 1 : 0);
   return (int)hipGetLastError();
 }
 bool x3_operands_ok(const GemmArgsB& p, long a_rows, long b_rows) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 3)) return false;
-  // (the three interleaved planes of an operand are addressed through ONE buffer resource with 32-bit byte offsets)
-  return a_rows * p.lda * 6 + 192 < (1L << 31) && b_rows * p.ldb * 6 + 192 < (1L << 31);
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.lda & 31) || (p.ldb & 31) || (p.ldc & 3)) return false;
+  // (the three planes of an operand are addressed through ONE buffer resource with 32-bit byte offsets)
+  return (long)x3::elems(a_rows, p.lda) * 2 < (1L << 31) && (long)x3::elems(b_rows, p.ldb) * 2 < (1L << 31);
 }
 }  // namespace
 
@@ -1300,12 +1387,15 @@ int gemm_bf16x3_dual(const GemmArgsB& nt, const GemmArgsB& tn, hipStream_t strea
   if (!on || tiles < 256) return -1;
   const int key = (nt.epi == EPI_DACT ? 2 : 0) + (tn.epi == EPI_ACCUM ? 1 : 0);
   switch (key) {
-    case 0: return x3_waves() == 8 ? launch_x3_dual<0, 0, 4>(nt, tn, stream) : launch_x3_dual<0, 0, 2>(nt, tn, stream);
-    case 1: return x3_waves() == 8 ? launch_x3_dual<0, EPI_ACCUM, 4>(nt, tn, stream) : launch_x3_dual<0, EPI_ACCUM, 2>(nt, tn, stream);
-    case 2: return x3_waves() == 8 ? launch_x3_dual<EPI_DACT, 0, 4>(nt, tn, stream) : launch_x3_dual<EPI_DACT, 0, 2>(nt, tn, stream);
-    default:
-      return x3_waves() == 8 ? launch_x3_dual<EPI_DACT, EPI_ACCUM, 4>(nt, tn, stream)
-                             : launch_x3_dual<EPI_DACT, EPI_ACCUM, 2>(nt, tn, stream);
+#define TFK_X3_DUAL(E1, E2)                                                                \
+  (x3_waves() == 8    ? launch_x3_dual<E1, E2, 4>(nt, tn, stream)                            \
+   : x3_waves() == 44 ? launch_x3_dual<E1, E2, 0>(nt, tn, stream)                            \
+                      : launch_x3_dual<E1, E2, 2>(nt, tn, stream))
+    case 0: return TFK_X3_DUAL(0, 0);
+    case 1: return TFK_X3_DUAL(0, EPI_ACCUM);
+    case 2: return TFK_X3_DUAL(EPI_DACT, 0);
+    default: return TFK_X3_DUAL(EPI_DACT, EPI_ACCUM);
+#undef TFK_X3_DUAL
   }
 }
 

@@ -25,9 +25,9 @@ constexpr int kMaxRowSplits = 256;
 
 // Mixed-precision mode: kernels that produce a GEMM operand also store its bf16 twin (p == nullptr: fp32 mode).
 // ld in bf16 elements, a multiple of 8; padding columns of the twin stay zero from its allocation.
-// x3 != 0 ("bf16x3", gemm_bf16.h): the twin is THREE bf16 planes whose sum is the fp32 value exactly (twin_split3 below),
-// interleaved per 32 elements of the flat index row * ld + col (x3_layout.h: element i of plane q at (i >> 5) * 96 + 32 q +
-// (i & 31) -- 3 * rows * ld elements in all); x3 == 0: one plane, round to nearest even.
+// x3 != 0 ("bf16x3", gemm_bf16.h): the twin is THREE bf16 planes whose sum is the fp32 value exactly (twin_split3 below), in
+// the tiled layout of x3_layout.h (2-row x 32-column units of three 128-byte lines; ld a multiple of 32; x3::elems(rows, ld)
+// elements in all; a row offset into such a twin must be even); x3 == 0: one plane, round to nearest even.
 struct Twin {
   uint16_t* p = nullptr;
   int ld = 0;
@@ -44,14 +44,14 @@ __device__ __forceinline__ void twin_split3(float x, uint16_t& p1, uint16_t& p2,
   p2 = (uint16_t)(b2 >> 16);
   p3 = (uint16_t)(__builtin_bit_cast(uint32_t, r2) >> 16);
 }
-__device__ __forceinline__ void twin_put(const Twin& t, size_t idx, float v) {
+__device__ __forceinline__ void twin_put(const Twin& t, size_t row, int col, float v) {
   if (t.x3) {
     uint16_t a, b, c;
     twin_split3(v, a, b, c);
-    const size_t at = x3::il(idx);
-    t.p[at] = a; t.p[at + 32] = b; t.p[at + 64] = c;
+    const size_t at = x3::at(row, col, t.ld);
+    t.p[at] = a; t.p[at + 64] = b; t.p[at + 128] = c;
   } else {
-    t.p[idx] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    t.p[row * t.ld + col] = __builtin_bit_cast(uint16_t, (__bf16)v);
   }
 }
 
@@ -136,14 +136,25 @@ void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bo
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
                   const float* prior);
 
+// Where the weight matrices' x3 twins are, for the optimiser: matrix l occupies arena elements [begin[l], begin[l] + rows[l] *
+// ld[l]) (row-major, leading dimension ld[l]) and its twin starts `twin[l]` elements behind the shadow's base with leading
+// dimension ld_twin[l].  Up to kShadowMapMax matrices (deeper nets rebuild the twins after the update instead).
+constexpr int kShadowMapMax = 16;
+struct ShadowMap {
+  int n;
+  uint32_t begin[kShadowMapMax], rows[kShadowMapMax], ld[kShadowMapMax], ld_twin[kShadowMapMax];
+  uint64_t twin[kShadowMapMax];
+};
+
 // ---- optimiser (trainer.py:174-184): g = clip(G / num_frames, -1, 1); TF Adam (G is left as is) ----
 // grid_cap > 0 limits the number of blocks (grid-stride loop does the rest)
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0, int wb_x3 = 0,
-                size_t wb_first = 0);
-// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update.  wb_x3: three interleaved
-// planes -- `wb` is then the base of the interleaved array and w[0] its flat element wb_first
-// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns (x3: three interleaved planes whose sum is the value exactly)
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb = nullptr, size_t n_wb = 0,
+                const struct ShadowMap* map = nullptr, size_t first = 0);
+// wb: bf16 shadow of the first n_wb parameters (the weight matrices), written with the update: element for element behind
+// `wb` (mixed precision), or -- map != nullptr, x3 -- into the tiled three-plane twins the map describes; w[0] is then arena
+// element `first`
+// fp32 [rows, lds] -> bf16 [rows, ldd] with zero padding columns (x3: the tiled three-plane twin, ldd a multiple of 32)
 void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, int x3 = 0);
 // end of a step in one launch: moving <- decay^{num_microbatches} * moving + E, E <- 0, and
 // host[0..3] <- scalars[0..3] (host = device address of mapped pinned memory)

@@ -109,10 +109,10 @@ __device__ __forceinline__ void st4_twin(const Twin& t, size_t row, int col, flo
     q1.x = a[0]; q1.y = a[1]; q1.z = a[2]; q1.w = a[3];
     q2.x = b[0]; q2.y = b[1]; q2.z = b[2]; q2.w = b[3];
     q3.x = c[0]; q3.y = c[1]; q3.z = c[2]; q3.w = c[3];
-    uint16_t* d = t.p + x3::il(row * t.ld + col);  // (col is a multiple of 4: the four values share a block)
+    uint16_t* d = t.p + x3::at(row, col, t.ld);  // (col is a multiple of 4: the four values share a unit)
     *reinterpret_cast<u16x4*>(d) = q1;
-    *reinterpret_cast<u16x4*>(d + 32) = q2;
-    *reinterpret_cast<u16x4*>(d + 64) = q3;
+    *reinterpret_cast<u16x4*>(d + 64) = q2;
+    *reinterpret_cast<u16x4*>(d + 128) = q3;
     return;
   }
   u16x4 q;
@@ -822,7 +822,7 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
       for (int c = threadIdx.x; c < O; c += 256) {
         const float g = expf(zr[c] - mx) * inv - (c == label ? 1.f : 0.f);
         zr[c] = g;
-        if (tw.p) twin_put(tw, (size_t)row * tw.ld + c, g);
+        if (tw.p) twin_put(tw, (size_t)row, c, g);
       }
     }
   }
@@ -946,7 +946,7 @@ template <bool NT, int UN>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
             const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps, uint16_t* __restrict__ wb,
-            size_t n4_wb, int wb_x3, size_t wb_first) {
+            size_t n4_wb, ShadowMap map, size_t first) {
   // a step without frames (G / 0): the reference would write NaN into every parameter; here the parameters are
   // left alone and tfk_apply_end reports the error
   if (!(scalars[1] > 0.f)) return;
@@ -980,10 +980,21 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
       st4s<NT>(m + 4 * i, mv[u]);
       st4s<NT>(v + 4 * i, vv[u]);
       st4(w + 4 * i, wv[u]);
-      if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices (same element offsets as the fp32 arena)
+      if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices
         Twin sh;
-        sh.p = wb; sh.ld = 1; sh.x3 = wb_x3;
-        st4_twin(sh, wb_first + 4 * i, 0, wv[u]);  // (leading dimension 1: the "row" is the flat index)
+        if (map.n == 0) {  // same element offsets as the fp32 arena
+          sh.p = wb; sh.ld = 1;
+          st4_twin(sh, 4 * i, 0, wv[u]);  // (leading dimension 1: the "row" is the flat index)
+        } else {  // x3: the tiled twin of the matrix this group of four belongs to (padding between matrices: none)
+          const uint32_t e = (uint32_t)(first + 4 * i);
+          int l = 0;
+          while (l + 1 < map.n && e >= map.begin[l + 1]) ++l;
+          const uint32_t rel = e - map.begin[l], r = rel / map.ld[l];
+          if (r < map.rows[l]) {
+            sh.p = wb + map.twin[l]; sh.ld = (int)map.ld_twin[l]; sh.x3 = 1;
+            st4_twin(sh, r, (int)(rel - r * map.ld[l]), wv[u]);
+          }
+        }
       }
       // init_grads (trainer.py:350) costs no traffic: the next step's first micro-batch overwrites G
     }
@@ -1026,10 +1037,10 @@ to_bf16_rows_kernel(const float* __restrict__ src, int lds, uint16_t* __restrict
     uint16_t o1[8], o2[8], o3[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) twin_split3((c + k < cols) ? src[(size_t)r * lds + c + k] : 0.f, o1[k], o2[k], o3[k]);
-    uint16_t* d = dst + x3::il((size_t)r * ldd + c);
+    uint16_t* d = dst + x3::at((size_t)r, c, ldd);
     *reinterpret_cast<u32x4*>(d) = pack(o1);
-    *reinterpret_cast<u32x4*>(d + 32) = pack(o2);
-    *reinterpret_cast<u32x4*>(d + 64) = pack(o3);
+    *reinterpret_cast<u32x4*>(d + 64) = pack(o2);
+    *reinterpret_cast<u32x4*>(d + 128) = pack(o3);
     return;
   }
   uint16_t o[8];
@@ -1230,7 +1241,11 @@ void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, floa
 }
 
 void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n, const float* scalars, float lr_t,
-                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb, int wb_x3, size_t wb_first) {
+                float beta1, float beta2, float eps, int grid_cap, uint16_t* wb, size_t n_wb, const ShadowMap* map,
+                size_t first) {
+  ShadowMap sm;
+  if (map) sm = *map;
+  else sm.n = 0;
   const size_t n4 = n / 4;
   static const int un_div = [] { const char* q = getenv("TFK_ADAM_UNROLL"); const int u = q ? atoi(q) : 2; return u == 4 ? 4 : u == 2 ? 2 : 1; }();
   size_t blocks = ((n4 + un_div - 1) / un_div + 255) / 256;
@@ -1246,7 +1261,7 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
   static const int un = [] { const char* q = getenv("TFK_ADAM_UNROLL"); return q ? atoi(q) : 2; }();
 #define TFK_ADAM_LAUNCH(NTV, UNV)                                                                                  \
   hipLaunchKernelGGL((adam_kernel<NTV, UNV>), dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, \
-                     beta1, beta2, eps, wb, n_wb / 4, wb_x3, wb_first)
+                     beta1, beta2, eps, wb, n_wb / 4, sm, first)
   if (nt) {
     if (un == 4) TFK_ADAM_LAUNCH(true, 4); else if (un == 2) TFK_ADAM_LAUNCH(true, 2); else TFK_ADAM_LAUNCH(true, 1);
   } else {

@@ -1,28 +1,29 @@
 // Memory and LDS layouts of the fp32-emulating contraction ("bf16x3", gemm_bf16.h) -- index arithmetic only, shared by the
 // kernels (gemm_bf16.hip, kernels.hip) and by a host-side checker (tools/x3_layout_check.cpp, runs without a GPU).
 //
-// MEMORY.  An fp32 array [rows, ld] (ld a multiple of 8) is held as three bf16 planes p0 + p1 + p2 = x exactly, INTERLEAVED per
-// 32 consecutive elements of the flat index i = row * ld + col:
-//       element i, plane q  at  (i >> 5) * 96 + q * 32 + (i & 31)                       (bf16 elements from the array's base)
-// so the 32-k row segment a ring slot stages is 192 contiguous bytes (ld a multiple of 32) instead of three 64-byte pieces
-// 2 * rows * ld bytes apart, and an element-wise producer writes its three planes into one 192-byte neighbourhood.  With
-// separate planes (round 4) a k-contiguous operand filled LDS at ~21 B/clk/CU -- every 64-byte piece pulls a 128-byte line
-// through the L1-miss path -- against ~36 for 256-byte rows (profiles/r04_gemm_f32x3_ablation.txt, r03_lds_fill_paths.txt).
-// The interleave is a function of the FLAT index: the optimiser writes the shadow of the weight matrices straight from the
-// arena offset (no row / column arithmetic), and a matrix whose leading dimension is not a multiple of 32 (2000 pdfs) still
-// works -- its odd rows just start in the middle of a block.
+// MEMORY.  An fp32 matrix [rows, ld] (ld a multiple of 32, rows rounded up to even) is held as three bf16 planes
+// p0 + p1 + p2 = x exactly, TILED: the unit is the 2-row x 32-column block (R, B) = (row / 2, col / 32), 384 bytes =
+// three 128-byte lines, one per plane, each line holding the block's two rows of that plane:
+//       element (row, col), plane q  at  ((row / 2) * (ld / 32) + col / 32) * 192 + q * 64 + (row & 1) * 32 + col % 32
+// (bf16 elements from the matrix's base).  Why: the L1-miss path from L2 into a CU moves whole 128-byte lines at ~36 B/clk/CU,
+// and a ring slot of the contraction holds 32 k of both operands.  With one plane per array (round 4) a k-contiguous operand
+// fetched a 64-byte piece per row, plane and slot -- half of every line it pulled, 21 B/clk/CU of useful bytes
+// (profiles/r04_gemm_f32x3_ablation.txt); planes interleaved per row gave 192-byte runs, 1.5 lines each of which the second was
+// shared with the NEXT slot: 27 B/clk/CU.  Here whatever a block stages in one slot consists of COMPLETE lines in both uses of a
+// matrix: as the k-contiguous operand (a tile of 128 rows x 32 k = 64 units, each wholly inside it) and as the k-strided operand
+// (32 k-rows x 128 columns = 16 row pairs x 4 units).
 //
 // LDS (one ring slot = 32 k of all three planes of both operands; every image is written lane-linearly by
 // `buffer_load_dwordx4 ... lds`, 16-byte chunk n of an image at byte 16 n, so the permutations below are applied on the SOURCE
-// side of the DMA and undone by the fragment reads):
-//   k-contiguous operand, EXT rows:   row r at r * 192: plane q at + q * 64, its k-chunk c (8 k) at slot c ^ ((r >> 2) & 3).
-//       A lane's MFMA operand (8 consecutive k of one row and plane) is one ds_read_b128; the 16 lanes of a service group
-//       (rows with i & 3 = 0..3 four times, (i >> 2) & 3 distinct among equals) touch 16 distinct 16-byte bank slots.
-//   k-strided operand, EXT columns:   k-row r at r * EXT * 6: 64-byte QUADRANT Q = 3 * (ext / 32) + q (32 ext of plane q) at
-//       quadrant Q ^ (r & 3) (EXT = 128: 768-byte rows, all starting on bank 0) or Q ^ ((r >> 1) & 1) (EXT = 64: 384-byte
-//       rows alternating between bank 0 and bank 32).  ds_read_b64_tr_b16 reads the four k-rows of a 16-lane group from four
-//       different quadrants of the 256-byte bank row.
+// side of the DMA and undone by the fragment reads; consecutive chunks of an image come from consecutive memory):
+//   k-contiguous operand, EXT rows:   row pair P at P * 384: [plane q][row parity h][4 chunks of 8 k], the k-chunk c of row r at
+//       slot c ^ ((r >> 2) & 3).  A lane's MFMA operand (8 consecutive k of one row and plane) is one ds_read_b128; the 16 lanes
+//       of a service group touch 16 distinct 16-byte bank slots.
+//   k-strided operand, EXT columns:   k-row pair P at P * (EXT / 32) * 384: per 32-column block b the unit's six 64-byte QUADRANTS
+//       n = 6 b + 2 q + h (plane q, row parity h), quadrant n stored at n ^ (2 * (P & 1)): the four k-rows a 16-lane group of
+//       ds_read_b64_tr_b16 reads (two pairs) then sit in four different quadrants of the 256-byte bank row.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -34,42 +35,67 @@
 namespace tfk {
 namespace x3 {
 
-constexpr int kBlock = 32;     // elements per interleave block
-constexpr int kSlotK = 32;     // k per ring slot
+constexpr int kSlotK = 32;  // k per ring slot = columns per unit
 
-// element offset of plane 0 of flat element i (planes 1, 2: + 32, + 64)
-X3_HD size_t il(size_t i) { return (i >> 5) * 96 + (i & 31); }
+// elements a matrix of `rows` rows occupies (all three planes)
+X3_HD size_t elems(size_t rows, int ld) { return ((rows + 1) >> 1) * (size_t)(ld >> 5) * 192; }
+// element offset of plane 0 of element (row, col); planes 1, 2: + 64, + 128
+X3_HD size_t at(size_t row, int col, int ld) {
+  return ((row >> 1) * (size_t)(ld >> 5) + (size_t)(col >> 5)) * 192 + (row & 1) * 32 + (col & 31);
+}
 
-// ---- k-contiguous image: 12 chunks of 16 bytes per row ----
+// ---- k-contiguous image: 24 chunks of 16 bytes per row pair ----
 X3_HD int kc_swz(int r) { return (r >> 2) & 3; }
 // chunk n of the image holds k-chunk c (k = 8 c .. 8 c + 7) of plane q of row r
 X3_HD void kc_decode(int n, int& r, int& q, int& c) {
-  r = n / 12;
-  const int rem = n - r * 12;
-  q = rem >> 2;
+  const int P = n / 24, rem = n - P * 24;
+  q = rem >> 3;
+  r = 2 * P + ((rem >> 2) & 1);
   c = (rem & 3) ^ kc_swz(r);
 }
-X3_HD int kc_addr(int r, int q, int c) { return r * 192 + q * 64 + ((c ^ kc_swz(r)) << 4); }
+X3_HD int kc_addr(int r, int q, int c) { return (r >> 1) * 384 + q * 128 + (r & 1) * 64 + ((c ^ kc_swz(r)) << 4); }
 
-// ---- k-strided image: EXT * 6 bytes per k-row = EXT / 32 * 3 quadrants of 4 chunks ----
-template <int EXT>
-X3_HD int ks_swz(int r) {
-  return EXT == 64 ? ((r >> 1) & 1) : (r & 3);
-}
+// ---- k-strided image: EXT / 32 units of 6 quadrants (64 bytes) per k-row pair ----
 // chunk n of the image holds ext-chunk e8 (8 ext) of block b (32 ext), plane q, of k-row r
 template <int EXT>
 X3_HD void ks_decode(int n, int& r, int& b, int& q, int& e8) {
-  constexpr int CPR = EXT * 6 / 16;
-  r = n / CPR;
-  const int pos = n - r * CPR;
-  const int Q = (pos >> 2) ^ ks_swz<EXT>(r);
-  b = Q / 3;
-  q = Q - 3 * b;
+  constexpr int CPP = EXT / 32 * 24;  // chunks per row pair
+  const int P = n / CPP, pos = n - P * CPP;
+  const int nq = (pos >> 2) ^ ((P & 1) << 1);
+  b = nq / 6;
+  const int rem = nq - 6 * b;
+  q = rem >> 1;
+  r = 2 * P + (rem & 1);
   e8 = pos & 3;
 }
 template <int EXT>
 X3_HD int ks_addr(int r, int b, int q, int e8) {
-  return r * (EXT * 6) + ((((3 * b + q) ^ ks_swz<EXT>(r)) << 2) + e8) * 16;
+  const int P = r >> 1;
+  return P * (EXT / 32 * 384) + ((((6 * b + 2 * q + (r & 1)) ^ ((P & 1) << 1)) << 2) + e8) * 16;
+}
+
+// ---- fragment reads: two per-lane byte offsets per operand, everything else an immediate ----
+// k-contiguous (ds_read_b128): lane (i = lane & 31, kb = lane >> 5) reads row 32 * frag + i, k-chunk 2 ks + kb of plane q at
+//   kc_lane_off(lane, frag0, ks) + kc_imm(f, q),  frag = frag0 + f
+X3_HD int kc_lane_off(int lane, int frag0, int ks) { return kc_addr(frag0 * 32 + (lane & 31), 0, 2 * ks + (lane >> 5)); }
+X3_HD int kc_imm(int f, int q) { return f * (16 * 384) + q * 128; }
+// k-strided (two ds_read_b64_tr_b16, the second `hi` four k-rows further): lane (kb, half, j, qq) = (lane >> 5, (lane >> 4) & 1,
+//   (lane >> 2) & 3, lane & 3) reads 8 bytes of k-row 16 ks + 8 kb + j (+ 4), columns 32 * frag + 16 half + 4 qq .. + 3, at
+//   ks_lane_off(lane, frag0, X & 1) + ks_imm(X, ks, hi),  X = 3 f + q.  The 128-byte line of (frag, q) inside a row pair is
+//   Xt = 3 frag + q, stored at Xt ^ t (t = parity of the lane's row pair): Xt + t for even Xt, Xt - t for odd.
+template <int EXT>
+X3_HD int ks_lane_off(int lane, int frag0, int x_odd) {
+  const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, qq = lane & 3;
+  const int t = (j >> 1) & 1;
+  const int base = (4 * kb + (j >> 1)) * (EXT / 32 * 384) + (j & 1) * 64 + (2 * half + (qq >> 1)) * 16 + ((qq & 1) << 3) +
+                   128 * 3 * frag0;
+  const int xt_odd = (frag0 + x_odd) & 1;  // parity of Xt = 3 frag0 + X
+  // the immediate is 128 * X for even X and 128 * (X - 1) for odd X: an odd X carries its own + 128 here
+  return base + (xt_odd ? -128 * t : 128 * t) + (x_odd ? 128 : 0);
+}
+template <int EXT>
+X3_HD int ks_imm(int X, int ks, int hi) {
+  return 128 * (X & ~1) + (ks * 8 + hi * 2) * (EXT / 32 * 384);
 }
 
 }  // namespace x3

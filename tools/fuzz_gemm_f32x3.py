@@ -43,9 +43,9 @@ def main():
         Ad, Bd = A.double(), B.double()
         ref = (Ad.T if layout == 2 else Ad) @ (Bd.T if layout == 1 else Bd)
         sab = (Ad.abs().T if layout == 2 else Ad.abs()) @ (Bd.abs().T if layout == 1 else Bd.abs())
-        ld8 = bool(rng.integers(0, 2))  # leading dimensions of 8 q (rows start inside an interleave block) or 32 q
-        Ap, lda = _planes(lib, torch, A, ((A.shape[1] + 7) & ~7) if ld8 else None)
-        Bp, ldb = _planes(lib, torch, B, ((B.shape[1] + 7) & ~7) if ld8 else None)
+        wide = 32 * int(rng.integers(0, 2))  # leading dimensions one unit longer than needed, or tight
+        Ap, lda = _planes(lib, torch, A, ((A.shape[1] + 31) & ~31) + wide)
+        Bp, ldb = _planes(lib, torch, B, ((B.shape[1] + 31) & ~31) + wide)
         ldc = p4(N)
         C0 = torch.randn(M, ldc, device="cuda", generator=g)
         bias = torch.randn(N, device="cuda", generator=g)

@@ -7,12 +7,27 @@
 #include "../tfkaldi_amd/csrc/gemm_bf16.hip"
 
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 
-static uint16_t* random_planes(size_t elems, unsigned seed) {
-  std::vector<uint16_t> h(3 * elems);
+// TFK_ABL_DATA: random (default: every plane ~ +-1, the worst case for switching power) | zero | p0 (planes 1 and 2 zero) |
+// real (plane q scaled by 2^-8q: what a split fp32 value looks like)
+static void fill_planes(std::vector<uint16_t>& h, unsigned seed) {
+  const char* mode = getenv("TFK_ABL_DATA");
+  const int m = !mode ? 0 : !strcmp(mode, "zero") ? 1 : !strcmp(mode, "p0") ? 2 : !strcmp(mode, "real") ? 3 : 0;
   unsigned s = seed;
-  for (auto& x : h) { s = s * 1664525u + 1013904223u; x = (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) + ((s >> 8) & 0x8000u)); }
+  for (size_t i = 0; i < h.size(); ++i) {
+    s = s * 1664525u + 1013904223u;
+    const int q = (int)((i % 192) / 64);  // plane of element i of the tiled array
+    uint16_t v = (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) + ((s >> 8) & 0x8000u));
+    if (m == 1 || (m == 2 && q > 0)) v = 0;
+    if (m == 3) v = (uint16_t)(v - q * (8u << 7));  // exponent - 8 q
+    h[i] = v;
+  }
+}
+static uint16_t* random_planes(size_t rows, int ld, unsigned seed) {
+  std::vector<uint16_t> h(tfk::x3::elems(rows, ld));
+  fill_planes(h, seed);
   uint16_t* d;
   hipMalloc(&d, h.size() * 2);
   hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
@@ -22,9 +37,9 @@ static uint16_t* random_planes(size_t elems, unsigned seed) {
 static int dual(int T, int din, int dout) {
   auto p32 = [](int n) { return (n + 31) & ~31; };
   const int ld_in = p32(din), ld_out = p32(dout);
-  uint16_t* dz = random_planes((size_t)T * ld_out, 1u);   // [T, d_out]
-  uint16_t* w = random_planes((size_t)din * ld_out, 2u);  // [d_in, d_out]
-  uint16_t* in = random_planes((size_t)T * ld_in, 3u);    // [T, d_in]
+  uint16_t* dz = random_planes(T, ld_out, 1u);   // [T, d_out]
+  uint16_t* w = random_planes(din, ld_out, 2u);  // [d_in, d_out]
+  uint16_t* in = random_planes(T, ld_in, 3u);    // [T, d_in]
   float *dA, *dW;
   hipMalloc(&dA, (size_t)T * ld_in * 4); hipMalloc(&dW, (size_t)din * ld_out * 4);
   tfk::GemmArgsB a = {}, g = {};
@@ -55,11 +70,9 @@ int main(int argc, char** argv) {
   const int a_rows = layout == 2 ? K : M, a_cols = layout == 2 ? M : K;
   const int b_rows = layout == 1 ? N : K, b_cols = layout == 1 ? K : N;
   const int lda = p8(a_cols), ldb = p8(b_cols), ldc = (N + 3) & ~3;
-  std::vector<uint16_t> ha((size_t)3 * a_rows * lda), hb((size_t)3 * b_rows * ldb);
-  unsigned s = 12345u;
-  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) + ((s >> 8) & 0x8000u)); };
-  for (auto& x : ha) x = rnd();
-  for (auto& x : hb) x = rnd();
+  std::vector<uint16_t> ha(tfk::x3::elems(a_rows, lda)), hb(tfk::x3::elems(b_rows, ldb));
+  fill_planes(ha, 12345u);
+  fill_planes(hb, 54321u);
   uint16_t *dA, *dB;
   float* dC;
   hipMalloc(&dA, ha.size() * 2); hipMalloc(&dB, hb.size() * 2); hipMalloc(&dC, (size_t)M * ldc * 4);

@@ -2,7 +2,7 @@
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tfkaldi_amd import _lib
+from tfkaldi_amd import _lib, x3
 lib = _lib.load()
 layout, M, N, K = [int(x) for x in sys.argv[1:5]]
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
@@ -11,7 +11,7 @@ shape_a = (K, M) if layout == 2 else (M, K)
 shape_b = (N, K) if layout == 1 else (K, N)
 def planes(shape):  # (timing only: random bf16 values in the interleaved array's place)
     ld = p32(shape[1])
-    return torch.randn(3 * shape[0] * ld, device="cuda").to(torch.bfloat16), ld
+    return torch.randn(x3.elems(shape[0], ld), device="cuda").to(torch.bfloat16), ld
 a, lda = planes(shape_a)
 b, ldb = planes(shape_b)
 c = torch.zeros(M, (N + 3) & ~3, device="cuda")

@@ -1,6 +1,6 @@
 // CPU tool / test helper: the index arithmetic of the fp32-emulating contraction's operand layouts (tfkaldi_amd/csrc/x3_layout.h)
 // checked without a GPU.  For every operand kind the kernel instantiates it emulates (1) the LDS-DMA fill of one ring slot from a
-// plane-interleaved array -- thread t, piece j writes the 16-byte chunk t + j * NTH of the image from the source address
+// tiled three-plane array -- thread t, piece j writes the 16-byte chunk t + j * NTH of the image from the source address
 // DmaOperand3::init computes -- and (2) the fragment reads of Frag3, and asserts that every lane receives exactly the elements the
 // MFMA operand needs; then it simulates the LDS bank schedule of those reads (ds_read_b128: four 16-lane service groups;
 // ds_read_b64_tr_b16: two 32-lane groups) and asserts that no group touches a bank twice.
@@ -27,11 +27,12 @@ static int g_fail = 0;
 // value stored for (flat index, plane): unique per element
 static uint32_t tag(size_t flat, int q) { return (uint32_t)(flat * 3 + q + 1); }
 
-// the interleaved array of an [rows, ld] matrix
+// the tiled three-plane array of an [rows, ld] matrix
 static std::vector<uint32_t> make_array(int rows, int ld) {
-  std::vector<uint32_t> a((((size_t)rows * ld + 31) / 32) * 96, 0);
-  for (size_t i = 0; i < (size_t)rows * ld; ++i)
-    for (int q = 0; q < 3; ++q) a[x3::il(i) + q * 32] = tag(i, q);
+  std::vector<uint32_t> a(x3::elems(rows, ld), 0);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < ld; ++c)
+      for (int q = 0; q < 3; ++q) a[x3::at(r, c, ld) + q * 64] = tag((size_t)r * ld + c, q);
   return a;
 }
 
@@ -48,42 +49,44 @@ static void check(int rows, int ld, int ext0, int k0, const char* name) {
       if (KC) {
         int r, q, c;
         x3::kc_decode(n, r, q, c);
-        src = x3::il((size_t)(ext0 + r) * ld + c * 8) + q * 32 + (size_t)k0 * 3;  // soff = k0 * 6 bytes
+        src = x3::at(ext0 + r, c * 8, ld) + q * 64 + (size_t)k0 * 6;  // soff = k0 * 12 bytes
       } else {
         int r, b, q, e8;
         x3::ks_decode<EXT>(n, r, b, q, e8);
-        src = x3::il((size_t)r * ld + ext0 + b * 32 + e8 * 8) + q * 32 + (size_t)k0 * ld * 3;  // soff = k0 * ld * 6 bytes
+        src = x3::at(r, ext0 + b * 32 + e8 * 8, ld) + q * 64 + (size_t)k0 * ld * 3;  // soff = k0 * ld * 6 bytes
       }
       EXPECT(src + 8 <= arr.size(), "%s: source chunk out of range", name);
       for (int e = 0; e < 8; ++e) img[(size_t)n * 8 + e] = src + e < arr.size() ? arr[src + e] : 0;
     }
-  // ---- fragment reads (Frag3::init + read) ----
+  // ---- fragment reads (Frag3::init + read), for a wave whose first fragment is frag0 ----
   const int NF = EXT / 32;
+  for (int frag0 = 0; frag0 < NF; ++frag0)
   for (int pl = 0; pl < 3; ++pl)
-    for (int f = 0; f < NF; ++f)
+    for (int f = 0; frag0 + f < NF; ++f)
       for (int ks = 0; ks < 2; ++ks) {
         std::vector<int> addr(64), addr_hi(64);
         for (int lane = 0; lane < 64; ++lane) {
           if (KC) {
             const int i = lane & 31, kb = lane >> 5;
-            const int a = x3::kc_addr(0 * 32 + i, 0, 2 * ks + kb) + f * (32 * 192) + pl * 64;
+            const int a = x3::kc_lane_off(lane, frag0, ks) + x3::kc_imm(f, pl);
             addr[lane] = a;
-            const int row = ext0 + f * 32 + i;
+            const int row = ext0 + (frag0 + f) * 32 + i;
             for (int e = 0; e < 8; ++e)
-              EXPECT(img[a / 2 + e] == tag((size_t)row * ld + k0 + 16 * ks + 8 * kb + e, pl), "%s: KC fragment f%d ks%d pl%d lane %d", name,
-                     f, ks, pl, lane);
+              EXPECT(img[a / 2 + e] == tag((size_t)row * ld + k0 + 16 * ks + 8 * kb + e, pl), "%s: KC fragment f%d+%d ks%d pl%d lane %d",
+                     name, frag0, f, ks, pl, lane);
           } else {
-            constexpr int ROWB = EXT * 6;
             const int kb = lane >> 5, half = (lane >> 4) & 1, j = (lane >> 2) & 3, q = lane & 3;
-            const int a = x3::ks_addr<EXT>(8 * kb + j, f, pl, 2 * half + (q >> 1)) + ((q & 1) << 3) + ks * 16 * ROWB;
-            addr[lane] = a;
-            addr_hi[lane] = a + 4 * ROWB;
+            const int X = 3 * f + pl;
+            EXPECT(x3::ks_lane_off<EXT>(lane, frag0, X & 1) >= 0, "%s: negative lane offset", name);
             for (int hi = 0; hi < 2; ++hi) {
+              const int a = x3::ks_lane_off<EXT>(lane, frag0, X & 1) + x3::ks_imm<EXT>(X, ks, hi);
+              (hi ? addr_hi : addr)[lane] = a;
+              EXPECT(x3::ks_imm<EXT>(X, ks, hi) < 65536, "%s: immediate out of range", name);
               const int krow = k0 + 16 * ks + 8 * kb + j + 4 * hi;
-              const int ext = ext0 + f * 32 + 16 * half + 4 * q;
+              const int ext = ext0 + (frag0 + f) * 32 + 16 * half + 4 * q;
               for (int e = 0; e < 4; ++e)
-                EXPECT(img[(a + hi * 4 * ROWB) / 2 + e] == tag((size_t)krow * ld + ext + e, pl), "%s: KS fragment f%d ks%d pl%d lane %d hi%d",
-                       name, f, ks, pl, lane, hi);
+                EXPECT(img[a / 2 + e] == tag((size_t)krow * ld + ext + e, pl), "%s: KS fragment f%d+%d ks%d pl%d lane %d hi%d",
+                       name, frag0, f, ks, pl, lane, hi);
             }
           }
         }
@@ -123,11 +126,11 @@ static void check(int rows, int ld, int ext0, int k0, const char* name) {
         if (KC) {
           int r, q, c;
           x3::kc_decode(n, r, q, c);
-          src = x3::il((size_t)(ext0 + r) * ld + c * 8) + q * 32 + (size_t)k0 * 3;
+          src = x3::at(ext0 + r, c * 8, ld) + q * 64 + (size_t)k0 * 6;
         } else {
           int r, b, q, e8;
           x3::ks_decode<EXT>(n, r, b, q, e8);
-          src = x3::il((size_t)r * ld + ext0 + b * 32 + e8 * 8) + q * 32 + (size_t)k0 * ld * 3;
+          src = x3::at(r, ext0 + b * 32 + e8 * 8, ld) + q * 64 + (size_t)k0 * ld * 3;
         }
         ln.insert(src * 2 / 128);
       }
@@ -139,15 +142,17 @@ static void check(int rows, int ld, int ext0, int k0, const char* name) {
 }
 
 int main() {
-  for (int ld : {2048, 448, 2016, 2000}) {
+  for (int ld : {2048, 448, 2016}) {
     for (int k0 : {0, 32, 96}) {
       check<true, 128, 256>(256, ld, 128, k0, "k-contiguous, 128 rows, 4 waves");
+      check<true, 128, 512>(256, ld, 128, k0, "k-contiguous, 128 rows, 8 waves");
       check<true, 64, 256>(256, ld, 64, k0, "k-contiguous,  64 rows, 4 waves");
     }
   }
-  for (int ld : {2048, 2016, 2000, 448}) {
+  for (int ld : {2048, 2016, 448}) {
     for (int k0 : {0, 32, 64}) {
       check<false, 128, 256>(128, ld, 128, k0, "k-strided, 128 columns, 4 waves");
+      check<false, 128, 512>(128, ld, 128, k0, "k-strided, 128 columns, 8 waves");
       check<false, 64, 256>(128, ld, 192, k0, "k-strided,  64 columns, 4 waves");
     }
   }
