@@ -185,6 +185,17 @@ int tfk_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int
 int tfk_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
                                const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn,
                                const int32_t* seg_utts, int32_t k, int flags);
+/* Trainer.evaluate (reference neuralNetworks/trainer.py:356-441: one update_valid_loss run per micro-batch) over k micro-batches
+ * in ONE call.  In evaluation mode the rows of a micro-batch are independent (batch norm normalises with the moving statistics,
+ * dropout is the identity, L2Norm is row-wise), so the k runs are one pass of the GEMMs over the concatenated rows -- every
+ * activation chain, no padding between segments; passes are cut at micro-batch boundaries once they hold TFK_EVAL_PASS_ROWS rows
+ * (default 16384).  batch_loss / num_frames end up as k tfk_eval_accumulate[_raw] calls leave them, up to the fp32 order of the
+ * loss sum.  Arguments as the training entry points above. */
+int tfk_eval_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, const int32_t* seg_rows,
+                                int32_t k, int flags);
+int tfk_eval_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
+                                    const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn,
+                                    const int32_t* seg_utts, int32_t k, int flags);
 
 /* CTC loss instead of the frame-level cross-entropy (BASELINE configs[4]): what the reference's
  * CTCTrainer.compute_loss means to build with tf.nn.ctc_loss (trainer.py:533-570; its code cannot run, so this is a
@@ -213,6 +224,9 @@ int tfk_eval_accumulate_ctc_raw(tfk_engine* e, const float* raw, int64_t ldraw, 
  * pre-update, train-mode loss); zeroes G, batch_loss, num_frames.  With data parallelism the host
  * all-reduces the reduce region (below) between the last tfk_accumulate and tfk_apply. */
 int tfk_apply(tfk_engine* e, float* average_loss);
+/* tfk_apply in two halves: tfk_apply_enqueue puts the whole optimiser step on the engine's streams without waiting for it,
+ * tfk_apply_end (below) waits for the step's loss.  Between the two the host is free (the dispenser's prefetch). */
+int tfk_apply_enqueue(tfk_engine* e);
 
 /* Replaces `update_valid_loss.run(feed_dict)` (trainer.py:188-195, 433): eval-mode forward + loss. */
 int tfk_eval_accumulate(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, int flags);
@@ -344,6 +358,10 @@ int tfk_comm_destroy(tfk_comm* c);  /* before tfk_destroy of its engine */
 int tfk_comm_info(tfk_comm* c, int* rank, int* world, int* mode, int* gathers_shadow);
 const char* tfk_comm_backend(tfk_comm* c);  /* "rccl" | "loopback" */
 int tfk_comm_apply(tfk_comm* c, float* average_loss);
+/* the same in two halves (as tfk_apply_enqueue / tfk_apply_end): _enqueue launches the tail collectives, Adam on this rank's
+ * spans and the parameter gathers; _end waits for the loss (and runs the replica check of the first sharded steps). */
+int tfk_comm_apply_enqueue(tfk_comm* c);
+int tfk_comm_apply_end(tfk_comm* c, float* average_loss);
 int tfk_comm_eval_finish(tfk_comm* c, float* average_loss);
 /* (tests / diagnostics) launch what is still coalescing and make the engine stream wait for every collective of the step,
  * WITHOUT the optimiser: the reduce region then holds the summed gradients -- of a reduce-scattered span only this rank's
@@ -402,12 +420,18 @@ int tfk_gemm_f32(void* stream, int layout, const float* A, int lda, const float*
 int tfk_gemm_bf16(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                   int M, int N, int K, const float* bias, int epi);
 /* Stand-alone fp32-emulating GEMM (TFK_DTYPE_F32X3's contraction; gemm_bf16.h: gemm_bf16x3) on device pointers: A and B are given
- * as three bf16 planes each, INTERLEAVED per 32 elements of the flat index i = row * ld + col (ld a multiple of 8; element i of
- * plane q at (i / 32) * 96 + 32 q + i % 32: csrc/x3_layout.h), 3 * ceil(rows * ld / 32) * 32 elements in all; tfk_split3 makes such
- * an array from an fp32 matrix [rows, lds]: src == plane 0 + plane 1 + plane 2 exactly, padding columns zero.
- * tfk_gemm_bf16x3_dual: the backward pair of a layer in one launch (as tfk_gemm_bf16_dual).  Tests and tools.  (ABI 7: the
- * separate-plane form of ABI 6 -- `a_plane` / `b_plane` arguments -- is gone.) */
+ * as three bf16 planes each in the TILED layout of csrc/x3_layout.h (ld a multiple of 32; 2-row x 32-column units of three 128-byte
+ * lines, one per plane: element (r, c) of plane q at ((r / 2) * (ld / 32) + c / 32) * 192 + 64 q + 32 (r % 2) + c % 32;
+ * ceil(rows / 2) * (ld / 32) * 192 elements in all); tfk_split3 makes such a twin from an fp32 matrix [rows, lds]:
+ * src == plane 0 + plane 1 + plane 2 exactly, padding columns zero.  tfk_gemm_bf16x3_dual: the backward pair of a layer in one
+ * launch (as tfk_gemm_bf16_dual).  Tests and tools.  (ABI 7: the separate-plane form of ABI 6 -- `a_plane` / `b_plane`
+ * arguments -- is gone.) */
 int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols);
+/* tests: mark a ticket of the engine's split-K workspace as taken, as an interrupted launch would leave it.  The next step whose
+ * contractions split their K must then FAIL (tfk_apply / tfk_eval_finish / tfk_posteriors return non-zero, tfk_last_error names
+ * the timeout) -- a block that waits ~1 s for its partner's partial sums reports it through mapped memory -- and the step after
+ * that must work again. */
+int tfk_debug_poison_splitk(tfk_engine* e);
 int tfk_gemm_bf16x3(void* stream, int layout, const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M,
                     int N, int K, const float* bias, int epi);
 int tfk_gemm_bf16x3_dual(void* stream, const uint16_t* A_nt, int lda_nt, const uint16_t* B_nt, int ldb_nt, float* C_nt,

@@ -166,3 +166,55 @@ def test_ranks_agree_to_leave_the_in_library_exchange(tmp_path):
     one closes it; TFK_DP_COMM=native-only turns the agreement into an error"""
     mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok0")) and os.path.exists(os.path.join(str(tmp_path), "ok1"))
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_engine import OracleEngine
+    from tfkaldi_amd.dataparallel import DataParallel, init_from_env, partition
+    init_from_env()
+    dp = DataParallel(mode="allreduce")
+    eng = OracleEngine(_oracle())
+    order = []
+
+    def overlap():
+        order.append("overlap")
+        if rank == 1:
+            raise IOError("short read of the next batch")
+
+    red = dp.reducer(eng)
+    orig = red.finish_and_apply
+
+    def spy(engine, ov=None):
+        # the hook runs INSIDE finish_and_apply -- behind everything the step launches, in front of the wait -- not before it
+        order.append("finish_and_apply")
+        return orig(engine, ov)
+    red.finish_and_apply = spy
+    mbs = _data(4, seed=0)
+    start, end = partition(len(mbs), world)[rank]
+    try:
+        loss = dp.train_own(eng, mbs[start:end], len(mbs) - end, overlap)
+        raised = None
+    except IOError as exc:
+        loss, raised = None, str(exc)
+    assert order == ["finish_and_apply", "overlap"], order
+    assert (raised is not None) == (rank == 1), raised
+    # the step itself completed on BOTH ranks (the failing rank took part in every collective before it re-raised): the next
+    # one runs, and the replicas still agree
+    loss2 = dp.train_step(eng, _data(4, seed=1))
+    eng.sync_params()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss2=loss2, **eng.o.params())
+    dist.destroy_process_group()
+
+
+def test_a_failing_overlap_hook_does_not_strand_the_peers(tmp_path):
+    """round-4 advisor: `overlap()` -- the dispenser's prefetch -- ran before the tail collectives and the optimiser were launched,
+    and an exception in it (a short read) unwound one rank out of the step while its peers waited in their collectives.  Now it
+    runs once the whole step is enqueued, and what it raises is re-raised after the step has completed on every rank."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

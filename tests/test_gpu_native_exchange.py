@@ -141,6 +141,31 @@ def test_loopback_ranks_equal_the_serial_run_fp32(gpu, world, num_mb, mode):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("world,num_mb", [(2, 2), (4, 3), (8, 8)])
+def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode):
+    """the fp32-emulating arithmetic under the exchange: a different path from both others -- the sharded mode gathers the fp32
+    parameters (the three-plane twins of the weights live outside the arena) and every rank REBUILDS its twins from them before
+    the next forward pass (engine.hip: refresh_shadow), the all-reduce mode updates them with the full Adam step.  Same bounds as
+    fp32 (it claims to be fp32), replicas bit-identical, and no stale masters: nothing is left sharded in this mode"""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    group = _Group(world, mode, dtype="float32x3")
+    try:
+        results = group.run(_rank_program(num_mb))
+    finally:
+        group.close()
+    ref = _serial(num_mb, dtype="float32x3")
+    for rank, (got, info) in enumerate(results):
+        _compare(ref, got, 2e-5, 2e-4, "rank %d" % rank)
+        for k, v in results[0][0].items():
+            np.testing.assert_array_equal(got[k], v, err_msg="rank %d %s" % (rank, k))
+        if mode == "sharded":
+            assert any("reduce_scatter" in n for n in info["executed"]) and any("all_gather" in n for n in info["executed"])
+            assert not any("shadow" in n for n in info["executed"])  # fp32 parameters on the wire, not a bf16 shadow
+        assert not info["stale"]
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("world,num_mb", [(2, 2), (4, 6), (8, 8), (8, 2)])
 def test_loopback_ranks_mixed_precision_sharded_masters(gpu, world, num_mb):
     """bf16 GEMMs: what travels back is the bf16 SHADOW (2 B per parameter); the fp32 masters of a span stay on the rank
@@ -236,21 +261,22 @@ def _region(eng):
     return out
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float32x3"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world):
+def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype):
     """BEFORE Adam (which amplifies round-off): after the collectives of a step, rank r's 1/world of every reduce-scattered
     span and the whole of every all-reduced span hold the gradient sums of the serial run.  One micro-batch per rank: the
     ranks' sums are added in rank order = the order the serial run accumulates micro-batches in, so the sums are
     bit-identical (the scalar tail's BN increments excepted: their closed form is another arithmetic)."""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
     mbs = _data(world, 0)
-    serial = _engine(torch_state=False)
+    serial = _engine(torch_state=False, dtype=dtype)
     for i, (X, y) in enumerate(mbs):
         serial.accumulate(X, y, last=(i == world - 1))
     want = _region(serial)
     num_params = serial.buckets()[-1][0]
     serial.close()
-    group = _Group(world, "sharded")
+    group = _Group(world, "sharded", dtype=dtype)
 
     def program(rank, eng, dp):
         red = dp.reducer(eng)

@@ -43,7 +43,8 @@ def _train(tmp_path, paths, name, capsys, **over):
     return out, model, reader.reader.bytes_read
 
 
-@pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}, {"compute_dtype": "bfloat16"},
+@pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}, {"compute_dtype": "bfloat16"}, {"compute_dtype": "float32x3"},
+                                  {"compute_dtype": "float32x3", "dropout": "0.8"},
                                   {"add_layer_period": "5", "valid_adapt": "False"}])
 def test_packed_feed_equals_list_feed(gpu, tmp_path, capsys, over, monkeypatch):
     """6 utterances per batch in micro-batches of 4 (the reference's quirk: the last two are one micro-batch), a
@@ -82,7 +83,7 @@ def _losses(out):
     return [float(x) for x in re.findall(r"loss(?: at step \d+)?: ([-0-9.e]+)", out)]
 
 
-@pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}])
+@pytest.mark.parametrize("over", [{}, {"dropout": "0.8"}, {"compute_dtype": "float32x3"}])
 def test_packed_feed_with_stacked_passes_tracks_the_list_feed(gpu, tmp_path, capsys, over):
     """the default: the packed feed hands all micro-batches of a step to the engine at once and the engine stacks them into
     one pass of the GEMMs -- same statistics per micro-batch, same dropout stream, another summation order inside dW and the

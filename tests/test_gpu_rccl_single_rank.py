@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
+def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native", dtype="float32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64",
                       TFK_DP_COMM="native" if comm == "unloadable" else comm)
@@ -37,7 +37,7 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
     assert dist.get_backend() == "nccl"
     dp = DataParallel(mode=mode)
     assert dp.enabled
-    eng = _engine(torch_state=True)
+    eng = _engine(torch_state=True, dtype=dtype)
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
     # who launched the collectives: the library itself (csrc/exchange.hip) or BucketReducer through torch.distributed
     assert dp.reducer(eng).native == (comm == "native")
@@ -55,13 +55,16 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("comm", ["native", "torch", "unloadable"])
+@pytest.mark.parametrize("comm,dtype", [("native", "float32"), ("torch", "float32"), ("unloadable", "float32"),
+                                        ("native", "float32x3"), ("torch", "float32x3")])
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
-def test_single_rank_rccl_is_identity(gpu, tmp_path, mode, comm):
+def test_single_rank_rccl_is_identity(gpu, tmp_path, mode, comm, dtype):
+    """(float32x3: the exchange gathers fp32 parameters and the engine rebuilds its three-plane twins from them -- with one
+    rank that must be the identity too, bit for bit)"""
     import torch.multiprocessing as mp
     num_mb = 3
-    mp.spawn(_worker, args=(_free_port(), num_mb, str(tmp_path), mode, comm), nprocs=1, join=True)
-    eng = _engine(torch_state=False)
+    mp.spawn(_worker, args=(_free_port(), num_mb, str(tmp_path), mode, comm, dtype), nprocs=1, join=True)
+    eng = _engine(torch_state=False, dtype=dtype)
     want = []
     for step in range(3):
         mbs = _data(num_mb, step)

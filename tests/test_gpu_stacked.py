@@ -192,3 +192,38 @@ def test_stacked_at_cfg2_size_against_sequential(gpu):
         assert abs(l_stk - l_seq) <= tol * abs(l_seq)
         assert np.abs(stk.get(_lib.BN_MOVING_VAR, 4) - seq.get(_lib.BN_MOVING_VAR, 4)).max() <= 1e-5 + tol
         stk.close(); seq.close()
+
+
+@pytest.mark.parametrize("kw_over", [{}, {"nonlin": "tanh", "l2_norm": True}, {"keep_prob": 0.7}, {"compute_dtype": "bfloat16"}])
+def test_stacked_evaluation_equals_one_pass_per_microbatch(gpu, kw_over, monkeypatch):
+    """Trainer.evaluate over k micro-batches in ONE engine call (tfk_eval_accumulate_stacked, reference trainer.py:356-441): in
+    evaluation mode rows are independent, so the stack is one pass over the concatenation -- for every activation chain, ragged
+    segments and single-row ones included.  Same frame count, the loss to the fp32 order of its sum; also when the stack is cut
+    into several passes (TFK_EVAL_PASS_ROWS)."""
+    from util import make_pair, batch
+    kw = dict(input_dim=40, num_layers=3, num_units=96, output_dim=30, nonlin="relu", batch_norm=True, init_learning_rate=1e-3,
+              num_steps=10)
+    kw.update(kw_over)
+    rng = np.random.default_rng(5)
+    eng, _ = make_pair(rng, **kw)
+    X0, y0 = batch(rng, 64, 40, 30)
+    eng.accumulate(X0, y0, last=True)  # (a step, so that the moving statistics are not the initial ones)
+    eng.apply()
+    rows = [57, 1, 130, 256, 33]
+    mbs = [batch(rng, r, 40, 30) for r in rows]
+    for X, y in mbs:
+        eng.eval_accumulate(X, y)
+    frames_seq = eng.scalar(5)  # NUM_FRAMES
+    want = eng.eval_finish()
+    Xs, ys = np.concatenate([m[0] for m in mbs], 0), np.concatenate([m[1] for m in mbs], 0)
+    tol = 2e-6 if kw.get("compute_dtype", "float32") != "bfloat16" else 2e-5
+    for cap in (None, "200", "1"):
+        if cap:
+            monkeypatch.setenv("TFK_EVAL_PASS_ROWS", cap)
+        eng.eval_accumulate_stacked(Xs, ys, rows)
+        assert eng.scalar(5) == frames_seq == sum(rows)
+        got = eng.eval_finish()
+        assert abs(got - want) <= tol * abs(want), (cap, got, want)
+    with pytest.raises(RuntimeError, match="hold"):
+        eng.eval_accumulate_stacked(Xs, ys, rows[:-1])
+    eng.close()

@@ -416,15 +416,19 @@ def test_async_gather_waits_layer_by_layer():
 def test_traffic_record_is_stamped_for_the_gemm_sources_of_this_tree():
     """bench.py drops `roofline.traffic` when profiles/hbm_traffic.json was measured on other kernels than the ones in this
     tree (round 2 lost the figure that way: a header edit for the feature path changed a hash that covered every source).
-    The stamp now covers exactly what the measured kernels compile from -- and this test fails when the record was
-    not re-measured (tools/profile_round.sh + tools/hbm_traffic.py) after the fp32 GEMM last changed."""
+    The stamp covers exactly what the measured kernels compile from -- and this test fails when a record was not re-measured
+    (tools/hbm_counters.sh + tools/hbm_traffic.py) after a GEMM last changed.  One record per BASELINE configuration and
+    arithmetic the bench runs (round 5: cfg3 / cfg4 counters, BASELINE configs[3] "rocprof GB/s reported")."""
     import json
     from tfkaldi_amd import build
-    assert set(build.TRAFFIC_STAMP_SOURCES) == {"gemm_f32.hip", "gemm_f32.h"}
-    rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-    assert rec["_meta"]["csrc_sha16"] == build.csrc_hash(), (
-        "profiles/hbm_traffic.json is stale: re-run tools/profile_round.sh + tools/hbm_traffic.py on the GPU box")
-    assert rec["gemm_f32_dual(dA+dW)"]["bytes_per_launch"] > 0
+    assert set(build.TRAFFIC_STAMP_SOURCES) == {"gemm_f32.hip", "gemm_f32.h", "gemm_bf16.hip", "gemm_bf16.h", "x3_layout.h"}
+    book = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    for key, dominant in (("cfg2/float32", "gemm_bf16x3_dual(dA+dW)"), ("cfg2/float32_mfma", "gemm_f32_dual(dA+dW)"),
+                          ("cfg3/bfloat16", "gemm_bf16_dual(dA+dW)"), ("cfg4/bfloat16", "gemm_bf16_dual(dA+dW)")):
+        rec = book[key]
+        assert rec["_meta"]["csrc_sha16"] == build.csrc_hash(), (
+            "profiles/hbm_traffic.json[%s] is stale: re-run tools/hbm_counters.sh + tools/hbm_traffic.py on the GPU box" % key)
+        assert rec[dominant]["bytes_per_launch"] > 0 and rec["_meta"]["bytes_per_step"] > 0
 
 
 def test_compat_install_takes_no_reference_path():

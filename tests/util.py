@@ -45,11 +45,11 @@ def make_pair(rng, output_too=True, **kw):
     """(Engine, OracleDNN) of the same shape holding the same parameters."""
     from tfkaldi_amd import _lib
     from tfkaldi_amd.engine import Engine
-    # "bfloat16": engine in mixed precision, oracle rounding GEMM operands.  TFK_TEST_DTYPE=float32x3 (tests/test_gpu_f32x3.py)
-    # re-runs the fp32 suites with the fp32 arithmetic emulated on the bf16 pipe: same oracle, same bounds
+    # "bfloat16": engine in mixed precision, oracle rounding GEMM operands.  "float32" (the default) = fp32 emulated on the bf16
+    # pipe; TFK_TEST_DTYPE=float32_mfma (tests/test_gpu_f32x3.py) re-runs the fp32 suites on the exact fp32 matrix instructions:
+    # same oracle, same bounds -- both claim to be fp32
     dtype = kw.get("compute_dtype", os.environ.get("TFK_TEST_DTYPE", "float32"))
-    # ("float32x3": fp32 emulated on the bf16 pipe -- the oracle is the fp32 one, the bounds are the fp32 bounds)
-    oracle = OracleDNN(gemm_dtype="float32" if dtype == "float32x3" else dtype, **oracle_kwargs(kw))
+    oracle = OracleDNN(gemm_dtype="float32" if dtype.startswith("float32") else dtype, **oracle_kwargs(kw))
     randomize(oracle, rng, output_too)
     cfg = _lib.make_config(max_frames=kw.get("max_frames", 256), seed=kw.get("seed", 1234), compute_dtype=dtype,
                            device=kw.get("device", 0), **oracle_kwargs(kw))

@@ -14,7 +14,30 @@ ABI_VERSION = 7
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
-DTYPES = {"float32": 0, "bfloat16": 1, "float32x3": 2}  # TFK_DTYPE_*: arithmetic of the GEMMs (bfloat16 = mixed precision)
+# Arithmetic of the contractions (tfkaldi_hip.h: TFK_DTYPE_*; parameters, statistics, loss, gradient sums and Adam are fp32 in
+# every mode):
+#   "float32"       the reference's arithmetic (fp32 `tf.matmul`, layer.py:52).  Since round 5 it runs EMULATED on the bf16 matrix
+#                   pipe -- every operand split exactly into three bf16 planes, six exact plane products accumulated in fp32
+#                   (TFK_DTYPE_F32X3; error bound and evidence: DESIGN.md 4) -- which is closer to float64 than the fp32 matrix
+#                   instruction chain and ~1.3x as fast.  "float32x3" names the same thing explicitly.
+#   "float32_mfma"  the exact fp32 matrix instructions (v_mfma_f32_32x32x2_f32; TFK_DTYPE_F32): the default of rounds 1-4.
+#   "bfloat16"      mixed precision: operands ROUNDED to bf16 (BASELINE cfg3 / cfg4).
+# env TFK_F32_ARITHMETIC = mfma | x3 overrides what "float32" means for the whole process (a site's policy, A/B runs).
+DTYPES = {"float32": 2, "float32x3": 2, "float32_mfma": 0, "bfloat16": 1}
+
+
+def resolve_dtype(name):
+    """the TFK_DTYPE_* value of a compute_dtype name"""
+    if name not in DTYPES:
+        raise ValueError("compute_dtype must be one of %s" % sorted(DTYPES))
+    if name == "float32":
+        policy = os.environ.get("TFK_F32_ARITHMETIC", "x3")
+        if policy not in ("x3", "mfma"):
+            raise ValueError("TFK_F32_ARITHMETIC=%r (x3 | mfma)" % policy)
+        return 0 if policy == "mfma" else 2
+    return DTYPES[name]
+
+
 WEIGHTS, BIASES, BN_BETA, BN_MOVING_MEAN, BN_MOVING_VAR = range(5)
 SLOT_PARAM, SLOT_GRAD, SLOT_ADAM_M, SLOT_ADAM_V = range(4)
 (GLOBAL_STEP, LEARNING_RATE_FACT, INITIALISED_LAYERS, ADAM_STEPS, BATCH_LOSS, NUM_FRAMES,
@@ -82,6 +105,9 @@ SYMBOLS = {
     "tfk_accumulate_stacked": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int]),
     "tfk_accumulate_stacked_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
                                            c_void_p, c_int32, c_int]),
+    "tfk_eval_accumulate_stacked": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int]),
+    "tfk_eval_accumulate_stacked_raw": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                                c_void_p, c_int32, c_int]),
     "tfk_accumulate_ctc": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int]),
     "tfk_eval_accumulate_ctc": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_int]),
@@ -92,6 +118,7 @@ SYMBOLS = {
     "tfk_posteriors_raw": (c_int, [_E, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                    c_int64, c_int]),
     "tfk_apply": (c_int, [_E, POINTER(c_float)]),
+    "tfk_apply_enqueue": (c_int, [_E]),
     "tfk_eval_accumulate": (c_int, [_E, c_void_p, c_int64, c_void_p, c_int32, c_int]),
     "tfk_eval_finish": (c_int, [_E, POINTER(c_float)]),
     "tfk_halve_learning_rate": (c_int, [_E]),
@@ -121,6 +148,8 @@ SYMBOLS = {
     "tfk_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "tfk_comm_backend": (c_char_p, [c_void_p]),
     "tfk_comm_apply": (c_int, [c_void_p, POINTER(c_float)]),
+    "tfk_comm_apply_enqueue": (c_int, [c_void_p]),
+    "tfk_comm_apply_end": (c_int, [c_void_p, POINTER(c_float)]),
     "tfk_comm_eval_finish": (c_int, [c_void_p, POINTER(c_float)]),
     "tfk_comm_idle": (c_int, [c_void_p]),
     "tfk_comm_finish_reduce": (c_int, [c_void_p]),
@@ -141,6 +170,7 @@ SYMBOLS = {
                              c_int, c_void_p, c_int, c_int]),
     "tfk_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int]),
+    "tfk_debug_poison_splitk": (c_int, [_E]),
     "tfk_split3": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int]),
     "tfk_gemm_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                 c_int]),
@@ -195,10 +225,20 @@ def load():
         fn.argtypes = args
     if lib.tfk_abi_version() != ABI_VERSION:
         raise ImportError("libtfkaldi_hip.so ABI %d != binding ABI %d" % (lib.tfk_abi_version(), ABI_VERSION))
-    built_from, tree = lib.tfk_build_id().decode(), source_id()
-    if built_from != tree and os.environ.get("TFK_ALLOW_STALE_LIB") != "1":
-        raise ImportError("%s was built from other sources (its build id %s, this tree %s): rebuild it with python -m "
-                          "tfkaldi_amd.build (TFK_ALLOW_STALE_LIB=1 loads it anyway)" % (path, built_from, tree))
+    if os.environ.get("TFK_ALLOW_STALE_LIB") != "1":
+        built_from = lib.tfk_build_id().decode()
+        try:
+            tree = source_id()
+        except (IOError, OSError) as exc:
+            # a deployment that ships the built library without its sources (a wheel, a container layer): there is nothing to
+            # compare the baked id with -- say so once and accept the library for what it says it is
+            import warnings
+            warnings.warn("tfkaldi_amd: cannot verify %s against its sources (%s); loading build %s as it is"
+                          % (path, exc, built_from))
+            tree = built_from
+        if built_from != tree:
+            raise ImportError("%s was built from other sources (its build id %s, this tree %s): rebuild it with python -m "
+                              "tfkaldi_amd.build (TFK_ALLOW_STALE_LIB=1 loads it anyway)" % (path, built_from, tree))
     _lib = lib
     return lib
 
@@ -214,8 +254,6 @@ def make_config(input_dim, num_layers, num_units, output_dim, nonlin="relu", bat
                 num_steps=1, max_frames=1024, seed=0, device=0, compute_dtype="float32"):
     if nonlin not in NONLIN:
         raise Exception('unkown nonlinearity')  # spelling as neuralNetworks/nnet.py:65
-    if compute_dtype not in DTYPES:
-        raise ValueError("compute_dtype must be one of %s" % sorted(DTYPES))
     c = TfkConfig()
     c.struct_size = ctypes.sizeof(TfkConfig)
     c.device = device
@@ -225,5 +263,5 @@ def make_config(input_dim, num_layers, num_units, output_dim, nonlin="relu", bat
     c.keep_prob = float(keep_prob)
     c.init_learning_rate, c.learning_rate_decay = float(init_learning_rate), float(learning_rate_decay)
     c.num_steps, c.max_frames, c.seed = int(num_steps), int(max_frames), int(seed)
-    c.compute_dtype = DTYPES[compute_dtype]
+    c.compute_dtype = resolve_dtype(compute_dtype)
     return c

@@ -22,15 +22,15 @@ def lib_path():
     return os.path.join(LIBDIR, LIBNAME)
 
 
-TRAFFIC_STAMP_SOURCES = ("gemm_f32.hip", "gemm_f32.h")
+TRAFFIC_STAMP_SOURCES = ("gemm_f32.hip", "gemm_f32.h", "gemm_bf16.hip", "gemm_bf16.h", "x3_layout.h")
 
 
 def csrc_hash():
-    """sha256 (first 16 hex digits) over the sources the fp32 GEMM kernels compile from -- nothing else.  It stamps
-    profiles/hbm_traffic.json, the PMC traffic figure of bench.py's dominant kernel (gemm_f32_dual / gemm_f32_kernel):
-    the figure is valid exactly as long as those kernels are unchanged.  (Round 2 hashed every source plus the public
-    header, so an enum added for the feature path invalidated the GEMM's traffic record; tests/test_host_logic.py now
-    fails when the committed record and this hash disagree.)"""
+    """sha256 (first 16 hex digits) over the sources the GEMM kernels compile from -- nothing else.  It stamps
+    profiles/hbm_traffic.json, the PMC traffic figures of bench.py's dominant kernels (one record per configuration and
+    arithmetic): a figure is valid exactly as long as those kernels are unchanged.  (Round 2 hashed every source plus the public
+    header, so an enum added for the feature path invalidated the GEMM's traffic record; tests/test_host_logic.py fails when the
+    committed record and this hash disagree.)"""
     import hashlib
     h = hashlib.sha256()
     for name in sorted(TRAFFIC_STAMP_SOURCES):

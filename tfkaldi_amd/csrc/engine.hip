@@ -290,6 +290,7 @@ void compute_layout(const tfk_config* c, std::vector<LayerLayout>& lay, size_t& 
 }
 
 constexpr size_t kScalarFloats = 64;
+constexpr int kErrWord = 8;  // index into h_scalars (mapped pinned memory): a kernel-reported failure, see check_kernel_errors
 // Mixed precision: when every weight matrix has a leading dimension that is a multiple of 8 the bf16 shadow mirrors the
 // fp32 arena element for element and lives at the END of the state arena (w_end bf16 values = w_end / 2 floats), so a
 // host that owns the arena (torch.distributed) can all-gather SHARDS OF THE SHADOW ITSELF -- half the bytes of the
@@ -463,6 +464,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
       }
       b.splitk_ws = e->ws_splitk;
       b.splitk_ws_floats = e->ws_splitk_floats;
+      b.err = reinterpret_cast<unsigned*>(e->h_scalars_dev + kErrWord);
     }
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
@@ -644,12 +646,16 @@ int reserve(tfk_engine* e, int T) {
     CHK(dev_alloc(e, (void**)&e->dY[s], (size_t)cap * sizeof(int32_t), false));
     CHK(grow_zero(e, &e->dA[s], (size_t)cap * e->ldH));
     HIPCHK(hipHostMalloc((void**)&e->hX[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
+    // (zeroed: a stacked pass copies whole padded slots to the device, and a padding row of the host buffer that happened to
+    //  hold a NaN bit pattern would poison dW = X^T dZ although its dZ row is zero -- pinned pages are not cleared by the driver)
+    memset(e->hX[s], 0, (size_t)cap * e->F * sizeof(float));
     HIPCHK(hipHostMalloc((void**)&e->hY[s], (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
     // raw frames: at most F columns (context 0); one utterance per frame at worst
     CHK(grow_zero(e, &e->dRaw[s], (size_t)cap * e->ldF));
     // utterance offsets [U + 1]; stacked passes add the utterances' output rows [U] and the row_vend table [cap / 64 + 1]
     CHK(dev_alloc(e, (void**)&e->dSeg[s], seg_ints(cap) * sizeof(int32_t), false));
     HIPCHK(hipHostMalloc((void**)&e->hRaw[s], (size_t)cap * e->F * sizeof(float), hipHostMallocDefault));
+    memset(e->hRaw[s], 0, (size_t)cap * e->F * sizeof(float));
     HIPCHK(hipHostMalloc((void**)&e->hSeg[s], seg_ints(cap) * sizeof(int32_t), hipHostMallocDefault));
     e->slot_used[s] = false;
   }
@@ -1092,6 +1098,19 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
 }
 
 // materialise the logical zeros of the scalar accumulators (only when something reads them before a micro-batch)
+// A kernel reported a failure the host could not see at launch time (today: a split-K block of the fp32-emulating
+// contraction whose partner's partial sums never arrived, gemm_bf16.h): the word sits in mapped pinned memory, so reading it
+// behind a synchronisation costs nothing.  Called wherever the engine hands results to the host.
+int check_kernel_errors(tfk_engine* e) {
+  volatile unsigned* w = reinterpret_cast<volatile unsigned*>(e->h_scalars + kErrWord);
+  if (*w == 0) return 0;
+  *w = 0;
+  if (e->ws_splitk)  // (flag words of the interrupted exchange may be left set: start the next launch from zeros)
+    (void)hipMemsetAsync(e->ws_splitk, 0, e->ws_splitk_floats * sizeof(float), e->stream);
+  return fail(-1, "split-K exchange timed out: a block of the fp32-emulating contraction waited ~1 s for its partner's partial "
+                  "sums (workspace not zeroed, or the partner block failed); the results of this step are invalid");
+}
+
 int settle_scalars(tfk_engine* e) {
   if (e->scalars_fresh) {
     HIPCHK(hipMemsetAsync(e->p_scalars(), 0, kScalarFloats * sizeof(float), e->stream));
@@ -1104,7 +1123,7 @@ int read_scalars(tfk_engine* e) {
   HIPCHK(hipMemcpyAsync(e->h_scalars, e->p_scalars(), 4 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->scalars_fresh = true;  // init_loss / init_num_frames
-  return 0;
+  return check_kernel_errors(e);
 }
 
 struct TensorRef {
@@ -1231,6 +1250,7 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   if (cfg->batch_norm)  // moving_variance initialises to 1, moving_mean to 0
     for (int l = 0; l < e->L; ++l) fill(e->stream, e->mov_var(l), (size_t)e->H, 1.0f);
   HIPB(hipHostMalloc((void**)&e->h_scalars, 16 * sizeof(float), hipHostMallocMapped));
+  memset(e->h_scalars, 0, 16 * sizeof(float));
   HIPB(hipHostGetDevicePointer((void**)&e->h_scalars_dev, e->h_scalars, 0));
   e->mean.assign(e->L, nullptr);
   e->rstd.assign(e->L, nullptr);
@@ -1998,6 +2018,77 @@ int tfk_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, c
   });
 }
 
+// ---- validation over several micro-batches in one call (reference neuralNetworks/trainer.py:356-441: one
+// update_valid_loss run per micro-batch).  In evaluation mode the rows of a micro-batch are independent -- batch norm normalises
+// with the MOVING statistics, dropout is the identity, L2Norm is row-wise -- so k runs are one pass of the GEMMs over the
+// concatenated rows: no per-segment statistics, no padding between segments, every activation chain.  Passes are cut at
+// micro-batch boundaries once they hold TFK_EVAL_PASS_ROWS rows (default 16384: bounds the activation buffers; one longer
+// micro-batch still runs alone).  batch_loss += the k sums and num_frames += T as k tfk_eval_accumulate calls leave them, up to
+// the fp32 order of the loss sum.
+static int eval_pass_rows() {
+  const char* q = getenv("TFK_EVAL_PASS_ROWS");
+  const int n = q ? atoi(q) : 16384;
+  return n > 0 ? n : 16384;
+}
+int tfk_eval_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, const int32_t* seg_rows,
+                                int32_t k, int flags) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (!X || !y || !seg_rows) return fail(-1, "X / y / seg_rows is NULL");
+  if (k <= 0) return fail(-1, "no micro-batch (k = %d)", k);
+  long total = 0;
+  for (int i = 0; i < k; ++i) {
+    if (seg_rows[i] <= 0) return fail(-1, "micro-batch %d of the stack is empty (%d rows)", i, seg_rows[i]);
+    total += seg_rows[i];
+  }
+  if (total != T) return fail(-1, "the micro-batches hold %ld rows, expected T = %d", total, T);
+  const int cap = eval_pass_rows();
+  for (int i0 = 0, r0 = 0; i0 < k;) {
+    int n = 0, rows = 0;
+    while (i0 + n < k && (n == 0 || rows + seg_rows[i0 + n] <= cap)) rows += seg_rows[i0 + n++];
+    CHK(train_or_eval(e, X + (size_t)r0 * ldx, ldx, y + r0, rows, flags & ~TFK_LAST_MICROBATCH, 0));
+    i0 += n;
+    r0 += rows;
+  }
+  return 0;
+}
+int tfk_eval_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,
+                                    const int32_t* utt_len, int32_t U, int32_t context_width, const float* cmvn,
+                                    const int32_t* seg_utts, int32_t k, int flags) {
+  if (!e) return fail(-1, "engine is NULL");
+  if (!raw || !y || !utt_len || !seg_utts) return fail(-1, "raw / y / utt_len / seg_utts is NULL");
+  if (flags & (TFK_DEVICE_PTRS | TFK_RAW_DEVICE)) return fail(-1, "tfk_eval_accumulate_stacked_raw takes host pointers");
+  if (k <= 0) return fail(-1, "no micro-batch (k = %d)", k);
+  const int win = 2 * context_width + 1;
+  if (context_width < 0 || e->F % win) return fail(-1, "input_dim %d is not a multiple of 2*context_width+1 = %d", e->F, win);
+  const int D = e->F / win;
+  std::vector<int> first_utt(k + 1, 0), first_row(k + 1, 0);
+  for (int i = 0; i < k; ++i) {
+    if (seg_utts[i] <= 0) return fail(-1, "micro-batch %d of the stack holds no utterance", i);
+    first_utt[i + 1] = first_utt[i] + seg_utts[i];
+    if (first_utt[i + 1] > U) return fail(-1, "the micro-batches hold more than U = %d utterances", U);
+    int rows = 0;
+    for (int u = first_utt[i]; u < first_utt[i + 1]; ++u) {
+      if (utt_len[u] < 0) return fail(-1, "negative utterance length");
+      rows += utt_len[u];
+    }
+    if (rows <= 0) return fail(-1, "micro-batch %d of the stack is empty", i);
+    first_row[i + 1] = first_row[i] + rows;
+  }
+  if (first_utt[k] != U || first_row[k] != T)
+    return fail(-1, "the micro-batches hold %d utterances / %d frames, expected U = %d / T = %d", first_utt[k], first_row[k], U, T);
+  const int cap = eval_pass_rows();
+  for (int i0 = 0; i0 < k;) {
+    int n = 1;
+    while (i0 + n < k && first_row[i0 + n + 1] - first_row[i0] <= cap) ++n;
+    const RawSpec r = {utt_len + first_utt[i0], first_utt[i0 + n] - first_utt[i0], context_width,
+                       cmvn ? cmvn + (size_t)first_utt[i0] * 2 * D : nullptr};
+    CHK(train_or_eval(e, raw + (size_t)first_row[i0] * ldraw, ldraw, y + first_row[i0], first_row[i0 + n] - first_row[i0],
+                      flags & ~TFK_LAST_MICROBATCH, 0, &r));
+    i0 += n;
+  }
+  return 0;
+}
+
 int tfk_accumulate_ctc(tfk_engine* e, const float* X, int64_t ldx, int32_t T, const int32_t* utt_len, int32_t U,
                        const int32_t* labels, const int32_t* label_len, int flags) {
   const CtcSpec c = {utt_len, U, labels, label_len};
@@ -2096,6 +2187,10 @@ int apply_end(tfk_engine* e, float* average_loss) {
   HIPCHK(hipEventSynchronize(e->ev_loss));
   e->grads_fresh = true;
   e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
+  if (check_kernel_errors(e)) {
+    if (average_loss) *average_loss = NAN;
+    return -1;
+  }
   if (!(e->h_scalars[1] > 0.f)) {
     // no frame reached this step (on any rank): G / num_frames is 0/0.  The optimiser kernel left the parameters
     // alone (adam_kernel); undo the step bookkeeping and say so instead of returning a NaN loss.
@@ -2123,6 +2218,15 @@ int tfk_apply_end(tfk_engine* e, float* average_loss) {
   if (!e) return fail(-1, "engine is NULL");
   HIPCHK(hipSetDevice(e->cfg.device));
   return apply_end(e, average_loss);
+}
+
+int tfk_apply_enqueue(tfk_engine* e) {
+  // tfk_apply without its wait: everything of the optimiser step is on the streams, tfk_apply_end collects the loss
+  if (!e) return fail(-1, "engine is NULL");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(apply_begin(e));
+  if (e->opt_overlap) return apply_overlapped(e);
+  return apply_span(e, 0, e->P);
 }
 
 int tfk_apply(tfk_engine* e, float* average_loss) {
@@ -2304,7 +2408,9 @@ static int posteriors_impl(tfk_engine* e, const float* X, int64_t ldx, int32_t N
 }
 
 int tfk_posteriors(tfk_engine* e, const float* X, int64_t ldx, int32_t N, float* out, int64_t ldo, int flags) {
-  return posteriors_impl(e, X, ldx, N, out, ldo, flags, nullptr);
+  const int rc = posteriors_impl(e, X, ldx, N, out, ldo, flags, nullptr);
+  // (host output: the pass has been waited for, so a kernel-reported failure is visible)
+  return (rc == 0 && !(flags & TFK_DEVICE_PTRS)) ? check_kernel_errors(e) : rc;
 }
 int tfk_posteriors_raw(tfk_engine* e, const float* raw, int64_t ldraw, int32_t N, const int32_t* utt_len, int32_t U,
                        int32_t context_width, const float* cmvn, float* out, int64_t ldo, int flags) {
@@ -2540,6 +2646,18 @@ int tfk_split3(void* stream, const float* src, int lds, uint16_t* dst, int ldd, 
   if ((ldd & 31) || ldd < cols) return fail(-1, "tfk_split3: ldd %d (a multiple of 32, >= cols)", ldd);
   to_bf16_rows((hipStream_t)stream, src, lds, dst, ldd, rows, cols, 1);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tfk_debug_poison_splitk(tfk_engine* e) {
+  // tests: leave a ticket of the split-K workspace taken, as an interrupted launch would -- the next fp32-emulating contraction
+  // that splits its K finds no "first" block for tile 0, both halves wait for the other's partial sums, time out, and the step
+  // must FAIL (check_kernel_errors) instead of handing out sums of garbage
+  if (!e) return fail(-1, "engine is NULL");
+  if (!e->ws_splitk) return fail(-1, "no split-K workspace yet (run a step of a shape that splits first)");
+  const unsigned one = 1;
+  HIPCHK(hipMemcpyAsync(e->ws_splitk, &one, sizeof(one), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
 

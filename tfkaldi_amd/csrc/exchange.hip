@@ -362,6 +362,7 @@ struct tfk_comm {
   bool masters_stale = false;
   std::vector<std::pair<size_t, size_t>> shard_spans;
   int verify_left = 2;
+  bool apply_enqueued = false, apply_sharded = false, apply_via_shadow = false;  // between tfk_comm_apply_enqueue and _end
   int error = 0;  // a failure inside an engine hook (cannot propagate through the hook): raised by the next call
   std::string error_text;
   // what ran in the last completed step (tfk_comm_last_step)
@@ -772,8 +773,13 @@ struct Phases {
 };
 Phases g_phases;
 
-int tfk_comm_apply(tfk_comm* c, float* average_loss) {
+// The exchange + optimiser step in two halves: ENQUEUE (everything up to the last parameter gather is on the streams; the host
+// has not waited for anything) and END (the host waits for the step's loss).  Between the two the host is free -- the place
+// for work that should run while the GPU is busy (the dispenser's prefetch of the next batch): round 4 ran that work BEFORE
+// the tail collectives, Adam and the gathers were launched, so a rank with slow I/O held every peer in its collectives.
+int tfk_comm_apply_enqueue(tfk_comm* c) {
   if (!c) return failx(-1, "comm is NULL");
+  if (c->apply_enqueued) return failx(-1, "tfk_comm_apply_enqueue twice without tfk_comm_apply_end");
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
   g_phases.start();
@@ -871,14 +877,28 @@ int tfk_comm_apply(tfk_comm* c, float* average_loss) {
   c->num_spans = 0;
   c->waited_upto = 0;
   g_phases.mark(4);
+  c->apply_enqueued = true;
+  c->apply_sharded = !sharded.empty();
+  c->apply_via_shadow = via_shadow;
+  return 0;
+}
+int tfk_comm_apply_end(tfk_comm* c, float* average_loss) {
+  if (!c) return failx(-1, "comm is NULL");
+  if (!c->apply_enqueued) return failx(-1, "tfk_comm_apply_end without tfk_comm_apply_enqueue");
+  c->apply_enqueued = false;
+  XHIP(hipSetDevice(c->device));
   XCHK(tfk_apply_end(c->e, average_loss));
   g_phases.mark(5);
   g_phases.calls += 1;
-  if (c->verify_left > 0 && !sharded.empty()) {
+  if (c->verify_left > 0 && c->apply_sharded) {
     c->verify_left -= 1;
-    XCHK(verify_replicas(c, via_shadow));
+    XCHK(verify_replicas(c, c->apply_via_shadow));
   }
   return 0;
+}
+int tfk_comm_apply(tfk_comm* c, float* average_loss) {
+  XCHK(tfk_comm_apply_enqueue(c));
+  return tfk_comm_apply_end(c, average_loss);
 }
 
 int tfk_comm_finish_reduce(tfk_comm* c) {

@@ -46,6 +46,10 @@ struct GemmArgsB {
   // left zero in its flag words by every launch.  nullptr: never split
   float* splitk_ws;
   size_t splitk_ws_floats;
+  // gemm_bf16x3, optional: a word the HOST can read (mapped pinned memory) that a block sets to 1 when its split-K partner's
+  // partial sums did not arrive within ~1 s (a workspace that was not zero, a partner that died): the launch's results are
+  // then wrong and the owner of the word must fail the call that waits for them.  nullptr: the timeout goes unreported
+  unsigned* err;
 };
 
 // Tile configurations.  0-2: register-staged ring of round 1 (64x64 / 128x64 / 128x128 per 4-wave block).

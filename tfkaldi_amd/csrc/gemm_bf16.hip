@@ -846,9 +846,12 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     if (tid == 0) {
       // (the bound -- about a second -- only keeps a broken workspace from hanging the device: the partner holds its
       // ticket, so it is running and a few microseconds from its store)
-      for (int spin = 0; spin < (1 << 23) && __hip_atomic_load(&flags[2 * tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-           ++spin)
+      int spin = 0;
+      for (; spin < (1 << 23) && __hip_atomic_load(&flags[2 * tile + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
         __builtin_amdgcn_s_sleep(2);
+      // timed out: what this block is about to add is not the partner's sum.  Say so where the host will look before it
+      // hands out anything computed from this launch (round 4 carried on silently).
+      if (spin == (1 << 23) && p.err) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       // (both words back to zero for the next launch: the other block is past them)
       __hip_atomic_store(&flags[2 * tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&flags[2 * tile + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -119,8 +119,37 @@ def _eval_accumulate(engine, mb):
             engine.eval_accumulate_ctc(mb.X, mb.utt_lens, mb.labels, mb.label_lens)
     elif isinstance(mb, RawMicroBatch):
         engine.eval_accumulate_raw(mb.raw, mb.y, mb.lens, mb.context_width, cmvn=mb.cmvn)
+    elif isinstance(mb, StackedRawMicroBatches):
+        engine.eval_accumulate_stacked_raw(mb.raw, mb.y, mb.lens, mb.context_width, mb.seg_utts, cmvn=mb.cmvn)
     else:
         engine.eval_accumulate(mb[0], mb[1])
+
+
+def _eval_accumulate_all(engine, mine):
+    """validation over this rank's micro-batches (reference trainer.py:356-441: one run per micro-batch).  Rows are independent
+    in evaluation mode, so plain (X, y) micro-batches go to the engine as ONE stacked pass (tfk_eval_accumulate_stacked: the
+    weights are read once, the GEMMs fill the chip); anything else (CTC, already stacked) one by one"""
+    plain = all(isinstance(mb, tuple) and len(mb) == 2 for mb in mine)
+    if plain and len(mine) > 1 and hasattr(engine, "eval_accumulate_stacked") and os.environ.get("TFK_STACK", "1") != "0":
+        import numpy as np
+        engine.eval_accumulate_stacked(np.concatenate([np.asarray(x, dtype=np.float32) for x, _ in mine], 0),
+                                       np.concatenate([np.asarray(y) for _, y in mine], 0), [len(y) for _, y in mine])
+        return
+    for mb in mine:
+        _eval_accumulate(engine, mb)
+
+
+def _run_overlap(overlap):
+    """the host work a step overlaps with the GPU (the dispenser's prefetch): run it, and hand back what it raised instead of
+    letting it unwind in the middle of the step -- the collective part of the step must complete on every rank first (a rank
+    that leaves early would hang its peers in their collectives); the caller re-raises after its wait"""
+    if overlap is None:
+        return None
+    try:
+        overlap()
+    except BaseException as exc:  # noqa: BLE001 (re-raised by the caller, once the step is complete)
+        return exc
+    return None
 
 
 def partition(num_items, world):
@@ -418,8 +447,9 @@ class BucketReducer(object):
                              else "all_gather_into_tensor")
         return d.all_gather_into_tensor(whole, own, group=self.group, async_op=True)
 
-    def finish_and_apply(self, engine):
-        """The optimiser step pipelined behind the collectives: the engine's stream waits for the (small, early)
+    def finish_and_apply(self, engine, overlap=None):
+        """(`overlap`: host work to run once EVERYTHING of the step is launched -- collectives, Adam, gathers -- and before the
+        host waits for the loss.)  The optimiser step pipelined behind the collectives: the engine's stream waits for the (small, early)
         collective that carries the scalars, starts the step (tfk_apply_begin), then waits for each remaining
         collective in launch order and runs Adam on exactly the span of parameters whose gradient sum this rank now
         holds (tfk_apply_span) while the later collectives are still in flight; a reduce-scattered span's updated
@@ -427,7 +457,11 @@ class BucketReducer(object):
         (tfk_apply_end)."""
         if not hasattr(engine, "apply_span"):
             self.finish()
-            return engine.apply()
+            failed = _run_overlap(overlap)
+            loss = engine.apply()
+            if failed is not None:
+                raise failed
+            return loss
         t0 = time.perf_counter()
         self._launch()
         self._raise_errors()
@@ -483,12 +517,17 @@ class BucketReducer(object):
         self.last_launched, self.launched = self.launched, []
         self.last_kinds, self.kinds = self.kinds, []
         self.last_executed, self.executed = self.executed, []
+        self.host_s["finish_and_apply"] += time.perf_counter() - t0
+        failed = _run_overlap(overlap)
+        t0 = time.perf_counter()
         loss = engine.apply_end()
         if self.verify_left > 0 and sharded:
             self.verify_left -= 1
             self.verify_replicas(engine, via_shadow)
         self.host_s["finish_and_apply"] += time.perf_counter() - t0
         self.host_calls["finish_and_apply"] += 1
+        if failed is not None:
+            raise failed
         return loss
 
     def verify_replicas(self, engine, via_shadow):
@@ -629,14 +668,22 @@ class NativeExchange(object):
         """(tests) every collective of the step launched and awaited on the engine stream, the optimiser not yet run"""
         self._check(self.lib.tfk_comm_finish_reduce(self._h))
 
-    def finish_and_apply(self, engine):
+    def finish_and_apply(self, engine, overlap=None):
+        """tail collectives, Adam on this rank's spans and the parameter gathers launched (tfk_comm_apply_enqueue), then
+        `overlap()` -- host work while the GPU is busy --, then the wait for the loss (tfk_comm_apply_end)"""
         import ctypes
         t0 = time.perf_counter()
         loss = ctypes.c_float()
-        self._check(self.lib.tfk_comm_apply(self._h, ctypes.byref(loss)))
+        self._check(self.lib.tfk_comm_apply_enqueue(self._h))
+        self.host_s["finish_and_apply"] += time.perf_counter() - t0
+        failed = _run_overlap(overlap)
+        t0 = time.perf_counter()
+        self._check(self.lib.tfk_comm_apply_end(self._h, ctypes.byref(loss)))
         self.host_s["finish_and_apply"] += time.perf_counter() - t0
         self.host_calls["finish_and_apply"] += 1
         self._last_step()
+        if failed is not None:
+            raise failed
         return float(loss.value)
 
     def _last_step(self):
@@ -664,6 +711,90 @@ class NativeExchange(object):
 
     def gather_masters(self, engine):
         self._check(self.lib.tfk_comm_gather_masters(self._h))
+
+
+XGMI_LINK_GBPS = 153.0  # MI355X: 7 xGMI links per GPU, point to point, ~153 GB/s per direction each (8-GPU full mesh)
+
+
+def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="sharded", min_bytes=64 << 20, gather_elem_bytes=4,
+                   fixed_ms=0.045, link_gbps=XGMI_LINK_GBPS):
+    """What the exchange step of a `world`-GPU job should cost, from one GPU's measured step -- a PREDICTION to hold the first
+    real scaling line against (no multi-GPU node was available to any round of this build; reference seam
+    neuralNetworks/trainer.py:165-184).
+
+    buckets: the engine's announcements [(offset, floats)]: W_L .. W_0 in backward order, then the vectors, then the scalar +
+    BN tail.  fwd_ms / bwd_ms / adam_ms / step_ms: one rank's forward (incl. loss), backward, optimiser and whole-step time.
+    Model: weight buckets coalesce into spans of >= min_bytes in announcement order (BucketReducer.on_bucket /
+    csrc/exchange.hip); a span is ready when the backward pass has produced its last (lowest) layer, backward time spread
+    evenly over the layers; collectives of one communicator run one after the other.  Two wire models per collective over the
+    full mesh: `direct` -- every rank exchanges its 1/world sub-spans with all world - 1 peers at once, one sub-span per link
+    (what a reduce-scatter / all-gather IS on point-to-point links) -- and `ring` (one link's rate bounds the whole transfer).
+    sharded: reduce-scatter 4 B/param in, Adam on 1/world of the span, all-gather gather_elem_bytes/param out (2 with the bf16
+    shadow), the gathers hidden under the next forward pass except the first span's; allreduce: both halves before a full
+    Adam.  fixed_ms: stream bookkeeping measured with one RCCL rank (profiles/r04_dp_overhead.txt)."""
+    L1 = len(buckets) - 2  # weight matrices
+    min_floats = max(1, min_bytes // 4)
+    spans, lo = [], None
+    for b in range(L1):  # announcement order: W_L first
+        off, n = buckets[b]
+        if lo is None:
+            lo, hi, first = off, off + n, b
+        elif off + n == lo:
+            lo = off
+        elif off == hi:
+            hi = off + n
+        else:
+            spans.append((lo, hi - lo, first, b - 1))
+            lo, hi, first = off, off + n, b
+        if hi - lo >= min_floats:
+            spans.append((lo, hi - lo, first, b))
+            lo = None
+    if lo is not None:
+        spans.append((lo, hi - lo, first, L1 - 1))
+    tail = sum(n for _, n in buckets[L1:])
+    per_layer_bwd = bwd_ms / float(L1)
+    out = {"world": world, "mode": mode, "link_GBps_per_direction": link_gbps, "links_used": world - 1, "spans": [],
+           "min_span_bytes": min_bytes}
+
+    def wire_ms(bytes_total, kind):
+        """one in-place collective over `bytes_total` bytes per rank buffer"""
+        shard = bytes_total / float(world)
+        if kind == "direct":
+            return shard / (link_gbps * 1e9) * 1e3            # world - 1 links in parallel, one shard each
+        return shard * (world - 1) / (link_gbps * 1e9) * 1e3  # ring: world - 1 steps over one link
+
+    for model in ("direct", "ring"):
+        t = 0.0  # the communicator's clock, from the start of backward
+        for i, (off, n, b0, b1) in enumerate(spans):
+            ready = (b1 + 1) * per_layer_bwd
+            cost = wire_ms(4.0 * n, model) * (1 if mode == "sharded" else 2)
+            t = max(t, ready) + cost
+            if model == "direct":
+                out["spans"].append({"offset": off, "floats": n, "layers": [L1 - 1 - b1, L1 - 1 - b0], "ready_ms_into_backward": ready,
+                                     "reduce_ms_direct": cost})
+            else:
+                out["spans"][i]["reduce_ms_ring"] = cost
+        t += wire_ms(4.0 * tail, model) * 2  # vectors + scalar tail: all-reduced behind the last backward kernel
+        exposed_reduce = max(0.0, t - bwd_ms)
+        p_w = sum(n for _, n, _, _ in spans)
+        if mode == "sharded":
+            first_gather = wire_ms(float(gather_elem_bytes) * spans[-1][1], model) if spans else 0.0  # (layer 0's span: read first)
+            all_gather = wire_ms(float(gather_elem_bytes) * p_w, model)
+            # the remaining gathers run under the next forward pass; they show only if they outlast it
+            exposed_gather = first_gather + max(0.0, (all_gather - first_gather) - fwd_ms)
+            adam = adam_ms / world
+        else:
+            exposed_gather, adam = 0.0, adam_ms
+        out["exposed_ms_" + model] = {"reduce": exposed_reduce, "gather": exposed_gather}
+        out["predicted_ms_per_step_" + model] = step_ms - adam_ms + adam + exposed_reduce + exposed_gather + fixed_ms
+    out["wire_bytes_per_rank_per_step"] = {
+        "reduce_scatter_in_out" if mode == "sharded" else "all_reduce_in_out": 4.0 * p_w * (world - 1) / world * (1 if mode == "sharded" else 2),
+        "all_gather_in_out": (float(gather_elem_bytes) * p_w * (world - 1) / world) if mode == "sharded" else 0.0,
+        "tail_all_reduce": 8.0 * tail * (world - 1) / world}
+    out["overlap_window_ms"] = bwd_ms - (out["spans"][0]["ready_ms_into_backward"] if out["spans"] else 0.0)
+    out["single_rank"] = {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "adam_ms": adam_ms, "step_ms": step_ms, "fixed_ms": fixed_ms}
+    out["predicted_weak_scaling_efficiency_direct"] = step_ms / out["predicted_ms_per_step_direct"]
+    return out
 
 
 class DataParallel(object):
@@ -810,14 +941,23 @@ class DataParallel(object):
     def train_own(self, engine, mine, later, overlap=None):
         """One optimiser step from THIS rank's micro-batches only (`later` = micro-batches of the step that belong to
         higher ranks: the BN moving averages compose in the reference's serial order).  `overlap`, if given, is called once
-        the rank's last micro-batch is enqueued and before the host waits for the step: the place for host work that
-        should run while the GPU is busy (the dispenser's prefetch of the next batch)."""
+        the WHOLE step is enqueued -- micro-batches, tail collectives, optimiser, parameter gathers -- and before the host
+        waits for its loss: the place for host work that should run while the GPU is busy (the dispenser's prefetch of the
+        next batch).  What it raises is re-raised after the step has completed (under data parallelism the peers are waiting
+        in collectives this rank must still take part in)."""
         if not self.enabled:
             for i, mb in enumerate(mine):
                 _accumulate(engine, mb, i == len(mine) - 1)
-            if overlap is not None:
-                overlap()
-            return engine.apply()
+            if overlap is None or not hasattr(engine, "apply_enqueue"):
+                failed = _run_overlap(overlap)
+                loss = engine.apply()
+            else:
+                engine.apply_enqueue()
+                failed = _run_overlap(overlap)
+                loss = engine.apply_end()
+            if failed is not None:
+                raise failed
+            return loss
         engine.set_later_microbatches(later)
         reducer = self.reducer(engine)
         reducer.begin_step(engine)
@@ -828,9 +968,7 @@ class DataParallel(object):
                 reducer.idle(engine)
         finally:
             reducer.end_step(engine)
-        if overlap is not None:
-            overlap()
-        loss = reducer.finish_and_apply(engine)
+        loss = reducer.finish_and_apply(engine, overlap)
         self.last_collectives = reducer.last_launched
         self.last_kinds = reducer.last_kinds
         self.last_executed = reducer.last_executed  # names of the torch.distributed calls that really ran
@@ -845,8 +983,7 @@ class DataParallel(object):
 
     def eval_own(self, engine, mine):
         """validation loss from THIS rank's micro-batches (all of them in a single-process run)"""
-        for mb in mine:
-            _eval_accumulate(engine, mb)
+        _eval_accumulate_all(engine, mine)
         if not self.enabled:
             return engine.eval_finish()
         if not mine:  # nothing on this rank: contribute physical zeros (the accumulators reset lazily)

@@ -282,6 +282,27 @@ class Engine(object):
                                                   cmvn_ptr, seg.ctypes.data_as(c_void_p), seg.size,
                                                   _lib.LAST_MICROBATCH if last else 0))
 
+    def eval_accumulate_stacked(self, X, y, seg_rows):
+        """Trainer.evaluate's micro-batches X[rows_0 + rows_1 + ..., F] back to back in ONE call: rows are independent in
+        evaluation mode, so the engine runs one pass of the GEMMs over all of them (tfk_eval_accumulate_stacked)"""
+        X, y = self._host_batch(X, y)
+        seg = np.ascontiguousarray(seg_rows, dtype=np.int32)
+        check(self.lib.tfk_eval_accumulate_stacked(self._h, X.ctypes.data_as(c_void_p), X.shape[1], y.ctypes.data_as(c_void_p),
+                                                   X.shape[0], seg.ctypes.data_as(c_void_p), seg.size, 0))
+
+    def eval_accumulate_stacked_raw(self, raw, y, lens, context_width, seg_utts, cmvn=None):
+        """the same from unspliced frames (CMVN + splice on the device), seg_utts utterances per micro-batch"""
+        raw, lens = self._raw_batch(raw, lens)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        seg = np.ascontiguousarray(seg_utts, dtype=np.int32)
+        cmvn, cmvn_ptr = self._cmvn_table(cmvn, raw, lens)
+        if y.shape != (raw.shape[0],):
+            raise ValueError("targets %s do not match %d frames" % (y.shape, raw.shape[0]))
+        check(self.lib.tfk_eval_accumulate_stacked_raw(self._h, raw.ctypes.data_as(c_void_p), raw.shape[1],
+                                                       y.ctypes.data_as(c_void_p), raw.shape[0], lens.ctypes.data_as(c_void_p),
+                                                       lens.size, int(context_width), cmvn_ptr, seg.ctypes.data_as(c_void_p),
+                                                       seg.size, 0))
+
     def eval_accumulate_raw(self, raw, y, lens, context_width, cmvn=None):
         raw, lens = self._raw_batch(raw, lens)
         y = np.ascontiguousarray(y, dtype=np.int32)
@@ -374,6 +395,10 @@ class Engine(object):
         loss = c_float()
         check(self.lib.tfk_apply(self._h, byref(loss)))
         return float(loss.value)
+
+    def apply_enqueue(self):
+        """the optimiser step on the streams, not waited for: apply_end() collects the loss"""
+        check(self.lib.tfk_apply_enqueue(self._h))
 
     def eval_accumulate(self, X, y):
         X, y = self._host_batch(X, y)

@@ -37,8 +37,9 @@ class DNN(Classifier):
 
     def __init__(self, output_dim, num_layers, num_units, activation, layerwise_init=True,
                  compute_dtype="float32"):
-        """(reference dnn.py:17-35) + compute_dtype: "float32" = the reference's arithmetic, "bfloat16" = mixed
-        precision (bf16 MFMA contractions, everything else fp32; BASELINE cfg3 / cfg4)"""
+        """(reference dnn.py:17-35) + compute_dtype: "float32" = the reference's arithmetic (emulated exactly-split on the
+        bf16 matrix pipe; "float32_mfma" = the exact fp32 matrix instructions), "bfloat16" = mixed precision (bf16 MFMA
+        contractions, everything else fp32; BASELINE cfg3 / cfg4) -- tfkaldi_amd/_lib.py: DTYPES"""
         super(DNN, self).__init__(output_dim)
         self.num_layers = num_layers
         self.num_units = num_units

@@ -46,7 +46,7 @@ class Nnet(object):
         os.makedirs(os.path.join(self.conf['savedir'], 'training'), exist_ok=True)
         self.input_dim = (1 + 2 * int(self.conf['context_width'])) * input_dim  # after the +-context splice
         grows = int(self.conf['add_layer_period']) > 0
-        # optional key compute_dtype = float32 (default, the reference's arithmetic) | bfloat16 (mixed precision)
+        # optional key compute_dtype = float32 (default, the reference's arithmetic) | float32_mfma | bfloat16 (_lib.DTYPES)
         self.dnn = DNN(num_labels, int(self.conf['num_hidden_layers']), int(self.conf['num_hidden_units']),
                        _activation_chain(self.conf), grows, compute_dtype=self.conf.get('compute_dtype', 'float32'))
 

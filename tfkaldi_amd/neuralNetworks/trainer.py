@@ -248,7 +248,7 @@ class Trainer(object, metaclass=ABCMeta):
             self._selector = MicrobatchSelector(self.numutterances_per_minibatch, self.dp.rank, self.dp.world)
         return self._selector
 
-    def _packed_microbatches(self, batch, stack=False):
+    def _packed_microbatches(self, batch, stack=False, train=True):
         """the micro-batches of a PackedBatch as the engine takes them; stack: ONE object for all of them (training with
         the cross-enthropy loss: the engine runs consecutive micro-batches as one pass of the GEMMs when it can)"""
         out = []
@@ -257,7 +257,9 @@ class Trainer(object, metaclass=ABCMeta):
             bad = int(np.flatnonzero(batch.lens != batch.target_lens)[0])
             raise ValueError("utterance %s: %d input frames but %d targets (the cross-enthropy trainer needs equal "
                              "lengths)" % (batch.utt_ids[bad], batch.lens[bad], batch.target_lens[bad]))
-        if stack and ce and len(batch.groups) > 1 and hasattr(self.engine, "accumulate_stacked_raw"):
+        entry = "accumulate_stacked_raw" if train else "eval_accumulate_stacked_raw"
+        if stack and ce and len(batch.groups) > 1 and hasattr(self.engine, entry) and (
+                train or os.environ.get("TFK_STACK", "1") != "0"):
             return [StackedRawMicroBatches(batch.frames, batch.targets, batch.lens, batch.context_width, batch.cmvn,
                                            [u1 - u0 for u0, u1, _, _, _, _ in batch.groups])]
         for u0, u1, r0, r1, t0, t1 in batch.groups:
@@ -285,7 +287,8 @@ class Trainer(object, metaclass=ABCMeta):
         """Trainer.evaluate for a PackedBatch selected with self.selector(); None when there is no data"""
         if batch is None:
             return None
-        return self.dp.eval_own(self.engine, self._packed_microbatches(batch))
+        # (one stacked pass over all of this rank's micro-batches: rows are independent in evaluation mode)
+        return self.dp.eval_own(self.engine, self._packed_microbatches(batch, stack=True, train=False))
 
     def halve_learning_rate(self):
         self.engine.halve_learning_rate()

@@ -76,9 +76,14 @@ class ArkReader(object):
         nbytes = rows * cols * dtype.itemsize
         if out.dtype != dtype or out.nbytes != nbytes or not out.flags.c_contiguous:
             raise ValueError("read_into: the buffer does not match the %d x %d %s matrix" % (rows, cols, dtype))
-        got = os.preadv(fd, [memoryview(out).cast("B")], offset) if nbytes else 0
-        if got != nbytes:
-            raise IOError("short read in %s: %d of %d bytes" % (self.scp_data[index][0], got, nbytes))
+        # one positioned read in the common case; a read may legally return fewer bytes than asked for (network / FUSE file
+        # systems, signals, the kernel's 0x7ffff000 cap per call): carry on where it stopped, and only an END OF FILE is an error
+        view, got = memoryview(out).cast("B"), 0
+        while got < nbytes:
+            n = os.preadv(fd, [view[got:]], offset + got)
+            if n <= 0:
+                raise IOError("unexpected end of %s: %d of %d bytes of the matrix" % (self.scp_data[index][0], got, nbytes))
+            got += n
         self.bytes_read += nbytes
 
     def read_utt_data(self, index):

@@ -144,6 +144,11 @@ class BatchDispenser(object, metaclass=ABCMeta):
         return hasattr(self.feature_reader, "next_entry")
 
     def _produce(self, select, num_utt):
+        # WHERE the normalisation and the splice happen on this path is fixed: float32 archives with float32 statistics travel
+        # raw and are normalised + spliced in HBM (bit-identical to the host's arithmetic: tests/test_gpu_device_splice.py,
+        # tests/test_packed_feed.py), float64 data is normalised on the host in float64 as the reference does.  The reader's
+        # `cmvn_on_device` / `splice_on_device` flags select the same thing for get_utt() / get_batch() ONLY; a user who wants the
+        # host to do this work feeds the reference's way (`[nnet] packed_feed = False`, trainer.update(*dispenser.get_batch())).
         reader = self.feature_reader
         ark_reader = reader.reader
         plan, warnings = self._plan(num_utt)

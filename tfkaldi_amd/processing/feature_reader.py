@@ -49,6 +49,8 @@ def cmvn_table(utterances):
 
 class FeatureReader(object):
     """Reads features from a Kaldi archive, mean/variance-normalises them per speaker and splices them.
+    (These two flags concern get_utt() and everything built on it -- get_batch(), Decoder input.  The packed feed,
+    BatchDispenser.next_packed, always defers both steps to the device for float32 data: same bits, see there.)
     With splice_on_device=True get_utt() returns `Unspliced` frames (same None-when-too-short rule) and the
     splice happens in HBM; cmvn_on_device=True (implies splice_on_device) also defers the normalisation: the
     frames stay as read from the ark and carry their speaker's (mean, std) table.  Archives that are not float32
