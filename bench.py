@@ -296,6 +296,42 @@ def decode_leg(w, eng, batches):
     return out
 
 
+def eval_leg(w, eng, batches):
+    """Validation (reference neuralNetworks/trainer.py:356-441, nnet.py:168-207): the loss of 8 held-out micro-batches in
+    evaluation mode, host frames in, as ONE stacked pass (tfk_eval_accumulate_stacked: rows are independent in evaluation mode)
+    and as the reference's one run per micro-batch.  Median of 5; frames/s and the forward contractions' share of the matrix peak."""
+    mbs = batches[:8]
+    Xs = np.ascontiguousarray(np.concatenate([b[0] for b in mbs], 0))
+    ys = np.concatenate([b[1] for b in mbs], 0)
+    rows = [len(b[1]) for b in mbs]
+
+    def stacked():
+        eng.eval_accumulate_stacked(Xs, ys, rows)
+        return eng.eval_finish()
+
+    def one_by_one():
+        for X, y in mbs:
+            eng.eval_accumulate(X, y)
+        return eng.eval_finish()
+
+    def med(fn):
+        fn(); fn()
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            loss = fn()
+            times.append(time.perf_counter() - t0)
+        return sorted(times)[2], loss
+    t_st, l_st = med(stacked)
+    t_seq, l_seq = med(one_by_one)
+    frames = int(Xs.shape[0])
+    return {"unit": "frames/s", "frames": frames, "microbatches": len(mbs), "value": frames / t_st,
+            "one_pass_per_microbatch": frames / t_seq, "stacked_over_sequential": t_seq / t_st,
+            "loss_stacked": l_st, "loss_sequential": l_seq, "flop_per_frame": 2 * w.macs,
+            "step_frac_of_peak": frames / t_st * 2 * w.macs / 1e12 / w.peak,
+            "note": "host numpy in (PCIe inside the clock), loss out; forward only"}
+
+
 def kernel_label(w, family):
     """the engine names its kernel families after the fp32 kernels; say which arithmetic actually ran"""
     return family.replace("gemm_f32", {"float32": "gemm_bf16x3", "float32_mfma": "gemm_f32", "bfloat16": "gemm_bf16"}[w.dtype])
@@ -317,6 +353,11 @@ def api_fed_leg(w, world, steps):
         for key, packed in (("api_fed_value_recipe", True), ("api_fed_value_recipe_list_feed", False)):
             out[key] = measure(w.name, 8 * UTT_PER_GPU, UTT_PER_GPU, 20 + 4, 4, packed=packed, utt_len=w.utt_len,
                                compute_dtype=w.dtype)["value"]
+        # ... and with the recipe's validation inside the clock: 2 held-out batches evaluated every 10 steps (nnet.py:168-207)
+        out["api_fed_value_recipe_with_validation"] = measure(
+            w.name, 8 * UTT_PER_GPU, UTT_PER_GPU, 30 + 4, 4, packed=True, utt_len=w.utt_len, compute_dtype=w.dtype,
+            valid_batches=2, valid_frequency=10)["value"]
+        out["validation_cost"] = 1.0 - out["api_fed_value_recipe_with_validation"] / out["api_fed_value_recipe"]
     out["api_fed_note"] = ("frames/s of Nnet.train (reference nnet.py:80-244) on a synthetic ark corpus: ark reads, batch "
                            "dispenser, micro-batch construction, PCIe, engine, printed loss line -- everything between two "
                            "optimiser steps.  api_fed_value: %d utterances x %d frames per GPU per step (the work of "
@@ -574,10 +615,13 @@ def main():
         shadow_gather = args.dtype == "bfloat16"  # (mixed precision gathers the bf16 shadow: 2 B per parameter)
         mode = (reducer.mode if reducer else (args.exchange or os.environ.get("TFK_DP_EXCHANGE", "sharded")))
         min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", "64")) * (1 << 20))
+        wire = "bf16" if os.environ.get("TFK_DP_WIRE") == "bf16" else "fp32"
+        out["exchange_wire"] = getattr(reducer, "wire", "fp32") if reducer else None
         out["exchange_model"] = {
             "note": "predicted from one rank's measured kernel times; weak scaling (the step of every rank is this step)",
             "per_world": {str(n): exchange_model(eng.buckets(), n, fwd_ms, bwd_ms, adam_ms, step_single, mode=mode, min_bytes=min_bytes,
-                                                 gather_elem_bytes=2 if shadow_gather and mode == "sharded" else 4)
+                                                 gather_elem_bytes=2 if shadow_gather and mode == "sharded" else 4,
+                                                 reduce_elem_bytes=2 if wire == "bf16" and mode == "sharded" else 4)
                           for n in ([world] if world > 1 else [2, 4, 8])}}
         if world > 1:
             m = out["exchange_model"]["per_world"][str(world)]
@@ -608,6 +652,8 @@ def main():
             out["posterior_max_err"] = posterior_error(w, eng, batches[0][0][:w.utt_len])
         if world == 1 and not args.no_decode:
             out["decode"] = decode_leg(w, eng, batches)
+        if world == 1 and not args.no_eval:
+            out["eval"] = eval_leg(w, eng, batches)
         if world == 1 and args.dtype.startswith("float32") and not args.no_other:
             other = "float32_mfma" if args.dtype == "float32" else "float32"
             out["exact_fp32" if other == "float32_mfma" else "emulated_fp32"] = other_arithmetic_leg(

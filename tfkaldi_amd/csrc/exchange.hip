@@ -72,6 +72,9 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  // (only the bf16 wire format needs these two: bound without complaint, checked where they are used)
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   std::string error;
 };
 Rccl* rccl() {
@@ -106,6 +109,8 @@ Rccl* rccl() {
     BIND(GroupStart, "ncclGroupStart");
     BIND(GroupEnd, "ncclGroupEnd");
 #undef BIND
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.handle, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.handle, "ncclRecv"));
   });
   return &r;
 }
@@ -124,6 +129,8 @@ struct Backend {
   // every rank's shard (bytes_per_rank at rank * bytes_per_rank) -> all shards everywhere
   virtual int all_gather(void* buf, size_t bytes_per_rank, hipStream_t st) = 0;
   virtual int all_reduce(float* buf, size_t count, hipStream_t st) = 0;
+  // all-to-all of byte blocks: send[q * bytes, +bytes) goes to rank q's recv[rank * bytes, +bytes) (own block included)
+  virtual int exchange_shards(const void* send, void* recv, size_t bytes, hipStream_t st) = 0;
   // host-level: v[0] = min over ranks, v[1] = max over ranks of the value passed in v[0] (blocks the calling thread)
   virtual int min_max(unsigned long long* v, hipStream_t st) = 0;
   // the collectives posted between the two calls (all on ONE stream) may be launched as one operation
@@ -150,6 +157,25 @@ struct RcclBackend : Backend {
   }
   int all_reduce(float* buf, size_t count, hipStream_t st) override {
     XNCCL(rccl()->AllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, st));
+    return 0;
+  }
+  int exchange_shards(const void* send, void* recv, size_t bytes, hipStream_t st) override {
+    Rccl* r = rccl();
+    if (!r->Send || !r->Recv) return failx(-1, "this RCCL has no ncclSend / ncclRecv: TFK_DP_WIRE=bf16 is not available");
+    const char* s = static_cast<const char*>(send);
+    char* d = static_cast<char*>(recv);
+    // one group: every rank sends world blocks and receives world blocks over its world - 1 links at once -- on point-to-point
+    // xGMI this IS the direct reduce-scatter's data movement, at half the bytes
+    XNCCL(r->GroupStart());
+    for (int q = 0; q < world; ++q) {
+      ncclResult_t a = r->Send(s + (size_t)q * bytes, bytes, ncclInt8, q, comm, st);
+      ncclResult_t b = a == ncclSuccess ? r->Recv(d + (size_t)q * bytes, bytes, ncclInt8, q, comm, st) : a;
+      if (b != ncclSuccess) {
+        (void)r->GroupEnd();
+        return failx((int)b, "ncclSend / ncclRecv failed: %s", r->GetErrorString(b));
+      }
+    }
+    XNCCL(r->GroupEnd());
     return 0;
   }
   int min_max(unsigned long long* v, hipStream_t st) override {
@@ -187,6 +213,23 @@ __global__ void loop_sum_kernel(float* __restrict__ dst, SrcList src, int world,
   }
 }
 
+// ---- bf16 wire format of the gradient reduce-scatter (TFK_DP_WIRE=bf16) ----
+// pack: send[i] = bf16(round to nearest even) of g[i], the whole span (world sub-spans of `per` floats back to back)
+__global__ void wire_pack_kernel(const float* __restrict__ g, uint16_t* __restrict__ send, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    send[i] = __builtin_bit_cast(uint16_t, (__bf16)g[i]);
+}
+// sum: shard[i] = sum over ranks q, in rank order, of (q == rank ? this rank's own fp32 value : the bf16 value rank q sent);
+// fp32 accumulate on the owner, the owner's own contribution exact (world = 1 is the identity)
+__global__ void wire_sum_kernel(float* __restrict__ shard, const uint16_t* __restrict__ recv, int rank, int world, size_t per) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < world; ++q)
+      s += q == rank ? shard[i] : __builtin_bit_cast(float, (uint32_t)recv[(size_t)q * per + i] << 16);
+    shard[i] = s;
+  }
+}
+
 }  // namespace
 
 struct tfk_loopback {
@@ -196,8 +239,9 @@ struct tfk_loopback {
   int arrived = 0;
   unsigned long long generation = 0;
   struct Slot {
-    int kind = 0;  // 0 reduce-scatter, 1 all-gather, 2 all-reduce, 3 min / max
+    int kind = 0;  // 0 reduce-scatter, 1 all-gather, 2 all-reduce, 3 min / max, 4 all-to-all of byte blocks
     void* buf = nullptr;
+    const void* send = nullptr;  // (kind 4: buf = recv)
     size_t count = 0;  // per-rank floats (0), per-rank bytes (1), floats (2)
     hipStream_t st = nullptr;
     hipEvent_t arrive = nullptr, finish = nullptr;
@@ -252,6 +296,11 @@ struct LoopBackend : Backend {
         const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
         hipLaunchKernelGGL(loop_sum_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, g->slot[r].st, dst, src, W, n);
       }
+    } else if (s0.kind == 4) {
+      for (int r = 0; r < W; ++r)
+        for (int q = 0; q < W; ++q)
+          XHIP(hipMemcpyAsync(static_cast<char*>(g->slot[r].buf) + (size_t)q * n,
+                              static_cast<const char*>(g->slot[q].send) + (size_t)r * n, n, hipMemcpyDeviceToDevice, g->slot[r].st));
     } else if (s0.kind == 1) {
       for (int r = 0; r < W; ++r)
         for (int q = 0; q < W; ++q)
@@ -284,7 +333,7 @@ struct LoopBackend : Backend {
         if (q != r) XHIP(hipStreamWaitEvent(g->slot[r].st, g->slot[q].finish, 0));
     return 0;
   }
-  int post(int kind, void* buf, size_t count, hipStream_t st, unsigned long long value = 0) {
+  int post(int kind, void* buf, size_t count, hipStream_t st, unsigned long long value = 0, const void* send = nullptr) {
     if (!arrive) {
       XHIP(hipEventCreateWithFlags(&arrive, hipEventDisableTiming));
       XHIP(hipEventCreateWithFlags(&finish, hipEventDisableTiming));
@@ -294,6 +343,7 @@ struct LoopBackend : Backend {
     if (g->error) return failx(g->error, "loopback group failed earlier: %s", g->error_text.c_str());
     tfk_loopback::Slot& s = g->slot[rank];
     s.kind = kind; s.buf = buf; s.count = count; s.st = st; s.arrive = arrive; s.finish = finish; s.value = value;
+    s.send = send;
     const unsigned long long gen = g->generation;
     if (++g->arrived == g->world) {
       const int rc = run(g);
@@ -313,6 +363,9 @@ struct LoopBackend : Backend {
   int reduce_scatter(float* buf, size_t per_rank, hipStream_t st) override { return post(0, buf, per_rank, st); }
   int all_gather(void* buf, size_t bytes_per_rank, hipStream_t st) override { return post(1, buf, bytes_per_rank, st); }
   int all_reduce(float* buf, size_t count, hipStream_t st) override { return post(2, buf, count, st); }
+  int exchange_shards(const void* send, void* recv, size_t bytes, hipStream_t st) override {
+    return post(4, recv, bytes, st, 0, send);
+  }
   int min_max(unsigned long long* v, hipStream_t st) override {
     XCHK(post(3, nullptr, 0, st, v[0]));
     // (the values stay valid until the next operation completes, which needs this rank again)
@@ -363,6 +416,10 @@ struct tfk_comm {
   std::vector<std::pair<size_t, size_t>> shard_spans;
   int verify_left = 2;
   bool apply_enqueued = false, apply_sharded = false, apply_via_shadow = false;  // between tfk_comm_apply_enqueue and _end
+  // TFK_DP_WIRE=bf16: reduce-scattered spans travel as bf16 (2 B per parameter in instead of 4), summed in fp32 by the owner
+  bool wire_bf16 = false;
+  uint16_t* wire_stage = nullptr;  // [send: span floats][recv: span floats] bf16 each, sized for the largest span
+  size_t wire_cap = 0;
   int error = 0;  // a failure inside an engine hook (cannot propagate through the hook): raised by the next call
   std::string error_text;
   // what ran in the last completed step (tfk_comm_last_step)
@@ -424,7 +481,7 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
     XHIP(hipEventRecord(c->spans[first].ready, c->engine_stream));
     XHIP(hipStreamWaitEvent(c->comm_stream, c->spans[first].ready, 0));
   }
-  const bool grouped = c->num_spans - first > 1;
+  const bool grouped = c->num_spans - first > 1 && !c->wire_bf16;
   struct Group {  // (closed on every way out: a failed collective must not leave RCCL inside a group)
     Backend* be;
     bool open;
@@ -436,7 +493,26 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
   }
   for (size_t k = first; k < c->num_spans; ++k) {
     Span& s = c->spans[k];
-    if (s.rs) {
+    if (s.rs && c->wire_bf16) {
+      // (never inside a group: the exchange must have been LAUNCHED, not deferred to a group's end, when the sum is enqueued)
+      const size_t per = s.n / c->be->world;
+      if (s.n > c->wire_cap) {
+        if (c->wire_stage) XHIP(hipFree(c->wire_stage));  // (synchronises: nothing still reads the old one)
+        c->wire_stage = nullptr;
+        c->wire_cap = 0;
+        XHIP(hipMalloc((void**)&c->wire_stage, 2 * std::max(s.n, c->num_params) * sizeof(uint16_t)));
+        c->wire_cap = std::max(s.n, c->num_params);
+      }
+      uint16_t *send = c->wire_stage, *recv = c->wire_stage + c->wire_cap;
+      const unsigned blocks = (unsigned)std::min<size_t>((s.n + 255) / 256, 1 << 14);
+      hipLaunchKernelGGL(wire_pack_kernel, dim3(blocks), dim3(256), 0, st, c->grad + s.off, send, s.n);
+      XCHK(c->be->exchange_shards(send, recv, per * sizeof(uint16_t), st));
+      const unsigned sb = (unsigned)std::min<size_t>((per + 255) / 256, 1 << 14);
+      hipLaunchKernelGGL(wire_sum_kernel, dim3(sb), dim3(256), 0, st, c->grad + s.off + (size_t)c->be->rank * per, recv,
+                         c->be->rank, c->be->world, per);
+      XHIP(hipGetLastError());
+      c->cur_rs += 1;
+    } else if (s.rs) {
       XCHK(c->be->reduce_scatter(c->grad + s.off, s.n / c->be->world, st));
       c->cur_rs += 1;
     } else {
@@ -575,6 +651,10 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   c->min_floats = std::max<size_t>(1, bucket_bytes / 4);
   if (const char* v = getenv("TFK_DP_MIN_SHARD")) c->min_shard_floats = (size_t)atol(v);
   if (const char* v = getenv("TFK_DP_VERIFY_STEPS")) c->verify_left = atoi(v);
+  if (const char* v = getenv("TFK_DP_WIRE")) {
+    if (!strcmp(v, "bf16")) c->wire_bf16 = true;
+    else if (strcmp(v, "fp32") && strcmp(v, "float32")) return bail(failx(-1, "TFK_DP_WIRE=%s (fp32 | bf16)", v));
+  }
   void* st = nullptr;
   if (tfk_stream(e, &st)) return bail(-1);
   c->engine_stream = (hipStream_t)st;
@@ -723,6 +803,7 @@ int tfk_comm_destroy(tfk_comm* c) {
   }
   for (hipEvent_t ev : c->gather_events) (void)hipEventDestroy(ev);
   if (c->ev_adam) (void)hipEventDestroy(c->ev_adam);
+  if (c->wire_stage) (void)hipFree(c->wire_stage);
   delete c->be;
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   delete c;

@@ -201,6 +201,9 @@ class BucketReducer(object):
     MIN_SHARD_FLOATS = int(os.environ.get("TFK_DP_MIN_SHARD", str(1 << 14)))  # smaller spans are all-reduced
 
     def __init__(self, engine, group=None, min_bytes=None, stream_ctx=None, mode=None):
+        if os.environ.get("TFK_DP_WIRE") == "bf16":
+            raise ValueError("TFK_DP_WIRE=bf16 is a feature of the in-library exchange (csrc/exchange.hip over RCCL); this job runs "
+                             "the exchange through torch.distributed (TFK_DP_COMM=torch, a gloo group, or the fallback)")
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -635,6 +638,8 @@ class NativeExchange(object):
         self.last_launched, self.last_kinds, self.last_executed = [], [], []
         self.host_s = {"on_bucket": 0.0, "on_layer": 0.0, "finish_and_apply": 0.0}
         self.host_calls = {"on_bucket": 0, "on_layer": 0, "finish_and_apply": 0}
+        # wire format of the reduce-scattered gradient spans (csrc/exchange.hip reads the same variable at attach)
+        self.wire = "bf16" if os.environ.get("TFK_DP_WIRE") == "bf16" else "fp32"
 
     def close(self):
         if self._h:
@@ -717,7 +722,7 @@ XGMI_LINK_GBPS = 153.0  # MI355X: 7 xGMI links per GPU, point to point, ~153 GB/
 
 
 def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="sharded", min_bytes=64 << 20, gather_elem_bytes=4,
-                   fixed_ms=0.045, link_gbps=XGMI_LINK_GBPS):
+                   fixed_ms=0.045, link_gbps=XGMI_LINK_GBPS, reduce_elem_bytes=4):
     """What the exchange step of a `world`-GPU job should cost, from one GPU's measured step -- a PREDICTION to hold the first
     real scaling line against (no multi-GPU node was available to any round of this build; reference seam
     neuralNetworks/trainer.py:165-184).
@@ -729,8 +734,8 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
     evenly over the layers; collectives of one communicator run one after the other.  Two wire models per collective over the
     full mesh: `direct` -- every rank exchanges its 1/world sub-spans with all world - 1 peers at once, one sub-span per link
     (what a reduce-scatter / all-gather IS on point-to-point links) -- and `ring` (one link's rate bounds the whole transfer).
-    sharded: reduce-scatter 4 B/param in, Adam on 1/world of the span, all-gather gather_elem_bytes/param out (2 with the bf16
-    shadow), the gathers hidden under the next forward pass except the first span's; allreduce: both halves before a full
+    sharded: reduce-scatter reduce_elem_bytes/param in (4; 2 with TFK_DP_WIRE=bf16), Adam on 1/world of the span, all-gather
+    gather_elem_bytes/param out (2 with the bf16 shadow), the gathers hidden under the next forward pass except the first span's; allreduce: both halves before a full
     Adam.  fixed_ms: stream bookkeeping measured with one RCCL rank (profiles/r04_dp_overhead.txt)."""
     L1 = len(buckets) - 2  # weight matrices
     min_floats = max(1, min_bytes // 4)
@@ -767,7 +772,7 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
         t = 0.0  # the communicator's clock, from the start of backward
         for i, (off, n, b0, b1) in enumerate(spans):
             ready = (b1 + 1) * per_layer_bwd
-            cost = wire_ms(4.0 * n, model) * (1 if mode == "sharded" else 2)
+            cost = wire_ms(float(reduce_elem_bytes) * n, model) * (1 if mode == "sharded" else 2)
             t = max(t, ready) + cost
             if model == "direct":
                 out["spans"].append({"offset": off, "floats": n, "layers": [L1 - 1 - b1, L1 - 1 - b0], "ready_ms_into_backward": ready,
@@ -788,7 +793,8 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
         out["exposed_ms_" + model] = {"reduce": exposed_reduce, "gather": exposed_gather}
         out["predicted_ms_per_step_" + model] = step_ms - adam_ms + adam + exposed_reduce + exposed_gather + fixed_ms
     out["wire_bytes_per_rank_per_step"] = {
-        "reduce_scatter_in_out" if mode == "sharded" else "all_reduce_in_out": 4.0 * p_w * (world - 1) / world * (1 if mode == "sharded" else 2),
+        "reduce_scatter_in_out" if mode == "sharded" else "all_reduce_in_out":
+            float(reduce_elem_bytes) * p_w * (world - 1) / world * (1 if mode == "sharded" else 2),
         "all_gather_in_out": (float(gather_elem_bytes) * p_w * (world - 1) / world) if mode == "sharded" else 0.0,
         "tail_all_reduce": 8.0 * tail * (world - 1) / world}
     out["overlap_window_ms"] = bwd_ms - (out["spans"][0]["ready_ms_into_backward"] if out["spans"] else 0.0)

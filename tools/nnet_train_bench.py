@@ -30,7 +30,7 @@ MODELS = {"cfg2": (6, 2048, 2000, 1.0, "float32"), "cfg3": (6, 2048, 4000, 1.0, 
 F_RAW, CONTEXT, UTT_LEN = 40, 5, 64
 
 
-def _conf(expdir, model, batch_utts, per_minibatch, epochs, packed, compute_dtype=None):
+def _conf(expdir, model, batch_utts, per_minibatch, epochs, packed, compute_dtype=None, valid_batches=0, valid_frequency=1000000):
     layers, units, _, keep, dtype = MODELS[model]
     dtype = compute_dtype or dtype
     c = configparser.ConfigParser()
@@ -40,17 +40,20 @@ def _conf(expdir, model, batch_utts, per_minibatch, epochs, packed, compute_dtyp
     for k, v in dict(name="net", context_width=str(CONTEXT), num_hidden_units=str(units), num_hidden_layers=str(layers),
                      add_layer_period="0", starting_step="0", nonlin="relu", l2_norm="False", dropout=str(keep),
                      batch_norm="True", num_epochs=str(epochs), initial_learning_rate="0.001", learning_rate_decay="1",
-                     batch_size=str(batch_utts), numutterances_per_minibatch=str(per_minibatch), valid_batches="0",
-                     valid_frequency="1000000", valid_adapt="False", valid_retries="1", check_freq="1000000",
+                     batch_size=str(batch_utts), numutterances_per_minibatch=str(per_minibatch),
+                     valid_batches=str(valid_batches), valid_frequency=str(valid_frequency), valid_adapt="False",
+                     valid_retries="1", check_freq="1000000",
                      visualise="False", compute_dtype=dtype, packed_feed=str(bool(packed))).items():
         c.set("nnet", k, v)
     return c
 
 
 def measure(model="cfg2", batch_utts=128, per_minibatch=16, steps=40, warmup=8, packed=True, workdir=None,
-            utt_len=UTT_LEN, compute_dtype=None):
+            utt_len=UTT_LEN, compute_dtype=None, valid_batches=0, valid_frequency=1000000):
     """Run Nnet.train for `steps` optimiser steps of `batch_utts` utterances x `utt_len` frames; returns a dict with
-    frames/s over the steps after `warmup` (whole job: all ranks' frames / slowest rank's time)."""
+    frames/s over the steps after `warmup` (whole job: all ranks' frames / slowest rank's time).  valid_batches > 0: a
+    held-out set of that many batches is evaluated every `valid_frequency` steps (nnet.py:168-207) INSIDE the clock; the rate
+    still counts training frames only."""
     from tfkaldi_amd import synthetic
     from tfkaldi_amd.dataparallel import init_from_env
     from tfkaldi_amd.neuralNetworks import nnet as nnet_mod
@@ -80,12 +83,12 @@ def measure(model="cfg2", batch_utts=128, per_minibatch=16, steps=40, warmup=8, 
             workdir = stack.enter_context(tempfile.TemporaryDirectory(prefix="tfkaldi_nnet_bench_"))
         corpus = os.path.join(workdir, "corpus_rank%d" % rank)  # (same seed on every rank: identical files)
         # ArkReader.split drops the LAST scp entry as the reference does (ark.py:161-165): one spare utterance
-        paths = synthetic.write_corpus(corpus, batch_utts * steps + 1, pdfs, feat_dim=F_RAW, utt_len=utt_len)
+        paths = synthetic.write_corpus(corpus, batch_utts * (steps + valid_batches) + 1, pdfs, feat_dim=F_RAW, utt_len=utt_len)
         reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, utt_len)
         coder = target_coder.AlignmentCoder(lambda x, y: x, pdfs)
         disp = batchdispenser.AlignmentBatchDispenser(reader, coder, batch_utts, paths["alignments"])
         net = nnet_mod.Nnet(_conf(os.path.join(workdir, "exp_rank%d" % rank), model, batch_utts, per_minibatch, 1, packed,
-                                  compute_dtype), F_RAW, pdfs)
+                                  compute_dtype, valid_batches, valid_frequency), F_RAW, pdfs)
         original = nnet_mod.CrossEnthropyTrainer
         nnet_mod.CrossEnthropyTrainer = Timed
         try:

@@ -6,7 +6,9 @@ import glob
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-FAMILIES = [("gemm_f32_dual_kernel", "gemm_f32_dual(dA+dW)"), ("gemm_f32_kernel", "gemm_f32 (fwd / dW0)"),
+FAMILIES = [("gemm_bf16x3_dual_kernel", "gemm_bf16x3_dual(dA+dW)"), ("gemm_bf16_dual_kernel", "gemm_bf16_dual(dA+dW)"),
+            ("gemm_bf16_dma_kernel", "gemm_bf16 / bf16x3 (fwd / dW0)"),
+            ("gemm_f32_dual_kernel", "gemm_f32_dual(dA+dW)"), ("gemm_f32_kernel", "gemm_f32 (fwd / dW0)"),
             ("adam_kernel", "adam_apply"), ("bn_act_forward", "bn_act_forward"), ("hb_apply", "hb_apply"),
             ("softmax_xent", "softmax_xent")]
 
@@ -28,9 +30,9 @@ for f in glob.glob("%s/pmc*/**/*counter_collection.csv" % src, recursive=True):
             dur[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(dst + "_bench_pmc.txt", "w") as out:
     out.write("# rocprofv3 --pmc (counter-only passes, tools/profile_round.sh) over `python bench.py --steps 10 --warmup 3 "
-              "--no-cpu-baseline` (BASELINE cfg2, fp32), 1x MI355X: mean per launch.\n"
+              "--no-cpu-baseline` (BASELINE cfg2 in the bench's default arithmetic), 1x MI355X: mean per launch.\n"
               "# SQ_* cycle counters are quad-cycles summed over all waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 "
-              "SIMDs (64 per v_mfma_f32_32x32x2_f32).\n"
+              "SIMDs (64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_32x32x16_bf16).\n"
               "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz nominal); l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS).\n")
     for fam, _ in [(n, 0) for _, n in FAMILIES]:
         if fam not in acc:
