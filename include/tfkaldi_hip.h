@@ -189,8 +189,9 @@ int tfk_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, c
  * in ONE call.  In evaluation mode the rows of a micro-batch are independent (batch norm normalises with the moving statistics,
  * dropout is the identity, L2Norm is row-wise), so the k runs are one pass of the GEMMs over the concatenated rows -- every
  * activation chain, no padding between segments; passes are cut at micro-batch boundaries once they hold TFK_EVAL_PASS_ROWS rows
- * (default 16384).  batch_loss / num_frames end up as k tfk_eval_accumulate[_raw] calls leave them, up to the fp32 order of the
- * loss sum.  Arguments as the training entry points above. */
+ * (default 4096: the host-fed input of the next pass crosses PCIe under the kernels of this one).  batch_loss / num_frames end
+ * up as k tfk_eval_accumulate[_raw] calls leave them, up to the fp32 order of the loss sum.  Arguments as the training entry
+ * points above. */
 int tfk_eval_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, const int32_t* seg_rows,
                                 int32_t k, int flags);
 int tfk_eval_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, int32_t T,

@@ -468,7 +468,7 @@ int run_gemm(tfk_engine* e, GemmLayout layout, const float* A, int lda, const fl
     }
     const int fam = layout == GEMM_NN ? KF_GEMM_NN : layout == GEMM_NT ? KF_GEMM_NT : KF_GEMM_TN;
     ProfScope ps(e, fam, 2.0 * M * N * K,
-                 2.0 * ((double)M * K + (double)K * N) + 4.0 * (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1), st);
+                 (e->x3 ? 6.0 : 2.0) * ((double)M * K + (double)K * N) + 4.0 * (double)M * N * ((epi & EPI_ACCUM) ? 2 : 1), st);
     const int rc = e->x3 ? gemm_bf16x3(layout, b, st) : gemm_bf16(layout, b, st);
     if (rc != 0) return fail(rc, "gemm_bf16%s launch failed: %s", e->x3 ? "x3" : "", hipGetErrorString((hipError_t)rc));
     return 0;
@@ -533,8 +533,9 @@ int run_gemm_dual(tfk_engine* e, const float* dz, int ld_dz, const float* W, int
     a.M = T; a.N = N_da; a.K = K_da; a.lda = ld_a; a.ldb = ld_b; a.ldc = ld_da; a.epi = act ? EPI_DACT : 0;
     w.C = Gw;
     w.M = d_in; w.N = d_out; w.K = T; w.lda = ld_c; w.ldb = ld_d; w.ldc = ld_g; w.epi = epi_w;
-    const double bytes = 2.0 * ((double)T * K_da + (double)K_da * N_da) + 4.0 * (double)T * N_da +
-                         2.0 * ((double)T * d_in + (double)T * d_out) + 4.0 * (double)d_in * d_out * ((epi_w & EPI_ACCUM) ? 2 : 1);
+    const double ob = e->x3 ? 6.0 : 2.0;  // operand bytes per element: one bf16 value, or three planes
+    const double bytes = ob * ((double)T * K_da + (double)K_da * N_da) + 4.0 * (double)T * N_da +
+                         ob * ((double)T * d_in + (double)T * d_out) + 4.0 * (double)d_in * d_out * ((epi_w & EPI_ACCUM) ? 2 : 1);
     hipEvent_t pa = nullptr, pb = nullptr;
     if (e->profiling) {
       pa = get_event(e); pb = get_event(e);
@@ -2022,13 +2023,15 @@ int tfk_accumulate_stacked_raw(tfk_engine* e, const float* raw, int64_t ldraw, c
 // update_valid_loss run per micro-batch).  In evaluation mode the rows of a micro-batch are independent -- batch norm normalises
 // with the MOVING statistics, dropout is the identity, L2Norm is row-wise -- so k runs are one pass of the GEMMs over the
 // concatenated rows: no per-segment statistics, no padding between segments, every activation chain.  Passes are cut at
-// micro-batch boundaries once they hold TFK_EVAL_PASS_ROWS rows (default 16384: bounds the activation buffers; one longer
-// micro-batch still runs alone).  batch_loss += the k sums and num_frames += T as k tfk_eval_accumulate calls leave them, up to
+// micro-batch boundaries once they hold TFK_EVAL_PASS_ROWS rows (default 4096: large enough for the GEMMs to fill the chip and
+// read the weights once per pass, small enough that the host-fed input of pass i + 1 -- staged through the double-buffered
+// pinned slots on the copy stream -- crosses PCIe under the kernels of pass i; one 16384-row pass measured SLOWER than eight
+// 2048-row ones at BASELINE cfg4, its 29 MB copy in front of everything.  One longer micro-batch still runs alone).  batch_loss += the k sums and num_frames += T as k tfk_eval_accumulate calls leave them, up to
 // the fp32 order of the loss sum.
 static int eval_pass_rows() {
   const char* q = getenv("TFK_EVAL_PASS_ROWS");
-  const int n = q ? atoi(q) : 16384;
-  return n > 0 ? n : 16384;
+  const int n = q ? atoi(q) : 4096;
+  return n > 0 ? n : 4096;
 }
 int tfk_eval_accumulate_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int32_t T, const int32_t* seg_rows,
                                 int32_t k, int flags) {
