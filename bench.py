@@ -586,8 +586,8 @@ def main():
                          "step_tflops": value / world * w.flop_per_frame / 1e12,
                          "step_frac": value / world * w.flop_per_frame / 1e12 / peak,
                          "peak_note": ("2500 / 6: six bf16 MFMAs per fp32 product.  Over operands with random significands the matrix "
-                                       "pipe is POWER-bound at ~0.67 of its nominal rate on this chip (profiles/"
-                                       "r05_gemm_f32x3_power.txt): this kernel takes the time of its MFMAs alone over zeros"
+                                       "pipe is POWER-bound on this chip: same cycles per launch as over zeros, clock 2.4 -> 1.87 GHz "
+                                       "(profiles/r05_gemm_f32x3_clock.txt); MFMAs alone on constant operands reach 0.67 of 2.5 PF"
                                        if args.dtype == "float32" else None),
                          "hbm": hbm},
             "host_fed_value": world * T * args.steps / elapsed_host,
