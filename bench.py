@@ -617,11 +617,16 @@ def main():
         min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", "64")) * (1 << 20))
         wire = "bf16" if os.environ.get("TFK_DP_WIRE") == "bf16" else "fp32"
         out["exchange_wire"] = getattr(reducer, "wire", "fp32") if reducer else None
+        # emulated fp32 under the sharded exchange: the three-plane twins are rebuilt from the gathered fp32 parameters (4 B read,
+        # 6 B written per weight; priced at 5 TB/s -- an estimate until a multi-GPU run measures it)
+        n_weights = sum(n for _, n in eng.buckets()[:len(eng.buckets()) - 2])
+        twin_rebuild_ms = n_weights * 10.0 / 5e12 * 1e3 if (args.dtype == "float32" and mode == "sharded") else 0.0
         out["exchange_model"] = {
             "note": "predicted from one rank's measured kernel times; weak scaling (the step of every rank is this step)",
             "per_world": {str(n): exchange_model(eng.buckets(), n, fwd_ms, bwd_ms, adam_ms, step_single, mode=mode, min_bytes=min_bytes,
                                                  gather_elem_bytes=2 if shadow_gather and mode == "sharded" else 4,
-                                                 reduce_elem_bytes=2 if wire == "bf16" and mode == "sharded" else 4)
+                                                 reduce_elem_bytes=2 if wire == "bf16" and mode == "sharded" else 4,
+                                                 twin_rebuild_ms=twin_rebuild_ms)
                           for n in ([world] if world > 1 else [2, 4, 8])}}
         if world > 1:
             m = out["exchange_model"]["per_world"][str(world)]

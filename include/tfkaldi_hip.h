@@ -303,6 +303,14 @@ int tfk_params_touched(tfk_engine* e);
  * waits for it layer by layer through tfk_set_layer_callback.  The fp32 masters then stay valid only on the rank that
  * owns the span until the host gathers them (checkpoints, tensor get / set).  Otherwise num_elems = 0. */
 int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* mirrors_arena);
+/* (ABI 7) The fp32 parameters [offset, offset + n) -- whole weight matrices -- were written behind the optimiser's back (a
+ * sharded exchange all-gathered them) and what the contractions READ is derived from them: under TFK_DTYPE_F32X3 the tiled
+ * three-plane twins (csrc/x3_layout.h).  Rebuilds the twins of those matrices on `stream` (NULL: the engine's) -- the exchange
+ * calls it on the stream the gather ran on, right behind it, so that the rebuild of layer l hides under the forward pass of
+ * the layers below instead of the whole set being rebuilt, all gathers awaited, in front of the next pass.  *current = 1: what
+ * the contractions read is current for that span (exact fp32: always; emulated fp32: rebuilt); 0: nothing was done (mixed
+ * precision without this path, or twins that were stale anyway) and the caller falls back to tfk_params_touched. */
+int tfk_twins_from_params(tfk_engine* e, size_t offset, size_t n, void* stream, int* current);
 /* Between tfk_apply_begin and tfk_apply_end: does tfk_apply_span write the bf16 shadow along with the parameters
  * (mixed precision, arena-mirroring shadow that was current when the step began)? */
 int tfk_apply_writes_shadow(tfk_engine* e, int* direct);

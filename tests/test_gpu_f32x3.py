@@ -299,6 +299,53 @@ def test_split_k_timeout_fails_the_step(gpu):
     eng.close()
 
 
+def test_twins_follow_parameters_written_behind_the_optimiser(gpu):
+    """tfk_twins_from_params: what the sharded exchange calls right behind every parameter all-gather under the emulated
+    arithmetic (csrc/exchange.hip: twins_behind_gather).  Engine A's fp32 weights are overwritten on the device, behind its back,
+    with those of engine B; until the twins are rebuilt A still computes with the OLD weights, afterwards it is B bit for bit;
+    a span that cuts through a matrix is refused; the exact fp32 arithmetic has nothing to rebuild (current), mixed precision
+    reports that nothing was done (the caller falls back to tfk_params_touched)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_pair
+    from tfkaldi_amd import _lib
+    from tfkaldi_amd._lib import EngineError
+    kw = dict(input_dim=40, num_layers=3, num_units=96, output_dim=24, nonlin="relu", batch_norm=True, init_learning_rate=1e-3,
+              num_steps=10, torch_state=True)
+    A, _ = make_pair(np.random.default_rng(3), compute_dtype="float32", **kw)
+    B, _ = make_pair(np.random.default_rng(4), compute_dtype="float32", **kw)
+    X = (np.random.default_rng(5).standard_normal((70, 40)) * 1.5).astype(np.float32)
+    old = A.posteriors(X, raw_logits=True).copy()  # (the first pass makes A's twins current)
+    want = B.posteriors(X, raw_logits=True).copy()
+    assert np.abs(old - want).max() > 1e-2
+    for what in (_lib.BIASES,):  # the vectors are read as they are: set them the ordinary way
+        for l in range(A.L + 1):
+            A.set(what, l, B.get(what, l))
+    for l in range(A.L):
+        for what in (_lib.BN_BETA, _lib.BN_MOVING_MEAN, _lib.BN_MOVING_VAR):
+            A.set(what, l, B.get(what, l))
+    A.posteriors(X, raw_logits=True)  # (the sets marked the twins stale: this pass rebuilds them, from A's OWN weights)
+    weights = sorted(A.buckets()[:A.L + 1])  # (offset, floats) of the weight matrices in the arena
+    w_end = weights[-1][0] + weights[-1][1]
+    A.param_view()[:w_end].copy_(B.param_view()[:w_end])
+    torch.cuda.synchronize()
+    stale = A.posteriors(X, raw_logits=True).copy()
+    assert np.abs(stale - want).max() > 1e-2, "the contractions must read the twins, not the fp32 arena"
+    with pytest.raises(EngineError, match="cuts through"):
+        A.twins_from_params(weights[1][0] + 4, weights[1][1] - 4)
+    assert A.twins_from_params(weights[0][0], weights[0][1]) is True  # span by span, as the gathers arrive
+    assert A.twins_from_params(weights[1][0], w_end - weights[1][0], stream=torch.cuda.current_stream().cuda_stream) is True
+    torch.cuda.synchronize()
+    got = A.posteriors(X, raw_logits=True)
+    assert np.array_equal(got, want)
+    A.close(); B.close()
+    for dtype, expect in (("float32_mfma", True), ("bfloat16", False)):
+        E, _ = make_pair(np.random.default_rng(3), compute_dtype=dtype, **kw)
+        E.posteriors(X, raw_logits=True)
+        assert E.twins_from_params(0, sorted(E.buckets()[:E.L + 1])[0][1]) is expect
+        E.close()
+
+
 @pytest.mark.timeout(1800)
 def test_fp32_suites_on_the_exact_fp32_matrix_instructions(gpu):
     """`compute_dtype = float32` runs emulated on the bf16 pipe (the default since round 5), so the fp32 suites -- every activation

@@ -136,6 +136,7 @@ SYMBOLS = {
     "tfk_set_bucket_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
     "tfk_set_later_microbatches": (c_int, [_E, c_int32]),
     "tfk_params_touched": (c_int, [_E]),
+    "tfk_twins_from_params": (c_int, [_E, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
     "tfk_set_layer_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
     "tfk_shadow_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "tfk_apply_writes_shadow": (c_int, [_E, POINTER(c_int)]),

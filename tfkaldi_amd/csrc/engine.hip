@@ -2482,6 +2482,24 @@ int tfk_params_touched(tfk_engine* e) {
   if (e->apply_open) e->apply_direct = false;  // tfk_apply_end must not declare the shadow current
   return 0;
 }
+int tfk_twins_from_params(tfk_engine* e, size_t offset, size_t n, void* stream, int* current) {
+  if (!e || !current) return fail(-1, "NULL argument");
+  *current = 0;
+  if (!e->bf16) { *current = 1; return 0; }  // exact fp32: the contractions read the parameters themselves
+  if (!e->x3 || !e->wb_aligned || e->shadow_dirty) return 0;  // (a shadow that is not current is rebuilt whole by the next pass)
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e->stream;
+  for (int l = 0; l <= e->L; ++l) {
+    const LayerLayout& y = e->lay[l];
+    if (y.w_off + y.w_sz <= offset || y.w_off >= offset + n) continue;
+    if (y.w_off < offset || y.w_off + y.w_sz > offset + n)
+      return fail(-1, "parameter span [%zu, +%zu) cuts through the weight matrix of layer %d", offset, n, l);
+    to_bf16_rows(st, e->p_param() + y.w_off, y.ld_out, e->Wb + e->wb_off[l], e->wb_ld[l], y.d_in, y.d_out, 1);
+  }
+  HIPCHK(hipGetLastError());
+  *current = 1;
+  return 0;
+}
 int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* mirrors_arena) {
   if (!e || !device_ptr || !num_elems || !mirrors_arena) return fail(-1, "NULL argument");
   // (x3: the shadow is three planes outside the arena -- nothing a sharded exchange could gather in place of the parameters)

@@ -599,6 +599,17 @@ int wait_layer(tfk_comm* c, int layer) {
   return 0;
 }
 
+// Emulated fp32: the contractions read three-plane twins of the weights, and a gather has just replaced the fp32 values of a
+// span behind the optimiser's back.  The twins of that span are rebuilt on the stream the gather ran on, right behind it --
+// under the forward pass of the layers below (the engine waits for `done` layer by layer) -- instead of all of them, every
+// gather awaited, in front of the next pass (what tfk_params_touched amounts to).
+int twins_behind_gather(tfk_comm* c, const std::pair<size_t, size_t>& span, hipStream_t st, bool* all_current) {
+  int current = 0;
+  XCHK(tfk_twins_from_params(c->e, span.first, span.second, st, &current));
+  if (!current) *all_current = false;
+  return 0;
+}
+
 void on_layer(void* user, int layer) {
   tfk_comm* c = static_cast<tfk_comm*>(user);
   remember(c, wait_layer(c, layer));
@@ -912,11 +923,13 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
     const size_t elem = via_shadow ? 2 : 4;
     c->gathers_used = 0;
     size_t first_on_comm = 0;
+    bool derived_current = true;  // what the contractions read (fp32 emulated: the three-plane twins) follows every gather
     if (inline_tail()) {
       // the span the next forward pass reads FIRST is gathered on the engine stream itself, right behind the optimiser: that
       // pass could not start before it anyway, and the hop to the comm stream and back is saved; the others follow on the
       // comm stream, under the first layers
       XCHK(c->be->all_gather(target + sharded[0].first * elem, sharded[0].second / W * elem, c->engine_stream));
+      if (!via_shadow) XCHK(twins_behind_gather(c, sharded[0], c->engine_stream, &derived_current));
       c->cur_ag += 1;
       first_on_comm = 1;
     }
@@ -933,6 +946,7 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
       }
       hipEvent_t done = c->gather_events[c->gathers_used++];
       XCHK(c->be->all_gather(target + s.first * elem, s.second / W * elem, c->comm_stream));
+      if (!via_shadow) XCHK(twins_behind_gather(c, s, c->comm_stream, &derived_current));
       XHIP(hipEventRecord(done, c->comm_stream));
       Gather g;
       g.off = s.first; g.n = s.second; g.done = done;
@@ -943,7 +957,7 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
       c->masters_stale = true;
       for (const auto& s : sharded)
         if (std::find(c->shard_spans.begin(), c->shard_spans.end(), s) == c->shard_spans.end()) c->shard_spans.push_back(s);
-    } else {
+    } else if (!derived_current) {
       XCHK(tfk_params_touched(c->e));  // parameters outside this rank's spans change behind the optimiser's back
     }
   }

@@ -474,7 +474,7 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
   constexpr int KSPT = BKT / 16;  // 16-k MFMA steps per ring slot
   static_assert(KSPT == 4 || KSPT == 2, "ring slot of 64 or 32 k");
   static_assert(NS >= 3 && (NS - 2) * NP + (NPL == 3 ? NP / 2 : 0) <= 63, "ring depth / vmcnt range");
-  static_assert(FM * FN >= 2, "two independent accumulator chains per wave");
+  static_assert(FM * FN >= 2 || NPL == 3, "two independent accumulator chains per wave");
   static_assert(NPL == 1 || (NPL == 3 && SCHED == 0), "planes");
   static_assert(KSPLIT == 1 || (KSPLIT == 2 && NPL == 3), "split-K: the fp32-emulating contraction only");
 
@@ -723,6 +723,8 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
     // half-steps between two barriers: the half-step after barrier kt sends the first half of tile kt+NS into the slot tile
     // kt just left, the half-step in front of the next barrier the second half.
     static_assert(KSPT == 2, "fp32-emulating contraction: 32 k per ring slot");
+    // (ordering the last three products so that consecutive MFMAs share an operand plane -- (0,1) (0,0) (1,0) -- changes
+    // nothing: 94.7 / 98.4 us against 102.9 / 97.7 for the pair of a layer, run to run)
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
     // Addresses: the fragment offsets of the slot being read are advanced ONCE per slot (four additions); every read is then
     // `offset register + immediate`.  The k-range guard of the pieces is peeled: all iterations but the last NS + 1 of a block
@@ -1165,7 +1167,7 @@ int launch_dma(const GemmArgsB& p, hipStream_t stream) {
 
 // fp32-emulating contraction on three bf16 planes per operand: 128x128 blocks (three 48 KB slots) when the result has a
 // tile of it for nearly every CU, else 128x64 (four 36 KB slots); 32 k per slot, four waves
-int g_x3_cfg = -2;  // env TFK_BF16X3_CFG (experiments): 0 = 128x64, 1 = 128x128, 2 = 128x128 split-K where eligible, -1 heuristic
+int g_x3_cfg = -2;  // env TFK_BF16X3_CFG (experiments): 0 = 128x64, 1 = 128x128, 2 = split-K where eligible, 3 = 64x64 (TN), -1 heuristic
 int x3_cfg() {
   if (g_x3_cfg == -2) {
     const char* q = getenv("TFK_BF16X3_CFG");
@@ -1215,6 +1217,10 @@ int launch_x3(const GemmArgsB& p, hipStream_t stream) {
              : wv == 44 ? launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2, 4>(p, stream)
                         : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
   } else {
+    // the weight gradient of a NARROW layer (layer 0: 440 x 2048 over 1024 frames): 224 blocks of 64x64 over all of K beat 256
+    // half-K blocks of 128x64 with their partial-sum exchange and their 14 % of padding rows (17.5 us against 20.8)
+    if ((forced == 3 || forced < 0) && m128 * n128 < 100 && (long)((p.M + 63) / 64) * ((p.N + 63) / 64) >= 192)
+      return launch_dma<A_KC, B_KC, EPI, 2, 2, 1, 1, 4, 32, 0, 3>(p, stream);
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape_tn(p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * ((p.N + 63) / 64) * 128 * 64)
       return launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 1, 4, 32, 0, 3, 2>(p, stream);

@@ -722,7 +722,7 @@ XGMI_LINK_GBPS = 153.0  # MI355X: 7 xGMI links per GPU, point to point, ~153 GB/
 
 
 def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="sharded", min_bytes=64 << 20, gather_elem_bytes=4,
-                   fixed_ms=0.045, link_gbps=XGMI_LINK_GBPS, reduce_elem_bytes=4):
+                   fixed_ms=0.045, link_gbps=XGMI_LINK_GBPS, reduce_elem_bytes=4, twin_rebuild_ms=0.0):
     """What the exchange step of a `world`-GPU job should cost, from one GPU's measured step -- a PREDICTION to hold the first
     real scaling line against (no multi-GPU node was available to any round of this build; reference seam
     neuralNetworks/trainer.py:165-184).
@@ -736,7 +736,9 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
     (what a reduce-scatter / all-gather IS on point-to-point links) -- and `ring` (one link's rate bounds the whole transfer).
     sharded: reduce-scatter reduce_elem_bytes/param in (4; 2 with TFK_DP_WIRE=bf16), Adam on 1/world of the span, all-gather
     gather_elem_bytes/param out (2 with the bf16 shadow), the gathers hidden under the next forward pass except the first span's; allreduce: both halves before a full
-    Adam.  fixed_ms: stream bookkeeping measured with one RCCL rank (profiles/r04_dp_overhead.txt)."""
+    Adam.  fixed_ms: stream bookkeeping measured with one RCCL rank (profiles/r04_dp_overhead.txt).  twin_rebuild_ms (emulated
+    fp32, sharded): the time to rebuild the three-plane twins of ALL weight matrices from gathered fp32 parameters; each span's
+    share runs right behind its gather on the gather's stream (tfk_twins_from_params), so only the first span's is exposed."""
     L1 = len(buckets) - 2  # weight matrices
     min_floats = max(1, min_bytes // 4)
     spans, lo = [], None
@@ -787,6 +789,8 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
             all_gather = wire_ms(float(gather_elem_bytes) * p_w, model)
             # the remaining gathers run under the next forward pass; they show only if they outlast it
             exposed_gather = first_gather + max(0.0, (all_gather - first_gather) - fwd_ms)
+            if spans and p_w:
+                exposed_gather += twin_rebuild_ms * spans[-1][1] / float(p_w)
             adam = adam_ms / world
         else:
             exposed_gather, adam = 0.0, adam_ms
@@ -798,7 +802,8 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
         "all_gather_in_out": (float(gather_elem_bytes) * p_w * (world - 1) / world) if mode == "sharded" else 0.0,
         "tail_all_reduce": 8.0 * tail * (world - 1) / world}
     out["overlap_window_ms"] = bwd_ms - (out["spans"][0]["ready_ms_into_backward"] if out["spans"] else 0.0)
-    out["single_rank"] = {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "adam_ms": adam_ms, "step_ms": step_ms, "fixed_ms": fixed_ms}
+    out["single_rank"] = {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "adam_ms": adam_ms, "step_ms": step_ms, "fixed_ms": fixed_ms,
+                          "twin_rebuild_ms": twin_rebuild_ms}
     out["predicted_weak_scaling_efficiency_direct"] = step_ms / out["predicted_ms_per_step_direct"]
     return out
 

@@ -475,6 +475,14 @@ class Engine(object):
     def params_touched(self):
         check(self.lib.tfk_params_touched(self._h))
 
+    def twins_from_params(self, offset, n, stream=None):
+        """the fp32 parameters [offset, offset + n) (whole weight matrices) were written behind the optimiser's back: rebuild
+        what the contractions read from them (emulated fp32: the three-plane twins) on `stream` (None: the engine's).  True
+        when that is now current for the span, False when nothing was done (the caller then uses params_touched)"""
+        cur = c_int()
+        check(self.lib.tfk_twins_from_params(self._h, int(offset), int(n), c_void_p(stream), byref(cur)))
+        return bool(cur.value)
+
     def shadow_view(self):
         """torch bfloat16 view of the arena-mirroring weight shadow (mixed precision, every leading dimension a multiple
         of 8; requires torch_state=True), element offsets = those of the fp32 weight arena; None when there is none"""
