@@ -150,6 +150,8 @@ struct tfk_engine {
   bool apply_open = false, apply_direct = false;  // between tfk_apply_begin and tfk_apply_end
   float cur_lr_t = 0.f;
   bool scalars_fresh = true;     // batch_loss / num_frames / #mb are logically zero (next loss_reduce overwrites)
+  bool colsum_done = false;      // the output layer's bias-gradient partial sums of THIS micro-batch are in the workspace already
+                                 // (colsum_loss, launched with the loss sum right behind softmax_xent)
   bool fuse_hb_enabled = true;   // env TFK_FUSE_HB=0: separate statistics pass (experiments)
   bool dual_gemm = true;         // env TFK_DUAL_GEMM=0: dA and dW of a layer as two launches
   bool stack_enabled = true;     // env TFK_STACK=0: tfk_accumulate_stacked* run their micro-batches one after the other
@@ -986,8 +988,11 @@ int backward(tfk_engine* e, const float* Xd, int ldx, int T, int nact, uint32_t 
   const int rs = row_splits(T);
   auto ws_of = [&](int l) { return e->ws_bwd + (size_t)l * e->ws_bwd_stride; };
   {
-    ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
-    colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));
+    if (!e->colsum_done) {  // (CTC: the loss has a reduction of its own)
+      ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
+      colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));
+    }
+    e->colsum_done = false;
     fin.it[fin.n++] = {ws_of(L), G + o.b_off, 0, rs, e->O, e->ldO};
   }
   int pp = 0;
@@ -1433,8 +1438,15 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
     {
       // (folding this sum into softmax_xent -- the block that finishes last adds up the frames' losses -- was measured in
       // round 3 and is SLOWER than the second launch: 21.4 vs 9.3 + 6.3 us at cfg2, profiles/r03_fusion_experiments.txt)
-      ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * T);
-      loss_reduce(e->stream, e->row_loss, T, e->p_scalars(), e->scalars_fresh);
+      // training: ONE launch with the column sums of dLogits the backward pass starts with (kernels.hip: colsum_loss_kernel)
+      ProfScope ps(e, train ? KF_COLSUM : KF_LOSS_REDUCE, 0, train ? 4.0 * T * e->O : 4.0 * T);
+      if (train) {
+        colsum_loss(e->stream, e->logits, T, e->ldO, e->ws_bwd + (size_t)e->L * e->ws_bwd_stride, e->row_loss, T, e->p_scalars(),
+                    e->scalars_fresh);
+        e->colsum_done = true;
+      } else {
+        loss_reduce(e->stream, e->row_loss, T, e->p_scalars(), e->scalars_fresh);
+      }
       e->scalars_fresh = false;
     }
   }
@@ -1539,8 +1551,11 @@ int backward_stacked(tfk_engine* e, const float* Xd, int ldx, const Stack& st, u
   fin.accumulate = acc;
   auto ws_of = [&](int l) { return e->ws_bwd + (size_t)l * e->ws_bwd_stride; };
   {
-    ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
-    colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));  // (padding rows of dLogits are zero)
+    if (!e->colsum_done) {
+      ProfScope ps(e, KF_COLSUM, 0, 4.0 * T * e->O);
+      colsum_partial(e->stream, e->logits, T, e->ldO, ws_of(L));  // (padding rows of dLogits are zero)
+    }
+    e->colsum_done = false;
     fin.it[fin.n++] = {ws_of(L), G + o.b_off, 0, row_splits(T), e->O, e->ldO};
   }
   int cfg_h, cfg_o;
@@ -1663,8 +1678,10 @@ int run_stacked(tfk_engine* e, const float* Xd, int ld, const int32_t* yd, const
     softmax_xent(e->stream, e->logits, yd, st.T_pad, e->O, e->ldO, e->row_loss, 1, tw);
   }
   {
-    ProfScope ps(e, KF_LOSS_REDUCE, 0, 4.0 * st.T_pad);
-    loss_reduce(e->stream, e->row_loss, st.T_pad, e->p_scalars(), e->scalars_fresh, st.T_valid, st.k);
+    ProfScope ps(e, KF_COLSUM, 0, 4.0 * st.T_pad * e->O);
+    colsum_loss(e->stream, e->logits, st.T_pad, e->ldO, e->ws_bwd + (size_t)e->L * e->ws_bwd_stride, e->row_loss, st.T_pad,
+                e->p_scalars(), e->scalars_fresh, st.T_valid, st.k);
+    e->colsum_done = true;
     e->scalars_fresh = false;
   }
   const bool fire = (flags & TFK_LAST_MICROBATCH) != 0;

@@ -104,6 +104,9 @@ void bn_stats_from_chunks(hipStream_t s, const float* stats, int chunk_rows, int
 // ws slabs 0 and 1 (EPI_DACT output): entry 0 <- sum of the first `chunks` entries
 void chunk_totals(hipStream_t s, float* ws, int chunks, int ld);
 void colsum_partial(hipStream_t s, const float* x, int T, int ld, float* ws);
+// colsum_partial(x, T, ld, ws) and loss_reduce(row_loss, T_loss, scalars, overwrite, frames, microbatches) in ONE launch
+void colsum_loss(hipStream_t s, const float* x, int T, int ld, float* ws, const float* row_loss, int T_loss, float* scalars,
+                 bool overwrite, int frames = -1, int microbatches = 1);
 int row_splits(int T);  // chunks the column-tiled kernels cut T rows into
 
 // g[c] (+)= sum over the chunks of slab `which` of ws -- for MANY (layer, vector) pairs in one launch

@@ -740,6 +740,50 @@ colsum_partial_kernel(const float* __restrict__ x, int T, int ld, int rows_per, 
   if (threadIdx.y == 0 && t.valid) st4(ws + (size_t)blockIdx.y * ld + t.col, s);
 }
 
+// the frames' losses summed by the 256 threads of ONE block (tid = flat thread index): strided partial sums, wave shuffles, the
+// four wave sums added in wave order -- the same sequence of additions in loss_reduce_kernel and in colsum_loss_kernel, so
+// training and evaluation report bit-identical sums for the same rows
+__device__ __forceinline__ float loss_sum_256(const float* __restrict__ row_loss, int T, int tid, float* sm4) {
+  float s = 0.f;
+  for (int i = tid; i < T; i += 256) s += row_loss[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((tid & 63) == 0) sm4[tid >> 6] = s;
+  __syncthreads();
+  return ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
+}
+__device__ __forceinline__ void loss_commit(float s, float* __restrict__ scalars, int overwrite, float frames, float microbatches) {
+  // overwrite: first micro-batch since the accumulators were (logically) re-initialised -- saves the memset
+  scalars[0] = overwrite ? s : scalars[0] + s;
+  scalars[1] = overwrite ? frames : scalars[1] + frames;
+  scalars[2] = overwrite ? microbatches : scalars[2] + microbatches;
+}
+// Training: the column sums of dLogits (the output layer's bias gradient) and the sum of the frames' losses are both due right
+// behind softmax_xent and independent of each other: ONE launch -- the column-sum grid plus a row of blocks (blockIdx.y == rs)
+// whose first block sums the losses.  (Two launches of ~4.5 us each before.)
+__global__ void __launch_bounds__(CT_X * CT_Y)
+colsum_loss_kernel(const float* __restrict__ x, int T, int ld, int rows_per, int rs, float* __restrict__ ws,
+                   const float* __restrict__ row_loss, int T_loss, float* __restrict__ scalars, int overwrite, float frames,
+                   float microbatches) {
+  __shared__ float4 sm[CT_Y][CT_X];
+  if ((int)blockIdx.y == rs) {
+    if (blockIdx.x != 0) return;
+    const int tid = threadIdx.y * CT_X + threadIdx.x;
+    const float s = loss_sum_256(row_loss, T_loss, tid, reinterpret_cast<float*>(sm));
+    if (tid == 0) loss_commit(s, scalars, overwrite, frames, microbatches);
+    return;
+  }
+  const ColTile t = col_tile(T, ld, rows_per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t.valid)
+    for (int r = t.r0 + threadIdx.y; r < t.r1; r += CT_Y) {
+      const float4 v = ld4(x + (size_t)r * ld + t.col);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  s = reduce_rows(s, sm);
+  if (threadIdx.y == 0 && t.valid) st4(ws + (size_t)blockIdx.y * ld + t.col, s);
+}
+
 // ---- softmax cross-entropy: one 256-thread block per frame, the row held in registers ----
 template <int NV>  // float4 per thread; NV == 0: generic (re-reads global)
 __global__ void __launch_bounds__(256)
@@ -828,19 +872,12 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
   }
 }
 
-__global__ void __launch_bounds__(1024) loss_reduce_kernel(const float* __restrict__ row_loss, int T,
-                                                           float* __restrict__ scalars, int overwrite, float frames,
-                                                           float microbatches) {
-  __shared__ float sm[16];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < T; i += 1024) s += row_loss[i];
-  s = block_sum(s, sm);
-  if (threadIdx.x == 0) {
-    // overwrite: first micro-batch since the accumulators were (logically) re-initialised -- saves the memset
-    scalars[0] = overwrite ? s : scalars[0] + s;
-    scalars[1] = overwrite ? frames : scalars[1] + frames;
-    scalars[2] = overwrite ? microbatches : scalars[2] + microbatches;
-  }
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const float* __restrict__ row_loss, int T,
+                                                          float* __restrict__ scalars, int overwrite, float frames,
+                                                          float microbatches) {
+  __shared__ float sm[4];
+  const float s = loss_sum_256(row_loss, T, threadIdx.x, sm);
+  if (threadIdx.x == 0) loss_commit(s, scalars, overwrite, frames, microbatches);
 }
 
 // decoder.py:44 softmax (prior == nullptr) or nnet.py:280-286 log(softmax / prior), one 256-thread block per frame;
@@ -1224,8 +1261,16 @@ void softmax_xent(hipStream_t s, float* logits, const int32_t* y, int T, int O, 
 }
 
 void loss_reduce(hipStream_t s, const float* row_loss, int T, float* scalars, bool overwrite, int frames, int microbatches) {
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, row_loss, T, scalars, overwrite ? 1 : 0,
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, T, scalars, overwrite ? 1 : 0,
                      (float)(frames >= 0 ? frames : T), (float)microbatches);
+}
+
+void colsum_loss(hipStream_t s, const float* x, int T, int ld, float* ws, const float* row_loss, int T_loss, float* scalars,
+                 bool overwrite, int frames, int microbatches) {
+  const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
+  const dim3 g = ct_grid(ld, rs);
+  hipLaunchKernelGGL(colsum_loss_kernel, dim3(g.x, rs + 1), ct_block(), 0, s, x, T, ld, rows_per, rs, ws, row_loss, T_loss,
+                     scalars, overwrite ? 1 : 0, (float)(frames >= 0 ? frames : T_loss), (float)microbatches);
 }
 
 void softmax_rows(hipStream_t s, const float* logits, int T, int O, int ld, float* out, int64_t ldo,
