@@ -49,7 +49,7 @@ static int dual(int T, int din, int dout) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 5; ++i)
     if (tfk::gemm_bf16x3_dual(a, g, 0) != 0) { printf("dual launch not eligible\n"); return 1; }
-  const int iters = 30;
+  const int iters = getenv("TFK_ABL_ITERS") ? atoi(getenv("TFK_ABL_ITERS")) : 30;
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) tfk::gemm_bf16x3_dual(a, g, 0);
   hipEventRecord(e1, 0);
@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 5; ++i) tfk::gemm_bf16x3((tfk::GemmLayout)layout, g, 0);
-  const int iters = 30;
+  const int iters = getenv("TFK_ABL_ITERS") ? atoi(getenv("TFK_ABL_ITERS")) : 30;  // (thousands: long enough to sample power)
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) tfk::gemm_bf16x3((tfk::GemmLayout)layout, g, 0);
   hipEventRecord(e1, 0);
