@@ -844,7 +844,7 @@ softmax_xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ y, i
     for (int c = threadIdx.x; c < O; c += 256) se += expf(zr[c] - mx);
   }
   se = block_sum(se, sm);
-  if (threadIdx.x == 0) row_loss[row] = (mx + logf(se)) - zy;  // summed by loss_reduce (a second, 6 us launch)
+  if (threadIdx.x == 0) row_loss[row] = (mx + logf(se)) - zy;  // summed by colsum_loss_kernel (training) / loss_reduce_kernel (evaluation)
   if (with_grad) {
     const float inv = 1.f / se;
     if (NV > 0) {
