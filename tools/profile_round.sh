@@ -18,6 +18,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_A
 cd $GRAFT_REPO_ROOT
 bash tools/hbm_counters.sh ${tag}_hbm_cfg2 cfg2 float32 profiles/$tag > $out.hbm_cfg2.log 2>&1
 bash tools/hbm_counters.sh ${tag}_hbm_cfg2m cfg2 float32_mfma profiles/${tag}_mfma > $out.hbm_cfg2m.log 2>&1
+bash tools/hbm_counters.sh ${tag}_hbm_cfg2b cfg2 bfloat16 profiles/${tag}_bf16 > $out.hbm_cfg2b.log 2>&1
 bash tools/hbm_counters.sh ${tag}_hbm_cfg3 cfg3 bfloat16 profiles/$tag > $out.hbm_cfg3.log 2>&1
 bash tools/hbm_counters.sh ${tag}_hbm_cfg4 cfg4 bfloat16 profiles/$tag > $out.hbm_cfg4.log 2>&1
 for c in cfg2 cfg2x3 cfg3 cfg4; do timeout 200 python tools/step_line.py $c $out.step_$c.json > /dev/null 2>&1; done
