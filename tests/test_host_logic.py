@@ -488,3 +488,53 @@ def test_library_carries_the_build_id_of_this_tree(tmp_path, monkeypatch):
         _lib.load()
     monkeypatch.setenv("TFK_ALLOW_STALE_LIB", "1")
     assert _lib.load().tfk_build_id().decode() == want
+
+
+def _cfg2_buckets():
+    """BASELINE cfg2's announcements as the engine makes them: W_L .. W_0 (floats incl. the padded leading dimension), vectors, tail"""
+    sizes = [2048 * 2000] + [2048 * 2048] * 5 + [440 * 2048]  # W6 (output), W5 .. W1, W0
+    offs, off = [], 0
+    for n in reversed(sizes):  # the arena holds W0 first
+        offs.append(off)
+        off += n
+    weights = list(zip(reversed(offs), sizes))
+    return weights + [(off, 30000), (off + 30000, 24580)]
+
+
+def test_exchange_model_arithmetic():
+    """dataparallel.exchange_model -- the prediction a first multi-GPU line is to be held against (bench.py: exchange_model):
+    spans as the coalescing rule cuts them, bytes on the wire, direct <= ring, Adam on 1/world, what the options change."""
+    b = _cfg2_buckets()
+    kw = dict(fwd_ms=0.33, bwd_ms=0.56, adam_ms=0.133, step_ms=1.09)
+    m = dataparallel.exchange_model(b, 8, **kw)
+    # >= 64 MiB in announcement order: W6 .. W2 (the fifth matrix crosses 16.78 M floats), then W1 + W0
+    assert [s["floats"] for s in m["spans"]] == [2048 * 2000 + 4 * 2048 * 2048, 2048 * 2048 + 440 * 2048]
+    assert m["spans"][0]["layers"] == [2, 6] and m["spans"][1]["layers"] == [0, 1]
+    p_w = sum(n for _, n in b[:7])
+    wire = m["wire_bytes_per_rank_per_step"]
+    assert wire["reduce_scatter_in_out"] == pytest.approx(4.0 * p_w * 7 / 8)
+    assert wire["all_gather_in_out"] == pytest.approx(4.0 * p_w * 7 / 8)
+    assert m["predicted_ms_per_step_direct"] < m["predicted_ms_per_step_ring"]
+    # direct: a span's reduce-scatter moves 1/world of it over every link at once
+    assert m["spans"][1]["reduce_ms_direct"] == pytest.approx(4.0 * m["spans"][1]["floats"] / 8 / (dataparallel.XGMI_LINK_GBPS * 1e9) * 1e3)
+    assert m["spans"][1]["reduce_ms_ring"] == pytest.approx(7 * m["spans"][1]["reduce_ms_direct"])
+    # the step keeps everything but 7/8 of Adam, plus what the wire exposes and the fixed stream bookkeeping
+    e = m["exposed_ms_direct"]
+    assert m["predicted_ms_per_step_direct"] == pytest.approx(1.09 - 0.133 * 7 / 8 + e["reduce"] + e["gather"] + 0.045)
+    assert e["reduce"] > 0 and e["gather"] > 0  # the last span is ready when backward ends; the first gather hides under nothing
+    # options: bf16 wire halves the reduce-scatter bytes, the bf16 shadow the gather bytes; emulated fp32 pays the FIRST span's
+    # share of the twin rebuild (the rest runs behind the gathers, under the forward pass)
+    h = dataparallel.exchange_model(b, 8, reduce_elem_bytes=2, gather_elem_bytes=2, **kw)
+    assert h["wire_bytes_per_rank_per_step"]["reduce_scatter_in_out"] == pytest.approx(wire["reduce_scatter_in_out"] / 2)
+    assert h["wire_bytes_per_rank_per_step"]["all_gather_in_out"] == pytest.approx(wire["all_gather_in_out"] / 2)
+    assert h["predicted_ms_per_step_direct"] < m["predicted_ms_per_step_direct"]
+    t = dataparallel.exchange_model(b, 8, twin_rebuild_ms=0.052, **kw)
+    share = m["spans"][1]["floats"] / float(p_w)
+    assert t["predicted_ms_per_step_direct"] - m["predicted_ms_per_step_direct"] == pytest.approx(0.052 * share)
+    # all-reduce: both halves of every span before a FULL Adam, nothing gathered
+    a = dataparallel.exchange_model(b, 8, mode="allreduce", **kw)
+    assert a["wire_bytes_per_rank_per_step"]["all_gather_in_out"] == 0.0
+    assert a["predicted_ms_per_step_direct"] > m["predicted_ms_per_step_direct"]
+    # two ranks: one link, direct == ring
+    two = dataparallel.exchange_model(b, 2, **kw)
+    assert two["predicted_ms_per_step_direct"] == pytest.approx(two["predicted_ms_per_step_ring"])
