@@ -618,7 +618,7 @@ def main():
         wire = "bf16" if os.environ.get("TFK_DP_WIRE") == "bf16" else "fp32"
         out["exchange_wire"] = getattr(reducer, "wire", "fp32") if reducer else None
         # emulated fp32 under the sharded exchange: the three-plane twins are rebuilt from the gathered fp32 parameters (4 B read,
-        # 6 B written per weight; priced at 5 TB/s -- an estimate until a multi-GPU run measures it)
+        # 6 B written per weight; priced at 5 TB/s = 52 us at cfg2, what one RCCL rank measures: profiles/r05_dp_overhead.txt)
         n_weights = sum(n for _, n in eng.buckets()[:len(eng.buckets()) - 2])
         twin_rebuild_ms = n_weights * 10.0 / 5e12 * 1e3 if (args.dtype == "float32" and mode == "sharded") else 0.0
         out["exchange_model"] = {

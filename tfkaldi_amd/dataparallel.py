@@ -737,8 +737,10 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
     sharded: reduce-scatter reduce_elem_bytes/param in (4; 2 with TFK_DP_WIRE=bf16), Adam on 1/world of the span, all-gather
     gather_elem_bytes/param out (2 with the bf16 shadow), the gathers hidden under the next forward pass except the first span's; allreduce: both halves before a full
     Adam.  fixed_ms: stream bookkeeping measured with one RCCL rank (profiles/r04_dp_overhead.txt).  twin_rebuild_ms (emulated
-    fp32, sharded): the time to rebuild the three-plane twins of ALL weight matrices from gathered fp32 parameters; each span's
-    share runs right behind its gather on the gather's stream (tfk_twins_from_params), so only the first span's is exposed."""
+    fp32, sharded): the time to rebuild the three-plane twins of ALL weight matrices from gathered fp32 parameters.  Each span's
+    share runs right behind its gather on the gather's stream (tfk_twins_from_params) -- no longer in front of the forward pass
+    with every gather awaited -- but it is charged IN FULL: an HBM-bound kernel beside power-bound contractions takes its own
+    time out of them (measured with one RCCL rank: sharded costs ~50 us more than all-reduce at cfg2, profiles/r05_dp_overhead.txt)."""
     L1 = len(buckets) - 2  # weight matrices
     min_floats = max(1, min_bytes // 4)
     spans, lo = [], None
@@ -789,8 +791,7 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
             all_gather = wire_ms(float(gather_elem_bytes) * p_w, model)
             # the remaining gathers run under the next forward pass; they show only if they outlast it
             exposed_gather = first_gather + max(0.0, (all_gather - first_gather) - fwd_ms)
-            if spans and p_w:
-                exposed_gather += twin_rebuild_ms * spans[-1][1] / float(p_w)
+            exposed_gather += twin_rebuild_ms
             adam = adam_ms / world
         else:
             exposed_gather, adam = 0.0, adam_ms
