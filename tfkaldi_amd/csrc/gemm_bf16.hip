@@ -1218,8 +1218,9 @@ int launch_x3(const GemmArgsB& p, hipStream_t stream) {
                         : launch_dma<A_KC, B_KC, EPI, 2, 2, 2, 2, 3, 32, 0, 3, 2>(p, stream);
   } else {
     // the weight gradient of a NARROW layer (layer 0: 440 x 2048 over 1024 frames): 224 blocks of 64x64 over all of K beat 256
-    // half-K blocks of 128x64 with their partial-sum exchange and their 14 % of padding rows (17.5 us against 20.8)
-    if ((forced == 3 || forced < 0) && m128 * n128 < 100 && (long)((p.M + 63) / 64) * ((p.N + 63) / 64) >= 192)
+    // half-K blocks of 128x64 with their partial-sum exchange and their 14 % of padding rows (17.5 us against 20.8); from 2048
+    // frames on (a stacked pass) the exchange is amortised and the wider block's fewer fragment bytes win (8192: 102 against 109)
+    if ((forced == 3 || (forced < 0 && p.K < 2048)) && m128 * n128 < 100 && (long)((p.M + 63) / 64) * ((p.N + 63) / 64) >= 192)
       return launch_dma<A_KC, B_KC, EPI, 2, 2, 1, 1, 4, 32, 0, 3>(p, stream);
     if ((forced == 2 || forced < 0) && p.splitk_ws && x3_split_shape_tn(p.M, p.N, p.K) &&
         p.splitk_ws_floats >= (size_t)kSplitFlagWords + (size_t)m128 * ((p.N + 63) / 64) * 128 * 64)
