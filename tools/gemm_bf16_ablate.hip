@@ -5,6 +5,7 @@
 #include "../tfkaldi_amd/csrc/gemm_bf16.hip"
 
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 
 int main(int argc, char** argv) {
@@ -17,8 +18,9 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> ha((size_t)a_rows * lda), hb((size_t)b_rows * ldb);
   unsigned s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (uint16_t)(0x3c00u + ((s >> 9) & 0x3ffu) + ((s >> 8) & 0x8000u)); };
-  for (auto& x : ha) x = rnd();
-  for (auto& x : hb) x = rnd();
+  const bool zeros = getenv("TFK_ABL_DATA") && !strcmp(getenv("TFK_ABL_DATA"), "zero");  // (operands that switch no bits)
+  for (auto& x : ha) x = zeros ? 0 : rnd();
+  for (auto& x : hb) x = zeros ? 0 : rnd();
   uint16_t *dA, *dB;
   float* dC;
   hipMalloc(&dA, ha.size() * 2); hipMalloc(&dB, hb.size() * 2); hipMalloc(&dC, (size_t)M * ldc * 4);
@@ -30,7 +32,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 5; ++i) tfk::gemm_bf16((tfk::GemmLayout)layout, g, 0);
-  const int iters = 30;
+  const int iters = getenv("TFK_ABL_ITERS") ? atoi(getenv("TFK_ABL_ITERS")) : 30;  // (thousands: long enough to sample power)
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i) tfk::gemm_bf16((tfk::GemmLayout)layout, g, 0);
   hipEventRecord(e1, 0);
