@@ -587,7 +587,8 @@ def main():
                          "step_frac": value / world * w.flop_per_frame / 1e12 / peak,
                          "peak_note": ("2500 / 6: six bf16 MFMAs per fp32 product.  Over operands with random significands the matrix "
                                        "pipe is POWER-bound on this chip: same cycles per launch as over zeros, clock 2.4 -> 1.87 GHz "
-                                       "(profiles/r05_gemm_f32x3_clock.txt); MFMAs alone on constant operands reach 0.67 of 2.5 PF"
+                                       "(profiles/r05_gemm_f32x3_clock.txt); nothing but bf16 MFMAs from registers sustains 0.72 of 2.5 PF under the "
+                                       "socket's 1400 W limit (profiles/r05_mfma_bf16_energy.txt)"
                                        if args.dtype == "float32" else
                                        ("dense bf16 operands run this socket into its 1400 W limit at ~1.09 PFLOP/s (1.77 GHz), this kernel and "
                                         "the vendor library's alike; 1.5 PF at 2.39 GHz over zeros (profiles/r05_gemm_bf16_power_smi.txt)"
