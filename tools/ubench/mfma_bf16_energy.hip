@@ -12,7 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // MODE: 0 random A and B, 1 half of A's elements zero, 2 half of B's elements zero, 3 zeros, 4 A = one plane pattern repeated
 // (the same A register for every MFMA: an operand that stays put)
-template <int SHAPE, int MODE>
+template <int SHAPE, int MODE, int BUBBLE = 0>
 __global__ void __launch_bounds__(512) k(float* out, int iters, unsigned seed) {
   const int tid = threadIdx.x;
   bf16x8 a[8], b[8];
@@ -39,8 +39,14 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, unsigned seed) {
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int m = 0; m < 16; ++m)
+      for (int m = 0; m < 16; ++m) {
         acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[MODE == 4 ? 0 : (m & 7)], b[(m * 3 + 1) & 7], acc[m & 3], 0, 0, 0);
+        // BUBBLE x 8 idle issue cycles behind every MFMA (two waves per SIMD take turns: the pipe idles when both sit in a bubble)
+        if (BUBBLE >= 1) asm volatile("s_nop 7" ::: "memory");
+        if (BUBBLE >= 2) asm volatile("s_nop 7" ::: "memory");
+        if (BUBBLE >= 4) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        if (BUBBLE >= 8) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -66,17 +72,18 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, unsigned seed) {
   out[blockIdx.x * blockDim.x + tid] = sum;
 }
 
-template <int SHAPE, int MODE>
+template <int SHAPE, int MODE, int BUBBLE = 0>
 void run(const char* name, float* out) {
+  const int threads = 512;
   const int iters = 2000;  // x 16 MFMAs of 32768 flop (or 32 of 16384) per wave
-  const double flops_per_launch = 256.0 * 8 * iters * 16 * 32768.0;
+  const double flops_per_launch = 256.0 * (threads / 64) * iters * 16 * 32768.0;
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   long launches = 0, late = 0;
   clk::time_point t_mid;
   bool mid = false;
   while (true) {
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<SHAPE, MODE>), dim3(256), dim3(512), 0, 0, out, iters, 12345u + (unsigned)launches + i);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<SHAPE, MODE, BUBBLE>), dim3(256), dim3(threads), 0, 0, out, iters, 12345u + (unsigned)launches + i);
     (void)hipDeviceSynchronize();
     launches += 20;
     const double t = std::chrono::duration<double>(clk::now() - t0).count();
@@ -97,6 +104,12 @@ int main() {
   run<32, 2>("32x32x16  half of B zero", out);
   run<32, 4>("32x32x16  A stays in place (one register), random B", out);
   run<16, 4>("16x16x32  A stays in place (one register), random B", out);
+  // is the limit POWER (the clock would rise when the pipe idles part of the time) or a clock cap that comes with matrix work?
+  // bubbles behind every MFMA lower the pipe's duty; the zeros line of a pair gives that duty (x 0.98), the random line the clock
+  run<32, 0, 4>("32x32x16  random, 32 idle issue cycles behind every MFMA", out);
+  run<32, 3, 4>("32x32x16  zeros,  32 idle issue cycles behind every MFMA", out);
+  run<32, 0, 8>("32x32x16  random, 64 idle issue cycles behind every MFMA", out);
+  run<32, 3, 8>("32x32x16  zeros,  64 idle issue cycles behind every MFMA", out);
   run<32, 3>("32x32x16  zeros", out);
   run<16, 3>("16x16x32  zeros", out);
   return 0;
