@@ -537,3 +537,21 @@ def test_exchange_model_arithmetic():
     # two ranks: one link, direct == ring
     two = dataparallel.exchange_model(b, 2, **kw)
     assert two["predicted_ms_per_step_direct"] == pytest.approx(two["predicted_ms_per_step_ring"])
+
+
+@pytest.mark.parametrize("m16", [0, 1])
+def test_x3_operand_layouts_on_the_cpu(tmp_path, m16):
+    """tools/x3_layout_check.cpp: the index arithmetic of the fp32-emulating contraction's operand layouts (csrc/x3_layout.h) without
+    a GPU -- the LDS-DMA fill of a ring slot from the tiled three-plane array, the fragment reads of every lane, the bank schedule of
+    those reads, whole 128-byte lines per wave instruction -- for the shipped MFMA shape and for the 16x16x32 variant."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "x3_layout_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DTFK_X3_M16=%d" % m16, "-I", os.path.join(root, "tfkaldi_amd", "csrc"),
+                    os.path.join(root, "tools", "x3_layout_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout[-2000:]
+    assert "8.0 128-byte lines" in out.stdout and " 16.0 " not in out.stdout  # every byte of every fetched line is used

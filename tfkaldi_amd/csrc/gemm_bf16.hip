@@ -432,6 +432,39 @@ struct Frag3 {
   }
 };
 
+// The same for the 16x16x32 MFMA shape (TFK_X3_M16, x3_layout.h): plane q of NF16 fragments of 16 rows (columns), all 32 k of a slot.
+// k-contiguous: one offset register; k-strided: four (parity of X = 3 * unit + plane, parity of the fragment inside its unit).
+template <bool KC, int EXT, int NF16>
+struct Frag3M {
+  int off[KC ? 1 : 4];
+  __device__ __forceinline__ void init(int lane, int frag0) {
+    if constexpr (KC) {
+      off[0] = x3::kc16_lane_off(lane, frag0);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) off[v] = x3::ks16_lane_off<EXT>(lane, frag0, v & 1, v >> 1);
+    }
+  }
+  __device__ __forceinline__ Frag3M at(int bytes) const {
+    Frag3M r;
+#pragma unroll
+    for (int v = 0; v < (KC ? 1 : 4); ++v) r.off[v] = off[v] + bytes;
+    return r;
+  }
+  __device__ __forceinline__ bf16x8 read(const char* img, int f, int pl) const {
+    if constexpr (KC) {
+      return *reinterpret_cast<const bf16x8*>(img + off[0] + x3::kc16_imm(f, pl));
+    } else {
+      typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+      const int X = 3 * (f >> 1) + pl;
+      const char* q = img + off[(X & 1) + 2 * (f & 1)];
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + x3::ks16_imm<EXT>(X, 0)));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + x3::ks16_imm<EXT>(X, 1)));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+};
+
 // TFKB_ABL (tools/gemm_bf16_ablate.hip only): timing-only variants of the DMA kernel with pieces of the K loop removed
 // -- 1 MFMAs, 2 LDS-DMA pieces, 4 fragment reads.  Results are wrong by construction.
 #ifndef TFKB_ABL
@@ -712,6 +745,116 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" : : : "memory");
       __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (NPL == 3 && TFK_X3_M16 != 0) {
+    // The 16x16x32 shape: a ring slot is ONE 32-k step of six plane products x FM16 x FN16 MFMAs.  The products run (0,0) (0,1)
+    // (0,2) | barrier | (1,0) (1,1) (2,0): every fragment register is read for the last time as early as possible, so one set of
+    // fragments (+ a second B plane 0) serves -- A1 and A2 of this slot are fetched under the first half, A0, B0, B2, B1 of the
+    // NEXT slot under the second, each into registers whose last use lies behind it.  The barrier sits where it sat (round 3):
+    // every read of this slot has been issued in front of it, the next slot's data is complete behind it.
+    static_assert(KSPT == 2, "fp32-emulating contraction: 32 k per ring slot");
+    constexpr int FM16 = 2 * FM, FN16 = 2 * FN;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    Frag3M<A_KC, BM, FM16> ma;
+    Frag3M<B_KC, BN, FN16> mb;
+    ma.init(lane, wm * FM16);
+    mb.init(lane, wn * FN16);
+    f32x4 c1[FM16][FN16], c2[FM16][FN16];
+#pragma unroll
+    for (int a = 0; a < FM16; ++a)
+#pragma unroll
+      for (int b = 0; b < FN16; ++b) {
+        c1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    bf16x8 ga[3][FM16], gb[3][FN16], gb0n[FN16];
+    auto rd_a = [&](const decltype(ma)& r, int pl) {
+#pragma unroll
+      for (int a = 0; a < FM16; ++a) ga[pl][a] = r.read(smem, a, pl);
+    };
+    auto rd_b = [&](const decltype(mb)& r, int pl, bf16x8 (&dst)[FN16]) {
+#pragma unroll
+      for (int b = 0; b < FN16; ++b) dst[b] = r.read(smem, b, pl);
+    };
+    auto mm = [&](int pa, int pb) {
+#pragma unroll
+      for (int a = 0; a < FM16; ++a)
+#pragma unroll
+        for (int b = 0; b < FN16; ++b) {
+          if (pa + pb == 0) c1[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[0][a], gb[0][b], c1[a][b], 0, 0, 0);
+          else c2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[pa][a], gb[pb][b], c2[a][b], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // third `part` of the pieces [j0, j1) of tile `tile` into slot `slot`
+    auto pieces = [&](auto guard, int part, int j0, int j1, int slot, int tile) {
+#pragma unroll
+      for (int j = j0 + part * (j1 - j0) / 3; j < j0 + (part + 1) * (j1 - j0) / 3; ++j) piece_g(guard, j, slot, tile);
+    };
+    {
+      const auto r0a = ma.at(0);
+      const auto r0b = mb.at(NPL * A_BYTES);
+      rd_a(r0a, 0);
+      rd_b(r0b, 0, gb[0]);
+      rd_b(r0b, 1, gb[1]);
+      rd_b(r0b, 2, gb[2]);
+    }
+    const int n_fast = max(0, min(nk, nk_full - NS));
+    auto iteration = [&](auto guard, int kt) {
+      const auto ra = ma.at(rs * STAGE);
+      rd_a(ra, 1);
+      pieces(guard, 0, NPH, NP, ws, kt + NS - 1);
+      mm(0, 0);
+      rd_a(ra, 2);
+      pieces(guard, 1, NPH, NP, ws, kt + NS - 1);
+      mm(0, 1);
+      pieces(guard, 2, NPH, NP, ws, kt + NS - 1);
+      mm(0, 2);
+      TFKB_WAIT_BARRIER((NS - 2) * NP);
+      rs = rs + 1 == NS ? 0 : rs + 1;
+      ws = ws + 1 == NS ? 0 : ws + 1;
+      const bool fetch = kt + 1 < nk;
+      const auto na = ma.at(rs * STAGE);
+      const auto nb = mb.at(rs * STAGE + NPL * A_BYTES);
+      if (fetch) {
+        rd_a(na, 0);
+        rd_b(nb, 0, gb0n);
+      }
+      pieces(guard, 0, 0, NPH, ws, kt + NS);
+      mm(1, 0);
+      if (fetch) rd_b(nb, 2, gb[2]);
+      pieces(guard, 1, 0, NPH, ws, kt + NS);
+      mm(1, 1);
+      if (fetch) rd_b(nb, 1, gb[1]);
+      pieces(guard, 2, 0, NPH, ws, kt + NS);
+      mm(2, 0);
+      if (fetch) {
+#pragma unroll
+        for (int b = 0; b < FN16; ++b) gb[0][b] = gb0n[b];
+      }
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < n_fast; ++kt) iteration(std::false_type(), kt);
+#pragma unroll 1
+    for (int kt = n_fast; kt < nk; ++kt) iteration(std::true_type(), kt);
+    // the 16x16 result tiles -> the 32x32 register layout the epilogues are written for: reg r of lane (i, h) is row
+    // 4 h + (r & 3) + 8 (r >> 2), column i of a 32x32 fragment; 16x16 tile (p, q) of it holds row 16 p + 4 (l >> 4) + s, column
+    // 16 q + (l & 15) in reg s of lane l.  One ds_bpermute per (register, column half), once per block.
+    {
+      const int src = (16 * h + (i & 15)) * 4;  // + 128 for the registers with (r >> 2) & 1
+#pragma unroll
+      for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int addr = src + (((r >> 2) & 1) ? 128 : 0);
+            const f32x4& t0 = c1[2 * a + (r >> 3)][2 * b], &u0 = c2[2 * a + (r >> 3)][2 * b];
+            const f32x4& t1 = c1[2 * a + (r >> 3)][2 * b + 1], &u1 = c2[2 * a + (r >> 3)][2 * b + 1];
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, t0[r & 3] + u0[r & 3])));
+            const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, t1[r & 3] + u1[r & 3])));
+            acc[a][b][r] = (i & 16) ? v1 : v0;
+          }
     }
   } else if constexpr (NPL == 3) {
     // One wave per SIMD, and per 16-k step 6 * FM * FN MFMAs for 3 * (FM + FN) fragment reads and a handful of LDS-DMA pieces:

@@ -37,6 +37,17 @@ namespace x3 {
 
 constexpr int kSlotK = 32;  // k per ring slot = columns per unit
 
+// TFK_X3_M16 = 1 (compile-time, off): the contraction issues v_mfma_f32_16x16x32_bf16 (one 32-k step per ring slot) instead of
+// 32x32x16 (two 16-k steps).  Built because a loop of nothing but MFMAs runs 12 % faster in that shape under the socket's power
+// limit (profiles/r05_mfma_bf16_energy.txt); in the kernel it buys nothing -- the pair of a layer 83.1 against 83.7 us sustained,
+// a stacked pass 307.4 against 311.2, the training step 1.113 against 1.113 ms (three runs each on one box) -- so the default
+// stays the shape the epilogues are written for.  The variant passes tests/test_gpu_f32x3.py and tools/x3_layout_check.cpp.
+// The images keep their structure; what changes is which lane reads what: lane l of a fragment of 16 rows (columns) holds the
+// 8 k of k-chunk l >> 4 of row (column) l & 15 -- and therefore the two swizzles that keep those reads free of bank conflicts.
+#ifndef TFK_X3_M16
+#define TFK_X3_M16 0
+#endif
+
 // elements a matrix of `rows` rows occupies (all three planes)
 X3_HD size_t elems(size_t rows, int ld) { return ((rows + 1) >> 1) * (size_t)(ld >> 5) * 192; }
 // element offset of plane 0 of element (row, col); planes 1, 2: + 64, + 128
@@ -45,7 +56,13 @@ X3_HD size_t at(size_t row, int col, int ld) {
 }
 
 // ---- k-contiguous image: 24 chunks of 16 bytes per row pair ----
+#if TFK_X3_M16
+// rows r, r + 4, r + 8, r + 12 of a 16-row fragment share the upper bank bits (from r & 3); a ds_read_b128 service group holds
+// them with k-chunks (c, c ^ 1, c ^ 1, c): {0, 0, 3, 3} separates the four in every group
+X3_HD int kc_swz(int r) { return ((r >> 3) & 1) * 3; }
+#else
 X3_HD int kc_swz(int r) { return (r >> 2) & 3; }
+#endif
 // chunk n of the image holds k-chunk c (k = 8 c .. 8 c + 7) of plane q of row r
 X3_HD void kc_decode(int n, int& r, int& q, int& c) {
   const int P = n / 24, rem = n - P * 24;
@@ -66,11 +83,18 @@ X3_HD void ks_decode(int n, int& r, int& b, int& q, int& e8) {
   const int rem = nq - 6 * b;
   q = rem >> 1;
   r = 2 * P + (rem & 1);
+#if TFK_X3_M16
+  e8 = (pos & 3) ^ (((P >> 2) & 1) << 1);  // the two 16-column halves of a quadrant swap in every other group of four row pairs
+#else
   e8 = pos & 3;
+#endif
 }
 template <int EXT>
 X3_HD int ks_addr(int r, int b, int q, int e8) {
   const int P = r >> 1;
+#if TFK_X3_M16
+  e8 ^= ((P >> 2) & 1) << 1;
+#endif
   return P * (EXT / 32 * 384) + ((((6 * b + 2 * q + (r & 1)) ^ ((P & 1) << 1)) << 2) + e8) * 16;
 }
 
@@ -96,6 +120,31 @@ X3_HD int ks_lane_off(int lane, int frag0, int x_odd) {
 template <int EXT>
 X3_HD int ks_imm(int X, int ks, int hi) {
   return 128 * (X & ~1) + (ks * 8 + hi * 2) * (EXT / 32 * 384);
+}
+
+// ---- fragment reads for the 16x16x32 shape (TFK_X3_M16): fragments of 16 rows (columns), one 32-k step per slot ----
+// k-contiguous (ds_read_b128): lane (i = lane & 15, g = lane >> 4) reads row 16 * frag + i, k-chunk g of plane q at
+//   kc16_lane_off(lane, frag0) + kc16_imm(f, q),  frag = frag0 + f  (frag0 even: a wave's tile starts on a 32-row boundary)
+X3_HD int kc16_lane_off(int lane, int frag0) { return kc_addr(frag0 * 16 + (lane & 15), 0, lane >> 4); }
+X3_HD int kc16_imm(int f, int q) { return f * (8 * 384) + q * 128; }
+// k-strided (two ds_read_b64_tr_b16, `hi` four k-rows further): lane (g, j, qq) = (lane >> 4, (lane >> 2) & 3, lane & 3) reads 8 bytes
+//   of k-row 8 g + j (+ 4), columns 16 * frag + 4 qq .. + 3, at  ks16_lane_off(lane, frag0, X & 1, f & 1) + ks16_imm(X, hi),
+//   X = 3 (f >> 1) + q (the 128-byte line of the fragment's 32-column unit and plane, as in ks_lane_off).  The fragment's half of
+//   the quadrant is (f & 1) ^ (g & 1): the halves swap in every other group of four row pairs (ks_decode), so that the two lane
+//   groups a 32-lane service group is made of -- same columns, k-rows 8 apart -- sit in different banks.
+template <int EXT>
+X3_HD int ks16_lane_off(int lane, int frag0, int x_odd, int f_odd) {
+  const int g = lane >> 4, j = (lane >> 2) & 3, qq = lane & 3;
+  const int t = (j >> 1) & 1;
+  const int unit0 = frag0 >> 1;  // (frag0 even)
+  const int base = (4 * g + (j >> 1)) * (EXT / 32 * 384) + (j & 1) * 64 + ((f_odd ^ (g & 1)) << 5) + (qq >> 1) * 16 + ((qq & 1) << 3) +
+                   128 * 3 * unit0;
+  const int xt_odd = (unit0 + x_odd) & 1;
+  return base + (xt_odd ? -128 * t : 128 * t) + (x_odd ? 128 : 0);
+}
+template <int EXT>
+X3_HD int ks16_imm(int X, int hi) {
+  return 128 * (X & ~1) + hi * 2 * (EXT / 32 * 384);
 }
 
 }  // namespace x3

@@ -4,7 +4,8 @@
 // DmaOperand3::init computes -- and (2) the fragment reads of Frag3, and asserts that every lane receives exactly the elements the
 // MFMA operand needs; then it simulates the LDS bank schedule of those reads (ds_read_b128: four 16-lane service groups;
 // ds_read_b64_tr_b16: two 32-lane groups) and asserts that no group touches a bank twice.
-//   g++ -O1 -std=c++17 -I tfkaldi_amd/csrc tools/x3_layout_check.cpp -o /tmp/x3_layout_check && /tmp/x3_layout_check
+//   g++ -O1 -std=c++17 [-DTFK_X3_M16=1] -I tfkaldi_amd/csrc tools/x3_layout_check.cpp -o /tmp/x3_layout_check && /tmp/x3_layout_check
+// (-DTFK_X3_M16=1: the 16x16x32 variant of x3_layout.h -- its swizzles and its fragment reads)
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -58,9 +59,65 @@ static void check(int rows, int ld, int ext0, int k0, const char* name) {
       EXPECT(src + 8 <= arr.size(), "%s: source chunk out of range", name);
       for (int e = 0; e < 8; ++e) img[(size_t)n * 8 + e] = src + e < arr.size() ? arr[src + e] : 0;
     }
+#if TFK_X3_M16
+  // ---- fragment reads of the 16x16x32 shape (Frag3M): fragments of 16 rows (columns), all 32 k of the slot ----
+  for (int frag0 = 0; frag0 < EXT / 16; frag0 += 2)
+    for (int pl = 0; pl < 3; ++pl)
+      for (int f = 0; frag0 + f < EXT / 16; ++f) {
+        std::vector<int> addr(64), addr_hi(64);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane >> 4;
+          if (KC) {
+            const int a = x3::kc16_lane_off(lane, frag0) + x3::kc16_imm(f, pl);
+            addr[lane] = a;
+            const int row = ext0 + (frag0 + f) * 16 + (lane & 15);
+            for (int e = 0; e < 8; ++e)
+              EXPECT(img[a / 2 + e] == tag((size_t)row * ld + k0 + 8 * g + e, pl), "%s: KC16 fragment f%d+%d pl%d lane %d", name, frag0, f, pl,
+                     lane);
+          } else {
+            const int j = (lane >> 2) & 3, q = lane & 3;
+            const int X = 3 * (f >> 1) + pl;
+            for (int hi = 0; hi < 2; ++hi) {
+              const int off = x3::ks16_lane_off<EXT>(lane, frag0, X & 1, f & 1);
+              EXPECT(off >= 0, "%s: negative lane offset", name);
+              const int a = off + x3::ks16_imm<EXT>(X, hi);
+              (hi ? addr_hi : addr)[lane] = a;
+              EXPECT(x3::ks16_imm<EXT>(X, hi) < 65536, "%s: immediate out of range", name);
+              const int krow = k0 + 8 * g + j + 4 * hi;
+              const int ext = ext0 + (frag0 + f) * 16 + 4 * q;
+              for (int e = 0; e < 4; ++e)
+                EXPECT(img[a / 2 + e] == tag((size_t)krow * ld + ext + e, pl), "%s: KS16 fragment f%d+%d pl%d lane %d hi%d", name, frag0, f, pl,
+                       lane, hi);
+            }
+          }
+        }
+        if (KC) {
+          static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                            {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                            {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                            {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+          for (auto& grp : groups) {
+            std::set<int> slots;
+            for (int l : grp) slots.insert((addr[l] / 16) % 16);
+            EXPECT(slots.size() == 16, "%s: ds_read_b128 bank conflict, 16x16x32 (f%d pl%d): %zu slots", name, f, pl, slots.size());
+          }
+        } else {
+          for (int hi = 0; hi < 2; ++hi)
+            for (int grp = 0; grp < 2; ++grp) {
+              std::set<int> banks;
+              for (int l = 32 * grp; l < 32 * grp + 32; ++l) {
+                const int a = hi ? addr_hi[l] : addr[l];
+                banks.insert((a / 4) % 64);
+                banks.insert((a / 4 + 1) % 64);
+              }
+              EXPECT(banks.size() == 64, "%s: ds_read_b64_tr_b16 bank conflict, 16x16x32 (f%d pl%d): %zu banks", name, f, pl, banks.size());
+            }
+        }
+      }
+#endif
   // ---- fragment reads (Frag3::init + read), for a wave whose first fragment is frag0 ----
   const int NF = EXT / 32;
-  for (int frag0 = 0; frag0 < NF; ++frag0)
+  for (int frag0 = 0; frag0 < (TFK_X3_M16 ? 0 : NF); ++frag0)
   for (int pl = 0; pl < 3; ++pl)
     for (int f = 0; frag0 + f < NF; ++f)
       for (int ks = 0; ks < 2; ++ks) {
