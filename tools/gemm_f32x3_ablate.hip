@@ -2,6 +2,8 @@
 // of the K loop removed (-DTFKB_ABL: 1 no MFMAs, 2 no LDS-DMA pieces, 4 no fragment reads; sums combine) and times a shape.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTFKB_ABL=<n> -I tfkaldi_amd/csrc tools/gemm_f32x3_ablate.hip -o tools/bin/x3abl<n>
 //   tools/bin/x3abl<n> <layout> <M> <N> <K>         (block geometry: env TFK_BF16X3_CFG)
+//   env: TFK_ABL_ITERS (launches in the timed loop, default 30; thousands for a SUSTAINED figure -- a burst starts on a cold clock),
+//        TFK_ABL_DATA = random | zero | p0 | real (below), TFK_BF16X3_WAVES / TFK_BF16X3_CFG (block form / geometry)
 //   tools/bin/x3abl<n> 3 <frames> <d_in> <d_out>    the backward pair of a layer in one launch (gemm_bf16x3_dual):
 //                                                   dA[frames, d_in] = dZ . W^T  and  dW[d_in, d_out] = in^T . dZ
 #include "../tfkaldi_amd/csrc/gemm_bf16.hip"
