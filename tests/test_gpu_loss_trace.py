@@ -1,8 +1,8 @@
 """SURVEY.md 8d, CE-loss parity over the first 20 optimiser steps at BASELINE cfg2 (6x2048 ReLU + BN, 1024 frames per step,
-the bench's weights and micro-batches), with the float64 oracle as the referee: the engine's distance to it must stay
-within 3x its measured worst (7e-4; the PyTorch-CPU fp32 restatement -- the same arithmetic in another summation order,
-Adam amplifies either one's rounding noise -- is traced beside it).  Reference: neuralNetworks/trainer.py:336-346
-(the value Trainer.update returns)."""
+the bench's weights and micro-batches), with the float64 oracle as the referee: the engine's distance to it is bounded by the
+distance of the PyTorch-CPU fp32 restatement IN THE SAME RUN (the same arithmetic in another summation order: Adam amplifies
+either one's rounding noise) -- not by the engine's own history.  Reference: neuralNetworks/trainer.py:336-346 (the value
+Trainer.update returns)."""
 import os
 import sys
 
@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-# worst measured distance of each arithmetic to the float64 referee over the 20 steps (MI355X, profiles/r05_loss_trace_f64.json);
-# the bound of the test is three times that
-MEASURED = {"float32_mfma": 2.2e-4, "float32": 6.1e-4}
+# for the record only (no bound is derived from these): worst distance of each arithmetic to the float64 referee over the 20 steps
+# as measured on MI355X -- exact fp32 MFMA 2.2e-4; emulated with the truncating split (round 5) 5.2e-4 .. 6.1e-4, with the
+# round-to-nearest split (round 6) see profiles/r06_loss_trace_f64.json; PyTorch-CPU fp32 6.2e-4
+FLOOR = 3e-4  # a CPU trace that happens to stay close must not make the bound tighter than two fp32 random walks can meet
 
 
 @pytest.mark.timeout(900)
@@ -35,17 +36,18 @@ def test_engine_tracks_the_float64_oracle_over_20_steps(gpu):
     assert abs(ref[0] - np.log(2000)) < 1e-9  # KAT 8c-1: zero output layer -> ln O exactly
     # Tolerances.  Steps 0-2 are the pure round-off regime (a 1024-frame sum of per-frame losses in fp32: ~1e-7 relative;
     # measured 5e-8 .. 3e-7 for every implementation; at step 3 the exact-fp32 engine is still there, the emulated one and the
-    # CPU stand-in are at 3.3e-6 / 1.5e-6).  From then on Adam has amplified the summation-order noise of the
-    # near-zero gradients (the first updates are ~lr * sign(g)) and EVERY fp32 trace wanders around the float64 one
-    # chaotically: on MI355X the exact-fp32 engine was further away than the CPU stand-in at steps 4-9 and closer at steps
-    # 10-19 (max 2.2e-4 vs 6.2e-4; the emulated arithmetic 5.2e-4 .. 6.1e-4 over five builds) -- profiles/r0*_loss_trace_f64.json.
-    # A step-by-step comparison of random walks is a coin toss, so each engine step is bounded ABSOLUTELY, like every other
-    # bound of the suite, by three times that arithmetic's own worst measured step.  The CPU stand-in's trace is printed for the
-    # record and bounded the same way (3 x its measured 6.2e-4): if IT moves, the comparison lost its meaning.
+    # CPU stand-in are at 3.3e-6 / 1.5e-6): bounded absolutely.  From then on Adam has amplified the summation-order noise of the
+    # near-zero gradients (the first updates are ~lr * sign(g)) and EVERY fp32 trace wanders around the float64 one chaotically:
+    # a step-by-step comparison of random walks is a coin toss, so the whole trace of each engine arithmetic is bounded by TWICE
+    # the worst distance the CPU fp32 trace reaches in this very run (or FLOOR) -- an fp32 implementation the engine had no part
+    # in.  (Round 5 bounded each arithmetic by 3x its own measured history: a tolerance calibrated on the output it checks.)
+    bound = 2.0 * max(max(c_rel), FLOOR)
+    print("bound on every step of either engine trace: 2 x max(cpu worst %.3e, %.1e) = %.3e; engine worst: %s" % (
+        max(c_rel), FLOOR, bound, {d: "%.3e" % max(r) for d, r in rel.items()}))
     for d, g_rel in rel.items():
         for k in range(3):
             assert g_rel[k] <= 2e-6, (d, k, g_rel[k])
         assert g_rel[3] <= 1e-5, (d, g_rel[3])
         for k in range(20):
-            assert g_rel[k] <= 3 * MEASURED[d] + 4e-5, (d, k, g_rel[k])
-    assert max(c_rel) <= 2e-3, max(c_rel)
+            assert g_rel[k] <= bound, (d, k, g_rel[k], bound)
+    assert max(c_rel) <= 2e-3, max(c_rel)  # (if the CPU stand-in itself moves this far, the comparison lost its meaning)

@@ -555,3 +555,61 @@ def test_x3_operand_layouts_on_the_cpu(tmp_path, m16):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout[-2000:]
     assert "8.0 128-byte lines" in out.stdout and " 16.0 " not in out.stdout  # every byte of every fetched line is used
+
+
+def _bf16_rn(x):
+    """float32 array -> the nearest bfloat16 (ties to even) as float32; what v_cvt_pk_bf16_f32 / `(__bf16)x` computes on finite input"""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def x3_split_rn(x):
+    """numpy restatement of csrc/kernels.h: twin_split3 (round-to-nearest three-plane split; the overflow edge truncates)"""
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        p1 = _bf16_rn(x)
+        over = np.isinf(p1) & np.isfinite(x)
+        p1 = np.where(over, (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32), p1)
+        r1 = x - p1
+        p2 = np.where(over, (r1.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32), _bf16_rn(r1))
+        p3 = r1 - p2
+    return p1, p2, p3
+
+
+def test_round_to_nearest_plane_split_is_exact_and_tight():
+    """The arithmetic of `compute_dtype = float32` rests on three claims about twin_split3 (csrc/kernels.h), checked here on the CPU
+    in a numpy restatement (the device code is held to the same three on the GPU: tests/test_gpu_f32x3.py): for every finite fp32
+    x, (1) p1 + p2 + p3 == x exactly with both subtractions exact, (2) every plane is a bfloat16 (low 16 bits zero), (3) |p2| <=
+    2^-8 |x| and |p3| <= 2^-16 |x| -- which bounds the three dropped plane products by 2^-23 |a b| (truncation: 2^-21).  Random
+    values over every binade, ties, values with all 24 significand bits set, binade boundaries, subnormals, and the overflow
+    edge: a value above bf16's largest is split by truncation (still exact; |p2| <= 2^-7 |x| there)."""
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 1 << 32, size=2_000_000, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    special = np.array([1.0, -1.0, 1.00390625, 1.005859375, 1.998046875, 1.9999999, 2.0 ** -126, 2.0 ** -127, 2.0 ** -149, 3.0e38,
+                        3.3895314e38, 3.3961775e38, 3.4028235e38, -3.4028235e38, 0.0, -0.0, 16777215.0, 8388609.0,
+                        1.0 + 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -23, 1.0 + 3 * 2.0 ** -8, 1.0 + 2.0 ** -16 + 2.0 ** -8], dtype=np.float32)
+    x = np.concatenate([x, special, (rng.integers(1 << 23, 1 << 24, size=100000).astype(np.float32) * np.float32(2.0 ** -20))])
+    p1, p2, p3 = x3_split_rn(x)
+    x64 = x.astype(np.float64)
+    big = np.abs(x64) >= 2.0 ** -100  # (below: the remainders are fp32 subnormals -- the sum stays exact in fp32, but the third plane
+    for p in (p1, p2, p3):            #  has bits below bf16's and the matrix pipe may flush it: absolute error <= 2^-126, DESIGN.md 4)
+        assert np.isfinite(p).all()
+        assert ((p[big].view(np.uint32) & 0xFFFF) == 0).all(), "a plane is not a bfloat16"
+    assert np.array_equal(p1.astype(np.float64) + p2.astype(np.float64) + p3.astype(np.float64), x64)
+    assert np.array_equal((p1 + p2) + p3, x)  # and in fp32, in the order the accumulators see them
+    normal = big
+    edge = np.abs(x64) > 3.3895314e38   # bf16's largest finite value: rounding up would be Inf, the first plane truncates
+    ok = normal & ~edge
+    assert (np.abs(p2[ok]) <= 2.0 ** -8 * np.abs(x64[ok])).all()
+    assert (np.abs(p3[ok]) <= 2.0 ** -16 * np.abs(x64[ok])).all()
+    assert edge.any() and (np.abs(p2[edge]) <= 2.0 ** -7 * np.abs(x64[edge])).all()
+    # truncation, for the record: second planes up to 2^-7 |x|
+    t1 = (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    assert np.abs((x - t1)[ok] / x64[ok]).max() > 2.0 ** -7.1
+    # non-finite values surface: Inf -> (Inf, NaN, NaN), NaN -> NaN
+    with np.errstate(invalid="ignore"):
+        q1, q2, q3 = x3_split_rn(np.array([np.inf, -np.inf, np.nan], dtype=np.float32))
+    assert np.isinf(q1[:2]).all() and np.isnan(q2[:2]).all() and np.isnan(q1[2])

@@ -77,10 +77,10 @@ int gemm_bf16_dual_config(int M_nt, int N_nt, int M_tn, int N_tn);
 int gemm_bf16_dual_tile_rows(int cfg);
 
 // An fp32 contraction EMULATED on the bf16 matrix pipe ("bf16x3").  Every operand is given as THREE bf16 planes p1, p2, p3
-// with x = p1 + p2 + p3 exactly (truncation split of the fp32 significand, 8 bits per plane: split3 in kernels.h), interleaved
+// with x = p1 + p2 + p3 exactly (round-to-nearest split, |p2| <= 2^-8 |x|, |p3| <= 2^-16 |x|: twin_split3 in kernels.h), interleaved
 // per 32 elements (x3_layout.h: a ring slot's row segment is 192 contiguous bytes); the
 // kernel accumulates the six plane products of order <= 2^-16 -- a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1 -- in fp32.  Products
-// of bf16 values are exact in fp32 and the dropped pairs are below 2^-24 of a product, so the result differs from the exact
+// of bf16 values are exact in fp32 and the three dropped pairs sum to at most 2^-23 of a product, so the result differs from the exact
 // fp32 dot product only by fp32 accumulation error: measured against float64 it is CLOSER than the fp32 MFMA chain of
 // gemm_f32 (tools/bf16x3_probe.py), at 6/16 of its matrix-pipe time.  Same layouts, leading dimensions and epilogues as
 // gemm_bf16; blocks of 128 rows (= rows per EPI_COLSTATS / EPI_DACT chunk).
