@@ -332,6 +332,105 @@ def eval_leg(w, eng, batches):
             "note": "host numpy in (PCIe inside the clock), loss out; forward only"}
 
 
+class PowerSampler(object):
+    """socket power (W) and shader clock (MHz) of this rank's GPU, sampled from a host thread while a leg runs.  The amdgpu hwmon
+    files when this user can read them (a read costs microseconds: one sample every 50 ms), else `rocm-smi --showpower
+    --showclocks` as tools/x3_power_sample.sh uses it (a Python process per sample: ~3 samples a second)."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.samples, self.source, self._stop = [], None, threading.Event()
+        self._power = self._clock = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
+        if device_index < len(cards):
+            hw = cards[device_index]
+            for name in ("power1_input", "power1_average"):
+                f = os.path.join(hw, name)
+                try:
+                    if float(open(f).read()) > 0:
+                        self._power = f
+                        break
+                except (OSError, ValueError):
+                    pass
+            self._clock = os.path.join(hw, "freq1_input")
+            try:
+                float(open(self._clock).read())
+            except (OSError, ValueError):
+                self._clock = None
+        self.device_index = device_index
+        self.source = "amdgpu hwmon (power1, freq1_input)" if self._power and self._clock else "rocm-smi --showpower --showclocks"
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _once(self):
+        if self._power and self._clock:
+            return float(open(self._power).read()) * 1e-6, float(open(self._clock).read()) * 1e-6
+        import re
+        out = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showpower", "--showclocks"], capture_output=True,
+                             text=True, timeout=10).stdout
+        pw = re.search(r"Package Power \(W\):\s*([0-9.]+)", out)
+        ck = re.search(r"sclk clock level:.*\((\d+)Mhz\)", out)
+        return (float(pw.group(1)) if pw else None), (float(ck.group(1)) if ck else None)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                pw, ck = self._once()
+                self.samples.append((time.perf_counter(), pw, ck))
+            except Exception:  # noqa: BLE001  (a sampler must never take the bench line down)
+                pass
+            self._stop.wait(0.05 if self._power else 0.1)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self, t_from):
+        pw = [p for t, p, _ in self.samples if t >= t_from and p]
+        ck = [c for t, _, c in self.samples if t >= t_from and c]
+        return {"sampler": self.source, "samples": len(pw),
+                "socket_power_w_mean": sum(pw) / len(pw) if pw else None, "socket_power_w_max": max(pw) if pw else None,
+                "shader_clock_mhz_mean": sum(ck) / len(ck) if ck else None, "shader_clock_mhz_min": min(ck) if ck else None}
+
+
+def clock_prewarm(eng, dtype, ms):
+    """Bring the GPU to its sustained clocks before anything is measured, ON THE PIPE UNDER TEST (round 5 ran fp32 MFMA GEMMs in
+    front of a bf16-pipe workload): `ms` milliseconds of the arithmetic's own contraction -- the three-plane emulated GEMM, the
+    bf16 GEMM, or the exact fp32 one -- on scratch operands with random significands (no model state is touched; the loss trace
+    still starts at the initial weights).  With a short run (the driver's --steps 20 --warmup 5 is 40 ms of GPU work) the first
+    timed steps otherwise run while clock and power management are still settling."""
+    import ctypes
+    import torch
+    from tfkaldi_amd import _lib, x3
+    M, N, K = 1024, 2048, 2048
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(K, N, device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if dtype == "float32":
+        Ap, lda = x3.split(eng.lib, A)
+        Bp, ldb = x3.split(eng.lib, B)
+        call = lambda: eng.lib.tfk_gemm_bf16x3(stream, 0, ctypes.c_void_p(Ap.data_ptr()), lda, ctypes.c_void_p(Bp.data_ptr()), ldb,  # noqa: E731
+                                               ctypes.c_void_p(C.data_ptr()), N, M, N, K, None, 0)
+    elif dtype == "bfloat16":
+        Ab, Bb = A.bfloat16(), B.bfloat16()
+        call = lambda: eng.lib.tfk_gemm_bf16(stream, 0, ctypes.c_void_p(Ab.data_ptr()), K, ctypes.c_void_p(Bb.data_ptr()), N,  # noqa: E731
+                                             ctypes.c_void_p(C.data_ptr()), N, M, N, K, None, 0)
+    else:
+        call = lambda: eng.lib.tfk_gemm_f32(stream, 0, ctypes.c_void_p(A.data_ptr()), K, ctypes.c_void_p(B.data_ptr()), N,  # noqa: E731
+                                            ctypes.c_void_p(C.data_ptr()), N, M, N, K, None, 0, -1)
+    t_end = time.perf_counter() + ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(50):
+            _lib.check(call())
+        torch.cuda.synchronize()
+
+
 def kernel_label(w, family):
     """the engine names its kernel families after the fp32 kernels; say which arithmetic actually ran"""
     return family.replace("gemm_f32", {"float32": "gemm_bf16x3", "float32_mfma": "gemm_f32", "bfloat16": "gemm_bf16"}[w.dtype])
@@ -386,6 +485,9 @@ def main():
                     help="skip the sub-record of the other fp32 arithmetic (`exact_fp32` beside an emulated headline, "
                          "`emulated_fp32` beside an exact one; fp32 runs on one GPU only)")
     ap.add_argument("--no-eval", action="store_true", help="skip the validation leg (`eval`, N = 1 only)")
+    ap.add_argument("--no-sustained", action="store_true",
+                    help="skip the sustained leg (>= 3 s of the same step back to back with socket power and shader clock sampled; "
+                         "also TFK_BENCH_SUSTAIN_S=0)")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (N = 1 only)")
     ap.add_argument("--no-api-fed", action="store_true",
                     help="skip the Nnet.train leg (api_fed_value; also TFK_BENCH_API_FED=0)")
@@ -472,23 +574,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Bring the GPU to its sustained clocks before anything is measured: a few hundred milliseconds of unrelated fp32
-    # GEMMs on scratch buffers (no model state is touched, the loss trace still starts at the initial weights).  With a
-    # short run (the driver's --steps 20 --warmup 5 is 40 ms of GPU work) the first timed steps otherwise run while
-    # the clocks are still ramping up from idle: ~3 % slower than the steady state the metric is about.
+    # Bring the GPU to its sustained clocks before anything is measured, on the pipe under test (clock_prewarm)
     prewarm_ms = float(os.environ.get("TFK_BENCH_PREWARM_MS", "300"))
     if prewarm_ms > 0:
-        import ctypes
-        sa = torch.randn(1024, 2048, device="cuda"); sb = torch.randn(2048, 2048, device="cuda")
-        sc = torch.empty(1024, 2048, device="cuda")
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        t_end = time.perf_counter() + prewarm_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(50):
-                _lib.check(eng.lib.tfk_gemm_f32(stream, 0, ctypes.c_void_p(sa.data_ptr()), 2048, ctypes.c_void_p(sb.data_ptr()),
-                                                2048, ctypes.c_void_p(sc.data_ptr()), 2048, 1024, 2048, 2048, None, 0, -1))
-            torch.cuda.synchronize()
-        del sa, sb, sc
+        clock_prewarm(eng, args.dtype, prewarm_ms)
     losses = [step() for _ in range(args.warmup)]
     fence()
     t0 = time.perf_counter()
@@ -525,6 +614,97 @@ def main():
         elapsed = max(float(g[0].item()) for g in gathered)
         elapsed_host = max(float(g[1].item()) for g in gathered)
         backend = dist.get_backend()
+
+    def timed_steps(n):
+        """n steps between two fences; seconds by the slowest rank's clock"""
+        fence()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        dt = time.perf_counter() - t
+        if dp.enabled:
+            v = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            dt = float(v.item())
+        return dt
+
+    # ---- sustained leg (after every region a rate or a roofline is quoted from): the same step() back to back for >= 3 s, the
+    # rate of its last 2 s, socket power and shader clock sampled meanwhile.  A training run lasts hours (reference nnet.py:153)
+    # and this step is power-bound: `value` comes from a window of tens of milliseconds, this says what it becomes.
+    sustained = None
+    sustain_s = float(os.environ.get("TFK_BENCH_SUSTAIN_S", "3.2"))
+    if sustain_s > 0 and not args.no_sustained:
+        n_sus = max(50, int(sustain_s / (elapsed / args.steps)) + 1)  # (`elapsed` is the slowest rank's: the same count everywhere)
+        marks = []
+        fence()
+        with PowerSampler(local_rank) as sampler:
+            t_s = time.perf_counter()
+            for i in range(n_sus):
+                step()
+                if i % 25 == 24:
+                    marks.append((time.perf_counter(), i + 1))
+            fence()
+            t_e = time.perf_counter()
+        marks.append((t_e, n_sus))
+        cut = next(((t, k) for t, k in marks if t >= t_e - 2.0), marks[0])  # first mark inside the last 2 s
+        tail_steps, tail_s = n_sus - cut[1], t_e - cut[0]
+        if tail_steps <= 0:
+            cut, tail_steps, tail_s = (t_s, 0), n_sus, t_e - t_s
+        sus = {"seconds": t_e - t_s, "steps": n_sus, "last_window_s": tail_s, "last_window_steps": tail_steps,
+               "ms_per_step_last_window": 1e3 * tail_s / tail_steps, "ms_per_step_whole_leg": 1e3 * (t_e - t_s) / n_sus}
+        sus.update(sampler.summary(cut[0]))
+        if dp.enabled:  # the slowest rank's window counts
+            v = torch.tensor([sus["ms_per_step_last_window"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            sus["ms_per_step_last_window"] = float(v.item())
+        # the dominant kernel while the chip is in that state: 20 event-bracketed steps right behind the leg
+        eng.profile_begin()
+        for _ in range(20):
+            step()
+        fence()
+        sus_stats = eng.profile_end()
+        sustained = (sus, sus_stats)
+
+    # ---- N > 1: the exchange step A/B (every algorithm x wire format the driver in use offers, ~10 steps each; `value` above came
+    # from the DEFAULT alone) and the device time of each phase of the default, per rank (tfk_comm_timing)
+    exchange_ab = exchange_phases = exchange_info = None
+    if dp.enabled and getattr(reducer, "native", False):
+        exchange_info = reducer.exchange_info()
+        default = (exchange_info["reduce_scatter"] if exchange_info["reduce_scatter"] == exchange_info["all_gather"] else None,
+                   exchange_info["wire"])
+        exchange_ab = {"steps_each": 10, "default": exchange_info, "ms_per_step": {}}
+        if reducer.mode == "sharded":
+            for algo in ("rccl", "direct"):
+                for wire in ("fp32", "bf16"):
+                    reducer.set_exchange(algo, wire)
+                    timed_steps(3)
+                    exchange_ab["ms_per_step"]["%s/%s" % (algo, wire)] = 1e3 * timed_steps(10) / 10
+            # back to what `value` ran with (a tuned choice may differ per operation: re-tuning would be a collective of its own,
+            # so the pair is restored through the environment-independent setter only when it was uniform)
+            if default[0] is not None:
+                reducer.set_exchange(default[0], default[1])
+            else:
+                reducer.set_exchange(None, default[1])
+                reducer.tune(max(n for _, n in eng.buckets()), 5)
+            timed_steps(3)
+        reducer.timing_begin()
+        timed_steps(10)
+        phases, n_timed = reducer.timing_read()
+        v = torch.tensor([phases[k] for k in reducer.PHASES], dtype=torch.float64, device="cuda")
+        allv = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(allv, v)
+        exchange_phases = {"steps": n_timed, "unit": "device ms per step, one list entry per rank",
+                           "per_rank": {k: [float(a[i].item()) for a in allv] for i, k in enumerate(reducer.PHASES)},
+                           "note": "timing events on the stream each phase runs on (tfk_comm_timing; every record costs its stream a "
+                                   "few microseconds, so these steps are slower than `value`'s): reduce_scatter / all_reduce / "
+                                   "all_gather / twin_rebuild = device time of the operation itself (mostly hidden under backward / "
+                                   "the next forward pass); tail_exposed = engine-stream time between the last backward kernel and "
+                                   "the first Adam kernel; gather_exposed = engine-stream time the forward pass waited for gathers"}
+    elif dp.enabled:
+        exchange_ab = {"unavailable": "the exchange runs through torch.distributed (dataparallel.BucketReducer): one algorithm (the "
+                                      "backend's own collectives), fp32 wire; the A/B needs the in-library exchange over RCCL",
+                       "ms_per_step": {"torch.distributed/fp32": 1e3 * timed_steps(min(10, args.steps)) / min(10, args.steps)}}
 
     if rank == 0:
         gemms = [s for s in stats if s["name"].startswith("gemm_")]
@@ -594,6 +774,7 @@ def main():
                                         "the vendor library's alike; 1.5 PF at 2.39 GHz over zeros (profiles/r05_gemm_bf16_power_smi.txt)"
                                         if args.dtype == "bfloat16" else None)),
                          "hbm": hbm},
+            "exchange_algorithm": exchange_info, "exchange_ab": exchange_ab, "exchange_phases": exchange_phases,
             "host_fed_value": world * T * args.steps / elapsed_host,
             "host_fed_note": "same step, micro-batch handed over as HOST numpy [%d, 440] + targets through "
                              "tfk_accumulate (PCIe inclusive; never `value`)" % T,
@@ -601,6 +782,22 @@ def main():
             "loss_trace_gpu": losses[:TRACE_STEPS],
             "kernel_ms_per_step": {kernel_label(w, s["name"]): s["total_ms"] / args.steps for s in stats},
         }
+        if sustained:
+            sus, sus_stats = sustained
+            sus["value"] = world * T / (1e-3 * sus["ms_per_step_last_window"])
+            sus["unit"] = "frames/s over the last window of the leg (slowest rank)"
+            sus["value_over_sustained"] = value / sus["value"]
+            sg = [x for x in sus_stats if x["name"].startswith("gemm_")]
+            if sg:
+                sd = max(sg, key=lambda x: x["total_ms"])
+                stf = sd["flops"] / sd["total_ms"] / 1e9
+                sus["roofline"] = {"kernel": kernel_label(w, sd["name"]), "avg_launch_us": 1e3 * sd["total_ms"] / sd["launches"],
+                                   "achieved": stf, "peak": peak, "unit": "TFLOP/s", "frac": stf / peak,
+                                   "note": "20 event-bracketed steps right behind the leg (the chip still in its sustained state)"}
+            sus["note"] = ("the contract's timed region is %d steps (%.0f ms) after a %.0f ms pre-warm on the same pipe; this leg runs the "
+                           "same step() back to back for %.1f s -- what the rate becomes once the socket sits at its power limit"
+                           % (args.steps, 1e3 * elapsed, prewarm_ms, sus["seconds"]))
+            out["sustained"] = sus
         # What the exchange step should cost on 2 / 4 / 8 GPUs, predicted from THIS rank's measured step (dataparallel.
         # exchange_model): bytes on the wire per rank, link-rate time over point-to-point xGMI (direct = all peers at once, ring =
         # one link's rate), the backward time left to overlap with once the first span is ready, the step time that follows.  A

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TFK_ABI_VERSION 7
+#define TFK_ABI_VERSION 8
 
 typedef struct tfk_engine tfk_engine;
 
@@ -387,6 +387,37 @@ int tfk_comm_gather_masters(tfk_comm* c);
  * (offset in floats, floats, 1 = reduce-scattered / 0 = all-reduced); spans holds 3 * capacity values */
 int tfk_comm_last_step(tfk_comm* c, int* reduce_scatters, int* all_gathers, int* all_reduces, size_t* spans, int capacity,
                        int* num_spans);
+/* (ABI 8) HOW a reduce-scattered span and a parameter gather travel (sharded mode; reference seam trainer.py:165-184 -- the sum
+ * `G += g` over the micro-batches of a step, here over ranks):
+ *   TFK_ALGO_RCCL    ncclReduceScatter / ncclAllGather: RCCL picks the algorithm (ring / tree over its channels) and with it the
+ *                    order the ranks' contributions are added in;
+ *   TFK_ALGO_DIRECT  the collective spelled out for a full mesh of point-to-point xGMI links: one grouped ncclSend / ncclRecv
+ *                    per peer -- sub-span q of every rank goes straight to rank q over the link between them, all world - 1
+ *                    links busy at once -- and the OWNER adds the world contributions in fp32 in RANK ORDER, i.e. in the order a
+ *                    single process adds its micro-batches: the reduced shard equals the serial run's G bit for bit.  The
+ *                    gather is the same movement backwards (own shard to every peer, in place).
+ * Wire format of the reduce-scatter: TFK_WIRE_FP32, or TFK_WIRE_BF16 (direct movement at half the bytes; the owner's own
+ * contribution stays exact).  Environment at attach: TFK_DP_ALGO = auto | rccl | direct, TFK_DP_WIRE = fp32 | bf16.  `auto`, the
+ * default with more than one RCCL rank: tfk_comm_create times both algorithms on scratch memory of a span's size (tfk_comm_tune,
+ * collective) and keeps the faster one per operation -- the slowest rank's time decides, identically on every rank.
+ * tfk_comm_set_exchange (-1 = keep): between steps only, every rank with the same arguments.
+ * tfk_comm_get_exchange: what is in force; chosen_by 0 default / 1 environment / 2 tuned / 3 set; tune_us[4] = microseconds of
+ * reduce-scatter rccl, direct, all-gather rccl, direct as tuned (0: never tuned). */
+enum { TFK_ALGO_RCCL = 0, TFK_ALGO_DIRECT = 1 };
+enum { TFK_WIRE_FP32 = 0, TFK_WIRE_BF16 = 1 };
+int tfk_comm_set_exchange(tfk_comm* c, int algo, int wire);
+int tfk_comm_get_exchange(tfk_comm* c, int* algo_reduce_scatter, int* algo_all_gather, int* wire, int* chosen_by, double* tune_us);
+int tfk_comm_tune(tfk_comm* c, size_t floats, int iters); /* COLLECTIVE */
+/* (ABI 8) Device time per phase of the exchange step, for diagnosis (bench.py --gpus N: `exchange_phases`): between
+ * tfk_comm_timing(c, 1) and tfk_comm_timing_read every phase is bracketed by timing events on the stream it runs on (each
+ * record costs that stream a few microseconds: a diagnostic pass, not the one a rate is quoted from).  ms_per_step[k], averaged
+ * over the steps completed in between: 0 reduce-scatters (pack / exchange / owner's sum included), 1 all-reduces (vectors, scalar
+ * tail), 2 engine-stream time from the last backward kernel to the first optimiser kernel (what the exchange leaves exposed in
+ * front of Adam), 3 Adam on this rank's spans, 4 parameter gathers, 5 three-plane twin rebuilds behind them, 6 engine-stream
+ * time the next forward pass spends waiting for gathers (the first span's gather + rebuild run on that stream and count in
+ * full).  tfk_comm_timing_read synchronises both streams and switches the timing off. */
+int tfk_comm_timing(tfk_comm* c, int on);
+int tfk_comm_timing_read(tfk_comm* c, double* ms_per_step, int capacity, long* steps);
 /* Tests: a group of `world` engines of ONE process on ONE device; each rank is driven by its own host thread and the
  * collectives are a rendezvous + plain kernels.  This is how the protocol above runs at world 2 / 4 / 8 on a single-GPU
  * box (RCCL refuses two ranks on one device). */

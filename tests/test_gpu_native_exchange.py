@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _Group(object):
     """a loopback group + one (engine, DataParallel, NativeExchange) per rank"""
 
-    def __init__(self, world, mode, dtype="float32", kw=None, min_bytes=1 << 12):
+    def __init__(self, world, mode, dtype="float32", kw=None, min_bytes=1 << 12, algo=None, wire=None):
         from tfkaldi_amd import _lib
         from tfkaldi_amd.dataparallel import DataParallel, NativeExchange
         self.lib = _lib.load()
@@ -38,6 +38,9 @@ class _Group(object):
             dp = DataParallel(mode=mode)
             dp.rank, dp.world, dp._forced = rank, world, True
             dp._reducers[eng] = NativeExchange(eng, mode=mode, min_bytes=min_bytes, loopback=(self.handle, rank))
+            if algo is not None or wire is not None:
+                dp._reducers[eng].set_exchange(algo, wire)
+                assert dp._reducers[eng].exchange_info()["reduce_scatter"] == (algo or "rccl")
             self.engines.append(eng)
             self.dps.append(dp)
 
@@ -116,14 +119,16 @@ def _compare(ref, got, loss_rtol, param_atol, tag):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("mode,algo", [("sharded", None), ("sharded", "direct"), ("allreduce", None)])
 @pytest.mark.parametrize("world,num_mb", [(2, 2), (2, 5), (4, 4), (4, 3), (8, 8), (8, 3)])
-def test_loopback_ranks_equal_the_serial_run_fp32(gpu, world, num_mb, mode):
+def test_loopback_ranks_equal_the_serial_run_fp32(gpu, world, num_mb, mode, algo):
     """even shards, uneven shards, idle ranks (fewer micro-batches than ranks); every rank ends with the same parameters,
     equal to the serial run's up to the fp32 summation order of G (ranks add their sums, the serial run adds micro-batch
-    after micro-batch), which Adam amplifies: bounds as tests/test_gpu_dp_two_ranks.py"""
+    after micro-batch), which Adam amplifies: bounds as tests/test_gpu_dp_two_ranks.py.  algo "direct": the reduce-scatter as
+    sub-span transfers to / from every peer + the owner's rank-ordered sum, the gather as the same movement backwards
+    (TFK_DP_ALGO=direct, csrc/exchange.hip) instead of the backend's own collectives"""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
-    group = _Group(world, mode)
+    group = _Group(world, mode, algo=algo)
     try:
         results = group.run(_rank_program(num_mb))
     finally:
@@ -141,15 +146,15 @@ def test_loopback_ranks_equal_the_serial_run_fp32(gpu, world, num_mb, mode):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("mode,algo", [("sharded", None), ("sharded", "direct"), ("allreduce", None)])
 @pytest.mark.parametrize("world,num_mb", [(2, 2), (4, 3), (8, 8)])
-def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode):
+def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode, algo):
     """the fp32-emulating arithmetic under the exchange: a different path from both others -- the sharded mode gathers the fp32
     parameters (the three-plane twins of the weights live outside the arena) and every rank REBUILDS its twins from them before
     the next forward pass (engine.hip: refresh_shadow), the all-reduce mode updates them with the full Adam step.  Same bounds as
     fp32 (it claims to be fp32), replicas bit-identical, and no stale masters: nothing is left sharded in this mode"""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
-    group = _Group(world, mode, dtype="float32x3")
+    group = _Group(world, mode, dtype="float32x3", algo=algo)
     try:
         results = group.run(_rank_program(num_mb))
     finally:
@@ -166,13 +171,14 @@ def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("algo", [None, "direct"])
 @pytest.mark.parametrize("world,num_mb", [(2, 2), (4, 6), (8, 8), (8, 2)])
-def test_loopback_ranks_mixed_precision_sharded_masters(gpu, world, num_mb):
+def test_loopback_ranks_mixed_precision_sharded_masters(gpu, world, num_mb, algo):
     """bf16 GEMMs: what travels back is the bf16 SHADOW (2 B per parameter); the fp32 masters of a span stay on the rank
     that owns it until gather_parameters -- afterwards every rank holds the same masters, close to the serial run's"""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
     kw = dict(KW, num_units=64, output_dim=24)  # (every leading dimension a multiple of 8: the shadow mirrors the arena)
-    group = _Group(world, "sharded", dtype="bfloat16", kw=kw)
+    group = _Group(world, "sharded", dtype="bfloat16", kw=kw, algo=algo)
     try:
         results = group.run(_rank_program(num_mb))
     finally:
@@ -193,13 +199,14 @@ def _data_cfg2(num_mb, seed):
 
 
 @pytest.mark.timeout(900)
-def test_eight_loopback_ranks_at_cfg2_size(gpu):
+@pytest.mark.parametrize("algo", [None, "direct"])
+def test_eight_loopback_ranks_at_cfg2_size(gpu, algo):
     """BASELINE cfg2's network (26 M parameters, 16 MB hidden-layer spans, the default 64 MiB coalescing): the spans an
     8-GPU job exchanges -- [scalar tail], W6..W2, W1 + W0, [vectors] -- every one dividing by 4 x 8"""
     os.environ.pop("TFK_DP_MIN_SHARD", None)
     kw = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=2000, nonlin="relu", batch_norm=True,
               init_learning_rate=1e-3, num_steps=10, max_frames=256)
-    group = _Group(8, "sharded", kw=kw, min_bytes=None)
+    group = _Group(8, "sharded", kw=kw, min_bytes=None, algo=algo)
     try:
         results = group.run(_rank_program(8, data=_data_cfg2))
     finally:
@@ -261,13 +268,16 @@ def _region(eng):
     return out
 
 
-@pytest.mark.parametrize("dtype", ["float32", "float32x3"])
+@pytest.mark.parametrize("algo", [None, "direct"])
+@pytest.mark.parametrize("dtype", ["float32", "float32x3", "bfloat16"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype):
+def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype, algo):
     """BEFORE Adam (which amplifies round-off): after the collectives of a step, rank r's 1/world of every reduce-scattered
     span and the whole of every all-reduced span hold the gradient sums of the serial run.  One micro-batch per rank: the
     ranks' sums are added in rank order = the order the serial run accumulates micro-batches in, so the sums are
-    bit-identical (the scalar tail's BN increments excepted: their closed form is another arithmetic)."""
+    bit-identical (the scalar tail's BN increments excepted: their closed form is another arithmetic).  With algo "direct" this
+    is a property of the PRODUCT's reduce-scatter on real RCCL too (the owner adds in rank order: direct_sum_kernel); RCCL's own
+    reduce-scatter promises no order -- the loopback backend's stand-in for it happens to add in rank order as well."""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
     mbs = _data(world, 0)
     serial = _engine(torch_state=False, dtype=dtype)
@@ -276,7 +286,7 @@ def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype)
     want = _region(serial)
     num_params = serial.buckets()[-1][0]
     serial.close()
-    group = _Group(world, "sharded", dtype=dtype)
+    group = _Group(world, "sharded", dtype=dtype, algo=algo)
 
     def program(rank, eng, dp):
         red = dp.reducer(eng)
@@ -370,3 +380,51 @@ def test_bf16_wire_reduce_scatter_against_the_fp32_wire(gpu, world, monkeypatch)
         assert np.allclose(bf[rank][0]["losses"], fp[rank][0]["losses"], rtol=2e-3, atol=0), (bf[rank][0]["losses"], fp[rank][0]["losses"])
         for k, v in bf[0][0].items():
             np.testing.assert_array_equal(bf[rank][0][k], v, err_msg="rank %d %s" % (rank, k))
+
+
+def test_exchange_options_tuning_and_phase_times(gpu):
+    """ABI 8: tfk_comm_set_exchange is refused in the middle of a step and takes effect between steps; tfk_comm_tune (what a
+    real RCCL group of more than one rank runs at attach under TFK_DP_ALGO=auto) times both algorithms on scratch memory, agrees
+    on the slowest rank's figures and leaves the same choice on every rank; tfk_comm_timing brackets the phases of the step with
+    timing events: three steps later every phase that must have run has a positive device time and the step count is three"""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    world = 4
+    group = _Group(world, "sharded", dtype="float32x3")
+
+    def program(rank, eng, dp):
+        red = dp.reducer(eng)
+        info0 = red.exchange_info()
+        assert info0 == {"reduce_scatter": "rccl", "all_gather": "rccl", "wire": "fp32", "chosen_by": "default"}, info0
+        tuned = red.tune(1 << 20, iters=3)
+        assert tuned["chosen_by"] == "tuned at attach" and all(v > 0 for v in tuned["tuned_us_slowest_rank"].values()), tuned
+        losses = [dp.train_step(eng, _data(world, 0))]
+        red.set_exchange("direct", "bf16")
+        losses.append(dp.train_step(eng, _data(world, 1)))
+        assert red.exchange_info()["wire"] == "bf16" and red.exchange_info()["chosen_by"] == "set"
+        red.set_exchange("direct", "fp32")
+        # refused while a step is in flight: announce a micro-batch, then try
+        eng.set_later_microbatches(world - 1 - rank)
+        eng.accumulate(*_data(world, 2)[rank], last=True)
+        with pytest.raises(RuntimeError, match="middle of a step"):
+            red.set_exchange("rccl", None)
+        losses.append(red.finish_and_apply(eng))
+        red.timing_begin()
+        for step in (3, 4, 5):
+            losses.append(dp.train_step(eng, _data(world, step)))
+        phases, steps = red.timing_read()
+        dp.gather_parameters(eng)
+        return tuned, phases, steps, losses
+
+    try:
+        results = group.run(program)
+    finally:
+        group.close()
+    assert all(r[0] == results[0][0] for r in results), [r[0] for r in results]  # the same figures, the same choice everywhere
+    for tuned, phases, steps, losses in results:
+        assert steps == 3 and np.isfinite(losses).all()
+        assert set(phases) == {"reduce_scatter", "all_reduce", "tail_exposed", "adam", "all_gather", "twin_rebuild", "gather_exposed"}
+        for k in ("reduce_scatter", "all_reduce", "tail_exposed", "adam", "all_gather", "twin_rebuild", "gather_exposed"):
+            assert phases[k] > 0.0, (k, phases)
+        assert all(v < 1e3 for v in phases.values()), phases
+    print("tuned (loopback, 4 ranks, 1 Mi floats):", results[0][0])
+    print("phases, ms per step (rank 0):", results[0][1])

@@ -5,12 +5,12 @@ engine fails loudly -- the product path never routes through a CPU implementatio
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+from ctypes import (POINTER, Structure, byref, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_long,
                     c_size_t, c_uint64, c_void_p)
 
 from .build import lib_path, source_id
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # enums of tfkaldi_hip.h
 NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
@@ -159,6 +159,11 @@ SYMBOLS = {
     "tfk_comm_gather_masters": (c_int, [c_void_p]),
     "tfk_comm_last_step": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t), c_int,
                                    POINTER(c_int)]),
+    "tfk_comm_set_exchange": (c_int, [c_void_p, c_int, c_int]),
+    "tfk_comm_get_exchange": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_double)]),
+    "tfk_comm_tune": (c_int, [c_void_p, c_size_t, c_int]),
+    "tfk_comm_timing": (c_int, [c_void_p, c_int]),
+    "tfk_comm_timing_read": (c_int, [c_void_p, POINTER(c_double), c_int, POINTER(c_long)]),
     "tfk_loopback_create": (c_int, [c_int, POINTER(c_void_p)]),
     "tfk_loopback_destroy": (c_int, [c_void_p]),
     "tfk_comm_create_loopback": (c_int, [_E, c_void_p, c_int, c_int, c_size_t, POINTER(c_void_p)]),

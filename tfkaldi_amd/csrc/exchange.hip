@@ -129,8 +129,12 @@ struct Backend {
   // every rank's shard (bytes_per_rank at rank * bytes_per_rank) -> all shards everywhere
   virtual int all_gather(void* buf, size_t bytes_per_rank, hipStream_t st) = 0;
   virtual int all_reduce(float* buf, size_t count, hipStream_t st) = 0;
-  // all-to-all of byte blocks: send[q * bytes, +bytes) goes to rank q's recv[rank * bytes, +bytes) (own block included)
+  // all-to-all of byte blocks: send[q * bytes, +bytes) goes to rank q's recv[rank * bytes, +bytes) for every q != rank (the own
+  // block does not travel: recv[rank * bytes, +bytes) is left as it is)
   virtual int exchange_shards(const void* send, void* recv, size_t bytes, hipStream_t st) = 0;
+  // all_gather as point-to-point transfers: this rank's shard goes to every peer and every peer's shard arrives in place, all
+  // world - 1 links at once (what an all-gather IS on a full mesh of point-to-point links)
+  virtual int all_gather_direct(void* buf, size_t bytes_per_rank, hipStream_t st) = 0;
   // host-level: v[0] = min over ranks, v[1] = max over ranks of the value passed in v[0] (blocks the calling thread)
   virtual int min_max(unsigned long long* v, hipStream_t st) = 0;
   // the collectives posted between the two calls (all on ONE stream) may be launched as one operation
@@ -161,18 +165,37 @@ struct RcclBackend : Backend {
   }
   int exchange_shards(const void* send, void* recv, size_t bytes, hipStream_t st) override {
     Rccl* r = rccl();
-    if (!r->Send || !r->Recv) return failx(-1, "this RCCL has no ncclSend / ncclRecv: TFK_DP_WIRE=bf16 is not available");
+    if (!r->Send || !r->Recv)
+      return failx(-1, "this RCCL has no ncclSend / ncclRecv: TFK_DP_ALGO=direct and TFK_DP_WIRE=bf16 are not available");
     const char* s = static_cast<const char*>(send);
     char* d = static_cast<char*>(recv);
-    // one group: every rank sends world blocks and receives world blocks over its world - 1 links at once -- on point-to-point
-    // xGMI this IS the direct reduce-scatter's data movement, at half the bytes
+    // one group: every rank sends world - 1 blocks and receives world - 1 blocks over its world - 1 links at once -- on
+    // point-to-point xGMI this IS the direct reduce-scatter's data movement
     XNCCL(r->GroupStart());
     for (int q = 0; q < world; ++q) {
+      if (q == rank) continue;
       ncclResult_t a = r->Send(s + (size_t)q * bytes, bytes, ncclInt8, q, comm, st);
       ncclResult_t b = a == ncclSuccess ? r->Recv(d + (size_t)q * bytes, bytes, ncclInt8, q, comm, st) : a;
       if (b != ncclSuccess) {
         (void)r->GroupEnd();
         return failx((int)b, "ncclSend / ncclRecv failed: %s", r->GetErrorString(b));
+      }
+    }
+    XNCCL(r->GroupEnd());
+    return 0;
+  }
+  int all_gather_direct(void* buf, size_t bytes_per_rank, hipStream_t st) override {
+    Rccl* r = rccl();
+    if (!r->Send || !r->Recv) return failx(-1, "this RCCL has no ncclSend / ncclRecv: TFK_DP_ALGO=direct is not available");
+    char* b = static_cast<char*>(buf);
+    XNCCL(r->GroupStart());
+    for (int q = 0; q < world; ++q) {
+      if (q == rank) continue;
+      ncclResult_t a = r->Send(b + (size_t)rank * bytes_per_rank, bytes_per_rank, ncclInt8, q, comm, st);
+      ncclResult_t c = a == ncclSuccess ? r->Recv(b + (size_t)q * bytes_per_rank, bytes_per_rank, ncclInt8, q, comm, st) : a;
+      if (c != ncclSuccess) {
+        (void)r->GroupEnd();
+        return failx((int)c, "ncclSend / ncclRecv failed: %s", r->GetErrorString(c));
       }
     }
     XNCCL(r->GroupEnd());
@@ -223,10 +246,28 @@ __global__ void wire_pack_kernel(const float* __restrict__ g, uint16_t* __restri
 // fp32 accumulate on the owner, the owner's own contribution exact (world = 1 is the identity)
 __global__ void wire_sum_kernel(float* __restrict__ shard, const uint16_t* __restrict__ recv, int rank, int world, size_t per) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int q = 0; q < world; ++q)
+    float s = rank == 0 ? shard[i] : __builtin_bit_cast(float, (uint32_t)recv[i] << 16);
+    for (int q = 1; q < world; ++q)
       s += q == rank ? shard[i] : __builtin_bit_cast(float, (uint32_t)recv[(size_t)q * per + i] << 16);
     shard[i] = s;
+  }
+}
+
+// ---- the direct reduce-scatter on the fp32 wire (TFK_DP_ALGO=direct) ----
+// shard[i] = ((g_0[i] + g_1[i]) + g_2[i]) + ... : the ranks' contributions added in RANK ORDER -- the order a serial run adds its
+// micro-batches in, so the owner's sum is that run's G bit for bit (a promise RCCL's own reduce-scatter does not make: its order
+// follows its ring).  g_rank is the shard itself, g_q (q != rank) what rank q sent: recv[q * per + i].  per % 4 == 0.
+__global__ void direct_sum_kernel(float* __restrict__ shard, const float* __restrict__ recv, int rank, int world, size_t per) {
+  const size_t n4 = per / 4;
+  float4* out = reinterpret_cast<float4*>(shard);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 own = out[i];
+    float4 s = rank == 0 ? own : reinterpret_cast<const float4*>(recv)[i];
+    for (int q = 1; q < world; ++q) {
+      const float4 v = q == rank ? own : reinterpret_cast<const float4*>(recv + (size_t)q * per)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[i] = s;
   }
 }
 
@@ -299,8 +340,9 @@ struct LoopBackend : Backend {
     } else if (s0.kind == 4) {
       for (int r = 0; r < W; ++r)
         for (int q = 0; q < W; ++q)
-          XHIP(hipMemcpyAsync(static_cast<char*>(g->slot[r].buf) + (size_t)q * n,
-                              static_cast<const char*>(g->slot[q].send) + (size_t)r * n, n, hipMemcpyDeviceToDevice, g->slot[r].st));
+          if (q != r)
+            XHIP(hipMemcpyAsync(static_cast<char*>(g->slot[r].buf) + (size_t)q * n,
+                                static_cast<const char*>(g->slot[q].send) + (size_t)r * n, n, hipMemcpyDeviceToDevice, g->slot[r].st));
     } else if (s0.kind == 1) {
       for (int r = 0; r < W; ++r)
         for (int q = 0; q < W; ++q)
@@ -366,6 +408,7 @@ struct LoopBackend : Backend {
   int exchange_shards(const void* send, void* recv, size_t bytes, hipStream_t st) override {
     return post(4, recv, bytes, st, 0, send);
   }
+  int all_gather_direct(void* buf, size_t bytes_per_rank, hipStream_t st) override { return post(1, buf, bytes_per_rank, st); }
   int min_max(unsigned long long* v, hipStream_t st) override {
     XCHK(post(3, nullptr, 0, st, v[0]));
     // (the values stay valid until the next operation completes, which needs this rank again)
@@ -418,8 +461,25 @@ struct tfk_comm {
   bool apply_enqueued = false, apply_sharded = false, apply_via_shadow = false;  // between tfk_comm_apply_enqueue and _end
   // TFK_DP_WIRE=bf16: reduce-scattered spans travel as bf16 (2 B per parameter in instead of 4), summed in fp32 by the owner
   bool wire_bf16 = false;
-  uint16_t* wire_stage = nullptr;  // [send: span floats][recv: span floats] bf16 each, sized for the largest span
-  size_t wire_cap = 0;
+  // TFK_DP_ALGO: how a reduce-scattered span / a parameter gather travels -- RCCL's own collective (its algorithm, its
+  // summation order) or DIRECT: grouped ncclSend / ncclRecv of the sub-spans to / from all world - 1 peers at once and, for the
+  // reduce-scatter, the owner's sum in rank order (direct_sum_kernel).  `auto` (default with more than one RCCL rank): both are
+  // timed at attach on scratch memory and the faster one is kept, per operation (tfk_comm_tune)
+  int algo_rs = TFK_ALGO_RCCL, algo_ag = TFK_ALGO_RCCL;
+  int chosen_by = 0;  // 0 default, 1 environment, 2 tuned, 3 tfk_comm_set_exchange
+  double tune_us[4] = {0, 0, 0, 0};  // reduce-scatter rccl / direct, all-gather rccl / direct (max over ranks; 0: not tuned)
+  // staging of the direct / bf16 exchanges: 4 B per parameter, EVERY span its own region (at its arena offset) -- spans are
+  // launched on two streams (comm stream under backward, engine stream for the tail) and must never share staging memory
+  //   fp32 direct: peers' sub-spans arrive at (float*)stage + span offset + q * per
+  //   bf16 wire:   packed span at (uint16_t*)stage + span offset, arrivals at (uint16_t*)stage + num_params + span offset + q * per
+  void* stage = nullptr;
+  // per-phase device times (tfk_comm_timing): pairs of timing events per phase, summed when read
+  struct TimedPair { int phase; hipEvent_t a, b; };
+  bool timing = false;
+  std::vector<hipEvent_t> timing_pool;
+  size_t timing_used = 0;
+  std::vector<TimedPair> timed;
+  long timed_steps = 0;
   int error = 0;  // a failure inside an engine hook (cannot propagate through the hook): raised by the next call
   std::string error_text;
   // what ran in the last completed step (tfk_comm_last_step)
@@ -453,6 +513,52 @@ bool shardable(const tfk_comm* c, size_t lo, size_t hi) {
 // evaluation sums): the collectives go to the ENGINE stream itself and no event is needed at all -- the record -> comm stream
 // -> record -> engine stream round trip measured ~26 us of idle time in front of the optimiser.  (One communicator on two
 // streams is legal for RCCL: it orders its operations itself.)
+int ensure_stage(tfk_comm* c) {
+  if (c->stage) return 0;
+  XHIP(hipMalloc(&c->stage, std::max<size_t>(c->num_params, 1) * sizeof(float)));
+  return 0;
+}
+
+enum { PH_RS = 0, PH_AR = 1, PH_TAIL_EXPOSED = 2, PH_ADAM = 3, PH_AG = 4, PH_TWINS = 5, PH_GATHER_EXPOSED = 6, PH_COUNT = 7 };
+// a pair of timing events around a piece of stream work; nothing at all unless tfk_comm_timing switched it on (an event record
+// between two kernels costs the stream ~6 us: profiles/r04_dp_trace.txt -- the timed steps are a diagnostic pass, never `value`)
+struct Timed {
+  tfk_comm* c;
+  hipStream_t st;
+  int phase;
+  hipEvent_t a = nullptr;
+  int rc = 0;
+  static hipEvent_t take(tfk_comm* c) {
+    if (c->timing_used == c->timing_pool.size()) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+      c->timing_pool.push_back(ev);
+    }
+    return c->timing_pool[c->timing_used++];
+  }
+  Timed(tfk_comm* c_, int phase_, hipStream_t st_) : c(c_), st(st_), phase(phase_) {
+    if (!c->timing) return;
+    a = take(c);
+    if (!a || hipEventRecord(a, st) != hipSuccess) rc = failx(-1, "timing event could not be recorded");
+  }
+  int end() {
+    if (!c->timing || rc || !a) return rc;
+    hipEvent_t b = take(c);
+    if (!b || hipEventRecord(b, st) != hipSuccess) return failx(-1, "timing event could not be recorded");
+    c->timed.push_back({phase, a, b});
+    a = nullptr;
+    return 0;
+  }
+};
+
+// a parameter gather of one sharded span, by the algorithm in force
+int gather_span(tfk_comm* c, void* buf, size_t bytes_per_rank, hipStream_t st) {
+  Timed t(c, PH_AG, st);
+  if (c->algo_ag == TFK_ALGO_DIRECT) XCHK(c->be->all_gather_direct(buf, bytes_per_rank, st));
+  else XCHK(c->be->all_gather(buf, bytes_per_rank, st));
+  return t.end();
+}
+
 bool inline_tail() {
   static const bool on = !getenv("TFK_DP_INLINE_TAIL") || atoi(getenv("TFK_DP_INLINE_TAIL")) != 0;
   return on;
@@ -481,50 +587,69 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
     XHIP(hipEventRecord(c->spans[first].ready, c->engine_stream));
     XHIP(hipStreamWaitEvent(c->comm_stream, c->spans[first].ready, 0));
   }
-  const bool grouped = c->num_spans - first > 1 && !c->wire_bf16;
+  // reduce-scattered spans that travel as point-to-point transfers (direct algorithm, bf16 wire) first, each on its own: the
+  // exchange must have been LAUNCHED, not deferred to the end of a group, when the owner's sum is enqueued behind it
+  const bool p2p = c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT;
+  const int W = c->be->world, R = c->be->rank;
+  size_t rest = 0;
+  for (size_t k = first; k < c->num_spans; ++k) {
+    Span& s = c->spans[k];
+    s.wait_on = inline_on_engine ? nullptr : c->spans[c->num_spans - 1].done;
+    if (!(s.rs && p2p)) {
+      rest += 1;
+      continue;
+    }
+    const size_t per = s.n / W;
+    XCHK(ensure_stage(c));
+    Timed t(c, PH_RS, st);
+    if (c->wire_bf16) {
+      uint16_t *send = static_cast<uint16_t*>(c->stage) + s.off, *recv = static_cast<uint16_t*>(c->stage) + c->num_params + s.off;
+      const unsigned blocks = (unsigned)std::min<size_t>((s.n + 255) / 256, 1 << 14);
+      hipLaunchKernelGGL(wire_pack_kernel, dim3(blocks), dim3(256), 0, st, c->grad + s.off, send, s.n);
+      XCHK(c->be->exchange_shards(send, recv, per * sizeof(uint16_t), st));
+      const unsigned sb = (unsigned)std::min<size_t>((per + 255) / 256, 1 << 14);
+      hipLaunchKernelGGL(wire_sum_kernel, dim3(sb), dim3(256), 0, st, c->grad + s.off + (size_t)R * per, recv, R, W, per);
+    } else {
+      float* recv = static_cast<float*>(c->stage) + s.off;
+      XCHK(c->be->exchange_shards(c->grad + s.off, recv, per * sizeof(float), st));
+      const unsigned sb = (unsigned)std::min<size_t>((per / 4 + 255) / 256, 1 << 13);
+      hipLaunchKernelGGL(direct_sum_kernel, dim3(sb ? sb : 1), dim3(256), 0, st, c->grad + s.off + (size_t)R * per, recv, R, W, per);
+    }
+    XHIP(hipGetLastError());
+    XCHK(t.end());
+    c->cur_rs += 1;
+  }
+  const bool grouped = rest > 1;
   struct Group {  // (closed on every way out: a failed collective must not leave RCCL inside a group)
     Backend* be;
     bool open;
     ~Group() { if (open) (void)be->group_end(); }
   } group = {c->be, false};
+  // (a group launches as one operation: timed as one and booked as all-reduce time -- in practice the vectors + the scalar tail)
+  int lone_phase = PH_AR;
+  for (size_t k = first; k < c->num_spans; ++k)
+    if (c->spans[k].rs && !p2p && !grouped) lone_phase = PH_RS;
+  Timed tg(c, lone_phase, st);
   if (grouped) {
     XCHK(c->be->group_begin());
     group.open = true;
   }
   for (size_t k = first; k < c->num_spans; ++k) {
     Span& s = c->spans[k];
-    if (s.rs && c->wire_bf16) {
-      // (never inside a group: the exchange must have been LAUNCHED, not deferred to a group's end, when the sum is enqueued)
-      const size_t per = s.n / c->be->world;
-      if (s.n > c->wire_cap) {
-        if (c->wire_stage) XHIP(hipFree(c->wire_stage));  // (synchronises: nothing still reads the old one)
-        c->wire_stage = nullptr;
-        c->wire_cap = 0;
-        XHIP(hipMalloc((void**)&c->wire_stage, 2 * std::max(s.n, c->num_params) * sizeof(uint16_t)));
-        c->wire_cap = std::max(s.n, c->num_params);
-      }
-      uint16_t *send = c->wire_stage, *recv = c->wire_stage + c->wire_cap;
-      const unsigned blocks = (unsigned)std::min<size_t>((s.n + 255) / 256, 1 << 14);
-      hipLaunchKernelGGL(wire_pack_kernel, dim3(blocks), dim3(256), 0, st, c->grad + s.off, send, s.n);
-      XCHK(c->be->exchange_shards(send, recv, per * sizeof(uint16_t), st));
-      const unsigned sb = (unsigned)std::min<size_t>((per + 255) / 256, 1 << 14);
-      hipLaunchKernelGGL(wire_sum_kernel, dim3(sb), dim3(256), 0, st, c->grad + s.off + (size_t)c->be->rank * per, recv,
-                         c->be->rank, c->be->world, per);
-      XHIP(hipGetLastError());
-      c->cur_rs += 1;
-    } else if (s.rs) {
-      XCHK(c->be->reduce_scatter(c->grad + s.off, s.n / c->be->world, st));
+    if (s.rs && p2p) continue;
+    if (s.rs) {
+      XCHK(c->be->reduce_scatter(c->grad + s.off, s.n / W, st));
       c->cur_rs += 1;
     } else {
       XCHK(c->be->all_reduce(c->grad + s.off, s.n, st));
       c->cur_ar += 1;
     }
-    s.wait_on = inline_on_engine ? nullptr : c->spans[c->num_spans - 1].done;
   }
   if (grouped) {
     group.open = false;
     XCHK(c->be->group_end());
   }
+  if (rest) XCHK(tg.end());
   if (!inline_on_engine) XHIP(hipEventRecord(c->spans[c->num_spans - 1].done, c->comm_stream));
   return 0;
 }
@@ -594,7 +719,9 @@ int wait_layer(tfk_comm* c, int layer) {
       if (c->pending[i].off < w.first + w.second && c->pending[i].off + c->pending[i].n > w.first) last = (int)i;
   if (last < 0) return 0;
   // (the gathers run in launch order on one stream: the last one that matters implies the earlier ones)
+  Timed exposed(c, PH_GATHER_EXPOSED, c->engine_stream);  // what the forward pass really waits: the gap this wait opens
   XHIP(hipStreamWaitEvent(c->engine_stream, c->pending[last].done, 0));
+  XCHK(exposed.end());
   c->pending.erase(c->pending.begin(), c->pending.begin() + last + 1);
   return 0;
 }
@@ -605,9 +732,10 @@ int wait_layer(tfk_comm* c, int layer) {
 // gather awaited, in front of the next pass (what tfk_params_touched amounts to).
 int twins_behind_gather(tfk_comm* c, const std::pair<size_t, size_t>& span, hipStream_t st, bool* all_current) {
   int current = 0;
+  Timed t(c, PH_TWINS, st);
   XCHK(tfk_twins_from_params(c->e, span.first, span.second, st, &current));
   if (!current) *all_current = false;
-  return 0;
+  return t.end();
 }
 
 void on_layer(void* user, int layer) {
@@ -666,6 +794,21 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
     if (!strcmp(v, "bf16")) c->wire_bf16 = true;
     else if (strcmp(v, "fp32") && strcmp(v, "float32")) return bail(failx(-1, "TFK_DP_WIRE=%s (fp32 | bf16)", v));
   }
+  bool tune = false;
+  {
+    const char* v = getenv("TFK_DP_ALGO");
+    if (!v || !strcmp(v, "auto")) {
+      // time both at attach -- only where there is something to choose between: more than one rank of a real RCCL group, sharded
+      tune = !strcmp(be->name(), "rccl") && be->world > 1 && mode == TFK_EXCHANGE_SHARDED;
+    } else if (!strcmp(v, "direct")) {
+      c->algo_rs = c->algo_ag = TFK_ALGO_DIRECT;
+      c->chosen_by = 1;
+    } else if (!strcmp(v, "rccl")) {
+      c->chosen_by = 1;
+    } else {
+      return bail(failx(-1, "TFK_DP_ALGO=%s (auto | rccl | direct)", v));
+    }
+  }
   void* st = nullptr;
   if (tfk_stream(e, &st)) return bail(-1);
   c->engine_stream = (hipStream_t)st;
@@ -701,6 +844,17 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   if (new_event(&c->ev_adam)) return bail(-1);
   if (tfk_set_bucket_callback(e, on_bucket, c) || tfk_set_layer_callback(e, mode == TFK_EXCHANGE_SHARDED ? on_layer : nullptr, c))
     return bail(-1);
+  // staging memory is allocated HERE, never in the middle of a step (hipMalloc synchronises the device)
+  if (mode == TFK_EXCHANGE_SHARDED && (c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT) && ensure_stage(c)) return bail(-1);
+  if (tune) {
+    // COLLECTIVE (tfk_comm_create is): every rank times RCCL's own reduce-scatter / all-gather and the direct forms on scratch
+    // memory of a span's size; the slowest rank's times decide, identically everywhere.  A failure here is a failure of the
+    // communicator itself and is reported as one.
+    size_t biggest = 0;
+    for (int b = 0; b <= c->L; ++b) biggest = std::max(biggest, c->buckets[b].second);
+    const size_t floats = std::max(biggest, std::min(c->min_floats, c->vec_off));
+    if (tfk_comm_tune(c, floats, 5)) return bail(-1);
+  }
   *out = c;
   return 0;
 }
@@ -814,7 +968,8 @@ int tfk_comm_destroy(tfk_comm* c) {
   }
   for (hipEvent_t ev : c->gather_events) (void)hipEventDestroy(ev);
   if (c->ev_adam) (void)hipEventDestroy(c->ev_adam);
-  if (c->wire_stage) (void)hipFree(c->wire_stage);
+  if (c->stage) (void)hipFree(c->stage);
+  for (hipEvent_t ev : c->timing_pool) (void)hipEventDestroy(ev);
   delete c->be;
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   delete c;
@@ -875,6 +1030,9 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
   g_phases.start();
+  // engine-stream time between the last backward kernel and the first optimiser kernel: the tail collectives, the waits for the
+  // spans still in flight, tfk_apply_begin -- what the exchange leaves exposed in front of Adam
+  Timed tail(c, PH_TAIL_EXPOSED, c->engine_stream);
   XCHK(flush_range(c, inline_tail()));
   g_phases.mark(0);
   const size_t head_off = c->buckets.back().first, head_n = c->buckets.back().second;
@@ -909,12 +1067,15 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
     }
   }
   std::sort(mine.begin(), mine.end());
+  XCHK(tail.end());
+  Timed adam(c, PH_ADAM, c->engine_stream);
   for (size_t i = 0; i < mine.size();) {
     size_t off = mine[i].first, n = mine[i].second, j = i + 1;
     while (j < mine.size() && mine[j].first == off + n) n += mine[j++].second;
     XCHK(tfk_apply_span(c->e, off, n));
     i = j;
   }
+  XCHK(adam.end());
   g_phases.mark(3);
   if (!sharded.empty()) {
     if (c->masters_stale && !via_shadow) return failx(-1, "sharded fp32 masters and a step that does not write the shadow");
@@ -928,8 +1089,10 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
       // the span the next forward pass reads FIRST is gathered on the engine stream itself, right behind the optimiser: that
       // pass could not start before it anyway, and the hop to the comm stream and back is saved; the others follow on the
       // comm stream, under the first layers
-      XCHK(c->be->all_gather(target + sharded[0].first * elem, sharded[0].second / W * elem, c->engine_stream));
+      Timed exposed(c, PH_GATHER_EXPOSED, c->engine_stream);  // (nothing runs beside it: the forward pass waits for exactly this)
+      XCHK(gather_span(c, target + sharded[0].first * elem, sharded[0].second / W * elem, c->engine_stream));
       if (!via_shadow) XCHK(twins_behind_gather(c, sharded[0], c->engine_stream, &derived_current));
+      XCHK(exposed.end());
       c->cur_ag += 1;
       first_on_comm = 1;
     }
@@ -945,7 +1108,7 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
         c->gather_events.push_back(ev);
       }
       hipEvent_t done = c->gather_events[c->gathers_used++];
-      XCHK(c->be->all_gather(target + s.first * elem, s.second / W * elem, c->comm_stream));
+      XCHK(gather_span(c, target + s.first * elem, s.second / W * elem, c->comm_stream));
       if (!via_shadow) XCHK(twins_behind_gather(c, s, c->comm_stream, &derived_current));
       XHIP(hipEventRecord(done, c->comm_stream));
       Gather g;
@@ -985,6 +1148,7 @@ int tfk_comm_apply_end(tfk_comm* c, float* average_loss) {
   XCHK(tfk_apply_end(c->e, average_loss));
   g_phases.mark(5);
   g_phases.calls += 1;
+  if (c->timing) c->timed_steps += 1;
   if (c->verify_left > 0 && c->apply_sharded) {
     c->verify_left -= 1;
     XCHK(verify_replicas(c, c->apply_via_shadow));
@@ -1041,10 +1205,129 @@ int tfk_comm_gather_masters(tfk_comm* c) {
   XHIP(hipEventRecord(c->ev_adam, c->engine_stream));
   XHIP(hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
   for (const auto& s : c->shard_spans)
-    XCHK(c->be->all_gather(c->param + s.first, s.second / c->be->world * sizeof(float), c->comm_stream));
+    XCHK(gather_span(c, c->param + s.first, s.second / c->be->world * sizeof(float), c->comm_stream));
   XHIP(hipEventRecord(c->ev_adam, c->comm_stream));
   XHIP(hipStreamWaitEvent(c->engine_stream, c->ev_adam, 0));
   c->masters_stale = false;
+  return 0;
+}
+
+int tfk_comm_set_exchange(tfk_comm* c, int algo, int wire) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_set_exchange in the middle of a step");
+  if (algo != -1 && algo != TFK_ALGO_RCCL && algo != TFK_ALGO_DIRECT) return failx(-1, "exchange algorithm %d", algo);
+  if (wire != -1 && wire != TFK_WIRE_FP32 && wire != TFK_WIRE_BF16) return failx(-1, "wire format %d", wire);
+  if (algo != -1) {
+    c->algo_rs = c->algo_ag = algo;
+    c->chosen_by = 3;
+  }
+  if (wire != -1) c->wire_bf16 = wire == TFK_WIRE_BF16;
+  if (c->mode == TFK_EXCHANGE_SHARDED && (c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT)) XCHK(ensure_stage(c));
+  return 0;
+}
+
+int tfk_comm_get_exchange(tfk_comm* c, int* algo_reduce_scatter, int* algo_all_gather, int* wire, int* chosen_by, double* tune_us) {
+  if (!c) return failx(-1, "comm is NULL");
+  if (algo_reduce_scatter) *algo_reduce_scatter = c->algo_rs;
+  if (algo_all_gather) *algo_all_gather = c->algo_ag;
+  if (wire) *wire = c->wire_bf16 ? TFK_WIRE_BF16 : TFK_WIRE_FP32;
+  if (chosen_by) *chosen_by = c->chosen_by;
+  if (tune_us) memcpy(tune_us, c->tune_us, sizeof(c->tune_us));
+  return 0;
+}
+
+int tfk_comm_tune(tfk_comm* c, size_t floats, int iters) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_tune in the middle of a step");
+  const int W = c->be->world, R = c->be->rank;
+  const size_t unit = 4 * (size_t)W;
+  floats = std::max(unit, floats / unit * unit);
+  iters = std::max(1, iters);
+  const size_t per = floats / W;
+  float *buf = nullptr, *recv = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  struct Scratch {  // (freed on every way out)
+    float **buf, **recv;
+    hipEvent_t *a, *b;
+    ~Scratch() {
+      if (*buf) (void)hipFree(*buf);
+      if (*recv) (void)hipFree(*recv);
+      if (*a) (void)hipEventDestroy(*a);
+      if (*b) (void)hipEventDestroy(*b);
+    }
+  } scratch = {&buf, &recv, &a, &b};
+  XHIP(hipMalloc((void**)&buf, floats * sizeof(float)));
+  XHIP(hipMalloc((void**)&recv, floats * sizeof(float)));
+  XHIP(hipMemsetAsync(buf, 0, floats * sizeof(float), c->comm_stream));
+  XHIP(hipEventCreate(&a));
+  XHIP(hipEventCreate(&b));
+  hipStream_t st = c->comm_stream;
+  auto run = [&](int what) -> int {  // 0 / 1: reduce-scatter rccl / direct, 2 / 3: all-gather rccl / direct
+    if (what == 0) return c->be->reduce_scatter(buf, per, st);
+    if (what == 1) {
+      XCHK(c->be->exchange_shards(buf, recv, per * sizeof(float), st));
+      const unsigned sb = (unsigned)std::min<size_t>((per / 4 + 255) / 256, 1 << 13);
+      hipLaunchKernelGGL(direct_sum_kernel, dim3(sb ? sb : 1), dim3(256), 0, st, buf + (size_t)R * per, recv, R, W, per);
+      XHIP(hipGetLastError());
+      return 0;
+    }
+    if (what == 2) return c->be->all_gather(buf, per * sizeof(float), st);
+    return c->be->all_gather_direct(buf, per * sizeof(float), st);
+  };
+  for (int what = 0; what < 4; ++what) {
+    XCHK(run(what));  // (warm-up: connection set-up, first-use kernels)
+    XHIP(hipStreamSynchronize(st));
+    XHIP(hipEventRecord(a, st));
+    for (int i = 0; i < iters; ++i) XCHK(run(what));
+    XHIP(hipEventRecord(b, st));
+    XHIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    XHIP(hipEventElapsedTime(&ms, a, b));
+    // the slowest rank's time counts, and every rank must reach the same decision: MAX over the ranks, in integer nanoseconds
+    unsigned long long v[2] = {(unsigned long long)(1e6 * ms / iters), 0};
+    XCHK(c->be->min_max(v, st));
+    c->tune_us[what] = 1e-3 * (double)v[1];
+  }
+  // RCCL's own collective unless the direct form is clearly faster (3 %: a tie goes to the vendor's code path)
+  c->algo_rs = c->tune_us[1] < 0.97 * c->tune_us[0] ? TFK_ALGO_DIRECT : TFK_ALGO_RCCL;
+  c->algo_ag = c->tune_us[3] < 0.97 * c->tune_us[2] ? TFK_ALGO_DIRECT : TFK_ALGO_RCCL;
+  c->chosen_by = 2;
+  if (c->mode == TFK_EXCHANGE_SHARDED && (c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT)) XCHK(ensure_stage(c));
+  if (R == 0 && getenv("TFK_DP_QUIET") == nullptr)
+    fprintf(stderr, "tfkaldi_amd exchange tuned on %zu floats, %d ranks (us, slowest rank): reduce-scatter rccl %.1f / direct %.1f -> %s; "
+            "all-gather rccl %.1f / direct %.1f -> %s\n", floats, W, c->tune_us[0], c->tune_us[1],
+            c->algo_rs == TFK_ALGO_DIRECT ? "direct" : "rccl", c->tune_us[2], c->tune_us[3],
+            c->algo_ag == TFK_ALGO_DIRECT ? "direct" : "rccl");
+  return 0;
+}
+
+int tfk_comm_timing(tfk_comm* c, int on) {
+  if (!c) return failx(-1, "comm is NULL");
+  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_timing in the middle of a step");
+  c->timing = on != 0;
+  c->timed.clear();
+  c->timing_used = 0;
+  c->timed_steps = 0;
+  return 0;
+}
+
+int tfk_comm_timing_read(tfk_comm* c, double* ms_per_step, int capacity, long* steps) {
+  if (!c || !ms_per_step) return failx(-1, "NULL argument");
+  XHIP(hipSetDevice(c->device));
+  XHIP(hipStreamSynchronize(c->engine_stream));
+  XHIP(hipStreamSynchronize(c->comm_stream));
+  double sum[PH_COUNT] = {0};
+  for (const tfk_comm::TimedPair& t : c->timed) {
+    float ms = 0.f;
+    XHIP(hipEventElapsedTime(&ms, t.a, t.b));
+    sum[t.phase] += ms;
+  }
+  const double per = c->timed_steps > 0 ? 1.0 / (double)c->timed_steps : 0.0;
+  for (int k = 0; k < capacity; ++k) ms_per_step[k] = k < PH_COUNT ? sum[k] * per : 0.0;
+  if (steps) *steps = c->timed_steps;
   return 0;
 }
 

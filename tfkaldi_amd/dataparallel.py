@@ -513,7 +513,12 @@ class BucketReducer(object):
                 self.masters_stale = True
                 self.shard_spans.update(sharded)
             elif hasattr(engine, "params_touched"):
-                engine.params_touched()  # parameters outside this rank's spans change behind the optimiser's back
+                # parameters outside this rank's spans change behind the optimiser's back.  Emulated fp32: the three-plane twins
+                # of each span are rebuilt right behind ITS gather on a side stream (tfk_twins_from_params, as csrc/exchange.hip
+                # does), and the forward pass waits for gather + rebuild layer by layer -- instead of all twins, every gather
+                # awaited, in front of the next pass (tfk_params_touched; round-5 advisor finding)
+                if not self._twins_behind_gathers(engine, len(sharded)):
+                    engine.params_touched()
             if not self.async_gather:
                 self.drain()
         del self.handles[:]
@@ -532,6 +537,37 @@ class BucketReducer(object):
         if failed is not None:
             raise failed
         return loss
+
+    def _twins_behind_gathers(self, engine, count):
+        """the last `count` pending gathers: what the contractions read of their spans rebuilt behind each, on a side stream;
+        False when the engine has nothing of the kind or refuses (nothing pending was changed then)"""
+        if not self.async_gather or not hasattr(engine, "twins_from_params") or getattr(engine, "torch_stream", None) is None:
+            return False
+        import torch
+
+        class _Behind(object):
+            def __init__(self, event):
+                self.event = event
+
+            def wait(self):
+                torch.cuda.current_stream().wait_event(self.event)
+
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        done = []
+        try:
+            with torch.cuda.stream(self._side):
+                for off, n, h in self.pending[-count:]:
+                    h.wait()
+                    if not engine.twins_from_params(off, n, stream=self._side.cuda_stream):
+                        return False
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    done.append((off, n, _Behind(ev)))
+        except Exception:  # noqa: BLE001  (a span the engine refuses: the general way, params_touched)
+            return False
+        self.pending[-count:] = done
+        return True
 
     def verify_replicas(self, engine, via_shadow):
         """every rank must hold the same parameters after the gathers (tfk_param_checksum); collective"""
@@ -709,6 +745,47 @@ class NativeExchange(object):
         loss = ctypes.c_float()
         self._check(self.lib.tfk_comm_eval_finish(self._h, ctypes.byref(loss)))
         return float(loss.value)
+
+    # ---- how the spans travel (include/tfkaldi_hip.h, ABI 8) ----
+    ALGOS, WIRES = ("rccl", "direct"), ("fp32", "bf16")
+    PHASES = ("reduce_scatter", "all_reduce", "tail_exposed", "adam", "all_gather", "twin_rebuild", "gather_exposed")
+
+    def set_exchange(self, algo=None, wire=None):
+        """between steps, every rank alike: algo "rccl" | "direct" (RCCL's own reduce-scatter / all-gather, or grouped
+        send / recv to all peers + the owner's rank-ordered sum), wire "fp32" | "bf16"; None keeps what is in force"""
+        a = -1 if algo is None else self.ALGOS.index(algo)
+        w = -1 if wire is None else self.WIRES.index(wire)
+        self._check(self.lib.tfk_comm_set_exchange(self._h, a, w))
+        if wire is not None:
+            self.wire = wire
+
+    def exchange_info(self):
+        import ctypes
+        rs, ag, w, by = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        us = (ctypes.c_double * 4)()
+        self._check(self.lib.tfk_comm_get_exchange(self._h, ctypes.byref(rs), ctypes.byref(ag), ctypes.byref(w), ctypes.byref(by), us))
+        out = {"reduce_scatter": self.ALGOS[rs.value], "all_gather": self.ALGOS[ag.value], "wire": self.WIRES[w.value],
+               "chosen_by": ("default", "environment", "tuned at attach", "set")[by.value]}
+        if any(us):
+            out["tuned_us_slowest_rank"] = {"reduce_scatter_rccl": us[0], "reduce_scatter_direct": us[1],
+                                            "all_gather_rccl": us[2], "all_gather_direct": us[3]}
+        return out
+
+    def tune(self, floats, iters=5):
+        """COLLECTIVE: time both algorithms on scratch memory and keep the faster per operation (what attach does under `auto`)"""
+        self._check(self.lib.tfk_comm_tune(self._h, int(floats), int(iters)))
+        return self.exchange_info()
+
+    def timing_begin(self):
+        self._check(self.lib.tfk_comm_timing(self._h, 1))
+
+    def timing_read(self):
+        """{phase: device ms per step} over the steps since timing_begin (tfk_comm_timing_read), and their number"""
+        import ctypes
+        ms, steps = (ctypes.c_double * 8)(), ctypes.c_long()
+        self._check(self.lib.tfk_comm_timing_read(self._h, ms, 8, ctypes.byref(steps)))
+        self._check(self.lib.tfk_comm_timing(self._h, 0))
+        return dict(zip(self.PHASES, list(ms)[:len(self.PHASES)])), int(steps.value)
 
     def drain(self):
         if self._h:
