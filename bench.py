@@ -342,10 +342,12 @@ class PowerSampler(object):
         import threading
         self.samples, self.source, self._stop = [], None, threading.Event()
         self._power = self._clock = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if device_index < len(cards):
-            hw = cards[device_index]
+        self.bdf = self._pci_bus_id(device_index)
+        self.smi_index = None
+        # the box may expose more cards in sysfs than this process can use: the hwmon directory is picked by PCI address
+        for hw in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+            if self.bdf is None or not os.path.realpath(os.path.dirname(os.path.dirname(hw))).lower().endswith(self.bdf):
+                continue
             for name in ("power1_input", "power1_average"):
                 f = os.path.join(hw, name)
                 try:
@@ -354,20 +356,51 @@ class PowerSampler(object):
                         break
                 except (OSError, ValueError):
                     pass
-            self._clock = os.path.join(hw, "freq1_input")
             try:
-                float(open(self._clock).read())
+                float(open(os.path.join(hw, "freq1_input")).read())
+                self._clock = os.path.join(hw, "freq1_input")
             except (OSError, ValueError):
-                self._clock = None
-        self.device_index = device_index
-        self.source = "amdgpu hwmon (power1, freq1_input)" if self._power and self._clock else "rocm-smi --showpower --showclocks"
+                pass
+            break
+        if not (self._power and self._clock):
+            self._power = self._clock = None
+            self.smi_index = self._smi_index()
+        self.source = ("amdgpu hwmon of %s (power1, freq1_input)" % self.bdf if self._power
+                       else "rocm-smi -d %s --showpower --showclocks (PCI %s)" % (self.smi_index, self.bdf))
         self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _pci_bus_id(device_index):
+        """'dddd:bb:dd.f' of HIP device `device_index` (hipDeviceGetPCIBusId), lower case; None when it cannot be asked"""
+        try:
+            import ctypes
+            import torch
+            hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+                return None
+            return buf.value.decode().strip().lower() or None
+        except Exception:  # noqa: BLE001
+            return None
+
+    def _smi_index(self):
+        """rocm-smi's index of the GPU at self.bdf (its numbering covers every card the box shows, not the visible ones)"""
+        import re
+        try:
+            out = subprocess.run(["rocm-smi", "--showbus"], capture_output=True, text=True, timeout=20).stdout
+        except Exception:  # noqa: BLE001
+            return 0
+        for line in out.splitlines():
+            m = re.search(r"GPU\[(\d+)\].*PCI Bus:\s*(\S+)", line)
+            if m and self.bdf and m.group(2).lower() == self.bdf:
+                return int(m.group(1))
+        return 0
 
     def _once(self):
         if self._power and self._clock:
             return float(open(self._power).read()) * 1e-6, float(open(self._clock).read()) * 1e-6
         import re
-        out = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showpower", "--showclocks"], capture_output=True,
+        out = subprocess.run(["rocm-smi", "-d", str(self.smi_index or 0), "--showpower", "--showclocks"], capture_output=True,
                              text=True, timeout=10).stdout
         pw = re.search(r"Package Power \(W\):\s*([0-9.]+)", out)
         ck = re.search(r"sclk clock level:.*\((\d+)Mhz\)", out)
@@ -393,7 +426,7 @@ class PowerSampler(object):
     def summary(self, t_from):
         pw = [p for t, p, _ in self.samples if t >= t_from and p]
         ck = [c for t, _, c in self.samples if t >= t_from and c]
-        return {"sampler": self.source, "samples": len(pw),
+        return {"sampler": self.source, "samples": len(pw), "pci_bus_id": self.bdf,
                 "socket_power_w_mean": sum(pw) / len(pw) if pw else None, "socket_power_w_max": max(pw) if pw else None,
                 "shader_clock_mhz_mean": sum(ck) / len(ck) if ck else None, "shader_clock_mhz_min": min(ck) if ck else None}
 

@@ -214,7 +214,8 @@ def test_eight_loopback_ranks_at_cfg2_size(gpu, algo):
     ref = _serial(8, kw=kw, data=_data_cfg2)
     spans = results[0][1]["spans"]
     assert [n for _, n in spans if n > 1 << 20] == [20873216, 5095424]  # (as bench.py's line reports them)
-    assert results[0][1]["executed"].count("loopback:reduce_scatter") == 2
+    assert sum(n.startswith("loopback:reduce_scatter") for n in results[0][1]["executed"]) == 2
+    assert all(("[direct]" in n) == (algo == "direct") for n in results[0][1]["executed"] if "all_reduce" not in n)
     for rank, (got, info) in enumerate(results):
         _compare(ref, got, 2e-5, 5e-4, "rank %d" % rank)
         for k, v in results[0][0].items():

@@ -100,6 +100,18 @@ def test_bench_dp_branch_over_rccl(gpu):
     assert line["collectives_last_step"].count("rccl:all_reduce") == 2
     assert [n for _, n in line["collective_spans_last_step"] if n > 1 << 20] == [20873216, 5095424]
     assert line["host_fed_value"] > 0 and len(line["loss_trace_gpu"]) == 7
+    # the self-diagnosing part of an N > 1 line: what is in force, the algorithm x wire A/B, the per-phase device times per rank
+    assert line["exchange_algorithm"] == {"reduce_scatter": "rccl", "all_gather": "rccl", "wire": "fp32", "chosen_by": "default"}
+    ab = line["exchange_ab"]["ms_per_step"]
+    assert sorted(ab) == ["direct/bf16", "direct/fp32", "rccl/bf16", "rccl/fp32"] and all(0.5 < v < 50 for v in ab.values()), ab
+    ph = line["exchange_phases"]["per_rank"]
+    assert sorted(ph) == sorted(["reduce_scatter", "all_reduce", "tail_exposed", "adam", "all_gather", "twin_rebuild", "gather_exposed"])
+    assert all(len(v) == 1 and v[0] >= 0 for v in ph.values()) and ph["adam"][0] > 0 and ph["reduce_scatter"][0] > 0, ph
+    print("exchange A/B (one RCCL rank):", ab)
+    print("exchange phases (one RCCL rank):", {k: round(v[0], 4) for k, v in ph.items()})
+    sus = line["sustained"]
+    assert sus["seconds"] >= 3.0 and sus["value"] > 0 and 0.8 < sus["value_over_sustained"] < 1.5, sus
+    assert sus["samples"] >= 3 and sus["socket_power_w_mean"] > 100 and sus["shader_clock_mhz_mean"] > 500, sus
 
 
 @pytest.mark.timeout(600)
@@ -139,7 +151,7 @@ def test_bench_eight_ranks_dry_run(gpu):
         pytest.skip("a real 8-GPU node runs the real thing (test_bench_self_launches_its_ranks covers the launcher)")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo", TFK_DP_EMULATE_RS="1", TFK_BENCH_PREWARM_MS="0",
-               OMP_NUM_THREADS="2")
+               OMP_NUM_THREADS="2", TFK_BENCH_SUSTAIN_S="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup",
                           "2"], env=env, capture_output=True, text=True, timeout=1100)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -152,6 +164,9 @@ def test_bench_eight_ranks_dry_run(gpu):
     assert any(c.startswith("all_gather") for c in line["collectives_last_step"])
     assert all(n % 32 == 0 for _, n in line["collective_spans_last_step"][1:5])
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
+    # the A/B block of an N > 1 line: over gloo the exchange runs through torch.distributed, which has one algorithm -- said so
+    print("exchange_ab (8 gloo ranks on one GPU):", line["exchange_ab"])
+    assert "torch.distributed/fp32" in line["exchange_ab"]["ms_per_step"] and "unavailable" in line["exchange_ab"]
 
 
 def _rccl_worker(rank, world, port, num_mb, out_dir, mode):

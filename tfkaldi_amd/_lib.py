@@ -19,7 +19,13 @@ NONLIN = {"relu": 0, "sigmoid": 1, "tanh": 2, "linear": 3}
 #   "float32"       the reference's arithmetic (fp32 `tf.matmul`, layer.py:52).  Since round 5 it runs EMULATED on the bf16 matrix
 #                   pipe -- every operand split exactly into three bf16 planes, six exact plane products accumulated in fp32
 #                   (TFK_DTYPE_F32X3; error bound and evidence: DESIGN.md 4) -- which is closer to float64 than the fp32 matrix
-#                   instruction chain and ~1.3x as fast.  "float32x3" names the same thing explicitly.
+#                   instruction chain and ~1.3x as fast.  "float32x3" names the same thing explicitly.  Two differences from the
+#                   fp32 matrix instruction a caller should know: (1) NON-FINITE operands -- an Inf splits into (Inf, NaN, NaN), so
+#                   an infinite activation or weight turns every result it touches into NaN where fp32 gives +-Inf (NaN stays
+#                   NaN; finite operands whose products overflow give +-Inf as in fp32) -- a diverged run shows as NaN, not Inf;
+#                   (2) MEMORY -- every GEMM operand (activations, weights, the loss gradient) has a three-plane twin of 6 bytes
+#                   per element beside its 4: about +50 % of the activation memory and +6 B per weight (cfg2: ~160 MB of 288 GB).
+#                   TFK_F32_ARITHMETIC=mfma (or "float32_mfma") has neither.
 #   "float32_mfma"  the exact fp32 matrix instructions (v_mfma_f32_32x32x2_f32; TFK_DTYPE_F32): the default of rounds 1-4.
 #   "bfloat16"      mixed precision: operands ROUNDED to bf16 (BASELINE cfg3 / cfg4).
 # env TFK_F32_ARITHMETIC = mfma | x3 overrides what "float32" means for the whole process (a site's policy, A/B runs).

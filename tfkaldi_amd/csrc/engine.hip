@@ -1414,6 +1414,9 @@ int train_or_eval(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   if (raw && (flags & TFK_DEVICE_PTRS)) return fail(-1, "the raw entry points take host pointers (TFK_RAW_DEVICE: raw alone on the device)");
   if (!raw && (flags & TFK_RAW_DEVICE)) return fail(-1, "TFK_RAW_DEVICE belongs to the *_raw entry points");
   HIPCHK(hipSetDevice(e->cfg.device));
+  // (a call that failed between the fused loss / column-sum launch and its backward pass must not leave the flag behind for a
+  // later micro-batch -- a CTC one has no fused column sums: round-5 advisor finding)
+  e->colsum_done = false;
   CHK(reserve(e, T));
   const float* Xd; const int32_t* yd; int ld;
   const int slot_before = e->slot;
@@ -1662,6 +1665,7 @@ void stack_layout(const tfk_engine* e, const int32_t* seg_rows, int k, Stack* st
 
 // forward + loss + backward of one stacked pass whose input is staged (Xd: [T_pad, ld], yd: labels with -1 on padding)
 int run_stacked(tfk_engine* e, const float* Xd, int ld, const int32_t* yd, const Stack& st, int flags, int slot_before) {
+  e->colsum_done = false;  // (as train_or_eval: never inherited from a call that failed half way)
   if (e->bf16) {
     const float* x = Xd;
     CHK(twin_input(e, &x, &ld, st.T_pad));

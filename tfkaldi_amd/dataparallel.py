@@ -736,8 +736,14 @@ class NativeExchange(object):
         self.last_launched = [(int(spans[3 * i]), int(spans[3 * i + 1])) for i in range(min(n.value, 32))]
         self.last_span_kinds = ["rs" if spans[3 * i + 2] else "ar" for i in range(min(n.value, 32))]
         gather = "all_gather(bf16 shadow)" if self.shadow else "all_gather"
-        self.last_executed = (["%s:reduce_scatter" % self.backend] * rs.value + ["%s:all_reduce" % self.backend] * ar.value
-                              + ["%s:%s" % (self.backend, gather)] * ag.value)
+        # (the backend's own collectives keep their plain names; the direct algorithm / the bf16 wire are said in brackets)
+        info = self.exchange_info()
+        rs_tag = "".join(t for t, on in (("[direct]", info["reduce_scatter"] == "direct" and info["wire"] == "fp32"),
+                                         ("[direct, bf16 wire]", info["wire"] == "bf16")) if on)
+        ag_tag = "[direct]" if info["all_gather"] == "direct" else ""
+        self.last_executed = (["%s:reduce_scatter%s" % (self.backend, rs_tag)] * rs.value
+                              + ["%s:all_reduce" % self.backend] * ar.value
+                              + ["%s:%s%s" % (self.backend, gather, ag_tag)] * ag.value)
         self.last_kinds = ["rs"] * rs.value + ["ar"] * ar.value
 
     def eval_finish(self, engine, dp):
