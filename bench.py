@@ -648,6 +648,38 @@ def main():
         elapsed_host = max(float(g[1].item()) for g in gathered)
         backend = dist.get_backend()
 
+    # From here on everything is DIAGNOSTICS (sustained leg, exchange A/B, per-phase times, the Nnet.train leg): the contract's
+    # numbers are known.  With more than one rank those legs run collectives this build could never rehearse on hardware, so a
+    # watchdog guards the line: if they are not through within the budget, rank 0 prints the contract's fields with
+    # `incomplete` set and every rank leaves (each rank runs its own timer: a rank stuck in a collective cannot be asked).
+    watchdog, final = None, {}
+    if dp.enabled:
+        import threading
+        budget_s = float(os.environ.get("TFK_BENCH_DIAG_BUDGET_S", "300"))
+        core_ms = 1e3 * elapsed / args.steps
+
+        def bail_out():
+            if rank == 0:
+                line = {"metric": "acoustic frames/sec (train step)", "value": world * T * args.steps / elapsed, "unit": "frames/s",
+                        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": core_ms,
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": Workload.DTYPE_TEXT[args.dtype],
+                        "data": "synthetic ark/scp/alignment files (SURVEY 8d) read through the feature reader + dispenser",
+                        "config": {"workload": "%s, %d frames/GPU/step, %s, Adam" % (w.text, T, Workload.ARITH_TEXT[args.dtype]),
+                                   "name": w.name, "frames_per_gpu": T, "global_frames": world * T, "parallelism": "dp%d" % world,
+                                   "flop_per_frame": w.flop_per_frame},
+                        "per_rank_ms_per_step": per_rank_ms, "dist_backend": backend,
+                        "exchange": reducer.mode if reducer else None,
+                        }
+                line = dict(final.get("line") or line)  # (everything, when only the teardown is stuck)
+                line["incomplete"] = ("the diagnostic legs behind the timed region did not finish within %.0f s "
+                                      "(TFK_BENCH_DIAG_BUDGET_S); the contract's fields were measured before them" % budget_s)
+                os.write(json_fd, (json.dumps(line) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(budget_s, bail_out)
+        watchdog.daemon = True
+        watchdog.start()
+
     def timed_steps(n):
         """n steps between two fences; seconds by the slowest rank's clock"""
         fence()
@@ -704,22 +736,26 @@ def main():
     exchange_ab = exchange_phases = exchange_info = None
     if dp.enabled and getattr(reducer, "native", False):
         exchange_info = reducer.exchange_info()
-        default = (exchange_info["reduce_scatter"] if exchange_info["reduce_scatter"] == exchange_info["all_gather"] else None,
-                   exchange_info["wire"])
-        exchange_ab = {"steps_each": 10, "default": exchange_info, "ms_per_step": {}}
+        in_force = (exchange_info["reduce_scatter"], exchange_info["all_gather"], exchange_info["wire"])
+        exchange_ab = {"steps_each": 10, "in_force_for_value": exchange_info, "ms_per_step": {}}
         if reducer.mode == "sharded":
             for algo in ("rccl", "direct"):
                 for wire in ("fp32", "bf16"):
                     reducer.set_exchange(algo, wire)
                     timed_steps(3)
                     exchange_ab["ms_per_step"]["%s/%s" % (algo, wire)] = 1e3 * timed_steps(10) / 10
-            # back to what `value` ran with (a tuned choice may differ per operation: re-tuning would be a collective of its own,
-            # so the pair is restored through the environment-independent setter only when it was uniform)
-            if default[0] is not None:
-                reducer.set_exchange(default[0], default[1])
+            # what TFK_DP_ALGO=auto would have chosen at attach: the library's own tuning pass (tfk_comm_tune, collective) on
+            # scratch memory of the largest span's size, and the step with that choice
+            reducer.set_exchange(None, "fp32")
+            biggest = max(n for _, n in getattr(reducer, "last_launched", []) or eng.buckets())
+            exchange_ab["auto"] = reducer.tune(biggest, 5)
+            timed_steps(3)
+            exchange_ab["ms_per_step"]["auto/fp32"] = 1e3 * timed_steps(10) / 10
+            # back to what `value` ran with
+            if in_force[0] == in_force[1]:
+                reducer.set_exchange(in_force[0], in_force[2])
             else:
-                reducer.set_exchange(None, default[1])
-                reducer.tune(max(n for _, n in eng.buckets()), 5)
+                reducer.set_exchange(None, in_force[2])  # (a per-operation choice can only come from a tuning pass: keep it)
             timed_steps(3)
         reducer.timing_begin()
         timed_steps(10)
@@ -728,6 +764,7 @@ def main():
         allv = [torch.zeros_like(v) for _ in range(world)]
         dist.all_gather(allv, v)
         exchange_phases = {"steps": n_timed, "unit": "device ms per step, one list entry per rank",
+                           "exchange": reducer.exchange_info(),
                            "per_rank": {k: [float(a[i].item()) for a in allv] for i, k in enumerate(reducer.PHASES)},
                            "note": "timing events on the stream each phase runs on (tfk_comm_timing; every record costs its stream a "
                                    "few microseconds, so these steps are slower than `value`'s): reduce_scatter / all_reduce / "
@@ -897,6 +934,8 @@ def main():
             other = "float32_mfma" if args.dtype == "float32" else "float32"
             out["exact_fp32" if other == "float32_mfma" else "emulated_fp32"] = other_arithmetic_leg(
                 w, other, batches, hidden, args.steps, args.warmup, local_rank, out.get("loss_trace_f64"))
+    if rank == 0:
+        final["line"] = out
     eng.close()
     if not args.no_api_fed and os.environ.get("TFK_BENCH_API_FED", "1") != "0":
         try:
@@ -907,6 +946,8 @@ def main():
             out.update(fed)
     if dp.enabled:
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         import ctypes
         sys.stdout.flush()

@@ -397,9 +397,11 @@ int tfk_comm_last_step(tfk_comm* c, int* reduce_scatters, int* all_gathers, int*
  *                    single process adds its micro-batches: the reduced shard equals the serial run's G bit for bit.  The
  *                    gather is the same movement backwards (own shard to every peer, in place).
  * Wire format of the reduce-scatter: TFK_WIRE_FP32, or TFK_WIRE_BF16 (direct movement at half the bytes; the owner's own
- * contribution stays exact).  Environment at attach: TFK_DP_ALGO = auto | rccl | direct, TFK_DP_WIRE = fp32 | bf16.  `auto`, the
- * default with more than one RCCL rank: tfk_comm_create times both algorithms on scratch memory of a span's size (tfk_comm_tune,
- * collective) and keeps the faster one per operation -- the slowest rank's time decides, identically on every rank.
+ * contribution stays exact).  Environment at attach: TFK_DP_ALGO = rccl (default) | direct | auto, TFK_DP_WIRE = fp32 | bf16.
+ * `auto` (more than one RCCL rank): tfk_comm_create times both algorithms on scratch memory of a span's size (tfk_comm_tune,
+ * collective) and keeps the faster one per operation -- the slowest rank's time decides, identically on every rank.  It is
+ * opt-in until a multi-GPU node has run it: bench.py --gpus N runs the same tuning pass and an algorithm x wire A/B BEHIND its
+ * timed region and reports both, so the first scaling line shows what `auto` would have chosen and gained.
  * tfk_comm_set_exchange (-1 = keep): between steps only, every rank with the same arguments.
  * tfk_comm_get_exchange: what is in force; chosen_by 0 default / 1 environment / 2 tuned / 3 set; tune_us[4] = microseconds of
  * reduce-scatter rccl, direct, all-gather rccl, direct as tuned (0: never tuned). */

@@ -103,7 +103,9 @@ def test_bench_dp_branch_over_rccl(gpu):
     # the self-diagnosing part of an N > 1 line: what is in force, the algorithm x wire A/B, the per-phase device times per rank
     assert line["exchange_algorithm"] == {"reduce_scatter": "rccl", "all_gather": "rccl", "wire": "fp32", "chosen_by": "default"}
     ab = line["exchange_ab"]["ms_per_step"]
-    assert sorted(ab) == ["direct/bf16", "direct/fp32", "rccl/bf16", "rccl/fp32"] and all(0.5 < v < 50 for v in ab.values()), ab
+    assert sorted(ab) == ["auto/fp32", "direct/bf16", "direct/fp32", "rccl/bf16", "rccl/fp32"] and all(0.5 < v < 50 for v in ab.values()), ab
+    assert line["exchange_ab"]["auto"]["chosen_by"] == "tuned at attach" and "tuned_us_slowest_rank" in line["exchange_ab"]["auto"]
+    assert line["exchange_phases"]["exchange"]["reduce_scatter"] == "rccl"  # back to what `value` ran with
     ph = line["exchange_phases"]["per_rank"]
     assert sorted(ph) == sorted(["reduce_scatter", "all_reduce", "tail_exposed", "adam", "all_gather", "twin_rebuild", "gather_exposed"])
     assert all(len(v) == 1 and v[0] >= 0 for v in ph.values()) and ph["adam"][0] > 0 and ph["reduce_scatter"][0] > 0, ph
@@ -112,6 +114,23 @@ def test_bench_dp_branch_over_rccl(gpu):
     sus = line["sustained"]
     assert sus["seconds"] >= 3.0 and sus["value"] > 0 and 0.8 < sus["value_over_sustained"] < 1.5, sus
     assert sus["samples"] >= 3 and sus["socket_power_w_mean"] > 100 and sus["shader_clock_mhz_mean"] > 500, sus
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_survives_stuck_diagnostics(gpu):
+    """bench.py at N > 1 measures the contract's fields first and runs its diagnostic legs (sustained leg, exchange A/B, phase
+    times, Nnet.train) behind them under a watchdog: with a budget those legs cannot meet, rank 0 still prints ONE line with the
+    contract's fields and `incomplete`, and the process leaves with status 0 (a rank stuck in a collective cannot be joined)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_BENCH_DIAG_BUDGET_S="1.0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup",
+                          "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert "incomplete" in line and line["value"] > 0 and line["n_gpus"] == 1 and line["ms_per_step"] > 0
+    assert line["config"]["name"] == "cfg2" and line["scaling"] == "weak" and "sustained" not in line
 
 
 @pytest.mark.timeout(600)

@@ -2530,6 +2530,21 @@ int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* 
   *mirrors_arena = mirrors ? 1 : 0;
   return 0;
 }
+int tfk_twin_region(tfk_engine* e, int layer, void** device_ptr, size_t* bytes, int* rows) {
+  if (!e || !device_ptr || !bytes || !rows) return fail(-1, "NULL argument");
+  *device_ptr = nullptr;
+  *bytes = 0;
+  *rows = 0;
+  if (layer < 0 || layer > e->L) return fail(-1, "layer %d out of range", layer);
+  // only where the optimiser writes the twins with the update (x3 with a map of the arena): what a sharded exchange may gather
+  // in place of the fp32 parameters
+  if (!e->bf16 || !e->x3 || !e->wb_aligned) return 0;
+  const LayerLayout& y = e->lay[layer];
+  *device_ptr = e->Wb + e->wb_off[layer];
+  *bytes = x3::elems(y.d_in, e->wb_ld[layer]) * sizeof(bf16_t);
+  *rows = y.d_in;
+  return 0;
+}
 int tfk_apply_writes_shadow(tfk_engine* e, int* direct) {
   if (!e || !direct) return fail(-1, "NULL argument");
   if (!e->apply_open) return fail(-1, "tfk_apply_writes_shadow outside tfk_apply_begin / tfk_apply_end");
@@ -2551,8 +2566,14 @@ int tfk_param_checksum(tfk_engine* e, int which, uint64_t* value) {
   } else if (which == 2) {
     p = reinterpret_cast<const uint32_t*>(e->p_param() + e->lay[0].b_off);
     words = e->P - e->lay[0].b_off;
+  } else if (which == 3) {
+    if (!e->bf16 || !e->x3) return fail(-1, "no three-plane twins to checksum");
+    p = reinterpret_cast<const uint32_t*>(e->Wb);
+    const LayerLayout& y = e->lay[e->L];
+    words = (e->wb_off[e->L] + x3::elems(y.d_in, e->wb_ld[e->L])) / 2;  // (every twin, padding included: zeros everywhere)
   } else {
-    return fail(-1, "tfk_param_checksum: which must be 0 (fp32 parameters), 1 (bf16 shadow) or 2 (fp32 bias / beta vectors)");
+    return fail(-1, "tfk_param_checksum: which must be 0 (fp32 parameters), 1 (bf16 shadow), 2 (fp32 bias / beta vectors) or 3 "
+                    "(three-plane twins of the weights)");
   }
   CHK(join_optimizer(e));
   if (!e->d_checksum) HIPCHK(hipMalloc((void**)&e->d_checksum, sizeof(unsigned long long)));

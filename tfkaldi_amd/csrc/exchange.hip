@@ -463,8 +463,8 @@ struct tfk_comm {
   bool wire_bf16 = false;
   // TFK_DP_ALGO: how a reduce-scattered span / a parameter gather travels -- RCCL's own collective (its algorithm, its
   // summation order) or DIRECT: grouped ncclSend / ncclRecv of the sub-spans to / from all world - 1 peers at once and, for the
-  // reduce-scatter, the owner's sum in rank order (direct_sum_kernel).  `auto` (default with more than one RCCL rank): both are
-  // timed at attach on scratch memory and the faster one is kept, per operation (tfk_comm_tune)
+  // reduce-scatter, the owner's sum in rank order (direct_sum_kernel).  `auto`: both are timed at attach on scratch memory and
+  // the faster one is kept, per operation (tfk_comm_tune)
   int algo_rs = TFK_ALGO_RCCL, algo_ag = TFK_ALGO_RCCL;
   int chosen_by = 0;  // 0 default, 1 environment, 2 tuned, 3 tfk_comm_set_exchange
   double tune_us[4] = {0, 0, 0, 0};  // reduce-scatter rccl / direct, all-gather rccl / direct (max over ranks; 0: not tuned)
@@ -796,17 +796,20 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   }
   bool tune = false;
   {
+    // default: RCCL's own collectives, the code path every RCCL user runs.  `auto` times both at attach and keeps the faster one
+    // per operation -- opt-in until a multi-GPU node has run it (no round of this build had one): a tuning pass that went wrong
+    // would take the whole job with it, the A/B of bench.py --gpus N only its diagnostics (it runs behind the timed region)
     const char* v = getenv("TFK_DP_ALGO");
-    if (!v || !strcmp(v, "auto")) {
-      // time both at attach -- only where there is something to choose between: more than one rank of a real RCCL group, sharded
+    if (!v || !strcmp(v, "rccl")) {
+      c->chosen_by = v ? 1 : 0;
+    } else if (!strcmp(v, "auto")) {
+      // (only where there is something to choose between: more than one rank of a real RCCL group, sharded mode)
       tune = !strcmp(be->name(), "rccl") && be->world > 1 && mode == TFK_EXCHANGE_SHARDED;
     } else if (!strcmp(v, "direct")) {
       c->algo_rs = c->algo_ag = TFK_ALGO_DIRECT;
       c->chosen_by = 1;
-    } else if (!strcmp(v, "rccl")) {
-      c->chosen_by = 1;
     } else {
-      return bail(failx(-1, "TFK_DP_ALGO=%s (auto | rccl | direct)", v));
+      return bail(failx(-1, "TFK_DP_ALGO=%s (rccl | direct | auto)", v));
     }
   }
   void* st = nullptr;

@@ -220,15 +220,13 @@ __device__ __forceinline__ void epilogue(const GemmArgsB& p, f32x16 (&acc)[FM][F
           p.C[(size_t)row * p.ldc + col] = v;
           if constexpr ((EPI & EPI_EVAL_ACT) != 0) {
             if (p.C_twin) {
-              if (p.ct_x3) {  // three interleaved planes whose sum is v exactly (truncation split; x3_layout.h)
-                float r = v;
+              if (p.ct_x3) {  // three interleaved planes whose sum is v exactly (x3_layout.h: split3, round to nearest)
                 const size_t at = x3::at((size_t)row, col, p.ldct);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                  const uint32_t bits = __builtin_bit_cast(uint32_t, r) & 0xffff0000u;
-                  p.C_twin[at + pl * 64] = (bf16_t)(bits >> 16);
-                  r -= __builtin_bit_cast(float, bits);
-                }
+                uint16_t q0, q1, q2;
+                x3::split3(v, q0, q1, q2);
+                p.C_twin[at] = (bf16_t)q0;
+                p.C_twin[at + 64] = (bf16_t)q1;
+                p.C_twin[at + 128] = (bf16_t)q2;
               } else {
                 p.C_twin[(size_t)row * p.ldct + col] = f2bf(v);
               }

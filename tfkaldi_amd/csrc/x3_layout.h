@@ -147,5 +147,28 @@ X3_HD int ks16_imm(int X, int hi) {
   return 128 * (X & ~1) + hi * 2 * (EXT / 32 * 384);
 }
 
+#if defined(__HIPCC__)
+// x = p1 + p2 + p3 exactly, each a bf16, by ROUND TO NEAREST (even): p1 = RN(x), p2 = RN(x - p1), p3 = x - p1 - p2.
+// Both subtractions are exact in fp32 (x - p1 keeps the low 16 bits of x's significand, sign included; the remainder after
+// two planes has at most 8 significant bits and IS a bf16).  |p2| <= 2^-8 |x| and |p3| <= 2^-16 |x| -- half of what truncation
+// leaves (rounds 4 / 5) -- so the three plane products the contraction drops (a2 b3, a3 b2, a3 b3) are bounded by 2^-23 |a b|
+// instead of 2^-21.  The planes of one value may differ in sign.  Edges: a finite |x| above bf16's largest value (2^127 * 1.9922)
+// would round to Inf: that value is split by truncation instead (the split stays exact, the bound for such a value is truncation's);
+// Inf splits into (Inf, NaN, NaN) and NaN into NaNs (Inf - Inf): a non-finite operand surfaces as NaN in every result it touches.
+__device__ __forceinline__ void split3(float x, uint16_t& p1, uint16_t& p2, uint16_t& p3) {
+  const uint32_t ux = __builtin_bit_cast(uint32_t, x);
+  uint32_t b1 = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)x) << 16;
+  const bool edge = (b1 & 0x7fffffffu) == 0x7f800000u && (ux & 0x7fffffffu) < 0x7f800000u;
+  if (edge) b1 = ux & 0xffff0000u;
+  const float r1 = x - __builtin_bit_cast(float, b1);
+  uint32_t b2 = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)r1) << 16;
+  if (edge) b2 = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;  // (planes of one sign: no partial sum of them exceeds |x|)
+  const float r2 = r1 - __builtin_bit_cast(float, b2);
+  p1 = (uint16_t)(b1 >> 16);
+  p2 = (uint16_t)(b2 >> 16);
+  p3 = (uint16_t)(__builtin_bit_cast(uint32_t, r2) >> 16);
+}
+#endif
+
 }  // namespace x3
 }  // namespace tfk

@@ -880,6 +880,17 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
             exposed_gather, adam = 0.0, adam_ms
         out["exposed_ms_" + model] = {"reduce": exposed_reduce, "gather": exposed_gather}
         out["predicted_ms_per_step_" + model] = step_ms - adam_ms + adam + exposed_reduce + exposed_gather + fixed_ms
+        if mode == "sharded" and twin_rebuild_ms > 0:
+            # the alternative under the emulated arithmetic (round-5 verdict 1c): the shard owner's Adam writes the three planes
+            # anyway -- gather THEM (6 B per weight instead of 4) and rebuild nothing; the fp32 masters then stay with their owner
+            # as in mixed precision.  Same model, 1.5 x the gather bytes, no rebuild term
+            fg = wire_ms(6.0 * spans[-1][1], model) if spans else 0.0
+            ag = wire_ms(6.0 * p_w, model)
+            eg = fg + max(0.0, (ag - fg) - fwd_ms)
+            alt = step_ms - adam_ms + adam + exposed_reduce + eg + fixed_ms
+            out.setdefault("plane_gather", {})["exposed_gather_ms_" + model] = eg
+            out["plane_gather"]["predicted_ms_per_step_" + model] = alt
+            out["plane_gather"]["gain_ms_" + model] = out["predicted_ms_per_step_" + model] - alt
     out["wire_bytes_per_rank_per_step"] = {
         "reduce_scatter_in_out" if mode == "sharded" else "all_reduce_in_out":
             float(reduce_elem_bytes) * p_w * (world - 1) / world * (1 if mode == "sharded" else 2),
@@ -889,6 +900,17 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
     out["single_rank"] = {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "adam_ms": adam_ms, "step_ms": step_ms, "fixed_ms": fixed_ms,
                           "twin_rebuild_ms": twin_rebuild_ms}
     out["predicted_weak_scaling_efficiency_direct"] = step_ms / out["predicted_ms_per_step_direct"]
+    if "plane_gather" in out:
+        # break-even: the planes' extra wire time (half of the fp32 gather's exposed part) against the rebuild they save --
+        # expressed as the all-gather rate per rank (bytes received / s) above which gathering planes wins
+        first = spans[-1][1] if spans else 0
+        extra_bytes = 2.0 * first * (world - 1) / world  # the exposed first span: 6 - 4 bytes per weight, from world - 1 peers
+        out["plane_gather"]["break_even_gather_GBps_per_rank"] = (extra_bytes / (twin_rebuild_ms * 1e-3) / 1e9
+                                                                  if twin_rebuild_ms > 0 else None)
+        out["plane_gather"]["note"] = ("gather the owner-written three-plane twins (6 B per weight) instead of fp32 parameters (4 B) + a "
+                                       "local rebuild (%.3f ms charged in full); wins when the exposed first-span gather runs faster "
+                                       "than break_even_gather_GBps_per_rank and the rest still fits under the forward pass -- NOT built: "
+                                       "see DESIGN.md 6" % twin_rebuild_ms)
     return out
 
 
