@@ -303,6 +303,14 @@ int tfk_params_touched(tfk_engine* e);
  * waits for it layer by layer through tfk_set_layer_callback.  The fp32 masters then stay valid only on the rank that
  * owns the span until the host gathers them (checkpoints, tensor get / set).  Otherwise num_elems = 0. */
 int tfk_shadow_region(tfk_engine* e, void** device_ptr, size_t* num_elems, int* mirrors_arena);
+/* (ABI 8) Emulated fp32 + sharded exchange: the tiled three-plane twin of weight matrix `layer` (0 .. L) -- what the
+ * contractions read and what tfk_apply_span writes with the update.  Rows come in pairs (csrc/x3_layout.h), so rank r's rows
+ * [r * rows / world, (r + 1) * rows / world) are the r-th of `world` equal, contiguous pieces of the region whenever rows is a
+ * multiple of 2 * world: the exchange may then all-gather the owner-written PLANES of the matrix (6 B per weight) in place of
+ * its fp32 parameters (4 B) + a local rebuild (tfk_twins_from_params); the fp32 masters of the matrix then stay valid on their
+ * owner only, as with the bf16 shadow.  bytes = 0 when the arithmetic has no such twins or the optimiser does not write them.
+ * tfk_param_checksum(e, 3, ..) sums every twin. */
+int tfk_twin_region(tfk_engine* e, int layer, void** device_ptr, size_t* bytes, int* rows);
 /* (ABI 7) The fp32 parameters [offset, offset + n) -- whole weight matrices -- were written behind the optimiser's back (a
  * sharded exchange all-gathered them) and what the contractions READ is derived from them: under TFK_DTYPE_F32X3 the tiled
  * three-plane twins (csrc/x3_layout.h).  Rebuilds the twins of those matrices on `stream` (NULL: the engine's) -- the exchange
@@ -410,6 +418,15 @@ enum { TFK_WIRE_FP32 = 0, TFK_WIRE_BF16 = 1 };
 int tfk_comm_set_exchange(tfk_comm* c, int algo, int wire);
 int tfk_comm_get_exchange(tfk_comm* c, int* algo_reduce_scatter, int* algo_all_gather, int* wire, int* chosen_by, double* tune_us);
 int tfk_comm_tune(tfk_comm* c, size_t floats, int iters); /* COLLECTIVE */
+/* (ABI 8) WHAT is gathered under the emulated fp32 arithmetic (sharded mode).  Default (`params`): the fp32 parameters of every
+ * span, and every rank rebuilds the three-plane twins of what it received (tfk_twins_from_params behind each gather).  `planes`
+ * (env TFK_DP_GATHER=planes at attach, or this call -- COLLECTIVE, between steps): the sharding unit becomes the weight matrix --
+ * rank r owns rows [r R / world, (r + 1) R / world) of every matrix of a span, the span's collectives are launched as one group
+ * -- and for every matrix whose rows divide by 2 * world the twin rows the owner's Adam wrote are gathered (tfk_twin_region: 6 B
+ * per weight on the wire, nothing rebuilt); the fp32 masters of those matrices stay with their owners until
+ * tfk_comm_gather_masters (tfk_comm_masters_stale says so; tfk_comm_info: gathers_shadow = 2).  Switching back gathers them.
+ * dataparallel.exchange_model prices both; bench.py --gpus N measures both (`exchange_ab`). */
+int tfk_comm_set_gather(tfk_comm* c, int planes);
 /* (ABI 8) Device time per phase of the exchange step, for diagnosis (bench.py --gpus N: `exchange_phases`): between
  * tfk_comm_timing(c, 1) and tfk_comm_timing_read every phase is bracketed by timing events on the stream it runs on (each
  * record costs that stream a few microseconds: a diagnostic pass, not the one a rate is quoted from).  ms_per_step[k], averaged

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _Group(object):
     """a loopback group + one (engine, DataParallel, NativeExchange) per rank"""
 
-    def __init__(self, world, mode, dtype="float32", kw=None, min_bytes=1 << 12, algo=None, wire=None):
+    def __init__(self, world, mode, dtype="float32", kw=None, min_bytes=1 << 12, algo=None, wire=None, planes=False):
         from tfkaldi_amd import _lib
         from tfkaldi_amd.dataparallel import DataParallel, NativeExchange
         self.lib = _lib.load()
@@ -41,6 +41,8 @@ class _Group(object):
             if algo is not None or wire is not None:
                 dp._reducers[eng].set_exchange(algo, wire)
                 assert dp._reducers[eng].exchange_info()["reduce_scatter"] == (algo or "rccl")
+            if planes:
+                dp._reducers[eng].set_gather(True)
             self.engines.append(eng)
             self.dps.append(dp)
 
@@ -146,15 +148,19 @@ def test_loopback_ranks_equal_the_serial_run_fp32(gpu, world, num_mb, mode, algo
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode,algo", [("sharded", None), ("sharded", "direct"), ("allreduce", None)])
+@pytest.mark.parametrize("mode,algo,planes", [("sharded", None, False), ("sharded", "direct", False), ("allreduce", None, False),
+                                              ("sharded", None, True), ("sharded", "direct", True)])
 @pytest.mark.parametrize("world,num_mb", [(2, 2), (4, 3), (8, 8)])
-def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode, algo):
+def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode, algo, planes):
     """the fp32-emulating arithmetic under the exchange: a different path from both others -- the sharded mode gathers the fp32
     parameters (the three-plane twins of the weights live outside the arena) and every rank REBUILDS its twins from them before
     the next forward pass (engine.hip: refresh_shadow), the all-reduce mode updates them with the full Adam step.  Same bounds as
-    fp32 (it claims to be fp32), replicas bit-identical, and no stale masters: nothing is left sharded in this mode"""
+    fp32 (it claims to be fp32), replicas bit-identical, and no stale masters: nothing is left sharded in this mode.
+    planes (TFK_DP_GATHER=planes / tfk_comm_set_gather): the sharding unit is the weight matrix, the twin ROWS the owner's Adam wrote
+    travel (6 B per weight) and nothing is rebuilt -- except for a matrix whose rows do not divide by 2 x world (40 input rows at
+    world 8), which keeps the fp32 gather + rebuild; the masters of the others stay with their owners until gather_parameters"""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
-    group = _Group(world, mode, dtype="float32x3", algo=algo)
+    group = _Group(world, mode, dtype="float32x3", algo=algo, planes=planes)
     try:
         results = group.run(_rank_program(num_mb))
     finally:
@@ -166,8 +172,9 @@ def test_loopback_ranks_equal_the_serial_run_f32x3(gpu, world, num_mb, mode, alg
             np.testing.assert_array_equal(got[k], v, err_msg="rank %d %s" % (rank, k))
         if mode == "sharded":
             assert any("reduce_scatter" in n for n in info["executed"]) and any("all_gather" in n for n in info["executed"])
-            assert not any("shadow" in n for n in info["executed"])  # fp32 parameters on the wire, not a bf16 shadow
-        assert not info["stale"]
+            assert not any("shadow" in n for n in info["executed"])  # fp32 parameters or twin rows on the wire, not a bf16 shadow
+            assert any("three-plane twins" in n for n in info["executed"]) == planes
+        assert info["stale"] == planes
 
 
 @pytest.mark.timeout(600)
@@ -199,19 +206,21 @@ def _data_cfg2(num_mb, seed):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("algo", [None, "direct"])
-def test_eight_loopback_ranks_at_cfg2_size(gpu, algo):
+@pytest.mark.parametrize("algo,dtype,planes", [(None, "float32", False), ("direct", "float32", False), ("direct", "float32x3", True)])
+def test_eight_loopback_ranks_at_cfg2_size(gpu, algo, dtype, planes):
     """BASELINE cfg2's network (26 M parameters, 16 MB hidden-layer spans, the default 64 MiB coalescing): the spans an
     8-GPU job exchanges -- [scalar tail], W6..W2, W1 + W0, [vectors] -- every one dividing by 4 x 8"""
     os.environ.pop("TFK_DP_MIN_SHARD", None)
     kw = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=2000, nonlin="relu", batch_norm=True,
               init_learning_rate=1e-3, num_steps=10, max_frames=256)
-    group = _Group(8, "sharded", kw=kw, min_bytes=None, algo=algo)
+    group = _Group(8, "sharded", kw=kw, min_bytes=None, algo=algo, dtype=dtype, planes=planes)
     try:
         results = group.run(_rank_program(8, data=_data_cfg2))
     finally:
         group.close()
-    ref = _serial(8, kw=kw, data=_data_cfg2)
+    ref = _serial(8, kw=kw, data=_data_cfg2, dtype=dtype)
+    # (planes: six of cfg2's seven matrices have 2048 rows = 8 x 256 and travel as twin rows; the 440 input rows do not divide by 16)
+    assert results[0][1]["stale"] == planes
     spans = results[0][1]["spans"]
     assert [n for _, n in spans if n > 1 << 20] == [20873216, 5095424]  # (as bench.py's line reports them)
     assert sum(n.startswith("loopback:reduce_scatter") for n in results[0][1]["executed"]) == 2
@@ -269,10 +278,10 @@ def _region(eng):
     return out
 
 
-@pytest.mark.parametrize("algo", [None, "direct"])
+@pytest.mark.parametrize("algo,planes", [(None, False), ("direct", False), (None, True), ("direct", True)])
 @pytest.mark.parametrize("dtype", ["float32", "float32x3", "bfloat16"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype, algo):
+def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype, algo, planes):
     """BEFORE Adam (which amplifies round-off): after the collectives of a step, rank r's 1/world of every reduce-scattered
     span and the whole of every all-reduced span hold the gradient sums of the serial run.  One micro-batch per rank: the
     ranks' sums are added in rank order = the order the serial run accumulates micro-batches in, so the sums are
@@ -280,6 +289,8 @@ def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype,
     is a property of the PRODUCT's reduce-scatter on real RCCL too (the owner adds in rank order: direct_sum_kernel); RCCL's own
     reduce-scatter promises no order -- the loopback backend's stand-in for it happens to add in rank order as well."""
     os.environ["TFK_DP_MIN_SHARD"] = "64"
+    if planes and dtype != "float32x3":
+        pytest.skip("owner-written twins exist under the emulated arithmetic only")
     mbs = _data(world, 0)
     serial = _engine(torch_state=False, dtype=dtype)
     for i, (X, y) in enumerate(mbs):
@@ -287,7 +298,7 @@ def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype,
     want = _region(serial)
     num_params = serial.buckets()[-1][0]
     serial.close()
-    group = _Group(world, "sharded", dtype=dtype, algo=algo)
+    group = _Group(world, "sharded", dtype=dtype, algo=algo, planes=planes)
 
     def program(rank, eng, dp):
         red = dp.reducer(eng)
@@ -296,21 +307,24 @@ def test_reduce_scattered_shards_hold_the_serial_gradient_sum(gpu, world, dtype,
         red.finish_reduce()
         got = _region(eng)
         red.finish_and_apply(eng)
-        return got, list(red.last_launched), list(red.last_span_kinds)
+        mine = {span: red.my_shards(*span) for span in red.last_launched}  # (plane gathers: a row block of every matrix of the span)
+        return got, list(red.last_launched), list(red.last_span_kinds), mine
 
     try:
         results = group.run(program)
     finally:
         group.close()
-    for rank, (got, spans, kinds) in enumerate(results):
+    for rank, (got, spans, kinds, mine) in enumerate(results):
         assert kinds.count("rs") >= 2 and kinds.count("ar") == 2, kinds
         for (off, n), kind in zip(spans, kinds):
             if off >= num_params:  # loss, frames, #micro-batches (exact) + BN increments (closed form: close)
                 np.testing.assert_array_equal(got[off + 1:off + 3], want[off + 1:off + 3])
                 assert np.allclose(got[off:off + n], want[off:off + n], rtol=1e-5, atol=1e-7)
                 continue
-            part = slice(off + rank * (n // world), off + (rank + 1) * (n // world)) if kind == "rs" else slice(off, off + n)
-            np.testing.assert_array_equal(got[part], want[part], err_msg="rank %d %s span %s" % (rank, kind, (off, n)))
+            parts = [slice(o, o + m) for o, m in mine[(off, n)]] if kind == "rs" else [slice(off, off + n)]
+            assert sum(p.stop - p.start for p in parts) == (n // world if kind == "rs" else n)
+            for part in parts:
+                np.testing.assert_array_equal(got[part], want[part], err_msg="rank %d %s span %s" % (rank, kind, (off, n)))
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -403,6 +417,12 @@ def test_exchange_options_tuning_and_phase_times(gpu):
         losses.append(dp.train_step(eng, _data(world, 1)))
         assert red.exchange_info()["wire"] == "bf16" and red.exchange_info()["chosen_by"] == "set"
         red.set_exchange("direct", "fp32")
+        red.set_gather(True)   # twin rows instead of parameters + rebuild ...
+        losses.append(dp.train_step(eng, _data(world, 6)))
+        assert red.masters_stale and "three-plane twins" in " ".join(dp.last_executed)
+        red.set_gather(False)  # ... and back: the masters come home inside the call (collective)
+        assert not red.masters_stale
+        losses.append(dp.train_step(eng, _data(world, 7)))
         # refused while a step is in flight: announce a micro-batch, then try
         eng.set_later_microbatches(world - 1 - rank)
         eng.accumulate(*_data(world, 2)[rank], last=True)

@@ -145,6 +145,8 @@ SYMBOLS = {
     "tfk_twins_from_params": (c_int, [_E, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
     "tfk_set_layer_callback": (c_int, [_E, BUCKET_FN, c_void_p]),
     "tfk_shadow_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
+    "tfk_twin_region": (c_int, [_E, c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
+    "tfk_comm_set_gather": (c_int, [c_void_p, c_int]),
     "tfk_apply_writes_shadow": (c_int, [_E, POINTER(c_int)]),
     "tfk_param_checksum": (c_int, [_E, c_int, POINTER(c_uint64)]),
     "tfk_param_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t)]),

@@ -458,7 +458,7 @@ struct tfk_comm {
   bool masters_stale = false;
   std::vector<std::pair<size_t, size_t>> shard_spans;
   int verify_left = 2;
-  bool apply_enqueued = false, apply_sharded = false, apply_via_shadow = false;  // between tfk_comm_apply_enqueue and _end
+  bool apply_enqueued = false, apply_sharded = false, apply_via_shadow = false, apply_planes = false;  // between _enqueue and _end
   // TFK_DP_WIRE=bf16: reduce-scattered spans travel as bf16 (2 B per parameter in instead of 4), summed in fp32 by the owner
   bool wire_bf16 = false;
   // TFK_DP_ALGO: how a reduce-scattered span / a parameter gather travels -- RCCL's own collective (its algorithm, its
@@ -466,6 +466,14 @@ struct tfk_comm {
   // reduce-scatter, the owner's sum in rank order (direct_sum_kernel).  `auto`: both are timed at attach on scratch memory and
   // the faster one is kept, per operation (tfk_comm_tune)
   int algo_rs = TFK_ALGO_RCCL, algo_ag = TFK_ALGO_RCCL;
+  // TFK_DP_GATHER=planes (emulated fp32, sharded): the sharding unit becomes the weight MATRIX instead of the coalesced span --
+  // rank r owns rows [r R / W, (r + 1) R / W) of every matrix of a span; collectives are still launched per span, as one group
+  // -- and what the owner's Adam wrote for a matrix, its three-plane twin rows, is gathered (6 B per weight) in place of the fp32
+  // parameters (4 B) + a rebuild on every rank.  Matrices whose rows do not divide by 2 W (row pairs are the twin's unit) keep the
+  // fp32 gather + rebuild.  The fp32 masters of a plane-gathered matrix stay with their owner (tfk_comm_gather_masters).
+  bool gather_planes = false;
+  struct TwinOf { void* ptr = nullptr; size_t bytes = 0; int rows = 0; };
+  std::vector<TwinOf> twin;  // per layer (0 .. L); bytes == 0: nothing to gather in place of the parameters
   int chosen_by = 0;  // 0 default, 1 environment, 2 tuned, 3 tfk_comm_set_exchange
   double tune_us[4] = {0, 0, 0, 0};  // reduce-scatter rccl / direct, all-gather rccl / direct (max over ranks; 0: not tuned)
   // staging of the direct / bf16 exchanges: 4 B per parameter, EVERY span its own region (at its arena offset) -- spans are
@@ -495,10 +503,43 @@ int new_event(hipEvent_t* ev) {
   return 0;
 }
 
+// What a rank owns of a reduce-scattered span is cut per PIECE: the span itself (one piece: rank r owns the r-th of world equal
+// sub-spans) or, under gather_planes, each weight matrix of the span (rank r owns the r-th of world equal row blocks of it).
+struct Piece {
+  size_t off = 0, n = 0;
+  int layer = -1;       // the weight matrix this piece is (gather_planes), else -1
+  bool planes = false;  // its twin rows are gathered in place of its parameters
+};
+std::vector<Piece> pieces_of(const tfk_comm* c, size_t off, size_t n) {
+  std::vector<Piece> out;
+  if (!c->gather_planes) {
+    Piece p;
+    p.off = off; p.n = n;
+    out.push_back(p);
+    return out;
+  }
+  for (int b = 0; b <= c->L; ++b) {  // bucket b = weight matrix of layer L - b
+    const size_t bo = c->buckets[b].first, bn = c->buckets[b].second;
+    if (bo < off || bo + bn > off + n) continue;
+    Piece p;
+    p.off = bo; p.n = bn; p.layer = c->L - b;
+    const tfk_comm::TwinOf& t = c->twin[p.layer];
+    p.planes = t.bytes > 0 && t.rows % (2 * c->be->world) == 0;
+    out.push_back(p);
+  }
+  std::sort(out.begin(), out.end(), [](const Piece& a, const Piece& b) { return a.off < b.off; });
+  return out;
+}
+
 bool shardable(const tfk_comm* c, size_t lo, size_t hi) {
   const size_t n = hi - lo;
-  return c->mode == TFK_EXCHANGE_SHARDED && hi <= c->vec_off && n % (4 * (size_t)c->be->world) == 0 &&
-         n >= c->min_shard_floats;
+  if (!(c->mode == TFK_EXCHANGE_SHARDED && hi <= c->vec_off && n >= c->min_shard_floats)) return false;
+  size_t covered = 0;
+  for (const Piece& p : pieces_of(c, lo, n)) {
+    if (p.n % (4 * (size_t)c->be->world) != 0) return false;
+    covered += p.n;
+  }
+  return covered == n;  // (a span is a union of whole weight matrices: anything else is all-reduced)
 }
 
 // One coalesced range of gradients is ready on the engine stream: its collective(s) go to the comm stream.
@@ -537,12 +578,12 @@ struct Timed {
     return c->timing_pool[c->timing_used++];
   }
   Timed(tfk_comm* c_, int phase_, hipStream_t st_) : c(c_), st(st_), phase(phase_) {
-    if (!c->timing) return;
+    if (!c->timing || phase < 0) return;
     a = take(c);
     if (!a || hipEventRecord(a, st) != hipSuccess) rc = failx(-1, "timing event could not be recorded");
   }
   int end() {
-    if (!c->timing || rc || !a) return rc;
+    if (!c->timing || rc || !a || phase < 0) return rc;
     hipEvent_t b = take(c);
     if (!b || hipEventRecord(b, st) != hipSuccess) return failx(-1, "timing event could not be recorded");
     c->timed.push_back({phase, a, b});
@@ -551,9 +592,24 @@ struct Timed {
   }
 };
 
-// a parameter gather of one sharded span, by the algorithm in force
-int gather_span(tfk_comm* c, void* buf, size_t bytes_per_rank, hipStream_t st) {
-  Timed t(c, PH_AG, st);
+struct Group {  // a backend group, closed on every way out: a failed collective must not leave RCCL inside a group
+  Backend* be;
+  bool open;
+  ~Group() { if (open) (void)be->group_end(); }
+  int begin() {
+    XCHK(be->group_begin());
+    open = true;
+    return 0;
+  }
+  int end() {
+    open = false;
+    return be->group_end();
+  }
+};
+
+// a parameter gather of `world` equal shards in place, by the algorithm in force
+int gather_span(tfk_comm* c, void* buf, size_t bytes_per_rank, hipStream_t st, bool timed = true) {
+  Timed t(c, timed ? PH_AG : -1, st);
   if (c->algo_ag == TFK_ALGO_DIRECT) XCHK(c->be->all_gather_direct(buf, bytes_per_rank, st));
   else XCHK(c->be->all_gather(buf, bytes_per_rank, st));
   return t.end();
@@ -588,67 +644,73 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
     XHIP(hipStreamWaitEvent(c->comm_stream, c->spans[first].ready, 0));
   }
   // reduce-scattered spans that travel as point-to-point transfers (direct algorithm, bf16 wire) first, each on its own: the
-  // exchange must have been LAUNCHED, not deferred to the end of a group, when the owner's sum is enqueued behind it
+  // exchange must have been LAUNCHED, not deferred to the end of a group, when the owner's sum is enqueued behind it.  The
+  // pieces of one span (gather_planes: its weight matrices) go out as ONE group -- one launch -- with the sums behind it.
   const bool p2p = c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT;
   const int W = c->be->world, R = c->be->rank;
-  size_t rest = 0;
+  size_t rest = 0;  // operations of the second pass
   for (size_t k = first; k < c->num_spans; ++k) {
     Span& s = c->spans[k];
     s.wait_on = inline_on_engine ? nullptr : c->spans[c->num_spans - 1].done;
+    const std::vector<Piece> pcs = s.rs ? pieces_of(c, s.off, s.n) : std::vector<Piece>();
     if (!(s.rs && p2p)) {
-      rest += 1;
+      rest += s.rs ? pcs.size() : 1;
       continue;
     }
-    const size_t per = s.n / W;
     XCHK(ensure_stage(c));
     Timed t(c, PH_RS, st);
+    Group g = {c->be, false};
     if (c->wire_bf16) {
       uint16_t *send = static_cast<uint16_t*>(c->stage) + s.off, *recv = static_cast<uint16_t*>(c->stage) + c->num_params + s.off;
       const unsigned blocks = (unsigned)std::min<size_t>((s.n + 255) / 256, 1 << 14);
       hipLaunchKernelGGL(wire_pack_kernel, dim3(blocks), dim3(256), 0, st, c->grad + s.off, send, s.n);
-      XCHK(c->be->exchange_shards(send, recv, per * sizeof(uint16_t), st));
-      const unsigned sb = (unsigned)std::min<size_t>((per + 255) / 256, 1 << 14);
-      hipLaunchKernelGGL(wire_sum_kernel, dim3(sb), dim3(256), 0, st, c->grad + s.off + (size_t)R * per, recv, R, W, per);
-    } else {
-      float* recv = static_cast<float*>(c->stage) + s.off;
-      XCHK(c->be->exchange_shards(c->grad + s.off, recv, per * sizeof(float), st));
-      const unsigned sb = (unsigned)std::min<size_t>((per / 4 + 255) / 256, 1 << 13);
-      hipLaunchKernelGGL(direct_sum_kernel, dim3(sb ? sb : 1), dim3(256), 0, st, c->grad + s.off + (size_t)R * per, recv, R, W, per);
+    }
+    if (pcs.size() > 1) XCHK(g.begin());
+    for (const Piece& p : pcs) {
+      const size_t per = p.n / W;
+      if (c->wire_bf16)
+        XCHK(c->be->exchange_shards(static_cast<uint16_t*>(c->stage) + p.off, static_cast<uint16_t*>(c->stage) + c->num_params + p.off,
+                                    per * sizeof(uint16_t), st));
+      else
+        XCHK(c->be->exchange_shards(c->grad + p.off, static_cast<float*>(c->stage) + p.off, per * sizeof(float), st));
+    }
+    if (pcs.size() > 1) XCHK(g.end());
+    for (const Piece& p : pcs) {
+      const size_t per = p.n / W;
+      if (c->wire_bf16) {
+        const unsigned sb = (unsigned)std::min<size_t>((per + 255) / 256, 1 << 14);
+        hipLaunchKernelGGL(wire_sum_kernel, dim3(sb), dim3(256), 0, st, c->grad + p.off + (size_t)R * per,
+                           static_cast<uint16_t*>(c->stage) + c->num_params + p.off, R, W, per);
+      } else {
+        const unsigned sb = (unsigned)std::min<size_t>((per / 4 + 255) / 256, 1 << 13);
+        hipLaunchKernelGGL(direct_sum_kernel, dim3(sb ? sb : 1), dim3(256), 0, st, c->grad + p.off + (size_t)R * per,
+                           static_cast<float*>(c->stage) + p.off, R, W, per);
+      }
     }
     XHIP(hipGetLastError());
     XCHK(t.end());
     c->cur_rs += 1;
   }
   const bool grouped = rest > 1;
-  struct Group {  // (closed on every way out: a failed collective must not leave RCCL inside a group)
-    Backend* be;
-    bool open;
-    ~Group() { if (open) (void)be->group_end(); }
-  } group = {c->be, false};
+  Group group = {c->be, false};
   // (a group launches as one operation: timed as one and booked as all-reduce time -- in practice the vectors + the scalar tail)
   int lone_phase = PH_AR;
   for (size_t k = first; k < c->num_spans; ++k)
-    if (c->spans[k].rs && !p2p && !grouped) lone_phase = PH_RS;
+    if (c->spans[k].rs && !p2p) lone_phase = PH_RS;
   Timed tg(c, lone_phase, st);
-  if (grouped) {
-    XCHK(c->be->group_begin());
-    group.open = true;
-  }
+  if (grouped) XCHK(group.begin());
   for (size_t k = first; k < c->num_spans; ++k) {
     Span& s = c->spans[k];
     if (s.rs && p2p) continue;
     if (s.rs) {
-      XCHK(c->be->reduce_scatter(c->grad + s.off, s.n / W, st));
+      for (const Piece& p : pieces_of(c, s.off, s.n)) XCHK(c->be->reduce_scatter(c->grad + p.off, p.n / W, st));
       c->cur_rs += 1;
     } else {
       XCHK(c->be->all_reduce(c->grad + s.off, s.n, st));
       c->cur_ar += 1;
     }
   }
-  if (grouped) {
-    group.open = false;
-    XCHK(c->be->group_end());
-  }
+  if (grouped) XCHK(group.end());
   if (rest) XCHK(tg.end());
   if (!inline_on_engine) XHIP(hipEventRecord(c->spans[c->num_spans - 1].done, c->comm_stream));
   return 0;
@@ -738,6 +800,39 @@ int twins_behind_gather(tfk_comm* c, const std::pair<size_t, size_t>& span, hipS
   return t.end();
 }
 
+// The gathers of one reduce-scattered span, launched as one group: per piece the shard owner's fp32 parameters (or bf16 shadow),
+// or -- gather_planes, a matrix whose rows divide -- the twin rows its Adam wrote.  What the contractions read of the fp32-gathered
+// pieces is rebuilt behind the group on the same stream.
+int gather_pieces(tfk_comm* c, const std::pair<size_t, size_t>& span, hipStream_t st, bool via_shadow, bool* derived_current,
+                  bool* planes_any) {
+  const std::vector<Piece> pcs = pieces_of(c, span.first, span.second);
+  const int W = c->be->world;
+  char* target = static_cast<char*>(via_shadow ? c->shadow : (void*)c->param);
+  const size_t elem = via_shadow ? 2 : 4;
+  {
+    Timed t(c, PH_AG, st);
+    Group g = {c->be, false};
+    if (pcs.size() > 1) XCHK(g.begin());
+    for (const Piece& p : pcs) {
+      if (p.planes) {
+        const tfk_comm::TwinOf& tw = c->twin[p.layer];
+        XCHK(gather_span(c, tw.ptr, tw.bytes / W, st, false));
+        *planes_any = true;
+        const std::pair<size_t, size_t> piece(p.off, p.n);
+        if (std::find(c->shard_spans.begin(), c->shard_spans.end(), piece) == c->shard_spans.end()) c->shard_spans.push_back(piece);
+      } else {
+        XCHK(gather_span(c, target + p.off * elem, p.n / W * elem, st, false));
+      }
+    }
+    if (pcs.size() > 1) XCHK(g.end());
+    XCHK(t.end());
+  }
+  if (!via_shadow)
+    for (const Piece& p : pcs)
+      if (!p.planes) XCHK(twins_behind_gather(c, {p.off, p.n}, st, derived_current));
+  return 0;
+}
+
 void on_layer(void* user, int layer) {
   tfk_comm* c = static_cast<tfk_comm*>(user);
   remember(c, wait_layer(c, layer));
@@ -757,10 +852,12 @@ int wait_span(tfk_comm* c, Span& s) {
   return 0;
 }
 
-int verify_replicas(tfk_comm* c, bool via_shadow) {
+int verify_replicas(tfk_comm* c, bool via_shadow, bool planes) {
   XCHK(drain(c));
-  const int which[2] = {via_shadow ? 1 : 0, 2};
-  for (int k = 0; k < (via_shadow ? 2 : 1); ++k) {
+  // what every rank must agree on after the gathers: the fp32 parameters -- or, where the masters stay with their owners, what
+  // the contractions read (bf16 shadow / every three-plane twin) + the all-reduced vectors
+  const int which[2] = {via_shadow ? 1 : planes ? 3 : 0, 2};
+  for (int k = 0; k < ((via_shadow || planes) ? 2 : 1); ++k) {
     uint64_t sum = 0;
     XCHK(tfk_param_checksum(c->e, which[k], &sum));
     unsigned long long v[2] = {(unsigned long long)sum, 0};
@@ -768,7 +865,8 @@ int verify_replicas(tfk_comm* c, bool via_shadow) {
     if (v[0] != v[1])
       return failx(-1, "data-parallel replicas diverged after the sharded exchange step: rank %d holds checksum %llu of "
                        "the %s, the ranks' values span %llu .. %llu", c->be->rank, (unsigned long long)sum,
-                   which[k] == 0 ? "fp32 parameters" : which[k] == 1 ? "bf16 shadow" : "bias / beta vectors", v[0], v[1]);
+                   which[k] == 0 ? "fp32 parameters" : which[k] == 1 ? "bf16 shadow" : which[k] == 3 ? "three-plane twins"
+                                                                                                       : "bias / beta vectors", v[0], v[1]);
   }
   return 0;
 }
@@ -842,6 +940,18 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   c->vec_off = c->buckets[nb - 2].first;
   if (tfk_shadow_region(e, &p, &n, &mirrors)) return bail(-1);
   c->shadow = (mirrors && n && mode == TFK_EXCHANGE_SHARDED) ? p : nullptr;
+  c->twin.resize(c->L + 1);
+  bool twins = false;
+  for (int l = 0; l <= c->L; ++l) {
+    if (tfk_twin_region(e, l, &c->twin[l].ptr, &c->twin[l].bytes, &c->twin[l].rows)) return bail(-1);
+    twins = twins || c->twin[l].bytes > 0;
+  }
+  if (const char* v = getenv("TFK_DP_GATHER")) {
+    // (an arithmetic without owner-written twins -- exact fp32, mixed precision -- has nothing to gather in place of the
+    // parameters / the shadow: the variable is a job-wide setting and is simply not applicable there)
+    if (!strcmp(v, "planes")) c->gather_planes = twins && mode == TFK_EXCHANGE_SHARDED;
+    else if (strcmp(v, "params")) return bail(failx(-1, "TFK_DP_GATHER=%s (params | planes)", v));
+  }
   hipError_t he = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   if (he != hipSuccess) return bail(failx((int)he, "hipStreamCreate failed: %s", hipGetErrorString(he)));
   if (new_event(&c->ev_adam)) return bail(-1);
@@ -984,7 +1094,7 @@ int tfk_comm_info(tfk_comm* c, int* rank, int* world, int* mode, int* gathers_sh
   if (rank) *rank = c->be->rank;
   if (world) *world = c->be->world;
   if (mode) *mode = c->mode;
-  if (gathers_shadow) *gathers_shadow = c->shadow ? 1 : 0;
+  if (gathers_shadow) *gathers_shadow = c->shadow ? 1 : c->gather_planes ? 2 : 0;
   return 0;
 }
 
@@ -1062,8 +1172,10 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
     Span& s = c->spans[i];
     XCHK(wait_span(c, s));
     if (s.rs) {
-      const size_t per = s.n / W;
-      mine.push_back({s.off + (size_t)R * per, per});
+      for (const Piece& p : pieces_of(c, s.off, s.n)) {
+        const size_t per = p.n / W;
+        mine.push_back({p.off + (size_t)R * per, per});
+      }
       sharded.push_back({s.off, s.n});
     } else {
       mine.push_back({s.off, s.n});  // (spans beyond the parameter arena are clipped by the engine)
@@ -1080,11 +1192,16 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
   }
   XCHK(adam.end());
   g_phases.mark(3);
+  bool planes_any = false;
   if (!sharded.empty()) {
-    if (c->masters_stale && !via_shadow) return failx(-1, "sharded fp32 masters and a step that does not write the shadow");
+    if (c->gather_planes) {
+      int direct = 0;
+      XCHK(tfk_apply_writes_shadow(c->e, &direct));
+      if (!direct) return failx(-1, "TFK_DP_GATHER=planes and an optimiser step that does not write the three-plane twins");
+    } else if (c->masters_stale && !via_shadow) {
+      return failx(-1, "sharded fp32 masters and a step that does not write the shadow");
+    }
     std::sort(sharded.begin(), sharded.end());  // lowest offsets (layer 0) first: the order the next forward pass reads in
-    char* target = static_cast<char*>(via_shadow ? c->shadow : (void*)c->param);
-    const size_t elem = via_shadow ? 2 : 4;
     c->gathers_used = 0;
     size_t first_on_comm = 0;
     bool derived_current = true;  // what the contractions read (fp32 emulated: the three-plane twins) follows every gather
@@ -1093,8 +1210,7 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
       // pass could not start before it anyway, and the hop to the comm stream and back is saved; the others follow on the
       // comm stream, under the first layers
       Timed exposed(c, PH_GATHER_EXPOSED, c->engine_stream);  // (nothing runs beside it: the forward pass waits for exactly this)
-      XCHK(gather_span(c, target + sharded[0].first * elem, sharded[0].second / W * elem, c->engine_stream));
-      if (!via_shadow) XCHK(twins_behind_gather(c, sharded[0], c->engine_stream, &derived_current));
+      XCHK(gather_pieces(c, sharded[0], c->engine_stream, via_shadow, &derived_current, &planes_any));
       XCHK(exposed.end());
       c->cur_ag += 1;
       first_on_comm = 1;
@@ -1111,8 +1227,7 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
         c->gather_events.push_back(ev);
       }
       hipEvent_t done = c->gather_events[c->gathers_used++];
-      XCHK(gather_span(c, target + s.first * elem, s.second / W * elem, c->comm_stream));
-      if (!via_shadow) XCHK(twins_behind_gather(c, s, c->comm_stream, &derived_current));
+      XCHK(gather_pieces(c, s, c->comm_stream, via_shadow, &derived_current, &planes_any));
       XHIP(hipEventRecord(done, c->comm_stream));
       Gather g;
       g.off = s.first; g.n = s.second; g.done = done;
@@ -1123,8 +1238,9 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
       c->masters_stale = true;
       for (const auto& s : sharded)
         if (std::find(c->shard_spans.begin(), c->shard_spans.end(), s) == c->shard_spans.end()) c->shard_spans.push_back(s);
-    } else if (!derived_current) {
-      XCHK(tfk_params_touched(c->e));  // parameters outside this rank's spans change behind the optimiser's back
+    } else {
+      if (planes_any) c->masters_stale = true;  // (gather_pieces noted which matrices)
+      if (!derived_current) XCHK(tfk_params_touched(c->e));  // parameters outside this rank's spans change behind the optimiser's back
     }
   }
   c->last_spans.clear();
@@ -1141,6 +1257,7 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
   c->apply_enqueued = true;
   c->apply_sharded = !sharded.empty();
   c->apply_via_shadow = via_shadow;
+  c->apply_planes = planes_any;
   return 0;
 }
 int tfk_comm_apply_end(tfk_comm* c, float* average_loss) {
@@ -1154,7 +1271,7 @@ int tfk_comm_apply_end(tfk_comm* c, float* average_loss) {
   if (c->timing) c->timed_steps += 1;
   if (c->verify_left > 0 && c->apply_sharded) {
     c->verify_left -= 1;
-    XCHK(verify_replicas(c, c->apply_via_shadow));
+    XCHK(verify_replicas(c, c->apply_via_shadow, c->apply_planes));
   }
   return 0;
 }
@@ -1228,6 +1345,27 @@ int tfk_comm_set_exchange(tfk_comm* c, int algo, int wire) {
   }
   if (wire != -1) c->wire_bf16 = wire == TFK_WIRE_BF16;
   if (c->mode == TFK_EXCHANGE_SHARDED && (c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT)) XCHK(ensure_stage(c));
+  return 0;
+}
+
+int tfk_comm_set_gather(tfk_comm* c, int planes) {
+  if (!c) return failx(-1, "comm is NULL");
+  XHIP(hipSetDevice(c->device));
+  XCHK(raise_remembered(c));
+  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_set_gather in the middle of a step");
+  if (planes) {
+    bool twins = false;
+    for (const tfk_comm::TwinOf& t : c->twin) twins = twins || t.bytes > 0;
+    if (!twins || c->mode != TFK_EXCHANGE_SHARDED)
+      return failx(-1, "nothing to gather in place of the parameters: owner-written three-plane twins exist under the emulated fp32 "
+                       "arithmetic and the sharded exchange only");
+    c->gather_planes = true;
+    return 0;
+  }
+  // back to fp32 gathers: the masters the plane gathers left with their owners come home first (COLLECTIVE, like this call)
+  XCHK(tfk_comm_gather_masters(c));
+  c->gather_planes = false;
+  c->shard_spans.clear();
   return 0;
 }
 

@@ -666,9 +666,10 @@ class NativeExchange(object):
         self.rank, self.world = r.value, w.value
         self.mode = "sharded" if m.value == 0 else "allreduce"
         self.backend = self.lib.tfk_comm_backend(self._h).decode()
-        self.shadow = bool(sh.value)
+        self.shadow = sh.value == 1   # mixed precision: the bf16 shadow is what is gathered
+        self.planes = sh.value == 2   # emulated fp32 with TFK_DP_GATHER=planes: owner-written three-plane twin rows
         self.buckets = engine.buckets()
-        if self.shadow:
+        if self.mode == "sharded":    # (either way the fp32 masters may be left with their owners: refuse to hand out stale ones)
             engine.param_access_hook = self._param_access
         engine.on_close.insert(0, self.close)  # (the comm goes before its engine)
         self.last_launched, self.last_kinds, self.last_executed = [], [], []
@@ -693,8 +694,26 @@ class NativeExchange(object):
         if self._h and self.masters_stale:
             raise RuntimeError(
                 "the fp32 master weights are sharded over the data-parallel ranks (mixed-precision sharded exchange: each "
-                "rank holds the masters of its own spans, everyone holds the bf16 shadow); call "
-                "DataParallel.gather_parameters(engine) on EVERY rank before reading or writing parameters")
+                "rank holds the masters of its own spans, everyone holds the bf16 shadow -- or, TFK_DP_GATHER=planes, the "
+                "three-plane twins); call DataParallel.gather_parameters(engine) on EVERY rank before reading or writing parameters")
+
+    def set_gather(self, planes):
+        """COLLECTIVE, between steps (tfk_comm_set_gather): gather the owner-written three-plane twin rows of every weight matrix
+        (emulated fp32) instead of fp32 parameters + a rebuild on every rank; False switches back and brings the masters home"""
+        self._check(self.lib.tfk_comm_set_gather(self._h, 1 if planes else 0))
+        self.planes = bool(planes)
+
+    def my_shards(self, off, n, rank=None):
+        """[(offset, floats)] of what rank `rank` (default: this one) owns of the reduce-scattered span [off, off + n): the
+        rank-th of world equal parts of the span -- or, with plane gathers, of every weight matrix in it"""
+        r = self.rank if rank is None else rank
+        if not self.planes:
+            return [(off + r * (n // self.world), n // self.world)]
+        out = []
+        for bo, bn in sorted(self.buckets[:len(self.buckets) - 2]):
+            if bo >= off and bo + bn <= off + n:
+                out.append((bo + r * (bn // self.world), bn // self.world))
+        return out
 
     def begin_step(self, engine):
         pass  # (the comm sits behind the engine's bucket hook since it was created)
@@ -735,7 +754,7 @@ class NativeExchange(object):
                                                 ctypes.byref(n)))
         self.last_launched = [(int(spans[3 * i]), int(spans[3 * i + 1])) for i in range(min(n.value, 32))]
         self.last_span_kinds = ["rs" if spans[3 * i + 2] else "ar" for i in range(min(n.value, 32))]
-        gather = "all_gather(bf16 shadow)" if self.shadow else "all_gather"
+        gather = "all_gather(bf16 shadow)" if self.shadow else "all_gather(three-plane twins)" if self.planes else "all_gather"
         # (the backend's own collectives keep their plain names; the direct algorithm / the bf16 wire are said in brackets)
         info = self.exchange_info()
         rs_tag = "".join(t for t, on in (("[direct]", info["reduce_scatter"] == "direct" and info["wire"] == "fp32"),
