@@ -737,6 +737,8 @@ def main():
     if dp.enabled and getattr(reducer, "native", False):
         exchange_info = reducer.exchange_info()
         in_force = (exchange_info["reduce_scatter"], exchange_info["all_gather"], exchange_info["wire"])
+        in_force_planes = bool(getattr(reducer, "planes", False))
+        exchange_info["gather"] = "three-plane twins" if in_force_planes else ("bf16 shadow" if reducer.shadow else "fp32 parameters")
         exchange_ab = {"steps_each": 10, "in_force_for_value": exchange_info, "ms_per_step": {}}
         if reducer.mode == "sharded":
             for algo in ("rccl", "direct"):
@@ -744,6 +746,15 @@ def main():
                     reducer.set_exchange(algo, wire)
                     timed_steps(3)
                     exchange_ab["ms_per_step"]["%s/%s" % (algo, wire)] = 1e3 * timed_steps(10) / 10
+            # emulated fp32: the owner-written three-plane twin rows on the wire instead of fp32 parameters + a rebuild on every rank
+            # (TFK_DP_GATHER=planes; dataparallel.exchange_model prices it: `plane_gather`)
+            if args.dtype == "float32":
+                reducer.set_gather(True)
+                for algo in ("rccl", "direct"):
+                    reducer.set_exchange(algo, "fp32")
+                    timed_steps(3)
+                    exchange_ab["ms_per_step"]["%s/fp32+planes" % algo] = 1e3 * timed_steps(10) / 10
+                reducer.set_gather(in_force_planes)  # (switching back brings the fp32 masters home: collective)
             # what TFK_DP_ALGO=auto would have chosen at attach: the library's own tuning pass (tfk_comm_tune, collective) on
             # scratch memory of the largest span's size, and the step with that choice
             reducer.set_exchange(None, "fp32")

@@ -101,9 +101,11 @@ def test_bench_dp_branch_over_rccl(gpu):
     assert [n for _, n in line["collective_spans_last_step"] if n > 1 << 20] == [20873216, 5095424]
     assert line["host_fed_value"] > 0 and len(line["loss_trace_gpu"]) == 7
     # the self-diagnosing part of an N > 1 line: what is in force, the algorithm x wire A/B, the per-phase device times per rank
-    assert line["exchange_algorithm"] == {"reduce_scatter": "rccl", "all_gather": "rccl", "wire": "fp32", "chosen_by": "default"}
+    assert line["exchange_algorithm"] == {"reduce_scatter": "rccl", "all_gather": "rccl", "wire": "fp32", "chosen_by": "default",
+                                          "gather": "fp32 parameters"}
     ab = line["exchange_ab"]["ms_per_step"]
-    assert sorted(ab) == ["auto/fp32", "direct/bf16", "direct/fp32", "rccl/bf16", "rccl/fp32"] and all(0.5 < v < 50 for v in ab.values()), ab
+    assert sorted(ab) == ["auto/fp32", "direct/bf16", "direct/fp32", "direct/fp32+planes", "rccl/bf16", "rccl/fp32",
+                          "rccl/fp32+planes"] and all(0.5 < v < 50 for v in ab.values()), ab
     assert line["exchange_ab"]["auto"]["chosen_by"] == "tuned at attach" and "tuned_us_slowest_rank" in line["exchange_ab"]["auto"]
     assert line["exchange_phases"]["exchange"]["reduce_scatter"] == "rccl"  # back to what `value` ran with
     ph = line["exchange_phases"]["per_rank"]

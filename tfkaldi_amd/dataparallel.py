@@ -928,8 +928,9 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
                                                                   if twin_rebuild_ms > 0 else None)
         out["plane_gather"]["note"] = ("gather the owner-written three-plane twins (6 B per weight) instead of fp32 parameters (4 B) + a "
                                        "local rebuild (%.3f ms charged in full); wins when the exposed first-span gather runs faster "
-                                       "than break_even_gather_GBps_per_rank and the rest still fits under the forward pass -- NOT built: "
-                                       "see DESIGN.md 6" % twin_rebuild_ms)
+                                       "than break_even_gather_GBps_per_rank and the rest still fits under the forward pass.  Built "
+                                       "(TFK_DP_GATHER=planes, off by default until a multi-GPU run has measured it: bench.py's "
+                                       "exchange_ab times both)" % twin_rebuild_ms)
     return out
 
 
