@@ -192,6 +192,22 @@ def measured_traffic(w, kernel_label_):
     return rec[kernel_label_]["bytes_per_launch"], meta, src
 
 
+def rocprof_reference(w):
+    """the dominant kernel's average launch by `rocprofv3 --kernel-trace --stats` of this command as committed under profiles/
+    (tools/kernel_stats_txt.py writes profiles/kernel_stats_ref.json), quoted BESIDE this run's own HIP-event figure -- the two
+    must agree (round-5 verdict: state both in the line).  None / a reason when there is no record for this build's GEMM sources"""
+    from tfkaldi_amd.build import csrc_hash
+    path = os.path.join(ROOT, "profiles", "kernel_stats_ref.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get("%s/%s" % (w.name, w.dtype))
+    if rec is None:
+        return None
+    if rec.get("csrc_sha16") != csrc_hash():
+        return {"stale": "measured on csrc %s, this build is %s" % (rec.get("csrc_sha16"), csrc_hash()), "source": rec.get("source")}
+    return {"avg_launch_us": rec["avg_launch_us"], "kernel": rec["kernel"], "calls": rec["calls"], "source": "profiles/" + rec["source"]}
+
+
 def other_arithmetic_leg(w, other, batches, hidden, steps, warmup, device, ref_trace):
     """The same workload in the OTHER fp32 arithmetic (w.dtype float32 = emulated on the bf16 pipe -> the exact fp32 matrix
     instructions, reported as `exact_fp32`; and vice versa, `emulated_fp32`).  Reported beside the headline, never as it.  Same
@@ -843,6 +859,7 @@ def main():
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                          "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
+                         "avg_launch_us_rocprofv3": rocprof_reference(w),
                          "all_gemm_tflops": all_gemm_tf,
                          "step_tflops": value / world * w.flop_per_frame / 1e12,
                          "step_frac": value / world * w.flop_per_frame / 1e12 / peak,

@@ -50,6 +50,10 @@ struct GemmArgsB {
   // partial sums did not arrive within ~1 s (a workspace that was not zero, a partner that died): the launch's results are
   // then wrong and the owner of the word must fail the call that waits for them.  nullptr: the timeout goes unreported
   unsigned* err;
+  // gemm_bf16x3 split-K hand-over: 1 = a block that KNOWS its partner runs on the same XCD (both publish HW_REG_XCC_ID when they
+  // start) leaves its partial sums in that XCD's L2 (plain stores) instead of writing them through to memory; 0 = always through
+  // memory.  Set by the launcher from env TFK_X3_HANDOVER (l2 | mem); correctness never depends on the placement
+  int splitk_local;
 };
 
 // Tile configurations.  0-2: register-staged ring of round 1 (64x64 / 128x64 / 128x128 per 4-wave block).

@@ -3,13 +3,13 @@
 # the summaries tools/hbm_traffic.py writes straight into profiles/<tag>_*).  rocprofv3 runs: kernel trace + stats of the default
 # bench command; FETCH_SIZE / WRITE_SIZE in separate counter-only passes per configuration (tools/hbm_counters.sh,
 # MI355X_MICROARCH.md); two SQ counter passes; then the un-profiled bench lines of every configuration and the loss traces.
-tag=${1:-r05}
+tag=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 # (the clock pre-warm GEMMs of bench.py are switched off under the profiler: they would fill the kernel statistics; so are the
 #  decode / eval / Nnet.train / other-arithmetic legs, measured un-profiled below)
-export TFK_BENCH_PREWARM_MS=0
+export TFK_BENCH_PREWARM_MS=0 TFK_BENCH_SUSTAIN_S=0   # (neither the pre-warm GEMMs nor the sustained leg's thousands of steps)
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-decode --no-api-fed --no-other-arithmetic --no-eval"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B --steps 50 --warmup 5 > $out.trace.log 2>&1
@@ -24,7 +24,7 @@ bash tools/hbm_counters.sh ${tag}_hbm_cfg4 cfg4 bfloat16 profiles/$tag > $out.hb
 for c in cfg2 cfg2x3 cfg3 cfg4; do timeout 200 python tools/step_line.py $c $out.step_$c.json > /dev/null 2>&1; done
 bash tools/step_kernel_stats.sh cfg3 $out.cfg3_kernel_stats.txt > /dev/null 2>&1
 bash tools/step_kernel_stats.sh cfg4 $out.cfg4_kernel_stats.txt > /dev/null 2>&1
-unset TFK_BENCH_PREWARM_MS
+unset TFK_BENCH_PREWARM_MS TFK_BENCH_SUSTAIN_S
 timeout 400 python bench.py --steps 100 --warmup 10 > $out.bench.json 2> $out.bench.err
 timeout 400 python bench.py --steps 100 --warmup 10 --dtype float32_mfma --no-cpu-baseline --no-api-fed > $out.bench_mfma.json 2> $out.bench_mfma.err
 timeout 300 python bench.py --steps 100 --warmup 10 --dtype bfloat16 --no-cpu-baseline > $out.bench_bf16.json 2> $out.bench_bf16.err
