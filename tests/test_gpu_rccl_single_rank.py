@@ -282,3 +282,59 @@ def test_two_real_rccl_ranks_match_serial(gpu, tmp_path, mode):
             else:
                 err = np.abs(got[k] - ref[k])
                 assert np.mean(err > 0.02 * lr * 3) < 0.01 and err.max() <= 2 * lr * 3, k
+
+
+_NNET_SCRIPT = r"""
+import configparser, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from tfkaldi_amd import compat, synthetic
+compat.install()
+from neuralNetworks import nnet
+from tfkaldi_amd.processing import batchdispenser, feature_reader, target_coder
+out = sys.argv[1]
+F_RAW, CONTEXT, O = 8, 2, 12
+lengths = np.random.default_rng(0).integers(6, 30, size=26)
+paths = synthetic.write_corpus(os.path.join(out, "data"), 26, O, feat_dim=F_RAW, lengths=lengths, num_speakers=3)
+conf = configparser.ConfigParser()
+conf.add_section("directories"); conf.set("directories", "expdir", out)
+conf.add_section("nnet")
+for k, v in dict(name="dnn", context_width=str(CONTEXT), num_hidden_units="32", num_hidden_layers="2", add_layer_period="3",
+                 starting_step="0", nonlin="relu", l2_norm="False", dropout="1", batch_norm="True", num_epochs="2",
+                 initial_learning_rate="0.01", learning_rate_decay="1", batch_size="4", numutterances_per_minibatch="2",
+                 valid_batches="1", valid_frequency="2", valid_adapt="False", valid_retries="3", check_freq="4",
+                 visualise="False", seed="11").items():
+    conf.set("nnet", k, v)
+net = nnet.Nnet(conf, F_RAW, O)
+reader = feature_reader.FeatureReader(paths["feats_scp"], paths["cmvn_scp"], paths["utt2spk"], CONTEXT, 30)
+disp = batchdispenser.AlignmentBatchDispenser(reader, target_coder.AlignmentCoder(lambda x, y: x, O), 4, paths["alignments"])
+net.train(disp)
+"""
+
+
+@pytest.mark.timeout(600)
+def test_nnet_train_under_one_rccl_rank_with_plane_gathers(gpu, tmp_path):
+    """`Nnet.train` itself -- layer-wise growth (control ops re-initialise the output layer), validation, check
+    points (roll-back after a worse validation loss: tests/test_gpu_nnet_e2e.py) -- under the in-library exchange with ONE RCCL rank in the configuration that leaves the fp32 masters with their owner
+    between steps (emulated fp32, TFK_DP_GATHER=planes, TFK_DP_ALGO=direct): every place that reads or writes parameters from
+    outside the optimiser must bring them home first (trainer.gather_parameters), or the param_access_hook raises.  With one rank
+    nothing is summed across ranks, so the final model equals the single-process run's bit for bit."""
+    script = tmp_path / "run_nnet.py"
+    script.write_text(_NNET_SCRIPT.format(root=ROOT))
+    models = {}
+    for tag, extra in (("plain", {}), ("dp", dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+                                                  LOCAL_RANK="0", TFK_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                                                  TFK_DP_GATHER="planes", TFK_DP_ALGO="direct", TFK_DP_MIN_SHARD="64"))):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TFK_FORCE_DP")}
+        env.update(extra)
+        out_dir = tmp_path / tag
+        out_dir.mkdir()
+        r = subprocess.run([sys.executable, str(script), str(out_dir)], env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        assert "adding layer" in r.stdout and "validation loss at step" in r.stdout
+        models[tag] = (dict(np.load(str(out_dir / "dnn" / "final"))), [l for l in r.stdout.splitlines() if "loss" in l])
+    plain, dp = models["plain"], models["dp"]
+    assert plain[1] == dp[1], (plain[1][-3:], dp[1][-3:])  # every printed loss line, training and validation
+    assert sorted(plain[0]) == sorted(dp[0])
+    for k, v in plain[0].items():
+        np.testing.assert_array_equal(dp[0][k], v, err_msg=k)
