@@ -30,6 +30,10 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native", dtype="f
                       TFK_DP_COMM="native" if comm == "unloadable" else comm)
     if comm == "unloadable":  # the library cannot bind RCCL: every rank agrees to run the exchange through torch.distributed
         os.environ["TFK_RCCL_LIB"] = "/nonexistent/librccl.so"
+    planes = comm == "native+planes"  # the direct algorithm (grouped send / recv: none with one rank) + twin rows gathered
+    if planes:
+        os.environ.update(TFK_DP_COMM="native", TFK_DP_ALGO="direct", TFK_DP_GATHER="planes")
+        comm = "native"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env
@@ -49,6 +53,11 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native", dtype="f
         assert any("reduce_scatter" in name for name in dp.last_executed), dp.last_executed
         assert any("all_gather" in name for name in dp.last_executed), dp.last_executed
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
+    if planes and mode == "sharded":
+        red = dp.reducer(eng)
+        assert red.planes and red.masters_stale and red.exchange_info()["reduce_scatter"] == "direct"
+        assert any("three-plane twins" in name for name in dp.last_executed), dp.last_executed
+    dp.gather_parameters(eng)
     np.savez(os.path.join(out_dir, "rccl.npz"), **_collect(eng, losses))
     eng.close()
     dist.destroy_process_group()
@@ -56,7 +65,7 @@ def _worker(rank, port, num_mb, out_dir, mode="sharded", comm="native", dtype="f
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("comm,dtype", [("native", "float32"), ("torch", "float32"), ("unloadable", "float32"),
-                                        ("native", "float32x3"), ("torch", "float32x3")])
+                                        ("native", "float32x3"), ("torch", "float32x3"), ("native+planes", "float32x3")])
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
 def test_single_rank_rccl_is_identity(gpu, tmp_path, mode, comm, dtype):
     """(float32x3: the exchange gathers fp32 parameters and the engine rebuilds its three-plane twins from them -- with one
