@@ -38,8 +38,14 @@ def child(name, mode):
         # "allreduce" / "sharded": the exchange launched by the library (csrc/exchange.hip, the default on RCCL);
         # "torch-allreduce" / "torch-sharded": the same protocol driven from Python through torch.distributed (round 3)
         os.environ["TFK_DP_COMM"] = "torch" if mode.startswith("torch-") else "native"
+        # "sharded+planes" / "sharded+direct" / "sharded+direct+planes" (round 6): the owner-written three-plane twin rows gathered
+        # in place of fp32 parameters + a rebuild; the direct algorithm (with one rank: empty send / recv groups + the owner's sum)
+        if "+planes" in mode:
+            os.environ["TFK_DP_GATHER"] = "planes"
+        if "+direct" in mode:
+            os.environ["TFK_DP_ALGO"] = "direct"
     init_from_env()
-    dp = DataParallel(mode=None if mode == "plain" else mode.replace("torch-", ""))
+    dp = DataParallel(mode=None if mode == "plain" else mode.replace("torch-", "").split("+")[0])
     eng = Engine(_lib.make_config(F, L, H, O, nonlin="relu", batch_norm=True, keep_prob=keep, max_frames=T,
                                   num_steps=1000, compute_dtype=dtype),
                  torch_state=dp.enabled or bool(os.environ.get("TFK_PLAIN_TORCH_STATE")))  # (experiment: plain step on a torch stream)
@@ -92,7 +98,9 @@ def main():
         return child(sys.argv[1], sys.argv[2])
     rows = []
     for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg4"]):
-        for mode in ("plain", "allreduce", "sharded", "torch-allreduce", "torch-sharded"):
+        x3 = CONFIGS[name][6] == "float32"
+        for mode in ("plain", "allreduce", "sharded") + (("sharded+planes", "sharded+direct", "sharded+direct+planes") if x3 else
+                                                          ("sharded+direct",)) + ("torch-allreduce", "torch-sharded"):
             env = dict(os.environ, MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                        HSA_ENABLE_IPC_MODE_LEGACY="0")
             r = subprocess.run([sys.executable, os.path.abspath(__file__), name, mode], env=env, capture_output=True,
