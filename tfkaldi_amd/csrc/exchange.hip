@@ -661,9 +661,10 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
     Timed t(c, PH_RS, st);
     Group g = {c->be, false};
     if (c->wire_bf16) {
-      uint16_t *send = static_cast<uint16_t*>(c->stage) + s.off, *recv = static_cast<uint16_t*>(c->stage) + c->num_params + s.off;
+      // (the whole span is packed at its arena offset in the first half of the staging buffer; arrivals land at the same offset
+      //  in the second half)
       const unsigned blocks = (unsigned)std::min<size_t>((s.n + 255) / 256, 1 << 14);
-      hipLaunchKernelGGL(wire_pack_kernel, dim3(blocks), dim3(256), 0, st, c->grad + s.off, send, s.n);
+      hipLaunchKernelGGL(wire_pack_kernel, dim3(blocks), dim3(256), 0, st, c->grad + s.off, static_cast<uint16_t*>(c->stage) + s.off, s.n);
     }
     if (pcs.size() > 1) XCHK(g.begin());
     for (const Piece& p : pcs) {
