@@ -537,6 +537,17 @@ def test_exchange_model_arithmetic():
     # two ranks: one link, direct == ring
     two = dataparallel.exchange_model(b, 2, **kw)
     assert two["predicted_ms_per_step_direct"] == pytest.approx(two["predicted_ms_per_step_ring"])
+    # plane gathers (emulated fp32, TFK_DP_GATHER=planes): priced only where there is a rebuild to save; 1.5 x the gather bytes,
+    # no rebuild -- at the full-mesh rate the first span's extra 2 bytes per weight cost less than the rebuild, at one link's
+    # rate they do not, and the break-even rate is where the exposed first span's extra bytes take exactly the rebuild's time
+    assert "plane_gather" not in m and "plane_gather" in t
+    pg = t["plane_gather"]
+    first = m["spans"][1]["floats"]
+    extra_direct = 2.0 * first / 8 / (dataparallel.XGMI_LINK_GBPS * 1e9) * 1e3  # one shard per link
+    assert pg["gain_ms_direct"] == pytest.approx(0.052 - extra_direct)
+    assert pg["gain_ms_direct"] > 0 > pg["gain_ms_ring"]
+    assert pg["predicted_ms_per_step_direct"] == pytest.approx(t["predicted_ms_per_step_direct"] - pg["gain_ms_direct"])
+    assert pg["break_even_gather_GBps_per_rank"] == pytest.approx(2.0 * first * 7 / 8 / 0.052e-3 / 1e9)
 
 
 @pytest.mark.parametrize("m16", [0, 1])
