@@ -775,6 +775,14 @@ def main():
                         timed_steps(3)
                         exchange_ab["ms_per_step"]["%s/fp32+planes" % algo] = 1e3 * timed_steps(10) / 10
                     reducer.set_gather(in_force_planes)  # (switching back brings the fp32 masters home: collective)
+            # how many weight matrices one collective carries (TFK_DP_BUCKET_MB; default 64 MiB, never tuned on real links)
+            reducer.set_exchange("rccl", "fp32")
+            exchange_ab["ms_per_step_by_span_MiB"] = {}
+            for mib in (16, 32, 64, 128):
+                reducer.set_bucket_bytes(mib << 20)
+                timed_steps(3)
+                exchange_ab["ms_per_step_by_span_MiB"][str(mib)] = 1e3 * timed_steps(10) / 10
+            reducer.set_bucket_bytes(int(float(os.environ.get("TFK_DP_BUCKET_MB", "64")) * (1 << 20)))
             # what TFK_DP_ALGO=auto would have chosen at attach: the library's own tuning pass (tfk_comm_tune, collective) on
             # scratch memory of the largest span's size, and the step with that choice
             reducer.set_exchange(None, "fp32")

@@ -334,6 +334,10 @@ int tfk_set_later_microbatches(tfk_engine* e, int32_t later);
 /* The fp32 parameter arena [P] (same float offsets as the gradient part of the reduce region): what a sharded exchange
  * step all-gathers into. */
 int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats);
+/* (ABI 8) Adam's first and second moments [P] each, same float offsets as the parameter arena.  Under a sharded exchange every
+ * rank updates the moments of its OWN shards only -- the optimiser state is sharded with the optimiser -- so whatever changes
+ * the assignment of shards to ranks (tfk_comm_set_bucket_bytes, tfk_comm_set_gather) gathers them first. */
+int tfk_moment_regions(tfk_engine* e, void** adam_m, void** adam_v, size_t* num_floats);
 
 /* ---- the exchange step inside the library: RCCL over xGMI, no host language in the step ------------------------
  *
@@ -427,6 +431,10 @@ int tfk_comm_tune(tfk_comm* c, size_t floats, int iters); /* COLLECTIVE */
  * tfk_comm_gather_masters (tfk_comm_masters_stale says so; tfk_comm_info: gathers_shadow = 2).  Switching back gathers them.
  * dataparallel.exchange_model prices both; bench.py --gpus N measures both (`exchange_ab`). */
 int tfk_comm_set_gather(tfk_comm* c, int planes);
+/* (ABI 8) the coalescing threshold of tfk_comm_create's `bucket_bytes`, changed between steps (every rank alike; 0 = the 64 MiB
+ * default): how many weight matrices one collective carries is the first thing to tune on real links -- bench.py sweeps it.
+ * COLLECTIVE: another span cut assigns shards to other ranks, so masters left with their owners are gathered first. */
+int tfk_comm_set_bucket_bytes(tfk_comm* c, size_t bucket_bytes);
 /* (ABI 8) Device time per phase of the exchange step, for diagnosis (bench.py --gpus N: `exchange_phases`): between
  * tfk_comm_timing(c, 1) and tfk_comm_timing_read every phase is bracketed by timing events on the stream it runs on (each
  * record costs that stream a few microseconds: a diagnostic pass, not the one a rate is quoted from).  ms_per_step[k], averaged

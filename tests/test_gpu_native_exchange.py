@@ -454,3 +454,61 @@ def test_exchange_options_tuning_and_phase_times(gpu):
         assert all(v < 1e3 for v in phases.values()), phases
     print("tuned (loopback, 4 ranks, 1 Mi floats):", results[0][0])
     print("phases, ms per step (rank 0):", results[0][1])
+
+
+@pytest.mark.parametrize("dtype,planes", [("bfloat16", False), ("float32x3", True), ("float32x3", "toggle"), ("float32", False)])
+def test_span_size_changes_between_steps_with_masters_left_at_their_owners(gpu, dtype, planes):
+    """tfk_comm_set_bucket_bytes (bench.py's span-size sweep) cuts the spans differently, i.e. assigns shards to other ranks.  In the
+    configurations that leave fp32 masters with their owners between steps (mixed precision: the bf16 shadow travels; emulated
+    fp32 with plane gathers) the new owner would update STALE masters unless they are gathered first -- and in EVERY configuration
+    Adam's moments are current on a shard's owner only (the optimiser state is sharded with the optimiser: this test caught the
+    first version of the call gathering the masters alone).  tfk_comm_set_bucket_bytes / tfk_comm_set_gather bring both home
+    (collective).  Who owns an element changes nothing in what is computed for it (Adam is element-wise, the loopback group adds
+    in rank order whatever the cut), so six steps over three span sizes -- "toggle": and over parameter gathers / plane gathers /
+    parameter gathers -- must equal six steps at ONE span size BIT FOR BIT, and the serial run at the arithmetic's usual tolerance."""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    world = 4
+    kw = dict(KW, num_units=64, output_dim=24)
+
+    stale = dtype == "bfloat16" or planes is True
+
+    def run(sizes, toggle=False):
+        group = _Group(world, "sharded", dtype=dtype, kw=kw, planes=planes is True)
+
+        def program(rank, eng, dp):
+            red = dp.reducer(eng)
+            losses, cuts = [], []
+            for k, size in enumerate(sizes):
+                red.set_bucket_bytes(size)
+                if toggle:
+                    red.set_gather(k == 1)
+                for step in (2 * k, 2 * k + 1):
+                    losses.append(dp.train_step(eng, _data(world, step)))
+                assert red.masters_stale == (stale or (toggle and k == 1))
+                cuts.append(tuple(n for _, n in red.last_launched))
+            dp.gather_parameters(eng)
+            return _collect(eng, losses), cuts
+
+        try:
+            return group.run(program)
+        finally:
+            group.close()
+
+    changing = run((1 << 12, 1 << 22, 1 << 14), toggle=planes == "toggle")
+    fixed = run((1 << 12, 1 << 12, 1 << 12))
+    assert len(set(changing[0][1])) >= 2, changing[0][1]  # the spans really were cut differently
+    assert len(set(fixed[0][1])) == 1
+    for rank in range(world):
+        for k, v in fixed[0][0].items():
+            np.testing.assert_array_equal(changing[rank][0][k], v, err_msg="rank %d %s" % (rank, k))
+    serial = _engine(torch_state=False, dtype=dtype, kw=kw)
+    want = []
+    for step in range(6):
+        mbs = _data(world, step)
+        for i, (X, y) in enumerate(mbs):
+            serial.accumulate(X, y, last=(i == len(mbs) - 1))
+        want.append(serial.apply())
+    ref = _collect(serial, want)
+    serial.close()
+    tol = (2e-3, 5e-3) if dtype == "bfloat16" else (2e-5, 4e-4)  # (six Adam steps: a little more room than the four-step tests)
+    _compare(ref, changing[0][0], tol[0], tol[1], "rank 0")

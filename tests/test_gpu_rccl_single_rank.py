@@ -115,6 +115,8 @@ def test_bench_dp_branch_over_rccl(gpu):
     ab = line["exchange_ab"]["ms_per_step"]
     assert sorted(ab) == ["auto/fp32", "direct/bf16", "direct/fp32", "direct/fp32+planes", "rccl/bf16", "rccl/fp32",
                           "rccl/fp32+planes"] and all(0.5 < v < 50 for v in ab.values()), ab
+    spans = line["exchange_ab"]["ms_per_step_by_span_MiB"]
+    assert sorted(spans, key=int) == ["16", "32", "64", "128"] and all(0.5 < v < 50 for v in spans.values()), spans
     assert line["exchange_ab"]["auto"]["chosen_by"] == "tuned at attach" and "tuned_us_slowest_rank" in line["exchange_ab"]["auto"]
     assert line["exchange_phases"]["exchange"]["reduce_scatter"] == "rccl"  # back to what `value` ran with
     ph = line["exchange_phases"]["per_rank"]

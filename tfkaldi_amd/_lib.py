@@ -147,9 +147,11 @@ SYMBOLS = {
     "tfk_shadow_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "tfk_twin_region": (c_int, [_E, c_int, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "tfk_comm_set_gather": (c_int, [c_void_p, c_int]),
+    "tfk_comm_set_bucket_bytes": (c_int, [c_void_p, c_size_t]),
     "tfk_apply_writes_shadow": (c_int, [_E, POINTER(c_int)]),
     "tfk_param_checksum": (c_int, [_E, c_int, POINTER(c_uint64)]),
     "tfk_param_region": (c_int, [_E, POINTER(c_void_p), POINTER(c_size_t)]),
+    "tfk_moment_regions": (c_int, [_E, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_size_t)]),
     "tfk_comm_available": (c_int, [_E, c_int]),
     "tfk_comm_unique_id": (c_int, [c_void_p, c_size_t, POINTER(c_size_t)]),
     "tfk_comm_create": (c_int, [_E, c_void_p, c_size_t, c_int, c_int, c_int, c_size_t, POINTER(c_void_p)]),

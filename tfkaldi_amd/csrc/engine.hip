@@ -2449,6 +2449,13 @@ int tfk_reduce_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {
   *num_floats = e->reduce_floats;
   return 0;
 }
+int tfk_moment_regions(tfk_engine* e, void** adam_m, void** adam_v, size_t* num_floats) {
+  if (!e || !adam_m || !adam_v || !num_floats) return fail(-1, "NULL argument");
+  *adam_m = e->p_m();
+  *adam_v = e->p_v();
+  *num_floats = e->P;
+  return 0;
+}
 int tfk_param_region(tfk_engine* e, void** device_ptr, size_t* num_floats) {
   if (!e || !device_ptr || !num_floats) return fail(-1, "NULL argument");
   *device_ptr = e->p_param();

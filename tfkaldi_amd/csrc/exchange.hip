@@ -457,6 +457,10 @@ struct tfk_comm {
   hipEvent_t ev_adam = nullptr;
   bool masters_stale = false;
   std::vector<std::pair<size_t, size_t>> shard_spans;
+  // every piece this comm has sharded since the shards were last assigned: Adam's moments of a piece are current on its owner
+  // only (the optimiser state is sharded with the optimiser), so a change of the assignment gathers them first (rehome)
+  std::vector<std::pair<size_t, size_t>> owned_pieces;
+  float *adam_m = nullptr, *adam_v = nullptr;
   int verify_left = 2;
   bool apply_enqueued = false, apply_sharded = false, apply_via_shadow = false, apply_planes = false;  // between _enqueue and _end
   // TFK_DP_WIRE=bf16: reduce-scattered spans travel as bf16 (2 B per parameter in instead of 4), summed in fp32 by the owner
@@ -929,6 +933,13 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   }
   if (tfk_param_region(e, &p, &n)) return bail(-1);
   c->param = static_cast<float*>(p);
+  {
+    void *m = nullptr, *v = nullptr;
+    size_t nm = 0;
+    if (tfk_moment_regions(e, &m, &v, &nm)) return bail(-1);
+    c->adam_m = static_cast<float*>(m);
+    c->adam_v = static_cast<float*>(v);
+  }
   int nb = 0, mirrors = 0;
   if (tfk_num_buckets(e, &nb)) return bail(-1);
   c->L = nb - 3;
@@ -1176,6 +1187,8 @@ int tfk_comm_apply_enqueue(tfk_comm* c) {
       for (const Piece& p : pieces_of(c, s.off, s.n)) {
         const size_t per = p.n / W;
         mine.push_back({p.off + (size_t)R * per, per});
+        const std::pair<size_t, size_t> piece(p.off, p.n);
+        if (std::find(c->owned_pieces.begin(), c->owned_pieces.end(), piece) == c->owned_pieces.end()) c->owned_pieces.push_back(piece);
       }
       sharded.push_back({s.off, s.n});
     } else {
@@ -1333,6 +1346,28 @@ int tfk_comm_gather_masters(tfk_comm* c) {
   return 0;
 }
 
+namespace {
+// Everything a rank holds of the optimiser's state becomes whole again: the fp32 masters left with their owners (if any) and
+// Adam's moments of every piece sharded so far.  COLLECTIVE.  After it any assignment of shards to ranks is as good as any other.
+int rehome(tfk_comm* c) {
+  XCHK(tfk_comm_gather_masters(c));
+  c->shard_spans.clear();
+  if (c->owned_pieces.empty()) return 0;
+  std::sort(c->owned_pieces.begin(), c->owned_pieces.end());
+  XHIP(hipEventRecord(c->ev_adam, c->engine_stream));
+  XHIP(hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
+  const size_t W = (size_t)c->be->world;
+  for (const auto& p : c->owned_pieces) {
+    XCHK(gather_span(c, c->adam_m + p.first, p.second / W * sizeof(float), c->comm_stream, false));
+    XCHK(gather_span(c, c->adam_v + p.first, p.second / W * sizeof(float), c->comm_stream, false));
+  }
+  XHIP(hipEventRecord(c->ev_adam, c->comm_stream));
+  XHIP(hipStreamWaitEvent(c->engine_stream, c->ev_adam, 0));
+  c->owned_pieces.clear();
+  return 0;
+}
+}  // namespace
+
 int tfk_comm_set_exchange(tfk_comm* c, int algo, int wire) {
   if (!c) return failx(-1, "comm is NULL");
   XHIP(hipSetDevice(c->device));
@@ -1360,13 +1395,26 @@ int tfk_comm_set_gather(tfk_comm* c, int planes) {
     if (!twins || c->mode != TFK_EXCHANGE_SHARDED)
       return failx(-1, "nothing to gather in place of the parameters: owner-written three-plane twins exist under the emulated fp32 "
                        "arithmetic and the sharded exchange only");
+    XCHK(rehome(c));  // (the sharding unit changes with the switch: nothing may be left with a previous owner)
     c->gather_planes = true;
     return 0;
   }
-  // back to fp32 gathers: the masters the plane gathers left with their owners come home first (COLLECTIVE, like this call)
-  XCHK(tfk_comm_gather_masters(c));
+  // back to fp32 gathers: the masters the plane gathers left with their owners, and Adam's moments, come home first
+  // (COLLECTIVE, like this call)
+  XCHK(rehome(c));
   c->gather_planes = false;
-  c->shard_spans.clear();
+  return 0;
+}
+
+int tfk_comm_set_bucket_bytes(tfk_comm* c, size_t bucket_bytes) {
+  if (!c) return failx(-1, "comm is NULL");
+  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_set_bucket_bytes in the middle of a step");
+  // another span cut is another assignment of shards to ranks: what lives with a shard's owner only -- fp32 masters (mixed
+  // precision, plane gathers) and Adam's moments (always) -- comes home first, COLLECTIVE like this call, or the new owner would
+  // update stale values
+  XCHK(rehome(c));
+  if (bucket_bytes == 0) bucket_bytes = (size_t)64 << 20;
+  c->min_floats = std::max<size_t>(1, bucket_bytes / 4);
   return 0;
 }
 

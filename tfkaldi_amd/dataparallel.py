@@ -703,6 +703,10 @@ class NativeExchange(object):
         self._check(self.lib.tfk_comm_set_gather(self._h, 1 if planes else 0))
         self.planes = bool(planes)
 
+    def set_bucket_bytes(self, nbytes):
+        """between steps, every rank alike: adjacent gradient buckets are coalesced until a collective carries this much (0: 64 MiB)"""
+        self._check(self.lib.tfk_comm_set_bucket_bytes(self._h, int(nbytes)))
+
     def my_shards(self, off, n, rank=None):
         """[(offset, floats)] of what rank `rank` (default: this one) owns of the reduce-scattered span [off, off + n): the
         rank-th of world equal parts of the span -- or, with plane gathers, of every weight matrix in it"""
