@@ -512,3 +512,41 @@ def test_span_size_changes_between_steps_with_masters_left_at_their_owners(gpu, 
     serial.close()
     tol = (2e-3, 5e-3) if dtype == "bfloat16" else (2e-5, 4e-4)  # (six Adam steps: a little more room than the four-step tests)
     _compare(ref, changing[0][0], tol[0], tol[1], "rank 0")
+
+
+@pytest.mark.parametrize("dtype", ["float32x3", "bfloat16"])
+def test_no_exchange_option_changes_what_is_computed(gpu, dtype):
+    """Algorithm, gather, span size, the tuning pass and the phase timing are about HOW the sums travel: on the fp32 wire none of
+    them may change a bit of the result (the loopback group adds in rank order under either algorithm).  Eight steps, an option
+    flipped before every one, against eight steps with everything at its default."""
+    os.environ["TFK_DP_MIN_SHARD"] = "64"
+    world = 4
+    kw = dict(KW, num_units=64, output_dim=24)
+    x3 = dtype == "float32x3"
+
+    def run(flip):
+        group = _Group(world, "sharded", dtype=dtype, kw=kw)
+
+        def program(rank, eng, dp):
+            red = dp.reducer(eng)
+            flips = [lambda: red.set_exchange("direct", None), lambda: red.tune(1 << 16, iters=2), lambda: red.timing_begin(),
+                     lambda: red.set_gather(True) if x3 else red.set_bucket_bytes(1 << 20), lambda: red.set_exchange("rccl", None),
+                     lambda: red.timing_read(), lambda: red.set_gather(False) if x3 else red.set_bucket_bytes(1 << 12),
+                     lambda: red.set_exchange("direct", "fp32")]
+            losses = []
+            for step in range(8):
+                if flip:
+                    flips[step]()
+                losses.append(dp.train_step(eng, _data(world, step)))
+            dp.gather_parameters(eng)
+            return _collect(eng, losses)
+
+        try:
+            return group.run(program)
+        finally:
+            group.close()
+
+    flipped, plain = run(True), run(False)
+    for rank in range(world):
+        for k, v in plain[0].items():
+            np.testing.assert_array_equal(flipped[rank][k], v, err_msg="rank %d %s" % (rank, k))
