@@ -448,6 +448,8 @@ struct tfk_comm {
 
   bool have_range = false;
   size_t lo = 0, hi = 0;
+  bool have_hold = false, have_head = false;  // ranges held back for the inline tail (hold_last): the last weight range; [scalars | E]
+  size_t hold_lo = 0, hold_hi = 0, head_lo = 0, head_hi = 0;
   std::vector<Span> spans;  // collectives of the current step, launch order
   size_t num_spans = 0;
   size_t waited_upto = 0;       // spans [0, waited_upto) of this step are complete as far as the engine stream is concerned
@@ -721,7 +723,45 @@ int launch_range(tfk_comm* c, size_t lo, size_t hi, bool inline_on_engine = fals
   return 0;
 }
 
+// env TFK_DP_HOLD_LAST (default on; needs the inline tail): the weight range still coalescing when the step's LAST announcement
+// arrives (the bias / beta vectors, behind the last backward kernel) is not flushed to the comm stream -- nothing is left to
+// overlap it with, and the `ready` record + comm stream + `done` wait round trip showed as ~6 + ~16 us of idle engine stream
+// in front of the optimiser (profiles/r06_dp_trace.txt) -- but held and launched with the vectors on the engine stream itself,
+// where RCCL's own collectives go out as ONE group (one launch).  The step's FIRST announcement ([scalars | BN increments])
+// joins that group too instead of costing the engine stream an event record in the middle of the backward pass.
+bool hold_last() {
+  static const bool on = inline_tail() && (!getenv("TFK_DP_HOLD_LAST") || atoi(getenv("TFK_DP_HOLD_LAST")) != 0);
+  return on;
+}
+
 int flush_range(tfk_comm* c, bool inline_on_engine = false) {
+  if (inline_on_engine && (c->have_head || c->have_hold)) {
+    // the tail of a step: [scalars + BN increments] held since the first announcement, the weight range held since the last one,
+    // the vectors -- on the engine stream, behind the last backward kernel
+    const bool p2p = c->mode == TFK_EXCHANGE_SHARDED && (c->wire_bf16 || c->algo_rs == TFK_ALGO_DIRECT);
+    // (point-to-point reduce-scatters enqueue the owner's sum behind their exchange and cannot wait for an outer group's end;
+    //  under tfk_comm_timing every operation keeps its own launch so that its events bracket it)
+    const bool one_launch = !p2p && !c->timing;
+    Group g = {c->be, false};
+    if (one_launch) XCHK(g.begin());
+    if (c->have_head) {
+      c->have_head = false;
+      XCHK(launch_range(c, c->head_lo, c->head_hi, true));
+    }
+    if (c->have_hold) {
+      c->have_hold = false;
+      XCHK(launch_range(c, c->hold_lo, c->hold_hi, true));
+    }
+    if (c->have_range) {
+      c->have_range = false;
+      XCHK(launch_range(c, c->lo, c->hi, true));
+    }
+    return one_launch ? g.end() : 0;
+  }
+  if (c->have_hold) {  // (a flush in the middle of a step: the held weight range goes first, in announcement order)
+    c->have_hold = false;
+    XCHK(launch_range(c, c->hold_lo, c->hold_hi, inline_on_engine));
+  }
   if (!c->have_range) return 0;
   c->have_range = false;
   return launch_range(c, c->lo, c->hi, inline_on_engine);
@@ -730,9 +770,26 @@ int flush_range(tfk_comm* c, bool inline_on_engine = false) {
 int announce(tfk_comm* c, int b) {
   if (b < 0 || b >= (int)c->buckets.size()) return failx(-1, "bucket %d out of range", b);
   const size_t off = c->buckets[b].first, n = c->buckets[b].second;
+  if (b == c->L + 2 && !c->have_range && !c->have_head && hold_last()) {
+    // [scalars + BN increments]: always the FIRST announcement of a step.  Its all-reduce used to go to the comm stream at once
+    // (a `ready` record between two kernels of the engine stream: ~6 us of idle time) so as to be long done when the optimiser
+    // needs the frame count; in the tail's one group launch it costs nothing and needs no event
+    c->have_head = true;
+    c->head_lo = off;
+    c->head_hi = off + n;
+    return 0;
+  }
   if (c->have_range && off + n == c->lo) {
     c->lo = off;
   } else if (c->have_range && off == c->hi) {
+    c->hi = off + n;
+  } else if (c->have_range && b == c->L + 1 && !c->have_hold && c->hi <= c->vec_off && hold_last()) {
+    // the vectors: always the last announcement of a step (engine.hip: backward, tfk_comm_idle) -- the pending weight range waits
+    // for tfk_comm_apply_enqueue / tfk_comm_finish_reduce, which follow at once, instead of taking the comm-stream round trip
+    c->have_hold = true;
+    c->hold_lo = c->lo;
+    c->hold_hi = c->hi;
+    c->lo = off;
     c->hi = off + n;
   } else {
     XCHK(flush_range(c));
@@ -1308,7 +1365,7 @@ int tfk_comm_eval_finish(tfk_comm* c, float* average_loss) {
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
   const size_t off = c->buckets.back().first, n = c->buckets.back().second;
-  if (c->num_spans || c->have_range) return failx(-1, "tfk_comm_eval_finish in the middle of a training step");
+  if (c->num_spans || c->have_range || c->have_hold || c->have_head) return failx(-1, "tfk_comm_eval_finish in the middle of a training step");
   XCHK(launch_range(c, off, off + n, inline_tail()));
   XCHK(wait_span(c, c->spans[0]));
   c->num_spans = 0;
@@ -1372,7 +1429,7 @@ int tfk_comm_set_exchange(tfk_comm* c, int algo, int wire) {
   if (!c) return failx(-1, "comm is NULL");
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
-  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_set_exchange in the middle of a step");
+  if (c->num_spans || c->have_range || c->have_hold || c->have_head || c->apply_enqueued) return failx(-1, "tfk_comm_set_exchange in the middle of a step");
   if (algo != -1 && algo != TFK_ALGO_RCCL && algo != TFK_ALGO_DIRECT) return failx(-1, "exchange algorithm %d", algo);
   if (wire != -1 && wire != TFK_WIRE_FP32 && wire != TFK_WIRE_BF16) return failx(-1, "wire format %d", wire);
   if (algo != -1) {
@@ -1388,7 +1445,7 @@ int tfk_comm_set_gather(tfk_comm* c, int planes) {
   if (!c) return failx(-1, "comm is NULL");
   XHIP(hipSetDevice(c->device));
   XCHK(raise_remembered(c));
-  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_set_gather in the middle of a step");
+  if (c->num_spans || c->have_range || c->have_hold || c->have_head || c->apply_enqueued) return failx(-1, "tfk_comm_set_gather in the middle of a step");
   if (planes) {
     bool twins = false;
     for (const tfk_comm::TwinOf& t : c->twin) twins = twins || t.bytes > 0;
@@ -1408,7 +1465,7 @@ int tfk_comm_set_gather(tfk_comm* c, int planes) {
 
 int tfk_comm_set_bucket_bytes(tfk_comm* c, size_t bucket_bytes) {
   if (!c) return failx(-1, "comm is NULL");
-  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_set_bucket_bytes in the middle of a step");
+  if (c->num_spans || c->have_range || c->have_hold || c->have_head || c->apply_enqueued) return failx(-1, "tfk_comm_set_bucket_bytes in the middle of a step");
   // another span cut is another assignment of shards to ranks: what lives with a shard's owner only -- fp32 masters (mixed
   // precision, plane gathers) and Adam's moments (always) -- comes home first, COLLECTIVE like this call, or the new owner would
   // update stale values
@@ -1431,7 +1488,7 @@ int tfk_comm_get_exchange(tfk_comm* c, int* algo_reduce_scatter, int* algo_all_g
 int tfk_comm_tune(tfk_comm* c, size_t floats, int iters) {
   if (!c) return failx(-1, "comm is NULL");
   XHIP(hipSetDevice(c->device));
-  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_tune in the middle of a step");
+  if (c->num_spans || c->have_range || c->have_hold || c->have_head || c->apply_enqueued) return failx(-1, "tfk_comm_tune in the middle of a step");
   const int W = c->be->world, R = c->be->rank;
   const size_t unit = 4 * (size_t)W;
   floats = std::max(unit, floats / unit * unit);
@@ -1496,7 +1553,7 @@ int tfk_comm_tune(tfk_comm* c, size_t floats, int iters) {
 
 int tfk_comm_timing(tfk_comm* c, int on) {
   if (!c) return failx(-1, "comm is NULL");
-  if (c->num_spans || c->have_range || c->apply_enqueued) return failx(-1, "tfk_comm_timing in the middle of a step");
+  if (c->num_spans || c->have_range || c->have_hold || c->have_head || c->apply_enqueued) return failx(-1, "tfk_comm_timing in the middle of a step");
   c->timing = on != 0;
   c->timed.clear();
   c->timing_used = 0;
