@@ -87,7 +87,8 @@ class Workload(object):
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: re-execute under torch.distributed.run, one rank per GPU."""
     import torch
-    share = os.environ.get("TFK_SHARE_DEVICE") == "1"  # tests only: several ranks on one GPU (gloo)
+    # tests only: several ranks on one GPU (over gloo, or over real RCCL with every rank claiming its own host)
+    share = os.environ.get("TFK_SHARE_DEVICE") == "1" or os.environ.get("TFK_FAKE_NODES") == "1"
     have = torch.cuda.device_count()
     if not share and have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))

@@ -19,6 +19,14 @@ import time
 import weakref
 
 
+def _share_device():
+    """tests only -- several ranks on ONE GPU.  TFK_SHARE_DEVICE=1: pair it with TFK_DIST_BACKEND=gloo (RCCL refuses two
+    ranks with the same host hash and PCI bus id).  TFK_FAKE_NODES=1: every rank claims a host of its own (NCCL_HOSTID), so
+    REAL RCCL accepts them and the ranks talk through its socket transport over the loopback interface -- slow, but it is
+    RCCL's own bootstrap, group launches and collective kernels at world > 1 on a 1-GPU box (tools/rccl_fake_nodes_probe.py)."""
+    return os.environ.get("TFK_SHARE_DEVICE") == "1" or os.environ.get("TFK_FAKE_NODES") == "1"
+
+
 def init_from_env():
     """Join the process group described by torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); a no-op for single-process runs."""
@@ -36,8 +44,12 @@ def init_from_env():
             if use_gpu:
                 # TFK_SHARE_DEVICE=1 (tests only): several ranks on one GPU -- RCCL refuses that, so pair it
                 # with TFK_DIST_BACKEND=gloo to exercise the host-side bucket / overlap logic on a 1-GPU box
-                if os.environ.get("TFK_SHARE_DEVICE") == "1":
+                if _share_device():
                     local_rank = local_rank % torch.cuda.device_count()
+                if os.environ.get("TFK_FAKE_NODES") == "1":  # (before RCCL is initialised: it reads these at init)
+                    os.environ["NCCL_HOSTID"] = "tfk-fake-node-%d" % rank
+                    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+                    os.environ.setdefault("NCCL_IB_DISABLE", "1")
                 torch.cuda.set_device(local_rank)
             backend = os.environ.get("TFK_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
             if backend == "nccl":
@@ -50,7 +62,7 @@ def init_from_env():
                                         device_id=torch.device("cuda", local_rank))
             else:
                 dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if os.environ.get("TFK_SHARE_DEVICE") == "1":
+    if _share_device():
         import torch
         if torch.cuda.is_available():
             local_rank = local_rank % torch.cuda.device_count()
