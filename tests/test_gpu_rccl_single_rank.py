@@ -390,3 +390,47 @@ def test_nnet_train_under_one_rccl_rank_with_plane_gathers(gpu, tmp_path):
     assert sorted(plain[0]) == sorted(dp[0])
     for k, v in plain[0].items():
         np.testing.assert_array_equal(dp[0][k], v, err_msg=k)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("options", ["", "direct+planes"])
+def test_nnet_train_under_two_real_rccl_ranks(gpu, tmp_path, options):
+    """`Nnet.train` -- packed feed (each rank reads its own utterances), layer-wise growth, validation, check points --
+    as `torchrun --nproc-per-node 2` over REAL RCCL (two GPUs, or one GPU with TFK_FAKE_NODES): every step has two
+    micro-batches, one per rank, so the exchanged sums are a + b against the serial run's a + b -- the training losses
+    printed by rank 0 must agree with the single-process run's to fp32 round-off (the BN moving averages are composed from
+    increments instead of updated one after the other, which moves the validation losses in their last digits)."""
+    import re
+    import torch
+    script = tmp_path / "run_nnet.py"
+    script.write_text(_NNET_SCRIPT.format(root=ROOT))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TFK_FORCE_DP")}
+    runs = {}
+    for tag in ("plain", "dp"):
+        env = dict(base)
+        out_dir = tmp_path / tag
+        out_dir.mkdir()
+        cmd = [sys.executable, str(script), str(out_dir)]
+        if tag == "dp":
+            env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64", TFK_DP_COMM="native-only", **OPTIONS[options])
+            if torch.cuda.device_count() < 2:
+                env["TFK_FAKE_NODES"] = "1"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                   "127.0.0.1", "--master-port", str(_free_port())] + cmd[1:]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        assert "adding layer" in r.stdout and "validation loss at step" in r.stdout
+        lines = [l for l in r.stdout.splitlines() if "loss" in l]
+        runs[tag] = (dict(np.load(str(out_dir / "dnn" / "final"))), lines)
+    plain, dp = runs["plain"], runs["dp"]
+    assert len(plain[1]) == len(dp[1]) and len(plain[1]) >= 8, (plain[1], dp[1])
+    number = re.compile(r"[-+]?\d+\.\d+(?:[eE][-+]?\d+)?")
+    for a, b in zip(plain[1], dp[1]):
+        va, vb = [float(x) for x in number.findall(a)], [float(x) for x in number.findall(b)]
+        assert number.sub("#", a) == number.sub("#", b), (a, b)  # same message, same step
+        assert np.allclose(va, vb, rtol=2e-3, atol=1e-5), (a, b)
+    assert sorted(plain[0]) == sorted(dp[0])
+    for k, v in plain[0].items():
+        assert dp[0][k].shape == v.shape, k
+        if v.dtype.kind == "f" and v.size > 1:
+            assert np.abs(dp[0][k] - v).mean() <= 2e-3 * (np.abs(v).mean() + 1e-3) + 1e-4, k

@@ -27,6 +27,16 @@ def _share_device():
     return os.environ.get("TFK_SHARE_DEVICE") == "1" or os.environ.get("TFK_FAKE_NODES") == "1"
 
 
+def local_device():
+    """the GPU this rank computes on: torchrun's LOCAL_RANK (folded onto the visible devices in the tests' shared-device modes)"""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if _share_device():
+        import torch
+        if torch.cuda.is_available():
+            local_rank %= torch.cuda.device_count()
+    return local_rank
+
+
 def init_from_env():
     """Join the process group described by torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); a no-op for single-process runs."""

@@ -25,7 +25,8 @@ class Decoder(object):
         self.graph = _Graph()
         self.max_length = max_length
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
+            from ..dataparallel import local_device
+            device = local_device()
         self.engine = classifier.create_engine(input_dim, max_frames=min(max(int(max_length), 1), 1 << 16), device=device)
         self.saver = ModelSaver(self.engine)
         self.graph.finalize()

@@ -20,7 +20,7 @@ from abc import ABCMeta, abstractmethod
 import numpy as np
 
 from .. import _lib
-from ..dataparallel import (CtcMicroBatch, DataParallel, RawMicroBatch, StackedRawMicroBatches, partition,
+from ..dataparallel import (CtcMicroBatch, DataParallel, RawMicroBatch, StackedRawMicroBatches, local_device, partition,
                             rank_seed)
 from ..processing.feature_reader import Unspliced, cmvn_table
 from .classifiers.dnn import ModelSaver
@@ -112,11 +112,11 @@ class Trainer(object, metaclass=ABCMeta):
             import torch.distributed as dist
             seed_t = torch.tensor([self._seed], dtype=torch.int64)
             if dist.get_backend(self.dp.group) == "nccl":
-                seed_t = seed_t.cuda(device if device is not None else int(os.environ.get("LOCAL_RANK", "0")))
+                seed_t = seed_t.cuda(device if device is not None else local_device())
             dist.broadcast(seed_t, src=0, group=self.dp.group)
             self._seed = int(seed_t.item())
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if self.dp.enabled else 0
+            device = local_device() if self.dp.enabled else 0
         self.graph = _Graph()
         # the loss is part of the graph: abstract in the base class (trainer.py:219-242)
         self.loss_kind = self.compute_loss(None, None, None, None)
