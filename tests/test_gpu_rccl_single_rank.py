@@ -322,8 +322,8 @@ def test_real_rccl_ranks_match_serial(gpu, tmp_path, world, num_mb, mode, option
         for k in ref:
             if k == "losses":
                 continue
-            if k.startswith("m"):
-                assert np.allclose(got[k], ref[k], rtol=1e-5, atol=1e-7), k
+            if k.startswith("m"):  # (BN moving averages: of layers above the first, they see the updated weights below them)
+                assert np.allclose(got[k], ref[k], rtol=1e-3 if bf16_wire else 1e-5, atol=1e-5 if bf16_wire else 1e-7), k
             else:
                 err = np.abs(got[k] - ref[k])
                 assert np.mean(err > 0.02 * lr * 3) < (0.05 if bf16_wire else 0.01) and err.max() <= 2 * lr * 3, k
