@@ -57,16 +57,25 @@ def _grads(eng):
     return g
 
 
-def _worker(rank, world, port, num_mb, out_dir, dtype="float32", mode="sharded", kw=None, frames=None):
+def _worker(rank, world, port, num_mb, out_dir, dtype="float32", mode="sharded", kw=None, frames=None, transport="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo", TFK_DP_MIN_SHARD="64",
-                      TFK_DP_EMULATE_RS="1")
+                      LOCAL_RANK=str(rank), TFK_DP_MIN_SHARD="64")
+    if transport == "gloo":
+        os.environ.update(TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo", TFK_DP_EMULATE_RS="1")
+    else:
+        # REAL RCCL: the in-library exchange (csrc/exchange.hip) -- "rccl-torch": the library refuses to load RCCL, every rank
+        # agrees on the torch.distributed driver (BucketReducer over the nccl backend).  On a box with fewer GPUs than ranks the
+        # ranks share a device and claim a host each (TFK_FAKE_NODES; dataparallel._share_device)
+        os.environ.update(HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_FAKE_NODES=transport.split(":")[1])
+        if transport.startswith("rccl-torch"):
+            os.environ["TFK_RCCL_LIB"] = "/nonexistent/librccl.so"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tfkaldi_amd.dataparallel import DataParallel, init_from_env, partition
     init_from_env()
     dp = DataParallel(mode=mode)
     assert dp.enabled
+    assert dist.get_backend() == ("gloo" if transport == "gloo" else "nccl")
     eng = _engine(torch_state=True, dtype=dtype, kw=kw)
     data = (lambda n, seed: _data(n, seed)) if frames is None else (lambda n, seed: _data_kw(n, seed, kw, frames))
     extra = {}
@@ -77,24 +86,34 @@ def _worker(rank, world, port, num_mb, out_dir, dtype="float32", mode="sharded",
         mbs = data(num_mb, 100)
         start, end = partition(len(mbs), world)[rank]
         eng.set_later_microbatches(len(mbs) - end)
-        eng.set_bucket_callback(red.on_bucket)
-        for i, (X, y) in enumerate(mbs[start:end]):
-            eng.accumulate(X, y, last=(i == end - start - 1))
-        if start == end:
-            eng.zero_accumulators()
-            for b in eng.bucket_order():
-                red.on_bucket(b)
-        eng.set_bucket_callback(None)
-        red.finish()
-        extra = _grads(eng)
-        extra["loss100"] = np.array(eng.apply())
+        if getattr(red, "native", False):  # the library sits behind the engine's hooks itself
+            for i, (X, y) in enumerate(mbs[start:end]):
+                eng.accumulate(X, y, last=(i == end - start - 1))
+            if start == end:
+                red.idle(eng)
+            red.finish_reduce()
+            extra = _grads(eng)
+            extra["loss100"] = np.array(red.finish_and_apply(eng))
+        else:
+            eng.set_bucket_callback(red.on_bucket)
+            for i, (X, y) in enumerate(mbs[start:end]):
+                eng.accumulate(X, y, last=(i == end - start - 1))
+            if start == end:
+                eng.zero_accumulators()
+                for b in eng.bucket_order():
+                    red.on_bucket(b)
+            eng.set_bucket_callback(None)
+            red.finish()
+            extra = _grads(eng)
+            extra["loss100"] = np.array(eng.apply())
     losses = [dp.train_step(eng, data(num_mb, step)) for step in range(3)]
     if mode == "sharded" and num_mb >= 1:
         assert "rs" in dp.last_kinds, dp.last_kinds  # the sharded protocol really ran (reduce-scatter emulated)
-        assert dp.reducer(eng).verify_left == 0
+        assert getattr(dp.reducer(eng), "verify_left", 0) == 0
     losses.append(dp.eval_step(eng, data(num_mb, 9)))
     losses.append(dp.train_step(eng, data(num_mb, 5)))  # (consumes the gathers that crossed the evaluation)
     red = dp.reducer(eng)
+    assert bool(getattr(red, "native", False)) == transport.startswith("rccl:"), (transport, type(red).__name__)
     stale = red.masters_stale
     if stale:  # mixed precision: the fp32 masters are sharded -- reading them must be refused until they are gathered
         try:
@@ -191,19 +210,51 @@ def test_ranks_match_serial(gpu, tmp_path, world, num_mb, dtype, mode, kw):
         assert bool(got["stale"]) == (dtype == "bfloat16" and mode == "sharded")
 
 
+def _rccl_transport(world, driver="rccl"):
+    """one rank per GPU when the box has them, else every rank on GPU 0 claiming a host of its own"""
+    import torch
+    return "%s:%d" % (driver, 1 if torch.cuda.device_count() < world else 0)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,num_mb,dtype,mode,kw,driver", [
+    (2, 9, "float32", "sharded", None, "rccl"), (2, 3, "bfloat16", "sharded", None, "rccl"), (2, 3, "bfloat16", "allreduce", None, "rccl"),
+    (2, 1, "float32", "sharded", LAYERWISE, "rccl"), (2, 3, "float32_mfma", "sharded", None, "rccl"),
+    (4, 3, "bfloat16", "sharded", LAYERWISE, "rccl"), (8, 9, "float32", "sharded", None, "rccl"), (8, 3, "bfloat16", "sharded", None, "rccl"),
+    (8, 1, "float32", "allreduce", LAYERWISE, "rccl"),
+    # the in-library exchange cannot load RCCL: every rank runs the torch.distributed driver over the nccl backend
+    (2, 3, "float32", "sharded", None, "rccl-torch"), (2, 3, "bfloat16", "sharded", None, "rccl-torch"),
+    (4, 5, "float32", "allreduce", None, "rccl-torch")])
+def test_ranks_match_serial_over_real_rccl(gpu, tmp_path, world, num_mb, dtype, mode, kw, driver):
+    """test_ranks_match_serial with the ranks talking through REAL RCCL: reduce-scatter / all-gather / all-reduce launched by the
+    library at world 2 / 4 / 8 in every arithmetic (bf16: shadow gathers, fp32 masters left with their owners), idle ranks under
+    layer-wise growth -- and the torch.distributed driver over the nccl backend when the library cannot bind RCCL"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(world, port, num_mb, str(tmp_path), dtype, mode, kw, None, _rccl_transport(world, driver)), nprocs=world,
+             join=True)
+    ref = _serial(num_mb, dtype, kw, mode)
+    _compare(tmp_path, world, ref, KW["init_learning_rate"], 5)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert bool(got["stale"]) == (dtype == "bfloat16" and mode == "sharded")
+
+
 CFG2 = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=2000, nonlin="relu", batch_norm=True,
             init_learning_rate=1e-3, num_steps=10)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype):
+@pytest.mark.parametrize("dtype,transport", [("float32", "gloo"), ("bfloat16", "gloo"), ("float32", "rccl"), ("bfloat16", "rccl")])
+def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype, transport):
     """BASELINE cfg2's network on eight ranks: the real span sizes (3.6 / 16.8 / 16.4 MB), 64 MiB coalescing, shards of
-    n / 8, an idle rank (seven micro-batches), real engines, the sharded protocol end to end"""
+    n / 8, an idle rank (seven micro-batches), real engines, the sharded protocol end to end -- over gloo with the torch driver,
+    and over REAL RCCL with the in-library exchange"""
     import torch.multiprocessing as mp
     world, num_mb = 8, 7
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(world, port, num_mb, str(tmp_path), dtype, "sharded", CFG2, 96), nprocs=world, join=True)
+    transport = "gloo" if transport == "gloo" else _rccl_transport(world)
+    mp.spawn(_worker, args=(world, port, num_mb, str(tmp_path), dtype, "sharded", CFG2, 96, transport), nprocs=world, join=True)
     ref = _serial(num_mb, dtype, CFG2, "sharded", frames=96)
     # (26 M parameters, generic starting point: after a few Adam steps the summation order of eight partial gradient sums
     # shows in the fifth digit of the loss, as the single-GPU loss traces do against float64 -- profiles/r03_loss_trace_f64.json)

@@ -149,8 +149,8 @@ def test_bench_line_survives_stuck_diagnostics(gpu):
 @pytest.mark.timeout(600)
 def test_bench_self_launches_its_ranks(gpu):
     """`python bench.py --gpus 2` from a bare environment (no WORLD_SIZE): bench.py starts its own ranks through
-    torch.distributed.run.  On the 1-GPU test box the two ranks share the device and talk over gloo (RCCL refuses
-    two ranks per GPU); with >= 2 GPUs this is the driver's RCCL command as it stands."""
+    torch.distributed.run.  On the 1-GPU test box the two ranks share the device and talk over gloo (the torch.distributed
+    driver; test_bench_over_real_rccl_ranks is the RCCL run); with >= 2 GPUs this is the driver's RCCL command as it stands."""
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     real = torch.cuda.device_count() >= 2
@@ -171,6 +171,48 @@ def test_bench_self_launches_its_ranks(gpu):
             assert "reduce_scatter_tensor" in line["collectives_last_step"]
         else:
             assert line["exchange"] == "allreduce" and set(line["collectives_last_step"]) == {"all_reduce"}
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world,config", [(2, "cfg2"), (4, "cfg2"), (2, "cfg3")])
+def test_bench_over_real_rccl_ranks(gpu, world, config):
+    """the driver's `bench.py --gpus N` with N REAL RCCL ranks (one per GPU, or all on GPU 0 claiming a host each: the transport
+    is then RCCL's socket path and the rates mean nothing): the contract's line from the in-library exchange, and the whole
+    self-diagnosis behind it -- exchange_ab over every algorithm x wire x gather x span size and the library's tuning pass,
+    per-phase device times per rank, the sustained leg, Nnet.train under N ranks -- inside its budget (`incomplete` absent)."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.device_count() < world:
+        env["TFK_FAKE_NODES"] = "1"
+    env.update(TFK_BENCH_SUSTAIN_S="1", TFK_BENCH_PREWARM_MS="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
+                          "--config", config], env=env, capture_output=True, text=True, timeout=1100)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "incomplete" not in line, line["incomplete"]
+    assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["dist_backend"] == "nccl"
+    assert line["value"] > 0 and len(line["per_rank_ms_per_step"]) == world and line["scaling"] == "weak"
+    assert line["config"]["name"] == config and line["config"]["global_frames"] == world * line["config"]["frames_per_gpu"]
+    assert line["exchange"] == "sharded" and line["exchange_driver"].startswith("library (csrc/exchange.hip, rccl)")
+    assert any("reduce_scatter" in c for c in line["collectives_last_step"])
+    assert any("all_gather" in c for c in line["collectives_last_step"])
+    assert abs(line["loss_first_last"][0] - np.log({"cfg2": 2000, "cfg3": 4000}[config])) < 1e-3
+    ab = line["exchange_ab"]
+    want = {"rccl/fp32", "rccl/bf16", "direct/fp32", "direct/bf16", "auto/fp32"}
+    if config == "cfg2":
+        want |= {"rccl/fp32+planes", "direct/fp32+planes"}
+    assert want <= set(ab["ms_per_step"]) and all(v > 0 for v in ab["ms_per_step"].values()), ab
+    assert set(ab["ms_per_step_by_span_MiB"]) == {"16", "32", "64", "128"}
+    assert set(ab["auto"]["tuned_us_slowest_rank"]) == {"reduce_scatter_rccl", "reduce_scatter_direct", "all_gather_rccl",
+                                                        "all_gather_direct"}
+    ph = line["exchange_phases"]
+    assert ph["steps"] == 10 and all(len(v) == world for v in ph["per_rank"].values())
+    assert all(x > 0 for x in ph["per_rank"]["reduce_scatter"] + ph["per_rank"]["all_gather"] + ph["per_rank"]["adam"])
+    assert line["sustained"]["value"] > 0 and line["api_fed_value"] > 0, line.get("api_fed_error")
+    assert line["exchange_model"]["per_world"][str(world)]["predicted_ms_per_step_direct"] > 0
+    print("bench --gpus %d %s over real RCCL: exchange_ab %s" % (world, config, ab["ms_per_step"]))
 
 
 @pytest.mark.timeout(1200)
