@@ -234,7 +234,9 @@ def test_ranks_match_serial_over_real_rccl(gpu, tmp_path, world, num_mb, dtype, 
     mp.spawn(_worker, args=(world, port, num_mb, str(tmp_path), dtype, mode, kw, None, _rccl_transport(world, driver)), nprocs=world,
              join=True)
     ref = _serial(num_mb, dtype, kw, mode)
-    _compare(tmp_path, world, ref, KW["init_learning_rate"], 5)
+    # (moving averages composed from the ranks' increments against one update after the other: a few ulps of the largest term --
+    # 2.2e-7 measured at world 4 with 5 micro-batches on every transport, gloo included)
+    _compare(tmp_path, world, ref, KW["init_learning_rate"], 5, stat_tol=(1e-5, 5e-7))
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         assert bool(got["stale"]) == (dtype == "bfloat16" and mode == "sharded")
