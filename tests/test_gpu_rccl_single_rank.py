@@ -174,7 +174,7 @@ def test_bench_self_launches_its_ranks(gpu):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("world,config", [(2, "cfg2"), (4, "cfg2"), (2, "cfg3")])
+@pytest.mark.parametrize("world,config", [(2, "cfg2"), (4, "cfg2"), (2, "cfg3"), (8, "cfg2")])
 def test_bench_over_real_rccl_ranks(gpu, world, config):
     """the driver's `bench.py --gpus N` with N REAL RCCL ranks (one per GPU, or all on GPU 0 claiming a host each: the transport
     is then RCCL's socket path and the rates mean nothing): the contract's line from the in-library exchange, and the whole
@@ -184,7 +184,8 @@ def test_bench_over_real_rccl_ranks(gpu, world, config):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     if torch.cuda.device_count() < world:
         env["TFK_FAKE_NODES"] = "1"
-    env.update(TFK_BENCH_SUSTAIN_S="1", TFK_BENCH_PREWARM_MS="0")
+    # (eight ranks on one GPU through sockets: ~0.3 s per step -- the diagnostics need more than the 300 s they get on a real node)
+    env.update(TFK_BENCH_SUSTAIN_S="1", TFK_BENCH_PREWARM_MS="0", TFK_BENCH_DIAG_BUDGET_S="900")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
                           "--config", config], env=env, capture_output=True, text=True, timeout=1100)
     assert out.returncode == 0, out.stderr[-3000:]
