@@ -282,7 +282,11 @@ def _rccl_worker(rank, world, port, num_mb, out_dir, mode, fake_nodes=False, ext
     shards = np.array([[i, o, m] for i, ((off, n), kind) in enumerate(zip(red.last_launched, red.last_span_kinds)) if kind == "rs"
                        for o, m in red.my_shards(off, n)] or np.zeros((0, 3)), dtype=np.int64)
     info = red.exchange_info()
-    assert info["reduce_scatter"] == os.environ.get("TFK_DP_ALGO", "rccl") and info["wire"] == os.environ.get("TFK_DP_WIRE", "fp32")
+    if os.environ.get("TFK_DP_ALGO") == "auto":  # timed at attach, the slowest rank's figures decide identically everywhere
+        assert info["chosen_by"] == "tuned at attach" and len(info["tuned_us_slowest_rank"]) == 4, info
+    else:
+        assert info["reduce_scatter"] == os.environ.get("TFK_DP_ALGO", "rccl"), info
+    assert info["wire"] == os.environ.get("TFK_DP_WIRE", "fp32")
     assert red.planes == (os.environ.get("TFK_DP_GATHER") == "planes" and mode == "sharded")
     losses = [dp.train_step(eng, _data(num_mb, step)) for step in range(3)]
     losses.append(dp.eval_step(eng, _data(num_mb, 9)))
@@ -295,14 +299,15 @@ def _rccl_worker(rank, world, port, num_mb, out_dir, mode, fake_nodes=False, ext
 
 OPTIONS = {"": {}, "direct": {"TFK_DP_ALGO": "direct"}, "direct+planes": {"TFK_DP_ALGO": "direct", "TFK_DP_GATHER": "planes"},
            "planes": {"TFK_DP_GATHER": "planes"}, "bf16wire": {"TFK_DP_WIRE": "bf16"}, "no-hold": {"TFK_DP_HOLD_LAST": "0"},
-           "comm-stream-tail": {"TFK_DP_INLINE_TAIL": "0"}}
+           "comm-stream-tail": {"TFK_DP_INLINE_TAIL": "0"}, "auto": {"TFK_DP_ALGO": "auto"},
+           "bf16wire+planes": {"TFK_DP_WIRE": "bf16", "TFK_DP_GATHER": "planes"}}
 
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,num_mb,mode,options", [
     (2, 4, "sharded", ""), (2, 4, "allreduce", ""), (2, 2, "sharded", "direct"), (2, 4, "sharded", "direct+planes"),
     (2, 4, "sharded", "planes"), (2, 4, "sharded", "bf16wire"), (2, 4, "sharded", "no-hold"), (2, 4, "sharded", "comm-stream-tail"),
-    (2, 1, "sharded", ""), (4, 4, "sharded", "direct"), (4, 6, "sharded", "planes"), (4, 8, "allreduce", ""),
+    (2, 1, "sharded", ""), (2, 4, "sharded", "auto"), (4, 4, "sharded", "bf16wire+planes"), (4, 4, "sharded", "direct"), (4, 6, "sharded", "planes"), (4, 8, "allreduce", ""),
     (8, 8, "sharded", "direct+planes"), (8, 11, "sharded", "")])
 def test_real_rccl_ranks_match_serial(gpu, tmp_path, world, num_mb, mode, options):
     """`world` ranks over REAL RCCL: the data-parallel step == the serial step.  With enough GPUs one rank per device; on a
@@ -335,7 +340,7 @@ def test_real_rccl_ranks_match_serial(gpu, tmp_path, world, num_mb, mode, option
     ref = _collect(eng, want)
     eng.close()
     lr = 1e-3
-    bf16_wire = options == "bf16wire"
+    bf16_wire = "bf16wire" in options
     # the summed gradients before the optimiser: same addends as the serial accumulation, another order (a block of
     # micro-batches per rank, then over the ranks) -- 1e-5 on the scale of the span, as the all-reduce variant of
     # tests/test_gpu_dp_two_ranks.py; bf16 payloads: 2^-8 of the other ranks' contributions (test_gpu_native_exchange.py)
@@ -477,3 +482,79 @@ def test_nnet_train_under_two_real_rccl_ranks(gpu, tmp_path, options):
         assert dp[0][k].shape == v.shape, k
         if v.dtype.kind == "f" and v.size > 1:
             assert np.abs(dp[0][k] - v).mean() <= 2e-3 * (np.abs(v).mean() + 1e-3) + 1e-4, k
+
+
+CTC_KW = dict(input_dim=20, num_layers=2, num_units=32, output_dim=9, nonlin="tanh", batch_norm=True,
+              init_learning_rate=1e-3, num_steps=50)
+
+
+def _ctc_data(num_mb, seed):
+    """micro-batches of two utterances each for the CTC loss: (frames, utterance lengths, labels back to back, label counts)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(num_mb):
+        utt, lab = [30 + 3 * i, 17 + i], [5 + i % 3, 3]
+        X = (rng.standard_normal((sum(utt), CTC_KW["input_dim"])) * 1.5).astype(np.float32)
+        labels = np.concatenate([rng.integers(0, CTC_KW["output_dim"] - 1, size=n) for n in lab]).astype(np.int32)
+        out.append((X, utt, labels, lab))
+    return out
+
+
+def _ctc_worker(rank, world, port, num_mb, out_dir, mode, fake_nodes):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_DP_MIN_SHARD="64", TFK_DP_COMM="native-only")
+    if fake_nodes:
+        os.environ["TFK_FAKE_NODES"] = "1"
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from tfkaldi_amd.dataparallel import CtcMicroBatch, DataParallel, init_from_env
+    from util import make_pair
+    _, _, local = init_from_env()
+    dp = DataParallel(mode=mode)
+    eng, _ = make_pair(np.random.default_rng(5), output_too=False, max_frames=256, torch_state=True, device=local, **CTC_KW)
+    losses = [dp.train_step(eng, [CtcMicroBatch(*mb) for mb in _ctc_data(num_mb, step)]) for step in range(3)]
+    assert dp.reducer(eng).native
+    losses.append(dp.eval_step(eng, [CtcMicroBatch(*mb) for mb in _ctc_data(num_mb, 9)]))
+    dp.gather_parameters(eng)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **_collect(eng, losses))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,num_mb,mode", [(2, 4, "sharded"), (4, 5, "sharded"), (2, 3, "allreduce")])
+def test_ctc_steps_over_real_rccl_ranks(gpu, tmp_path, world, num_mb, mode):
+    """BASELINE configs[4] (the CTCTrainer path, 1 -> 8 GPUs): micro-batches under the CTC loss dealt to REAL RCCL ranks
+    (uneven blocks, an idle-free 4-rank case) == the serial run: the loss is normalised by the label count SUMMED over the ranks
+    (the `frames` scalar of the reduce region), the gradients are summed like the cross-entropy path's"""
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_pair
+    mp.spawn(_ctc_worker, args=(world, _free_port(), num_mb, str(tmp_path), mode, torch.cuda.device_count() < world), nprocs=world,
+             join=True)
+    eng, _ = make_pair(np.random.default_rng(5), output_too=False, max_frames=256, **CTC_KW)
+    want = []
+    for step in range(3):
+        mbs = _ctc_data(num_mb, step)
+        for i, (X, utt, labels, lab) in enumerate(mbs):
+            eng.accumulate_ctc(X, utt, labels, lab, last=(i == len(mbs) - 1))
+        want.append(eng.apply())
+    for X, utt, labels, lab in _ctc_data(num_mb, 9):
+        eng.eval_accumulate_ctc(X, utt, labels, lab)
+    want.append(eng.eval_finish())
+    ref = _collect(eng, want)
+    eng.close()
+    lr = CTC_KW["init_learning_rate"]
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        assert np.allclose(got["losses"], ref["losses"], rtol=1e-5, atol=0), (got["losses"], ref["losses"])
+        for k in ref:
+            if k == "losses":
+                continue
+            if k.startswith("m"):
+                assert np.allclose(got[k], ref[k], rtol=1e-5, atol=5e-7), k
+            else:
+                err = np.abs(got[k] - ref[k])
+                assert np.mean(err > 0.02 * lr * 3) < 0.01 and err.max() <= 2 * lr * 3, k
