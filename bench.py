@@ -717,7 +717,7 @@ def main():
     sustained = None
     sustain_s = float(os.environ.get("TFK_BENCH_SUSTAIN_S", "3.2"))
     if sustain_s > 0 and not args.no_sustained:
-        n_sus = max(50, int(sustain_s / (elapsed / args.steps)) + 1)  # (`elapsed` is the slowest rank's: the same count everywhere)
+        n_sus = max(int(os.environ.get("TFK_BENCH_SUSTAIN_MIN_STEPS", "50")), int(sustain_s / (elapsed / args.steps)) + 1)  # (`elapsed` is the slowest rank's: the same count everywhere)
         marks = []
         fence()
         with PowerSampler(local_rank) as sampler:
@@ -756,13 +756,14 @@ def main():
         in_force = (exchange_info["reduce_scatter"], exchange_info["all_gather"], exchange_info["wire"])
         in_force_planes = bool(getattr(reducer, "planes", False))
         exchange_info["gather"] = "three-plane twins" if in_force_planes else ("bf16 shadow" if reducer.shadow else "fp32 parameters")
-        exchange_ab = {"steps_each": 10, "in_force_for_value": exchange_info, "ms_per_step": {}}
+        ab_steps = max(1, int(os.environ.get("TFK_BENCH_AB_STEPS", "10")))  # (tests shorten it)
+        exchange_ab = {"steps_each": ab_steps, "in_force_for_value": exchange_info, "ms_per_step": {}}
         if reducer.mode == "sharded":
             for algo in ("rccl", "direct"):
                 for wire in ("fp32", "bf16"):
                     reducer.set_exchange(algo, wire)
                     timed_steps(3)
-                    exchange_ab["ms_per_step"]["%s/%s" % (algo, wire)] = 1e3 * timed_steps(10) / 10
+                    exchange_ab["ms_per_step"]["%s/%s" % (algo, wire)] = 1e3 * timed_steps(ab_steps) / ab_steps
             # emulated fp32: the owner-written three-plane twin rows on the wire instead of fp32 parameters + a rebuild on every rank
             # (TFK_DP_GATHER=planes; dataparallel.exchange_model prices it: `plane_gather`)
             if args.dtype == "float32":
@@ -774,7 +775,7 @@ def main():
                     for algo in ("rccl", "direct"):
                         reducer.set_exchange(algo, "fp32")
                         timed_steps(3)
-                        exchange_ab["ms_per_step"]["%s/fp32+planes" % algo] = 1e3 * timed_steps(10) / 10
+                        exchange_ab["ms_per_step"]["%s/fp32+planes" % algo] = 1e3 * timed_steps(ab_steps) / ab_steps
                     reducer.set_gather(in_force_planes)  # (switching back brings the fp32 masters home: collective)
             # how many weight matrices one collective carries (TFK_DP_BUCKET_MB; default 64 MiB, never tuned on real links)
             reducer.set_exchange("rccl", "fp32")
@@ -782,7 +783,7 @@ def main():
             for mib in (16, 32, 64, 128):
                 reducer.set_bucket_bytes(mib << 20)
                 timed_steps(3)
-                exchange_ab["ms_per_step_by_span_MiB"][str(mib)] = 1e3 * timed_steps(10) / 10
+                exchange_ab["ms_per_step_by_span_MiB"][str(mib)] = 1e3 * timed_steps(ab_steps) / ab_steps
             reducer.set_bucket_bytes(int(float(os.environ.get("TFK_DP_BUCKET_MB", "64")) * (1 << 20)))
             # what TFK_DP_ALGO=auto would have chosen at attach: the library's own tuning pass (tfk_comm_tune, collective) on
             # scratch memory of the largest span's size, and the step with that choice
@@ -790,7 +791,7 @@ def main():
             biggest = max(n for _, n in getattr(reducer, "last_launched", []) or eng.buckets())
             exchange_ab["auto"] = reducer.tune(biggest, 5)
             timed_steps(3)
-            exchange_ab["ms_per_step"]["auto/fp32"] = 1e3 * timed_steps(10) / 10
+            exchange_ab["ms_per_step"]["auto/fp32"] = 1e3 * timed_steps(ab_steps) / ab_steps
             # back to what `value` ran with
             if in_force[0] == in_force[1]:
                 reducer.set_exchange(in_force[0], in_force[2])

@@ -186,6 +186,8 @@ def test_bench_over_real_rccl_ranks(gpu, world, config):
         env["TFK_FAKE_NODES"] = "1"
     # (eight ranks on one GPU through sockets: ~0.3 s per step -- the diagnostics need more than the 300 s they get on a real node)
     env.update(TFK_BENCH_SUSTAIN_S="1", TFK_BENCH_PREWARM_MS="0", TFK_BENCH_DIAG_BUDGET_S="900")
+    if world == 8:
+        env.update(TFK_BENCH_AB_STEPS="3", TFK_BENCH_SUSTAIN_MIN_STEPS="10")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
                           "--config", config], env=env, capture_output=True, text=True, timeout=1100)
     assert out.returncode == 0, out.stderr[-3000:]
