@@ -558,7 +558,7 @@ def main():
 
     import torch
     from tfkaldi_amd import _lib
-    from tfkaldi_amd.dataparallel import DataParallel, init_from_env
+    from tfkaldi_amd.dataparallel import DEFAULT_BUCKET_MB, DataParallel, init_from_env
     from tfkaldi_amd.engine import Engine
 
     rank, world, local_rank = init_from_env()
@@ -777,14 +777,15 @@ def main():
                         timed_steps(3)
                         exchange_ab["ms_per_step"]["%s/fp32+planes" % algo] = 1e3 * timed_steps(ab_steps) / ab_steps
                     reducer.set_gather(in_force_planes)  # (switching back brings the fp32 masters home: collective)
-            # how many weight matrices one collective carries (TFK_DP_BUCKET_MB; default 64 MiB, never tuned on real links)
+            # how many weight matrices one collective carries (TFK_DP_BUCKET_MB; default 32 MiB from dataparallel.exchange_timeline,
+            # never tuned on real links)
             reducer.set_exchange("rccl", "fp32")
             exchange_ab["ms_per_step_by_span_MiB"] = {}
             for mib in (16, 32, 64, 128):
                 reducer.set_bucket_bytes(mib << 20)
                 timed_steps(3)
                 exchange_ab["ms_per_step_by_span_MiB"][str(mib)] = 1e3 * timed_steps(ab_steps) / ab_steps
-            reducer.set_bucket_bytes(int(float(os.environ.get("TFK_DP_BUCKET_MB", "64")) * (1 << 20)))
+            reducer.set_bucket_bytes(int(float(os.environ.get("TFK_DP_BUCKET_MB", str(DEFAULT_BUCKET_MB))) * (1 << 20)))
             # what TFK_DP_ALGO=auto would have chosen at attach: the library's own tuning pass (tfk_comm_tune, collective) on
             # scratch memory of the largest span's size, and the step with that choice
             reducer.set_exchange(None, "fp32")
@@ -914,7 +915,7 @@ def main():
         # exchange_model): bytes on the wire per rank, link-rate time over point-to-point xGMI (direct = all peers at once, ring =
         # one link's rate), the backward time left to overlap with once the first span is ready, the step time that follows.  A
         # scaling line measured on hardware is to be held against this; at N > 1 the model uses the spans that really ran.
-        from tfkaldi_amd.dataparallel import exchange_model
+        from tfkaldi_amd.dataparallel import exchange_model, exchange_timeline_sweep
         per = {s["name"]: s["total_ms"] / args.steps for s in stats}
         fam = lambda *keys: sum(v for k, v in per.items() if any(q in k for q in keys))  # noqa: E731
         fwd_ms = fam("_nn(", "act_forward", "bn_stats", "softmax_xent", "loss_reduce")
@@ -927,7 +928,7 @@ def main():
             step_single = fwd_ms + bwd_ms + adam_ms + fam("bn_ema_apply", "misc")
         shadow_gather = args.dtype == "bfloat16"  # (mixed precision gathers the bf16 shadow: 2 B per parameter)
         mode = (reducer.mode if reducer else (args.exchange or os.environ.get("TFK_DP_EXCHANGE", "sharded")))
-        min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", "64")) * (1 << 20))
+        min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", str(DEFAULT_BUCKET_MB))) * (1 << 20))
         wire = "bf16" if os.environ.get("TFK_DP_WIRE") == "bf16" else "fp32"
         out["exchange_wire"] = getattr(reducer, "wire", "fp32") if reducer else None
         # emulated fp32 under the sharded exchange: the three-plane twins are rebuilt from the gathered fp32 parameters (4 B read,
@@ -941,6 +942,15 @@ def main():
                                                  reduce_elem_bytes=2 if wire == "bf16" and mode == "sharded" else 4,
                                                  twin_rebuild_ms=twin_rebuild_ms)
                           for n in ([world] if world > 1 else [2, 4, 8])}}
+        if mode == "sharded":
+            # the same question as a timeline -- a fixed latency per collective, every layer of the next forward pass waiting for
+            # the WHOLE gather that covers it -- over span sizes x wire rates x latencies: what the default span size was chosen from
+            # (dataparallel.exchange_timeline; the wire rate RCCL reaches on the mesh is the unknown, so it is a range)
+            out["exchange_model"]["timeline"] = {
+                str(n): exchange_timeline_sweep(eng.buckets(), n, fwd_ms, bwd_ms, adam_ms, step_single,
+                                                gather_elem_bytes=2 if shadow_gather else 4,
+                                                reduce_elem_bytes=2 if wire == "bf16" else 4)
+                for n in ([world] if world > 1 else [2, 4, 8])}
         if world > 1:
             m = out["exchange_model"]["per_world"][str(world)]
             out["exchange_model"]["measured_ms_per_step"] = 1e3 * elapsed / args.steps

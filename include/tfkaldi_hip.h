@@ -363,7 +363,8 @@ int tfk_moment_regions(tfk_engine* e, void** adam_m, void** adam_v, size_t* num_
  * (nothing is left to overlap with, and a round trip through another stream costs ~26 us; env TFK_DP_INLINE_TAIL=0:
  * everything on the comm stream).  RCCL orders the operations of one communicator itself.
  * bucket_bytes: adjacent gradient buckets are coalesced until a collective carries at least this much (0: default,
- * 64 MiB -- xGMI is point-to-point: few large collectives beat one per layer, and each costs the step a fixed 10-13 us).
+ * 32 MiB -- each collective under backward costs the step a fixed 6-10 us, but the next forward pass cannot start a layer before
+ * the whole gather covering it has arrived and the span still coalescing when backward ends is exposed: csrc/exchange.hip).
  * Bootstrap: EVERY rank first calls tfk_comm_available (local, no collective: RCCL loadable, engine and mode acceptable) and
  * the host agrees on the answers (one MIN all-reduce over whatever process group it already has) -- tfk_comm_create is
  * collective (ncclCommInitRank), so a rank that could not even load RCCL must be known BEFORE the others enter it and
@@ -431,7 +432,7 @@ int tfk_comm_tune(tfk_comm* c, size_t floats, int iters); /* COLLECTIVE */
  * tfk_comm_gather_masters (tfk_comm_masters_stale says so; tfk_comm_info: gathers_shadow = 2).  Switching back gathers them.
  * dataparallel.exchange_model prices both; bench.py --gpus N measures both (`exchange_ab`). */
 int tfk_comm_set_gather(tfk_comm* c, int planes);
-/* (ABI 8) the coalescing threshold of tfk_comm_create's `bucket_bytes`, changed between steps (every rank alike; 0 = the 64 MiB
+/* (ABI 8) the coalescing threshold of tfk_comm_create's `bucket_bytes`, changed between steps (every rank alike; 0 = the 32 MiB
  * default): how many weight matrices one collective carries is the first thing to tune on real links -- bench.py sweeps it.
  * COLLECTIVE: another span cut assigns shards to other ranks, so masters left with their owners are gathered first. */
 int tfk_comm_set_bucket_bytes(tfk_comm* c, size_t bucket_bytes);

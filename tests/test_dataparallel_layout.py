@@ -1,5 +1,5 @@
 """The exchange step at 2, 4 and 8 ranks on CPU (gloo) with the bucket layout of BASELINE cfg2 -- 26 M parameters, weight spans
-of 3.6 / 16.8 / 16.4 MB, 64 MiB coalescing, the n % (4 * world) shard rule -- driven by the PRODUCT's DataParallel /
+of 3.6 / 16.8 / 16.4 MB, 32 MiB coalescing, the n % (4 * world) shard rule -- driven by the PRODUCT's DataParallel /
 BucketReducer over tests/layout_engine.LayoutEngine (exact float32 arithmetic: a sharded run equals the serial run BIT FOR
 BIT).  Covers what the driver's `bench.py --gpus 8` meets: both exchange modes, idle ranks (fewer micro-batches than ranks),
 layer-wise growth below full depth, asynchronous parameter gathers consumed layer by layer by the next step, the
@@ -154,12 +154,12 @@ def test_cfg2_layout_ranks_equal_serial(tmp_path, world, mode, bf16, nact, num_m
             covered[off:off + n] += 1
         assert (covered[:lay_w[-1][0] + lay_w[-1][1]] == 1).all()  # every gradient reduced exactly once
         if mode == "sharded":
-            # the 64 MiB rule: [W_6 .. W_2] (83.5 MB: W_6 .. W_3 are 66.7 MB, just short of 64 MiB), then [W_1 + W_0] (20.4 MB,
-            # flushed at the end)
+            # the 32 MiB rule: [W_6 .. W_4] (49.9 MB: W_6 + W_5 are 33.2 MB, just short of 32 MiB), [W_3 + W_2] (32 MiB exactly), then
+            # [W_1 + W_0] (20.4 MB, flushed at the end)
             rs = [x for x, k in zip(launched, info["kinds"]) if k == "rs"]
-            assert rs == [(5095424, 20873216), (0, 5095424)], rs
+            assert rs == [(13484032, 12484608), (5095424, 8388608), (0, 5095424)], rs
             assert all(n % (4 * world) == 0 for _, n in rs)
-            assert info["executed"].count("reduce_scatter_tensor") == 2
+            assert info["executed"].count("reduce_scatter_tensor") == 3
             assert info["stale"] == bool(bf16)
         else:
             assert set(info["kinds"]) == {"ar"} and set(info["executed"]) == {"all_reduce"}

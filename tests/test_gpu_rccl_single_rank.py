@@ -102,12 +102,12 @@ def test_bench_dp_branch_over_rccl(gpu):
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert abs(line["loss_first_last"][0] - np.log(2000)) < 1e-3
     assert line["rccl_ranks"] == 1 and line["dist_backend"] == "nccl" and line["exchange"] == "sharded"
-    # what RAN: RCCL's own reduce-scatter / all-gather on views of the engine state, the 64 MiB coalescing of cfg2's spans
+    # what RAN: RCCL's own reduce-scatter / all-gather on views of the engine state, the 32 MiB coalescing of cfg2's spans
     assert line["exchange_driver"].startswith("library"), line["exchange_driver"]
-    assert line["collectives_last_step"].count("rccl:reduce_scatter") == 2, line["collectives_last_step"]
-    assert line["collectives_last_step"].count("rccl:all_gather") == 2
+    assert line["collectives_last_step"].count("rccl:reduce_scatter") == 3, line["collectives_last_step"]
+    assert line["collectives_last_step"].count("rccl:all_gather") == 3
     assert line["collectives_last_step"].count("rccl:all_reduce") == 2
-    assert [n for _, n in line["collective_spans_last_step"] if n > 1 << 20] == [20873216, 5095424]
+    assert [n for _, n in line["collective_spans_last_step"] if n > 1 << 20] == [12484608, 8388608, 5095424]
     assert line["host_fed_value"] > 0 and len(line["loss_trace_gpu"]) == 7
     # the self-diagnosing part of an N > 1 line: what is in force, the algorithm x wire A/B, the per-phase device times per rank
     assert line["exchange_algorithm"] == {"reduce_scatter": "rccl", "all_gather": "rccl", "wire": "fp32", "chosen_by": "default",

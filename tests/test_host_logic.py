@@ -506,6 +506,13 @@ def test_exchange_model_arithmetic():
     spans as the coalescing rule cuts them, bytes on the wire, direct <= ring, Adam on 1/world, what the options change."""
     b = _cfg2_buckets()
     kw = dict(fwd_ms=0.33, bwd_ms=0.56, adam_ms=0.133, step_ms=1.09)
+    # the default rule, >= 32 MiB in announcement order: W6 + W5 are 8.29 M floats, just short of 8.39 M, so W4 joins them; W3 + W2 are
+    # 32 MiB exactly; W1 + W0 are what is left when backward ends
+    d = dataparallel.exchange_model(b, 8, **kw)
+    assert [s["floats"] for s in d["spans"]] == [2048 * 2000 + 2 * 2048 * 2048, 2 * 2048 * 2048, 2048 * 2048 + 440 * 2048]
+    assert [s["layers"] for s in d["spans"]] == [[4, 6], [2, 3], [0, 1]]
+    assert dataparallel.DEFAULT_BUCKET_MB == 32
+    kw["min_bytes"] = 64 << 20
     m = dataparallel.exchange_model(b, 8, **kw)
     # >= 64 MiB in announcement order: W6 .. W2 (the fifth matrix crosses 16.78 M floats), then W1 + W0
     assert [s["floats"] for s in m["spans"]] == [2048 * 2000 + 4 * 2048 * 2048, 2048 * 2048 + 440 * 2048]
@@ -624,3 +631,40 @@ def test_round_to_nearest_plane_split_is_exact_and_tight():
     with np.errstate(invalid="ignore"):
         q1, q2, q3 = x3_split_rn(np.array([np.inf, -np.inf, np.nan], dtype=np.float32))
     assert np.isinf(q1[:2]).all() and np.isnan(q2[:2]).all() and np.isnan(q1[2])
+
+
+def test_exchange_timeline_prices_span_sizes():
+    """dataparallel.exchange_timeline -- the step as a timeline with a latency per collective and every layer of the next forward
+    pass waiting for the WHOLE gather that covers it: what the default span size (32 MiB) was chosen from."""
+    b = _cfg2_buckets()
+    kw = dict(fwd_ms=0.335, bwd_ms=0.60, adam_ms=0.131, step_ms=1.09)
+    assert [n for _, n, _, _ in dataparallel.coalesced_spans(b, 16 << 20)] == [
+        2048 * 2000 + 2048 * 2048, 2048 * 2048, 2048 * 2048, 2048 * 2048, 2048 * 2048, 440 * 2048]
+    assert [(b0, b1) for _, _, b0, b1 in dataparallel.coalesced_spans(b, 32 << 20)] == [(0, 2), (3, 4), (5, 6)]
+    # no wire time at all (one rank): the step keeps its time and loses nothing but the fixed cost per span launched under backward
+    one = dataparallel.exchange_timeline(b, 1, min_bytes=32 << 20, **kw)
+    assert one["predicted_ms_per_step"] == pytest.approx(1.09 + 2 * 0.006)
+    # an infinitely fast wire with no latency: Adam on 1/8, nothing exposed
+    fast = dataparallel.exchange_timeline(b, 8, min_bytes=32 << 20, rate_fraction=1e9, latency_ms=0.0, **kw)
+    assert fast["predicted_ms_per_step"] == pytest.approx(1.09 - 0.131 * 7 / 8 + 2 * 0.006)
+    assert fast["exposed_reduce_ms"] == pytest.approx(0.0, abs=1e-9) and fast["gather_wait_ms"] == pytest.approx(0.0, abs=1e-6)
+    # a slow wire: one span of everything (nothing overlaps: the reduce starts when backward ends, layer 0 waits for every byte)
+    slow = dataparallel.exchange_timeline(b, 8, min_bytes=1 << 30, rate_fraction=0.3, latency_ms=0.04, **kw)
+    p_w = sum(n for _, n in b[:7])
+    coll = 0.04 + 4.0 * p_w * 7 / 8 / (0.3 * 7 * dataparallel.XGMI_LINK_GBPS * 1e9) * 1e3
+    assert slow["spans"] == 1 and slow["exposed_reduce_ms"] == pytest.approx(coll + 0.04)
+    assert slow["gather_wait_ms"] == pytest.approx(coll)
+    assert slow["predicted_ms_per_step"] == pytest.approx(1.09 - 0.131 * 7 / 8 + 2 * coll + 0.04)
+    # the choice: over the sweep's wire rates and latencies the 32 MiB rule is never behind the 64 MiB rule at cfg2, at any world
+    for world in (2, 4, 8):
+        sweep = dataparallel.exchange_timeline_sweep(b, world, **kw)
+        t = sweep["ms_per_step"]
+        for rate in ("1.0", "0.5", "0.3"):
+            for lat in ("15", "40"):
+                assert t["32/%s/%s" % (rate, lat)] <= t["64/%s/%s" % (rate, lat)] + 1e-9, (world, rate, lat)
+                assert t["32/%s/%s" % (rate, lat)] <= t["128/%s/%s" % (rate, lat)] + 1e-9
+    # the optimiser (and the gathers) of upper spans right behind their reduce-scatter, on the ONE communicator: the gathers
+    # delay the reduce-scatters of the layers below -- no gain; that is why it is not built
+    early = dataparallel.exchange_timeline(b, 8, min_bytes=32 << 20, rate_fraction=0.5, latency_ms=0.04, early_apply=True, **kw)
+    late = dataparallel.exchange_timeline(b, 8, min_bytes=32 << 20, rate_fraction=0.5, latency_ms=0.04, **kw)
+    assert early["predicted_ms_per_step"] >= late["predicted_ms_per_step"]

@@ -504,6 +504,8 @@ struct tfk_comm {
 
 namespace {
 
+constexpr size_t kDefaultBucketBytes = (size_t)32 << 20;  // (tfk_comm_create: why)
+
 int new_event(hipEvent_t* ev) {
   XHIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
   return 0;
@@ -943,10 +945,16 @@ int attach(tfk_engine* e, Backend* be, int mode, size_t bucket_bytes, tfk_comm**
   };
   if (mode != TFK_EXCHANGE_SHARDED && mode != TFK_EXCHANGE_ALLREDUCE) return bail(failx(-1, "unknown exchange mode %d", mode));
   c->mode = mode;
-  // default: 64 MiB per collective.  Few, large collectives suit point-to-point xGMI links, and every collective costs the
-  // step a fixed ~10-13 us (an event record between two backward kernels, RCCL's own stream work) whatever it carries: at
-  // BASELINE cfg3 one RCCL rank measures +11.5 % with 24 MiB spans and +6.4 % with 64 (profiles/r04_dp_overhead*.txt)
-  if (bucket_bytes == 0) bucket_bytes = (size_t)64 << 20;
+  // default: 32 MiB per collective (kDefaultBucketBytes).  Every collective launched under backward costs the engine stream a
+  // fixed ~6-10 us (an event record between two backward kernels, RCCL's own stream work) whatever it carries -- with ONE RCCL rank
+  // fewer spans are simply cheaper (BASELINE cfg3: +11.5 % with 24 MiB spans, +6.4 % with 64: profiles/r04_dp_overhead*.txt), and
+  // rounds 4-6 kept 64 MiB on that evidence.  With wire time it is the other way round: the next forward pass cannot start a layer
+  // before the WHOLE gather covering it has arrived, and what is still coalescing when backward ends is reduce-scattered with
+  // nothing left to hide it under -- at cfg2 the 64 MiB rule cuts [W6 .. W2] (83 MB) + [W1, W0] (20 MB), the 32 MiB rule
+  // [W6 .. W4] + [W3, W2] + [W1, W0].  dataparallel.exchange_timeline prices both over a range of wire rates and latencies (no
+  // multi-GPU node was available to measure them): 32 MiB is ahead at cfg2 in every cell at 2 / 4 / 8 ranks (1-15 %), level at
+  // cfg3, and cfg4's 64 MiB matrices are spans of their own either way.  bench.py --gpus N sweeps 16 / 32 / 64 / 128 on the real links.
+  if (bucket_bytes == 0) bucket_bytes = kDefaultBucketBytes;
   c->min_floats = std::max<size_t>(1, bucket_bytes / 4);
   if (const char* v = getenv("TFK_DP_MIN_SHARD")) c->min_shard_floats = (size_t)atol(v);
   if (const char* v = getenv("TFK_DP_VERIFY_STEPS")) c->verify_left = atoi(v);
@@ -1470,7 +1478,7 @@ int tfk_comm_set_bucket_bytes(tfk_comm* c, size_t bucket_bytes) {
   // precision, plane gathers) and Adam's moments (always) -- comes home first, COLLECTIVE like this call, or the new owner would
   // update stale values
   XCHK(rehome(c));
-  if (bucket_bytes == 0) bucket_bytes = (size_t)64 << 20;
+  if (bucket_bytes == 0) bucket_bytes = kDefaultBucketBytes;
   c->min_floats = std::max<size_t>(1, bucket_bytes / 4);
   return 0;
 }

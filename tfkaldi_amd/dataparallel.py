@@ -246,10 +246,10 @@ class BucketReducer(object):
                 mode = "allreduce"
         self.mode = mode
         if min_bytes is None:
-            # 64 MiB per collective (csrc/exchange.hip has the same default and the measurements behind it): few, large
-            # collectives for point-to-point xGMI, and a fixed cost per collective that one RCCL rank measures at
-            # 10-13 us.  Not tuned on a multi-GPU node: none was available to this build
-            default_mb = "64"
+            # 32 MiB per collective (csrc/exchange.hip: tfk_comm_create has the same default and the reasoning: a fixed cost
+            # per collective speaks for few spans, the layer-by-layer consumption of the gathers and the exposed tail of
+            # backward for small ones; exchange_timeline prices it).  Not tuned on a multi-GPU node: none was available
+            default_mb = str(DEFAULT_BUCKET_MB)
             min_bytes = int(float(os.environ.get("TFK_DP_BUCKET_MB", default_mb)) * (1 << 20))
         self.min_floats = max(1, min_bytes // 4)
         self.num_params = self.buckets[-1][0]  # the scalar + BN tail starts where the gradient arena ends
@@ -726,7 +726,7 @@ class NativeExchange(object):
         self.planes = bool(planes)
 
     def set_bucket_bytes(self, nbytes):
-        """between steps, every rank alike: adjacent gradient buckets are coalesced until a collective carries this much (0: 64 MiB)"""
+        """between steps, every rank alike: adjacent gradient buckets are coalesced until a collective carries this much (0: the default, 32 MiB)"""
         self._check(self.lib.tfk_comm_set_bucket_bytes(self._h, int(nbytes)))
 
     def my_shards(self, off, n, rank=None):
@@ -846,10 +846,11 @@ class NativeExchange(object):
         self._check(self.lib.tfk_comm_gather_masters(self._h))
 
 
+DEFAULT_BUCKET_MB = 32   # coalescing threshold of the gradient spans, MiB (csrc/exchange.hip: kDefaultBucketBytes)
 XGMI_LINK_GBPS = 153.0  # MI355X: 7 xGMI links per GPU, point to point, ~153 GB/s per direction each (8-GPU full mesh)
 
 
-def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="sharded", min_bytes=64 << 20, gather_elem_bytes=4,
+def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="sharded", min_bytes=DEFAULT_BUCKET_MB << 20, gather_elem_bytes=4,
                    fixed_ms=0.045, link_gbps=XGMI_LINK_GBPS, reduce_elem_bytes=4, twin_rebuild_ms=0.0):
     """What the exchange step of a `world`-GPU job should cost, from one GPU's measured step -- a PREDICTION to hold the first
     real scaling line against (no multi-GPU node was available to any round of this build; reference seam
@@ -958,6 +959,132 @@ def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="shard
                                        "(TFK_DP_GATHER=planes, off by default until a multi-GPU run has measured it: bench.py's "
                                        "exchange_ab times both)" % twin_rebuild_ms)
     return out
+
+
+def coalesced_spans(buckets, min_bytes):
+    """the weight spans the coalescing rule of BucketReducer.on_bucket / csrc/exchange.hip cuts from the announcements
+    W_L .. W_0: adjacent buckets are merged until a span carries >= min_bytes.  [(offset, floats, first bucket, last bucket)]"""
+    L1 = len(buckets) - 2
+    min_floats = max(1, int(min_bytes) // 4)
+    spans, lo = [], None
+    for b in range(L1):
+        off, n = buckets[b]
+        if lo is None:
+            lo, hi, first = off, off + n, b
+        elif off + n == lo:
+            lo = off
+        elif off == hi:
+            hi = off + n
+        else:
+            spans.append((lo, hi - lo, first, b - 1))
+            lo, hi, first = off, off + n, b
+        if hi - lo >= min_floats:
+            spans.append((lo, hi - lo, first, b))
+            lo = None
+    if lo is not None:
+        spans.append((lo, hi - lo, first, L1 - 1))
+    return spans
+
+
+def exchange_timeline(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, min_bytes=DEFAULT_BUCKET_MB << 20, rate_fraction=1.0, latency_ms=0.03,
+                      gather_elem_bytes=4, reduce_elem_bytes=4, link_gbps=XGMI_LINK_GBPS, early_apply=False, record_ms=0.006):
+    """exchange_model's question asked as a TIMELINE of the sharded step, with the two things that model leaves out: a fixed
+    latency per collective, and the fact that a layer of the next forward pass waits for the WHOLE gather that covers it (so a
+    span of five matrices holds its first layer back until the fifth has arrived).  It exists to choose the span size and to say
+    what overlapping the optimiser with backward would buy, over a RANGE of wire rates -- no multi-GPU node was available to any
+    round of this build, so the rate RCCL really reaches on the mesh is the unknown, not a constant.
+
+    One communicator: its collectives run one after the other in launch order.  rate = rate_fraction x (world - 1) links x
+    link_gbps per rank (1.0: every link at its peak; measured vendor collectives on such meshes reach roughly 0.3-0.6 of that at
+    these sizes); a collective over B bytes per rank buffer costs latency_ms + B (world - 1) / world / rate.  Layer l's share of
+    the forward / backward pass is proportional to its parameter count.  Backward announces W_L first; a span's reduce-scatter
+    is launched when its lowest layer has been announced (the LAST span and the vectors: behind the last backward kernel, on the
+    engine stream); every span launched under backward costs the engine stream record_ms of idle time.  Adam on the rank's
+    1/world follows the last reduce (early_apply: each span's follows ITS reduce on the communicator's stream, and so does its
+    gather -- the optimiser overlapped with backward, which is possible because mean -> clip -> Adam is element-wise once the
+    frame count is known: reference trainer.py:174-184).  Gathers go lowest span first; the next forward pass starts layer l
+    when the gather covering it is complete.  Returns the steady-state step time and where it went."""
+    L1 = len(buckets) - 2
+    spans = coalesced_spans(buckets, min_bytes)
+    floats = [buckets[b][1] for b in range(L1)]            # announcement order: W_L .. W_0
+    total = float(sum(floats))
+    rate = rate_fraction * (world - 1) * link_gbps * 1e9   # bytes / s received (or sent) per rank
+
+    def coll(nbytes):
+        return latency_ms + (nbytes * (world - 1) / float(world)) / rate * 1e3 if world > 1 else 0.0
+
+    # backward: bucket b (layer L - b) is announced at done_b
+    done, t = [], 0.0
+    for b in range(L1):
+        t += bwd_ms * floats[b] / total
+        done.append(t)
+    comm = 0.0                      # the communicator's clock, from the start of backward
+    reduce_end, gather_end_early = {}, {}
+    engine_idle = 0.0
+    for i, (off, n, b0, b1) in enumerate(spans):
+        last = i == len(spans) - 1
+        ready = bwd_ms if last else done[b1]
+        if not last:
+            engine_idle += record_ms
+        comm = max(comm, ready) + coll(float(reduce_elem_bytes) * n)
+        reduce_end[i] = comm
+        if early_apply and not last:
+            comm += adam_ms * n / total / world
+            comm += coll(float(gather_elem_bytes) * n)
+            gather_end_early[i] = comm
+    tail_end = comm + (latency_ms if world > 1 else 0.0)  # vectors + scalars: one small grouped all-reduce behind the last reduce-scatter
+    exposed_reduce = max(0.0, tail_end - bwd_ms)
+    # optimiser: everything (apply at the end) or what early_apply left (the last span + the vectors)
+    if early_apply:
+        adam = adam_ms * spans[-1][1] / total / world if spans else 0.0
+    else:
+        adam = adam_ms / world
+    t0 = max(bwd_ms, tail_end) + adam + engine_idle      # the next forward pass may start here (if its first gather allows)
+    # gathers, lowest span first
+    g, gather_end = t0, {}
+    for i in reversed(range(len(spans))):
+        if i in gather_end_early:
+            gather_end[i] = gather_end_early[i]
+            continue
+        g += coll(float(gather_elem_bytes) * spans[i][1])
+        gather_end[i] = g
+    # next forward pass: layer l = bucket L - l; layer of bucket b is covered by the span holding b
+    span_of = {}
+    for i, (off, n, b0, b1) in enumerate(spans):
+        for b in range(b0, b1 + 1):
+            span_of[b] = i
+    f = t0
+    waited = 0.0
+    for b in reversed(range(L1)):   # W_0 first
+        start = max(f, gather_end[span_of[b]])
+        waited += start - f
+        f = start + fwd_ms * floats[b] / total
+    other = step_ms - fwd_ms - bwd_ms - adam_ms   # what a single-rank step spends outside the three (loss hand-over, launches)
+    predicted = (f - t0) + bwd_ms + (t0 - bwd_ms) + other
+    return {"world": world, "min_span_bytes": int(min_bytes), "spans": len(spans), "rate_fraction": rate_fraction,
+            "GBps_per_rank": rate / 1e9, "latency_ms": latency_ms, "early_apply": bool(early_apply),
+            "exposed_reduce_ms": exposed_reduce, "adam_ms": adam, "gather_wait_ms": waited, "engine_idle_ms": engine_idle,
+            "predicted_ms_per_step": predicted, "predicted_weak_scaling_efficiency": step_ms / predicted}
+
+
+def exchange_timeline_sweep(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, early=(False,), **kw):
+    """exchange_timeline over span sizes x wire rates x per-collective latencies x (apply at the end | optimiser under backward):
+    {"span_MiB/rate_fraction/latency_us[/early]": predicted ms per step}, and per (rate, latency) the best span size"""
+    table, best = {}, {}
+    for rate in (1.0, 0.5, 0.3):
+        for lat in (0.015, 0.04):
+            for early_apply in early:
+                row = {}
+                for mib in (16, 32, 64, 128):
+                    r = exchange_timeline(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, min_bytes=mib << 20, rate_fraction=rate,
+                                          latency_ms=lat, early_apply=early_apply, **kw)
+                    key = "%d/%.1f/%d%s" % (mib, rate, round(lat * 1e3), "/early" if early_apply else "")
+                    table[key] = r["predicted_ms_per_step"]
+                    row[mib] = r["predicted_ms_per_step"]
+                best["%.1f/%d%s" % (rate, round(lat * 1e3), "/early" if early_apply else "")] = min(row, key=row.get)
+    return {"ms_per_step": table, "best_span_MiB": best,
+            "key": "span MiB / fraction of (world - 1) x %.0f GB/s per rank / latency per collective in us [/ optimiser under backward]"
+                   % kw.get("link_gbps", XGMI_LINK_GBPS)}
 
 
 class DataParallel(object):
