@@ -397,7 +397,9 @@ from tfkaldi_amd.processing import batchdispenser, feature_reader, target_coder
 out = sys.argv[1]
 F_RAW, CONTEXT, O = 8, 2, 12
 lengths = np.random.default_rng(0).integers(6, 30, size=26)
-paths = synthetic.write_corpus(os.path.join(out, "data"), 26, O, feat_dim=F_RAW, lengths=lengths, num_speakers=3)
+# (every rank writes its own copy of the same deterministic corpus: two ranks writing ONE directory race with each other's reads)
+paths = synthetic.write_corpus(os.path.join(out, "data_rank" + os.environ.get("RANK", "0")), 26, O, feat_dim=F_RAW, lengths=lengths,
+                               num_speakers=3)
 conf = configparser.ConfigParser()
 conf.add_section("directories"); conf.set("directories", "expdir", out)
 conf.add_section("nnet")
