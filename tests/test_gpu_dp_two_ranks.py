@@ -64,10 +64,11 @@ def _worker(rank, world, port, num_mb, out_dir, dtype="float32", mode="sharded",
         os.environ.update(TFK_SHARE_DEVICE="1", TFK_DIST_BACKEND="gloo", TFK_DP_EMULATE_RS="1")
     else:
         # REAL RCCL: the in-library exchange (csrc/exchange.hip) -- "rccl-torch": the library refuses to load RCCL, every rank
-        # agrees on the torch.distributed driver (BucketReducer over the nccl backend).  On a box with fewer GPUs than ranks the
+        # agrees on the torch.distributed driver (BucketReducer over the nccl backend); "rccl-mixed": ONE rank cannot load it --
+        # the others must hear of that before they enter the collective ncclCommInitRank (tfk_comm_available, MIN-reduced).  On a box with fewer GPUs than ranks the
         # ranks share a device and claim a host each (TFK_FAKE_NODES; dataparallel._share_device)
         os.environ.update(HSA_ENABLE_IPC_MODE_LEGACY="0", TFK_FAKE_NODES=transport.split(":")[1])
-        if transport.startswith("rccl-torch"):
+        if transport.startswith("rccl-torch") or (transport.startswith("rccl-mixed") and rank == 1):
             os.environ["TFK_RCCL_LIB"] = "/nonexistent/librccl.so"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -224,7 +225,7 @@ def _rccl_transport(world, driver="rccl"):
     (8, 1, "float32", "allreduce", LAYERWISE, "rccl"),
     # the in-library exchange cannot load RCCL: every rank runs the torch.distributed driver over the nccl backend
     (2, 3, "float32", "sharded", None, "rccl-torch"), (2, 3, "bfloat16", "sharded", None, "rccl-torch"),
-    (4, 5, "float32", "allreduce", None, "rccl-torch")])
+    (4, 5, "float32", "allreduce", None, "rccl-torch"), (4, 5, "float32", "sharded", None, "rccl-mixed")])
 def test_ranks_match_serial_over_real_rccl(gpu, tmp_path, world, num_mb, dtype, mode, kw, driver):
     """test_ranks_match_serial with the ranks talking through REAL RCCL: reduce-scatter / all-gather / all-reduce launched by the
     library at world 2 / 4 / 8 in every arithmetic (bf16: shadow gathers, fp32 masters left with their owners), idle ranks under

@@ -174,7 +174,7 @@ def test_bench_self_launches_its_ranks(gpu):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("world,config", [(2, "cfg2"), (4, "cfg2"), (2, "cfg3"), (8, "cfg2")])
+@pytest.mark.parametrize("world,config", [(2, "cfg2"), (4, "cfg2"), (2, "cfg3"), (2, "cfg4"), (8, "cfg2")])
 def test_bench_over_real_rccl_ranks(gpu, world, config):
     """the driver's `bench.py --gpus N` with N REAL RCCL ranks (one per GPU, or all on GPU 0 claiming a host each: the transport
     is then RCCL's socket path and the rates mean nothing): the contract's line from the in-library exchange, and the whole
@@ -201,7 +201,7 @@ def test_bench_over_real_rccl_ranks(gpu, world, config):
     assert line["exchange"] == "sharded" and line["exchange_driver"].startswith("library (csrc/exchange.hip, rccl)")
     assert any("reduce_scatter" in c for c in line["collectives_last_step"])
     assert any("all_gather" in c for c in line["collectives_last_step"])
-    assert abs(line["loss_first_last"][0] - np.log({"cfg2": 2000, "cfg3": 4000}[config])) < 1e-3
+    assert abs(line["loss_first_last"][0] - np.log({"cfg2": 2000, "cfg3": 4000, "cfg4": 8000}[config])) < 1e-3
     ab = line["exchange_ab"]
     want = {"rccl/fp32", "rccl/bf16", "direct/fp32", "direct/bf16", "auto/fp32"}
     if config == "cfg2":
