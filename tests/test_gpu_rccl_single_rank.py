@@ -1,8 +1,11 @@
-"""The RCCL call path on the one GPU of the test box: a single-rank "nccl" process group (TFK_FORCE_DP=1) drives
+"""The RCCL call path on the one GPU of the test box.  (1) A single-rank "nccl" process group (TFK_FORCE_DP=1) drives
 DataParallel.train_step / eval_step exactly as a multi-GPU job does -- torch-owned engine state, bucket callback
 -> async all-reduce on RCCL's stream -> wait on the engine stream -> apply -- and must reproduce the plain
 single-process run bit for bit (a 1-rank SUM all-reduce is the identity).  bench.py's N>1 branch is run the same
-way."""
+way.  (2) SEVERAL real RCCL ranks: one per GPU when the box has them, else all on GPU 0 with a host name each
+(TFK_FAKE_NODES -> NCCL_HOSTID: RCCL's duplicate-device check compares host hash + bus id), the collectives going
+through RCCL's socket transport -- the exchange options against the serial run, `bench.py --gpus N`, `Nnet.train`
+under torchrun, the CTC loss."""
 import json
 import os
 import socket
