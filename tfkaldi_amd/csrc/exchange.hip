@@ -772,10 +772,11 @@ int flush_range(tfk_comm* c, bool inline_on_engine = false) {
 int announce(tfk_comm* c, int b) {
   if (b < 0 || b >= (int)c->buckets.size()) return failx(-1, "bucket %d out of range", b);
   const size_t off = c->buckets[b].first, n = c->buckets[b].second;
-  if (b == c->L + 2 && !c->have_range && !c->have_head && hold_last()) {
+  if (b == c->L + 2 && !c->have_range && hold_last()) {
     // [scalars + BN increments]: always the FIRST announcement of a step.  Its all-reduce used to go to the comm stream at once
     // (a `ready` record between two kernels of the engine stream: ~6 us of idle time) so as to be long done when the optimiser
-    // needs the frame count; in the tail's one group launch it costs nothing and needs no event
+    // needs the frame count; in the tail's one group launch it costs nothing and needs no event.  (Announced again before the
+    // tail went out -- a step the host gave up and started over -- it is still ONE all-reduce: the sums must not be taken twice)
     c->have_head = true;
     c->head_lo = off;
     c->head_hi = off + n;
