@@ -248,7 +248,7 @@ CFG2 = dict(input_dim=440, num_layers=6, num_units=2048, output_dim=2000, nonlin
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("dtype,transport", [("float32", "gloo"), ("float32", "rccl"), ("bfloat16", "rccl")])
+@pytest.mark.parametrize("dtype,transport", [("float32", "rccl"), ("bfloat16", "rccl"), ("bfloat16", "gloo-torch-driver")])
 def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype, transport):
     """BASELINE cfg2's network on eight ranks: the real span sizes (3.6 / 16.8 / 16.4 MB), 32 MiB coalescing, shards of
     n / 8, an idle rank (seven micro-batches), real engines, the sharded protocol end to end -- over gloo with the torch driver,
@@ -256,7 +256,10 @@ def test_eight_ranks_at_cfg2_size(gpu, tmp_path, dtype, transport):
     import torch.multiprocessing as mp
     world, num_mb = 8, 7
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    transport = "gloo" if transport == "gloo" else _rccl_transport(world)
+    # (the driver's GPU tier gives the suite 20 minutes: the torch.distributed driver meets this size once, over gloo with emulated
+    #  reduce-scatters, in the arithmetic that leaves the fp32 masters with their owners; test_bench_eight_ranks_dry_run is its
+    #  fp32 run at this size)
+    transport = "gloo" if transport.startswith("gloo") else _rccl_transport(world)
     mp.spawn(_worker, args=(world, port, num_mb, str(tmp_path), dtype, "sharded", CFG2, 96, transport), nprocs=world, join=True)
     ref = _serial(num_mb, dtype, CFG2, "sharded", frames=96)
     # (26 M parameters, generic starting point: after a few Adam steps the summation order of eight partial gradient sums

@@ -189,8 +189,8 @@ def test_bench_over_real_rccl_ranks(gpu, world, config):
         env["TFK_FAKE_NODES"] = "1"
     # (eight ranks on one GPU through sockets: ~0.3 s per step -- the diagnostics need more than the 300 s they get on a real node)
     env.update(TFK_BENCH_SUSTAIN_S="1", TFK_BENCH_PREWARM_MS="0", TFK_BENCH_DIAG_BUDGET_S="900")
-    if world == 8:
-        env.update(TFK_BENCH_AB_STEPS="3", TFK_BENCH_SUSTAIN_MIN_STEPS="10")
+    if world == 8:  # (Nnet.train under real ranks: the 2- and 4-rank cases)
+        env.update(TFK_BENCH_AB_STEPS="3", TFK_BENCH_SUSTAIN_MIN_STEPS="10", TFK_BENCH_API_FED="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2",
                           "--config", config], env=env, capture_output=True, text=True, timeout=1100)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -216,7 +216,9 @@ def test_bench_over_real_rccl_ranks(gpu, world, config):
     ph = line["exchange_phases"]
     assert ph["steps"] == 10 and all(len(v) == world for v in ph["per_rank"].values())
     assert all(x > 0 for x in ph["per_rank"]["reduce_scatter"] + ph["per_rank"]["all_gather"] + ph["per_rank"]["adam"])
-    assert line["sustained"]["value"] > 0 and line["api_fed_value"] > 0, line.get("api_fed_error")
+    assert line["sustained"]["value"] > 0
+    if world < 8:
+        assert line["api_fed_value"] > 0, line.get("api_fed_error")
     assert line["exchange_model"]["per_world"][str(world)]["predicted_ms_per_step_direct"] > 0
     print("bench --gpus %d %s over real RCCL: exchange_ab %s" % (world, config, ab["ms_per_step"]))
 
