@@ -120,6 +120,47 @@ __device__ __forceinline__ void st4_twin(const Twin& t, size_t row, int col, flo
   *reinterpret_cast<u16x4*>(t.p + row * t.ld + col) = q;
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming variants for the column-tiled BN / activation passes (env TFK_BN_NT, bit 0: the fp32 output, bit 1: the operand twins):
+// written once, read by a LATER kernel from another XCD's side of the fabric -- nothing this kernel's L2 needs to keep
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  v4f_nt q;
+  q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+  __builtin_nontemporal_store(q, reinterpret_cast<v4f_nt*>(p));
+}
+__device__ __forceinline__ void st4_twin_nt(const Twin& t, size_t row, int col, float4 v) {
+  if (!t.p) return;
+  if (t.x3) {
+    uint16_t a[4], b[4], c[4];
+    twin_split3(v.x, a[0], b[0], c[0]); twin_split3(v.y, a[1], b[1], c[1]);
+    twin_split3(v.z, a[2], b[2], c[2]); twin_split3(v.w, a[3], b[3], c[3]);
+    u16x4 q1, q2, q3;
+    q1.x = a[0]; q1.y = a[1]; q1.z = a[2]; q1.w = a[3];
+    q2.x = b[0]; q2.y = b[1]; q2.z = b[2]; q2.w = b[3];
+    q3.x = c[0]; q3.y = c[1]; q3.z = c[2]; q3.w = c[3];
+    uint16_t* d = t.p + x3::at(row, col, t.ld);
+    __builtin_nontemporal_store(q1, reinterpret_cast<u16x4*>(d));
+    __builtin_nontemporal_store(q2, reinterpret_cast<u16x4*>(d + 64));
+    __builtin_nontemporal_store(q3, reinterpret_cast<u16x4*>(d + 128));
+    return;
+  }
+  u16x4 q;
+  q.x = to_bf16(v.x); q.y = to_bf16(v.y); q.z = to_bf16(v.z); q.w = to_bf16(v.w);
+  __builtin_nontemporal_store(q, reinterpret_cast<u16x4*>(t.p + row * t.ld + col));
+}
+__device__ __forceinline__ float4 ld4s(const float* p, int nt) {  // (bit 2 of TFK_BN_NT: streaming loads of what is read once)
+  if (nt & 4) {
+    const v4f_nt q = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p));
+    return make_float4(q.x, q.y, q.z, q.w);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+int bn_nt_mode() {
+  // default 3 (round 6, tools/bn_nt_ablate.sh -> profiles/r06_bn_nt.txt): bn_act_forward 9.1 -> 7.8 us, hb_apply 9.8 -> 8.9 us per
+  // launch at cfg2, the step -8 .. -10 us; streaming loads on top (bit 2) change nothing measurable
+  static const int m = [] { const char* q = getenv("TFK_BN_NT"); return q ? atoi(q) : 3; }();
+  return m;
+}
 __device__ __forceinline__ float& el(float4& v, int i) { return reinterpret_cast<float*>(&v)[i]; }
 __device__ __forceinline__ float el(const float4& v, int i) { return reinterpret_cast<const float*>(&v)[i]; }
 
@@ -345,7 +386,7 @@ __global__ void __launch_bounds__(CT_X * CT_Y)
 bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict__ a, const float* __restrict__ st,
                       int nchunk, int chunk_rows, int T, int H, int ld, int rows_per, float eps, float decay,
                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ e_mean,
-                      float* __restrict__ e_var, const float* __restrict__ beta, Twin tw, int T_apply, int slab) {
+                      float* __restrict__ e_var, const float* __restrict__ beta, Twin tw, int T_apply, int slab, int nt) {
   // T rows carry the statistics; rows [T, T_apply) are the padding behind a segment of a stacked pass: they get
   // (finite) outputs from the segment's statistics and count for nothing.  slab = chunks per statistics slab.
   __shared__ float4 sm[CT_Y][CT_X];
@@ -372,7 +413,7 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int r = rb0 + j * CT_Y;
-    zv[j] = (t.valid && rb0 < t.r1) ? ld4(z + (size_t)(r < t.r1 ? r : rb0) * ld + t.col) : zero4;
+    zv[j] = (t.valid && rb0 < t.r1) ? ld4s(z + (size_t)(r < t.r1 ? r : rb0) * ld + t.col, nt) : zero4;
   }
   const float4 be = t.valid ? ld4(beta + t.col) : zero4;
   // Chan merge of the per-chunk (n, mean, M2): row lane y takes chunks y, y + 8, ...
@@ -448,7 +489,7 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       const int r = rbn + j * CT_Y;
-      zn[j] = rbn < t.r1 ? ld4(z + (size_t)(r < t.r1 ? r : rbn) * ld + t.col) : zero4;
+      zn[j] = rbn < t.r1 ? ld4s(z + (size_t)(r < t.r1 ? r : rbn) * ld + t.col, nt) : zero4;
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
@@ -464,8 +505,10 @@ bn_act_forward_kernel(ActDesc d, const float* __restrict__ z, float* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) el(v, k) = m.k[k] ? el(v, k) * inv_keep : 0.f;
       }
-      st4(a + (size_t)r * ld + t.col, v);
-      st4_twin(tw, r, t.col, v);
+      if (nt & 1) st4_nt(a + (size_t)r * ld + t.col, v);
+      else st4(a + (size_t)r * ld + t.col, v);
+      if (nt & 2) st4_twin_nt(tw, r, t.col, v);
+      else st4_twin(tw, r, t.col, v);
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) zv[j] = zn[j];
@@ -584,7 +627,7 @@ __global__ void __launch_bounds__(CT_X * CT_Y)
 hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __restrict__ a,
                 const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd, int T,
                 int H, int ld, int rows_per, int rs_in, float* __restrict__ ws, Twin tw, int T_apply,
-                float* __restrict__ ws_dz) {
+                float* __restrict__ ws_dz, int nt) {
   // rows [T, T_apply): padding behind a segment of a stacked pass -- their dz is written as ZERO (both contractions
   // that consume dz run over the padded rows) and they count for nothing.  ws_dz: where slab 2 of this launch goes.
   __shared__ float4 sm[CT_Y][CT_X];
@@ -600,9 +643,9 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
     const int r = rb0 + j * CT_Y;
     const bool ok = t.valid && rb0 < t.r1;
     const size_t off = (size_t)(r < t.r1 ? r : rb0) * ld + t.col;
-    g[j] = ok ? ld4(da + off) : zero4;
-    av[j] = (ok && !pre_du) ? ld4(a + off) : g[j];
-    zv[j] = (ok && d.bn) ? ld4(z + off) : g[j];
+    g[j] = ok ? ld4s(da + off, nt) : zero4;
+    av[j] = (ok && !pre_du) ? ld4s(a + off, nt) : g[j];
+    zv[j] = (ok && d.bn) ? ld4s(z + off, nt) : g[j];
   }
   float4 mu = sz, rsd = sz;
   if (d.bn && t.valid) {
@@ -640,9 +683,9 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
         const int r = rbn + j * CT_Y;
         const bool ok = rbn < t.r1;
         const size_t off = (size_t)(r < t.r1 ? r : rbn) * ld + t.col;
-        gn[j] = ok ? ld4(da + off) : zero4;
-        an[j] = (ok && !pre_du) ? ld4(a + off) : gn[j];
-        zn[j] = (ok && d.bn) ? ld4(z + off) : gn[j];
+        gn[j] = ok ? ld4s(da + off, nt) : zero4;
+        an[j] = (ok && !pre_du) ? ld4s(a + off, nt) : gn[j];
+        zn[j] = (ok && d.bn) ? ld4s(z + off, nt) : gn[j];
       }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
@@ -662,8 +705,12 @@ hb_apply_kernel(ActDesc d, int pre_du, float* __restrict__ da, const float* __re
           if (t.col + k >= H) el(dz, k) = 0.f;
         // mixed precision: both contractions that consume dz read its bf16 twin, nothing reads the fp32 copy again
         // (the bias gradient is the column sum taken right here): it is not stored -- a third of this kernel's traffic
-        if (tw.p) st4_twin(tw, r, t.col, dz);
-        else st4(da + (size_t)r * ld + t.col, dz);
+        if (tw.p) {
+          if (nt & 2) st4_twin_nt(tw, r, t.col, dz);
+          else st4_twin(tw, r, t.col, dz);
+        } else {
+          st4(da + (size_t)r * ld + t.col, dz);
+        }
         sz.x += dz.x; sz.y += dz.y; sz.z += dz.z; sz.w += dz.w;
       }
 #pragma unroll
@@ -977,9 +1024,13 @@ __device__ __forceinline__ void st4s(float* p, float4 v) {
     st4(p, v);
   }
 }
-// NT: streaming (non-temporal) accesses for g / m / v, which nothing re-reads before the next optimiser step
+// NT: 1 = streaming (non-temporal) accesses for g / m / v, which nothing re-reads before the next optimiser step (default);
+//     2 = also for the parameters (read back by the next optimiser step only, when the GEMMs read operand twins); 3 = also for the
+//     twins this kernel writes -- measured 131.5 -> 164.4 us at cfg2 (profiles/r06_bn_nt.txt): a thread's four weights are HALF of
+//     a plane's 128-byte line (the other row of the unit belongs to a thread 2048 weights away), and a streamed half line is
+//     not merged in the L2 the way a cached one is
 // UN: float4 groups per thread per trip (their loads are all issued before the first is consumed)
-template <bool NT, int UN>
+template <int NT, int UN>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4,
             const float* __restrict__ scalars, float lr_t, float b1, float b2, float eps, uint16_t* __restrict__ wb,
@@ -995,7 +1046,8 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
     for (int u = 0; u < UN; ++u) {
       const size_t i = i0 + u * stride;
       if (i < n4) {
-        gv[u] = ld4s<NT>(g + 4 * i); mv[u] = ld4s<NT>(m + 4 * i); vv[u] = ld4s<NT>(v + 4 * i); wv[u] = ld4(w + 4 * i);
+        gv[u] = ld4s<(NT > 0)>(g + 4 * i); mv[u] = ld4s<(NT > 0)>(m + 4 * i); vv[u] = ld4s<(NT > 0)>(v + 4 * i);
+        wv[u] = ld4s<(NT > 1)>(w + 4 * i);
       }
     }
 #pragma unroll
@@ -1014,14 +1066,15 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
         el(vv[u], k) = vk;
         el(wv[u], k) = __fsub_rn(el(wv[u], k), __fdiv_rn(__fmul_rn(lr_t, mk), __fadd_rn(__fsqrt_rn(vk), eps)));
       }
-      st4s<NT>(m + 4 * i, mv[u]);
-      st4s<NT>(v + 4 * i, vv[u]);
-      st4(w + 4 * i, wv[u]);
+      st4s<(NT > 0)>(m + 4 * i, mv[u]);
+      st4s<(NT > 0)>(v + 4 * i, vv[u]);
+      st4s<(NT > 1)>(w + 4 * i, wv[u]);
       if (wb && i < n4_wb) {  // bf16 shadow of the weight matrices
         Twin sh;
         if (map.n == 0) {  // same element offsets as the fp32 arena
           sh.p = wb; sh.ld = 1;
-          st4_twin(sh, 4 * i, 0, wv[u]);  // (leading dimension 1: the "row" is the flat index)
+          if constexpr (NT > 2) st4_twin_nt(sh, 4 * i, 0, wv[u]);
+          else st4_twin(sh, 4 * i, 0, wv[u]);  // (leading dimension 1: the "row" is the flat index)
         } else {  // x3: the tiled twin of the matrix this group of four belongs to (padding between matrices: none)
           const uint32_t e = (uint32_t)(first + 4 * i);
           int l = 0;
@@ -1029,7 +1082,8 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
           const uint32_t rel = e - map.begin[l], r = rel / map.ld[l];
           if (r < map.rows[l]) {
             sh.p = wb + map.twin[l]; sh.ld = (int)map.ld_twin[l]; sh.x3 = 1;
-            st4_twin(sh, r, (int)(rel - r * map.ld[l]), wv[u]);
+            if constexpr (NT > 2) st4_twin_nt(sh, r, (int)(rel - r * map.ld[l]), wv[u]);
+            else st4_twin(sh, r, (int)(rel - r * map.ld[l]), wv[u]);
           }
         }
       }
@@ -1190,7 +1244,7 @@ void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, c
   const int nchunk = (T + chunk_rows - 1) / chunk_rows;
   hipLaunchKernelGGL(bn_act_forward_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, z, a, stats, nchunk, chunk_rows, T, H,
                      ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta, tw, T_apply,
-                     slab_chunks > 0 ? slab_chunks : nchunk);
+                     slab_chunks > 0 ? slab_chunks : nchunk, bn_nt_mode());
 }
 
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
@@ -1220,7 +1274,7 @@ void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, con
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
                      rows_per, stats_chunks > 0 ? stats_chunks : rs, ws, tw, T_apply,
-                     ws_dz ? ws_dz : ws + (size_t)2 * kMaxRowSplits * ld);
+                     ws_dz ? ws_dz : ws + (size_t)2 * kMaxRowSplits * ld, bn_nt_mode());
 }
 
 void bn_stats_from_chunks(hipStream_t s, const float* stats, int chunk_rows, int T, int H, int ld, float eps, float decay,
@@ -1302,15 +1356,20 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
   if (grid_cap > 0 && blocks > (size_t)grid_cap) blocks = grid_cap;
   if (blocks == 0) return;
   // streaming accesses measured 116.7 -> 107.8 us on cfg2 (6.75 TB/s); TFK_ADAM_NT=0 restores cached ones
-  static const bool nt = [] { const char* q = getenv("TFK_ADAM_NT"); return !q || atoi(q) != 0; }();
+  // (TFK_ADAM_NT=2: also the parameters; 3: also the twins the kernel writes -- tools/adam_nt_ablate.sh)
+  static const int nt = [] { const char* q = getenv("TFK_ADAM_NT"); return q ? atoi(q) : 1; }();
   static const int un = [] { const char* q = getenv("TFK_ADAM_UNROLL"); return q ? atoi(q) : 2; }();
 #define TFK_ADAM_LAUNCH(NTV, UNV)                                                                                  \
   hipLaunchKernelGGL((adam_kernel<NTV, UNV>), dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, \
                      beta1, beta2, eps, wb, n_wb / 4, sm, first)
-  if (nt) {
-    if (un == 4) TFK_ADAM_LAUNCH(true, 4); else if (un == 2) TFK_ADAM_LAUNCH(true, 2); else TFK_ADAM_LAUNCH(true, 1);
+  if (nt >= 3) {
+    if (un == 4) TFK_ADAM_LAUNCH(3, 4); else if (un == 2) TFK_ADAM_LAUNCH(3, 2); else TFK_ADAM_LAUNCH(3, 1);
+  } else if (nt == 2) {
+    if (un == 4) TFK_ADAM_LAUNCH(2, 4); else if (un == 2) TFK_ADAM_LAUNCH(2, 2); else TFK_ADAM_LAUNCH(2, 1);
+  } else if (nt) {
+    if (un == 4) TFK_ADAM_LAUNCH(1, 4); else if (un == 2) TFK_ADAM_LAUNCH(1, 2); else TFK_ADAM_LAUNCH(1, 1);
   } else {
-    TFK_ADAM_LAUNCH(false, 1);
+    TFK_ADAM_LAUNCH(0, 1);
   }
 #undef TFK_ADAM_LAUNCH
 }
