@@ -1222,6 +1222,18 @@ int row_splits(int T) {
   return rs;
 }
 
+// bn_act_forward alone (env TFK_CT_ROWS_FWD): its row splits feed no partial-sum slab, so its blocks may be cut finer than the
+// backward pass's -- with streaming stores 16 rows per block beat 32 there (7.0 against 7.7 us at cfg2) while hb_apply loses
+// 2.8 us with them (profiles/r06_bn_nt.txt)
+int row_splits_fwd(int T) {
+  static const int rows = [] { const char* q = getenv("TFK_CT_ROWS_FWD"); const int v = q ? atoi(q) : 16; return v >= 8 ? v : 16; }();
+  if (getenv("TFK_CT_ROWS") && !getenv("TFK_CT_ROWS_FWD")) return row_splits(T);  // (the older switch alone: every column-tiled kernel)
+  int rs = (T + rows - 1) / rows;
+  if (rs < 1) rs = 1;
+  if (rs > kMaxRowSplits) rs = kMaxRowSplits;
+  return rs;
+}
+
 void bn_stats_train(hipStream_t s, const float* z, int T, int H, int ld, float eps, float decay, float* mean,
                     float* rstd, float* e_mean, float* e_var, float* ws) {
   const int rs = row_splits(T), rows_per = (T + rs - 1) / rs;
@@ -1240,7 +1252,7 @@ void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, c
                     int T, int H, int ld, float eps, float decay, float* mean, float* rstd, float* e_mean,
                     float* e_var, const float* beta, Twin tw, int T_apply, int slab_chunks) {
   if (T_apply < T) T_apply = T;
-  const int rs = row_splits(T_apply), rows_per = (T_apply + rs - 1) / rs;
+  const int rs = row_splits_fwd(T_apply), rows_per = (T_apply + rs - 1) / rs;
   const int nchunk = (T + chunk_rows - 1) / chunk_rows;
   hipLaunchKernelGGL(bn_act_forward_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, z, a, stats, nchunk, chunk_rows, T, H,
                      ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta, tw, T_apply,
