@@ -23,7 +23,7 @@ import csv, glob, json, sys
 out = sys.argv[1]
 keys = (("bn_act_forward", "bn_act_forward_kernel", ""), ("hb_apply", "hb_apply_kernel", ""), ("fwd split-K pair", "gemm_bf16_dma_kernel<true, false, 9, 2, 4", ""),
         ("dual", "gemm_bf16x3_dual_kernel", ""), ("adam", "adam_kernel", ""))
-print("# TFK_BN_NT variant: avg us per launch by rocprofv3 (calls) | un-profiled ms/step, three interleaved repetitions")
+print("# TFK_ADAM_NT variant: avg us per launch by rocprofv3 (calls) | un-profiled ms/step, three interleaved repetitions")
 for v in (1, 2):
     f = glob.glob("%s/nt%d/**/*kernel_stats.csv" % (out, v), recursive=True)
     row = []
