@@ -155,11 +155,16 @@ __device__ __forceinline__ float4 ld4s(const float* p, int nt) {  // (bit 2 of T
   }
   return *reinterpret_cast<const float4*>(p);
 }
-int bn_nt_mode() {
-  // default 3 (round 6, tools/bn_nt_ablate.sh -> profiles/r06_bn_nt.txt): bn_act_forward 9.1 -> 7.8 us, hb_apply 9.8 -> 8.9 us per
-  // launch at cfg2, the step -8 .. -10 us; streaming loads on top (bit 2) change nothing measurable
-  static const int m = [] { const char* q = getenv("TFK_BN_NT"); return q ? atoi(q) : 3; }();
-  return m;
+int bn_nt_mode(const Twin& tw, int rows, int ld) {
+  // default (round 6, tools/bn_nt_ablate.sh -> profiles/r06_bn_nt.txt): the fp32 output always streams (nothing reads it before the
+  // backward pass); the operand twin streams when it is too large for the next contraction to find it in the L2s anyway -- the
+  // three planes of the emulated arithmetic at cfg2 (12 MB: bn_act_forward 9.1 -> 7.8 us, hb_apply 9.8 -> 8.9 us, the step -8 ..
+  // -10 us), bf16 at cfg4 (16 MB) -- and stays cached when it fits (bf16 at cfg3, 4 MB: streamed, the pass gains 1 us and the
+  // contraction that reads it next loses 1.2 + 0.7 us).  Streaming loads on top (bit 2) change nothing measurable.
+  static const int forced = [] { const char* q = getenv("TFK_BN_NT"); return q ? atoi(q) : -1; }();
+  if (forced >= 0) return forced;
+  const size_t twin_bytes = tw.p ? (size_t)rows * ld * (tw.x3 ? 6 : 2) : 0;
+  return 1 | (twin_bytes >= ((size_t)8 << 20) ? 2 : 0);
 }
 __device__ __forceinline__ float& el(float4& v, int i) { return reinterpret_cast<float*>(&v)[i]; }
 __device__ __forceinline__ float el(const float4& v, int i) { return reinterpret_cast<const float*>(&v)[i]; }
@@ -1256,7 +1261,7 @@ void bn_act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, c
   const int nchunk = (T + chunk_rows - 1) / chunk_rows;
   hipLaunchKernelGGL(bn_act_forward_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, z, a, stats, nchunk, chunk_rows, T, H,
                      ld, rows_per, eps, decay, mean, rstd, e_mean, e_var, beta, tw, T_apply,
-                     slab_chunks > 0 ? slab_chunks : nchunk, bn_nt_mode());
+                     slab_chunks > 0 ? slab_chunks : nchunk, bn_nt_mode(tw, T_apply, ld));
 }
 
 void act_forward(hipStream_t s, const ActDesc& d, const float* z, float* a, float* v, float* rowscale,
@@ -1286,7 +1291,7 @@ void hidden_backward(hipStream_t s, const ActDesc& d, int pre_du, float* da, con
                        rows_per, rs, ws);
   hipLaunchKernelGGL(hb_apply_kernel, ct_grid(ld, rs), ct_block(), 0, s, d, pre_du, da, a, z, mean, rstd, T, H, ld,
                      rows_per, stats_chunks > 0 ? stats_chunks : rs, ws, tw, T_apply,
-                     ws_dz ? ws_dz : ws + (size_t)2 * kMaxRowSplits * ld, bn_nt_mode());
+                     ws_dz ? ws_dz : ws + (size_t)2 * kMaxRowSplits * ld, bn_nt_mode(tw, T_apply, ld));
 }
 
 void bn_stats_from_chunks(hipStream_t s, const float* stats, int chunk_rows, int T, int H, int ld, float eps, float decay,
