@@ -1373,8 +1373,12 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
   if (grid_cap > 0 && blocks > (size_t)grid_cap) blocks = grid_cap;
   if (blocks == 0) return;
   // streaming accesses measured 116.7 -> 107.8 us on cfg2 (6.75 TB/s); TFK_ADAM_NT=0 restores cached ones
-  // (TFK_ADAM_NT=2: also the parameters; 3: also the twins the kernel writes -- tools/adam_nt_ablate.sh)
-  static const int nt = [] { const char* q = getenv("TFK_ADAM_NT"); return q ? atoi(q) : 1; }();
+  // (TFK_ADAM_NT=2: also the parameters; 3: also the twins the kernel writes -- tools/adam_nt_ablate.sh, profiles/r06_bn_nt.txt.
+  //  Unset: 2 in mixed precision -- the fp32 masters are read and written by this kernel alone, and streamed they leave the L2s and
+  //  the Infinity Cache to the bf16 shadow and the activations: the optimiser itself takes 5 us longer at cfg3, the contractions
+  //  of the next step 8-15 us less, the step -1.3 % (cfg4 -1.0 %) -- and 1 elsewhere (emulated fp32 at cfg2: no difference))
+  static const int forced = [] { const char* q = getenv("TFK_ADAM_NT"); return q ? atoi(q) : -1; }();
+  const int nt = forced >= 0 ? forced : ((wb && sm.n == 0) ? 2 : 1);
   static const int un = [] { const char* q = getenv("TFK_ADAM_UNROLL"); return q ? atoi(q) : 2; }();
 #define TFK_ADAM_LAUNCH(NTV, UNV)                                                                                  \
   hipLaunchKernelGGL((adam_kernel<NTV, UNV>), dim3((unsigned)blocks), dim3(256), 0, s, w, g, m, v, n4, scalars, lr_t, \
