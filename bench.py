@@ -955,6 +955,26 @@ def main():
             m = out["exchange_model"]["per_world"][str(world)]
             out["exchange_model"]["measured_ms_per_step"] = 1e3 * elapsed / args.steps
             out["exchange_model"]["measured_over_predicted_direct"] = (1e3 * elapsed / args.steps) / m["predicted_ms_per_step_direct"]
+            # the rate the wire really ran at, to hold against the model's link rates: bytes a rank sends (= receives) per step in a
+            # phase (wire_bytes_per_rank_per_step) over the DEVICE time of that phase's collectives (exchange_phases: the
+            # operations themselves, whatever of them was hidden), per rank; the slowest rank is the one the step waits for
+            try:
+                if exchange_phases and exchange_phases.get("per_rank"):
+                    wb = m["wire_bytes_per_rank_per_step"]
+                    rates = {}
+                    for phase, key in (("reduce_scatter", "reduce_scatter_in_out"), ("all_gather", "all_gather_in_out"),
+                                       ("all_reduce", "all_reduce_in_out")):
+                        ms = exchange_phases["per_rank"].get(phase)
+                        if key in wb and wb[key] > 0 and ms and min(ms) > 0:
+                            rates[phase] = {"GB_per_s_per_rank": [wb[key] / (t * 1e-3) / 1e9 for t in ms],
+                                            "slowest_rank_GB_per_s": wb[key] / (max(ms) * 1e-3) / 1e9, "bytes_per_rank": wb[key]}
+                    exchange_phases["measured_wire_rate"] = dict(
+                        rates, note="bytes one rank sends in the phase (fp32 gradients / gathered parameters of the spans in force for "
+                                    "`value`) / device time of the phase's collectives on that rank; exchange_model's direct figure "
+                                    "moves one sub-span per link to all world - 1 peers at once at link_GBps_per_direction each, its ring figure runs "
+                                    "at one link's rate")
+            except Exception as exc:  # noqa: BLE001  (a diagnostic must never cost the line)
+                exchange_phases["measured_wire_rate"] = {"unavailable": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], trace_cpu = cpu_baseline(w, batches, hidden)
             out["loss_trace_cpu"] = trace_cpu

@@ -216,6 +216,10 @@ def test_bench_over_real_rccl_ranks(gpu, world, config):
     ph = line["exchange_phases"]
     assert ph["steps"] == 10 and all(len(v) == world for v in ph["per_rank"].values())
     assert all(x > 0 for x in ph["per_rank"]["reduce_scatter"] + ph["per_rank"]["all_gather"] + ph["per_rank"]["adam"])
+    # the rate the wire ran at (to hold against exchange_model's link rates): one figure per rank and phase
+    rate = ph["measured_wire_rate"]
+    for phase in ("reduce_scatter", "all_gather"):
+        assert len(rate[phase]["GB_per_s_per_rank"]) == world and rate[phase]["slowest_rank_GB_per_s"] > 0, rate
     assert line["sustained"]["value"] > 0
     if world < 8:
         assert line["api_fed_value"] > 0, line.get("api_fed_error")

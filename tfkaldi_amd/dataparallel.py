@@ -847,7 +847,9 @@ class NativeExchange(object):
 
 
 DEFAULT_BUCKET_MB = 32   # coalescing threshold of the gradient spans, MiB (csrc/exchange.hip: kDefaultBucketBytes)
-XGMI_LINK_GBPS = 153.0  # MI355X: 7 xGMI links per GPU, point to point, ~153 GB/s per direction each (8-GPU full mesh)
+XGMI_LINK_GBPS = 153.0  # MI355X: 7 xGMI links per GPU, point to point, ~153 GB/s per link (8-GPU full mesh) -- taken here as the rate of ONE
+# direction; if the quoted figure is the two directions' sum (MI300X's 128 GB/s per link is: 64 each way) every wire time below
+# doubles -- exchange_timeline_sweep therefore runs at 1.0 / 0.5 / 0.3 of it, and bench.py's measured_wire_rate says what a run got
 
 
 def exchange_model(buckets, world, fwd_ms, bwd_ms, adam_ms, step_ms, mode="sharded", min_bytes=DEFAULT_BUCKET_MB << 20, gather_elem_bytes=4,
