@@ -189,6 +189,77 @@ __global__ void __launch_bounds__(256) var_s(const float* __restrict__ g, const 
 }
 __global__ void var_empty() {}
 
+// H<0>: A + hb_apply's statistics prologue as the product has it (the dA epilogue's 8 partial sums per column for two quantities,
+// one per row lane, merged by two reduce_rows of two barriers each + a broadcast through LDS: five barriers before the first
+// store can go out) + its closing column sum (one more reduce_rows);  H<1>: the same sums, in the same order, behind ONE write +
+// barrier + row lane 0 summing both quantities + one broadcast barrier (two barriers)
+template <int MODE>
+__global__ void __launch_bounds__(256) var_h(const float* __restrict__ g, const float* __restrict__ z, uint16_t* __restrict__ tw, int ld,
+                                             const float* __restrict__ ws, float* __restrict__ ws_out) {
+  __shared__ float4 sm[8][32];
+  __shared__ float4 sm2[8][32];
+  __shared__ float4 smm[2][32];
+  const int col = (blockIdx.x * 32 + threadIdx.x) * 4;
+  const int r0 = blockIdx.y * 32 + threadIdx.y;
+  float4 gv[4], zv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    gv[j] = *reinterpret_cast<const float4*>(g + (size_t)(r0 + 8 * j) * ld + col);
+    zv[j] = *reinterpret_cast<const float4*>(z + (size_t)(r0 + 8 * j) * ld + col);
+  }
+  const float4 p1 = *reinterpret_cast<const float4*>(ws + ((size_t)0 * 64 + threadIdx.y) * ld + col);
+  const float4 p2 = *reinterpret_cast<const float4*>(ws + ((size_t)1 * 64 + threadIdx.y) * ld + col);
+  float4 m1, m2;
+  auto rr = [&](float4 v) {
+    sm[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.y == 0)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float4 q = sm[k][threadIdx.x]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+    __syncthreads();
+    return t;
+  };
+  if (MODE == 0) {
+    const float4 a = rr(p1), b = rr(p2);
+    if (threadIdx.y == 0) { smm[0][threadIdx.x] = a; smm[1][threadIdx.x] = b; }
+    __syncthreads();
+  } else {
+    sm[threadIdx.y][threadIdx.x] = p1;
+    sm2[threadIdx.y][threadIdx.x] = p2;
+    __syncthreads();
+    if (threadIdx.y < 2) {  // row lane 0 sums the first quantity, row lane 1 the second (two waves... one wave: y = 0, 1 share a wave)
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float4 q = threadIdx.y ? sm2[k][threadIdx.x] : sm[k][threadIdx.x]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+      smm[threadIdx.y][threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  m1 = smm[0][threadIdx.x];
+  m2 = smm[1][threadIdx.x];
+  float4 sz = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v[4] = {gv[j].x - m1.x - zv[j].x * m2.x, gv[j].y - m1.y - zv[j].y * m2.y, gv[j].z - m1.z - zv[j].z * m2.z,
+                        gv[j].w - m1.w - zv[j].w * m2.w};
+    sz.x += v[0]; sz.y += v[1]; sz.z += v[2]; sz.w += v[3];
+    u16x4 q0, q1, q2;
+    uint16_t a, b, c;
+    split(v[0], a, b, c); q0.x = a; q1.x = b; q2.x = c;
+    split(v[1], a, b, c); q0.y = a; q1.y = b; q2.y = c;
+    split(v[2], a, b, c); q0.z = a; q1.z = b; q2.z = c;
+    split(v[3], a, b, c); q0.w = a; q1.w = b; q2.w = c;
+    uint16_t* d = tw + x3::at((size_t)(r0 + 8 * j), col, ld);
+    __builtin_nontemporal_store(q0, reinterpret_cast<u16x4*>(d));
+    __builtin_nontemporal_store(q1, reinterpret_cast<u16x4*>(d + 64));
+    __builtin_nontemporal_store(q2, reinterpret_cast<u16x4*>(d + 128));
+  }
+  sz = rr(sz);
+  if (threadIdx.y == 0) *reinterpret_cast<float4*>(ws_out + (size_t)blockIdx.y * ld + col) = sz;
+}
+
+
 int main() {
   const int T = 1024, H = 2048, NBUF = 24, ITERS = 240;
   const size_t n = (size_t)T * H;
@@ -196,6 +267,8 @@ int main() {
   uint16_t* tw;
   CK(hipMalloc(&g, NBUF * n * 4)); CK(hipMalloc(&z, NBUF * n * 4)); CK(hipMalloc(&tw, NBUF * n * 6));
   CK(hipMemset(g, 0x3c, NBUF * n * 4)); CK(hipMemset(z, 0x3d, NBUF * n * 4));
+  float *wsp, *wso;
+  CK(hipMalloc(&wsp, 2 * 64 * H * 4)); CK(hipMalloc(&wso, 64 * H * 4)); CK(hipMemset(wsp, 0, 2 * 64 * H * 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const char* names[] = {"A: 4 columns x 4 rows, 8-byte streamed plane stores (the product's geometry)",
@@ -203,9 +276,10 @@ int main() {
                          "C: as A, cached stores",
                          "R1: 1 row per thread, 2048 blocks", "R2: 2 rows per thread, 1024 blocks", "R8: 8 rows per thread, 256 blocks",
                          "P: as A, two batches of two rows (second batch's loads over the first batch's stores)",
-                         "L: the loads of A alone (16 MB)", "S: the stores of A alone (12 MB)", "E: an empty kernel"};
+                         "L: the loads of A alone (16 MB)", "S: the stores of A alone (12 MB)", "E: an empty kernel",
+                         "H0: A + hb_apply's statistics prologue (five barriers) and closing column sum", "H1: the same sums behind two barriers"};
   for (int rep = 0; rep < 3; ++rep)
-    for (int var = 0; var < 10; ++var) {
+    for (int var = 0; var < 12; ++var) {
       for (int it = -10; it < ITERS; ++it) {
         if (it == 0) CK(hipEventRecord(e0, 0));
         const int b = (it + 10) % NBUF;
@@ -222,7 +296,9 @@ int main() {
           case 6: hipLaunchKernelGGL(var_p, dim3(H / 128, T / 32), dim3(32, 8), 0, 0, gp, zp, tp, H); break;
           case 7: hipLaunchKernelGGL(var_l, dim3(H / 128, T / 32), dim3(32, 8), 0, 0, gp, zp, tp, H); break;
           case 8: hipLaunchKernelGGL(var_s, dim3(H / 128, T / 32), dim3(32, 8), 0, 0, gp, zp, tp, H); break;
-          default: hipLaunchKernelGGL(var_empty, dim3(1), dim3(64), 0, 0); break;
+          case 9: hipLaunchKernelGGL(var_empty, dim3(1), dim3(64), 0, 0); break;
+          case 10: hipLaunchKernelGGL(var_h<0>, dim3(H / 128, T / 32), dim3(32, 8), 0, 0, gp, zp, tp, H, wsp, wso); break;
+          default: hipLaunchKernelGGL(var_h<1>, dim3(H / 128, T / 32), dim3(32, 8), 0, 0, gp, zp, tp, H, wsp, wso); break;
         }
       }
       CK(hipEventRecord(e1, 0));
