@@ -54,6 +54,10 @@ struct GemmArgsB {
   // start) leaves its partial sums in that XCD's L2 (plain stores) instead of writing them through to memory; 0 = always through
   // memory.  Set by the launcher from env TFK_X3_HANDOVER (l2 | mem); correctness never depends on the placement
   int splitk_local;
+  // gemm_bf16x3 split-K: ring tiles (32 k each) moved from the FIRST block's share of K to the second's (0 = equal halves).  The
+  // block with the shorter share -- dispatched first as well -- then reaches the hand-over ahead of its partner, whose wait for
+  // the partial sums shrinks by what it spends on the extra tiles.  Set by the launcher from env TFK_X3_KSKEW (experiments)
+  int splitk_skew;
 };
 
 // Tile configurations.  0-2: register-staged ring of round 1 (64x64 / 128x64 / 128x128 per 4-wave block).

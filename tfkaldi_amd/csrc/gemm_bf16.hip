@@ -537,8 +537,10 @@ __device__ __forceinline__ void dma_tile(const GemmArgsB& p, int tiles_m, int ti
 
   const int K8 = (p.K + 7) & ~7;
   const int nk_all = (p.K + BKT - 1) / BKT;
-  const int kbase = khalf ? (nk_all + 1) / 2 : 0;                               // first ring tile of this block ...
-  const int nk = KSPLIT == 2 ? (khalf ? nk_all - kbase : (nk_all + 1) / 2) : nk_all;  // ... and how many it multiplies
+  // (split-K: the first block's share is (nk_all + 1) / 2 - splitk_skew tiles, at least one)
+  const int h0 = KSPLIT == 2 ? max(1, (nk_all + 1) / 2 - p.splitk_skew) : nk_all;
+  const int kbase = khalf ? h0 : 0;                                   // first ring tile of this block ...
+  const int nk = KSPLIT == 2 ? (khalf ? nk_all - h0 : h0) : nk_all;  // ... and how many it multiplies
   const int k_end = (kbase + nk) * BKT;  // (tiles behind the block's share land as zeros, like the ones behind K)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem);
   OA la;
@@ -1393,10 +1395,25 @@ int x3_handover_local() {
   }();
   return v;
 }
+// ring tiles moved from the first block's share of a split-K tile to the second's (env TFK_X3_KSKEW, 0 .. 8; gemm_bf16.h: splitk_skew).
+// Default 1 (round 6, tools/kskew_ablate.sh -> profiles/r06_kskew.txt): with equal halves both blocks of a tile reach the hand-over
+// together and the adder waits out the whole chain -- partial sums written through, acknowledged, flag, poll, 64 KB read back: ~6 us
+// of a 47 us contraction (profiles/r05_gemm_f32x3_power.txt).  One 32-k tile (~1.25 us of MFMAs) moved to the second block lets
+// the first -- dispatched first as well -- finish ~2.5 us ahead: 47.3 -> 46.2 us per forward contraction, the cfg2 step -6 us in
+// three interleaved repetitions; two tiles give half of that back (46.9), three or more lose (47.7, 48.3).
+int x3_kskew() {
+  static const int v = [] {
+    const char* q = getenv("TFK_X3_KSKEW");
+    const int k = q ? atoi(q) : 1;
+    return k < 0 ? 0 : k > 8 ? 8 : k;
+  }();
+  return v;
+}
 template <bool A_KC, bool B_KC, int EPI>
 int launch_x3(const GemmArgsB& p_in, hipStream_t stream) {
   GemmArgsB p = p_in;
   p.splitk_local = x3_handover_local();
+  p.splitk_skew = x3_kskew();
   const int forced = x3_cfg();
   const long m128 = (p.M + 127) / 128, n128 = (p.N + 127) / 128;
   const int wv = x3_waves();
