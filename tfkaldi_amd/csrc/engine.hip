@@ -16,6 +16,7 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <math.h>
 #include <stdarg.h>
@@ -103,6 +104,11 @@ struct tfk_engine {
   bool opt_pending = false;          // updates of the last tfk_apply may still be running on opt_stream
   float* d_snap = nullptr;           // (loss, frames, #micro-batches) of the step being applied (step_finish)
   hipEvent_t ev_loss = nullptr;
+  // the loss hand-over without an event: step_finish writes loss_seq behind the scalars in mapped memory, tfk_apply_end polls it
+  // (env TFK_LOSS_EVENT=1: the event record + synchronise of rounds 1-5 instead)
+  unsigned loss_seq = 0;
+  bool loss_event = false;
+  bool slot_lazy = true;  // env TFK_SLOT_EVENT=1: record compute_done behind every micro-batch, as rounds 1-5 did
   hipEvent_t ev_grow = nullptr;          // orders the copy stream behind a stream-ordered (re)allocation
   std::vector<void*> host_garbage;       // outgrown pinned staging buffers: released at tfk_destroy (hipHostFree
                                          // synchronises the device, which growth must not do)
@@ -197,6 +203,11 @@ struct tfk_engine {
   bool shadow_dirty = true;
   hipEvent_t copy_done[2] = {nullptr, nullptr}, compute_done[2] = {nullptr, nullptr};
   bool slot_used[2] = {false, false};
+  // When the LAST micro-batch of a step has read an input slot, no `compute_done` event is recorded behind it (a record between two
+  // kernels costs the stream ~6 us, profiles/r06_loss_seq.txt): the slot is free once the HOST has seen that step's loss, which it
+  // normally has long before the slot comes round again.  slot_step[s] = the optimiser step (count of tfk_apply_begin calls) whose
+  // loss frees slot s, 0 = `compute_done[s]` was recorded as before;  steps_begun / steps_seen: apply_begin / apply_end (loss seen)
+  unsigned long long slot_step[2] = {0, 0}, steps_begun = 0, steps_seen = 0;
   int slot = 0;
 
   // host-side scalars (trainer.py:98-106, dnn.py:85-89)
@@ -713,6 +724,7 @@ struct Stack {
 };
 
 // Bring one micro-batch to HBM (or adopt device pointers).  Returns the GEMM-ready X (ld in *ldx_out).
+int wait_slot_free(tfk_engine* e, int s);  // (below, next to finish_slot)
 int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, int T, int flags, const float** Xd,
                 int* ldx_out, const int32_t** yd) {
   if (ldx < e->F) return fail(-1, "ldx %lld < input_dim %d", (long long)ldx, e->F);
@@ -740,7 +752,7 @@ int stage_input(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, in
   }
   if (y) memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
   // the device slot may still be read by the compute enqueued two calls ago
-  if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  CHK(wait_slot_free(e, s));
   HIPCHK(hipMemcpy2DAsync(e->dX[s], (size_t)e->ldF * 4, e->hX[s], (size_t)e->F * 4, (size_t)e->F * 4, T,
                           hipMemcpyHostToDevice, e->copy_stream));
   if (y) HIPCHK(hipMemcpyAsync(e->dY[s], e->hY[s], (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
@@ -824,7 +836,7 @@ int stage_raw(tfk_engine* e, const float* raw, int64_t ldraw, const int32_t* y, 
   } else if (y) {
     memcpy(e->hY[s], y, (size_t)T * sizeof(int32_t));
   }
-  if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  CHK(wait_slot_free(e, s));
   const int ldD = (D + 3) & ~3;
   if (!raw_on_device)
     HIPCHK(hipMemcpy2DAsync(e->dRaw[s], (size_t)ldD * 4, e->hRaw[s], (size_t)D * 4, (size_t)D * 4, T,
@@ -868,7 +880,24 @@ int twin_input(tfk_engine* e, const float** Xd, int* ld, int T) {
 }
 
 int finish_slot(tfk_engine* e, int flags, int slot_before) {
-  if (!(flags & TFK_DEVICE_PTRS) && e->slot != slot_before) HIPCHK(hipEventRecord(e->compute_done[slot_before], e->stream));
+  if ((flags & TFK_DEVICE_PTRS) || e->slot == slot_before) return 0;
+  if ((flags & TFK_LAST_MICROBATCH) && e->slot_lazy) {
+    e->slot_step[slot_before] = e->steps_begun + 1;  // the step the coming tfk_apply_begin opens
+    return 0;
+  }
+  e->slot_step[slot_before] = 0;
+  HIPCHK(hipEventRecord(e->compute_done[slot_before], e->stream));
+  return 0;
+}
+// the copy stream may overwrite input slot s once the compute that read it last is over
+int wait_slot_free(tfk_engine* e, int s) {
+  if (!e->slot_used[s]) return 0;
+  if (e->slot_step[s] == 0) {
+    HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  } else if (e->steps_seen < e->slot_step[s]) {
+    // the host has not collected that step's loss (a caller that accumulates again without tfk_apply in between): the slow way
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   return 0;
 }
 
@@ -1219,6 +1248,8 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
     if ((v = getenv("TFK_POST_CHUNK"))) e->post_chunk = atoi(v) > 0 ? (int)up((size_t)atoi(v), 64) : 0;
     if ((v = getenv("TFK_DUAL_GEMM"))) e->dual_gemm = atoi(v) != 0;
     if ((v = getenv("TFK_STACK"))) e->stack_enabled = atoi(v) != 0;
+    if ((v = getenv("TFK_LOSS_EVENT"))) e->loss_event = atoi(v) != 0;
+    if ((v = getenv("TFK_SLOT_EVENT"))) e->slot_lazy = atoi(v) == 0;
     if ((v = getenv("TFK_FUSE_EVAL"))) e->fuse_eval = atoi(v) != 0;
   }
   {
@@ -1255,7 +1286,8 @@ int create_impl(const tfk_config* cfg, void* state, size_t state_bytes, void* st
   HIPB(hipMemsetAsync(e->state, 0, e->state_floats * sizeof(float), e->stream));
   if (cfg->batch_norm)  // moving_variance initialises to 1, moving_mean to 0
     for (int l = 0; l < e->L; ++l) fill(e->stream, e->mov_var(l), (size_t)e->H, 1.0f);
-  HIPB(hipHostMalloc((void**)&e->h_scalars, 16 * sizeof(float), hipHostMallocMapped));
+  // (coherent = fine-grained: the host polls the sequence word while the stream is still running -- wait_loss)
+  HIPB(hipHostMalloc((void**)&e->h_scalars, 16 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
   memset(e->h_scalars, 0, 16 * sizeof(float));
   HIPB(hipHostGetDevicePointer((void**)&e->h_scalars_dev, e->h_scalars, 0));
   e->mean.assign(e->L, nullptr);
@@ -1716,7 +1748,7 @@ int stage_stacked(tfk_engine* e, const float* X, int64_t ldx, const int32_t* y, 
   int32_t* vend = e->hSeg[s];
   for (int i = 0; i < st->k; ++i)
     for (int unit = st->r0[i] / 64; unit < (st->r0[i] + st->span[i]) / 64; ++unit) vend[unit] = st->r0[i] + st->rows[i];
-  if (e->slot_used[s]) HIPCHK(hipStreamWaitEvent(e->copy_stream, e->compute_done[s], 0));
+  CHK(wait_slot_free(e, s));
   HIPCHK(hipMemcpyAsync(e->dSeg[s], vend, (size_t)(st->T_pad / 64) * sizeof(int32_t), hipMemcpyHostToDevice, e->copy_stream));
   st->d_vend = e->dSeg[s];
   const bool dense = st->T_pad == st->T_valid;  // every segment already a multiple of the alignment: no padding rows
@@ -2159,9 +2191,12 @@ int apply_begin(tfk_engine* e) {
   // BN moving averages + re-initialisation of their increments + the loss hand-over, one launch
   {
     ProfScope ps(e, KF_EMA, 0, 16.0 * e->E);
-    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev, e->d_snap);
+    e->steps_begun += 1;
+    e->loss_seq = e->loss_seq + 1 ? e->loss_seq + 1 : 1;  // (never 0: the word starts out as 0)
+    step_finish(e->stream, e->p_mov(), e->p_ema(), e->E, e->p_scalars(), e->bn_decay, e->h_scalars_dev, e->d_snap, e->loss_seq);
   }
-  HIPCHK(hipEventRecord(e->ev_loss, e->stream));
+  // (an event record here sits between step_finish and the optimiser: 5.9 us of idle stream per step, profiles/r06_loss_seq.txt)
+  if (e->loss_event) HIPCHK(hipEventRecord(e->ev_loss, e->stream));
   // An arena-mirroring shadow is ALWAYS written with the update: if it is not current (no forward pass since the
   // parameters were last set from outside -- e.g. a data-parallel rank that had no micro-batch in its first step) it is
   // made current first.  The decision must not depend on what this rank happened to run: under the sharded exchange
@@ -2203,12 +2238,37 @@ int apply_overlapped(tfk_engine* e) {
   e->opt_pending = true;
   return 0;
 }
+// The step's (loss, frames, #micro-batches) are in mapped memory once step_finish's sequence word shows this step's number.
+// The stream is asked now and then whether it is still alive: a failed launch must not leave the host spinning, and a stream
+// that has run dry without the word appearing is an error, not a reason to wait.
+// (Rarely -- every 20 ms: hipStreamQuery puts a marker with a completion signal behind the last launch, i.e. behind the optimiser,
+// and the next step's first kernel then waits ~6 us for it: asked once per step it gave back everything the missing event record
+// had gained, profiles/r06_loss_seq.txt.)
+int wait_loss(tfk_engine* e) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(e->h_scalars) + kStepSeqWord;
+  auto asked = std::chrono::steady_clock::now();
+  for (unsigned long spin = 1;; ++spin) {
+    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == e->loss_seq) return 0;
+    if ((spin & 0x3ff) == 0 && std::chrono::steady_clock::now() - asked > std::chrono::milliseconds(20)) {
+      asked = std::chrono::steady_clock::now();
+      const hipError_t q = hipStreamQuery(e->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == e->loss_seq) return 0;
+        return fail(-1, "the optimiser step's loss hand-over did not arrive (sequence word %u, expected %u)", *w, e->loss_seq);
+      }
+      if (q != hipErrorNotReady) return fail((int)q, "engine stream failed while the step was running: %s", hipGetErrorString(q));
+    }
+    __builtin_ia32_pause();
+  }
+}
 int apply_end(tfk_engine* e, float* average_loss) {
   if (!e->apply_open) return fail(-1, "tfk_apply_end without tfk_apply_begin");
   e->apply_open = false;
   if (!e->apply_direct) e->shadow_dirty = true;
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventSynchronize(e->ev_loss));
+  if (e->loss_event) HIPCHK(hipEventSynchronize(e->ev_loss));
+  else CHK(wait_loss(e));
+  e->steps_seen = e->steps_begun;  // (step_finish runs behind every micro-batch of the step: their input slots are free)
   e->grads_fresh = true;
   e->scalars_fresh = true;  // init_loss / init_num_frames (trainer.py:350-352) without a memset
   if (check_kernel_errors(e)) {

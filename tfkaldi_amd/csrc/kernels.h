@@ -153,8 +153,10 @@ void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int l
 // end of a step in one launch: moving <- decay^{num_microbatches} * moving + E, E <- 0, and
 // host[0..3] <- scalars[0..3] (host = device address of mapped pinned memory)
 // snap (nullable): device copy of scalars[0..3] that stays valid until the next step_finish
+// seq: written to word kStepSeqWord of `host` behind the scalars (system-scope release): what a polling host waits for
+constexpr int kStepSeqWord = 12;
 void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host,
-                 float* snap = nullptr);
+                 float* snap = nullptr, unsigned seq = 0);
 void scale_inplace(hipStream_t s, float* x, size_t n, float factor);
 void fill(hipStream_t s, float* x, size_t n, float value);
 // +-context splicing on the device (reference processing/feature_reader.py:117-156): raw[T, ldr] holds the

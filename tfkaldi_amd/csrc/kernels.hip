@@ -1100,18 +1100,23 @@ adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
 // End of an optimiser step, one launch: BN moving averages mov = decay^k * mov + increments (k = micro-batches of
 // the step), re-initialisation of the increments, and the step's (loss, frames, k) handed to the host through
 // mapped pinned memory (no copy kernel, no memset).
+// `seq` (never 0) goes into word kStepSeqWord of the mapped memory BEHIND the four scalars (one thread writes all five, a
+// system-scope fence in between): a host that polls that word has the step's loss without an event on the stream -- an event
+// record between this launch and the optimiser's cost the stream 5.9 us of idle time per step (profiles/r06_loss_seq.txt).
 __global__ void step_finish_kernel(float* __restrict__ mov, float* __restrict__ e, size_t n,
                                    const float* __restrict__ scalars, float decay, float* __restrict__ host,
-                                   float* __restrict__ snap) {
+                                   float* __restrict__ snap, unsigned seq) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     mov[i] = powf(decay, scalars[2]) * mov[i] + e[i];
     e[i] = 0.f;
   }
-  if (i < 4) {
-    if (snap) snap[i] = scalars[i];  // the step's (loss, frames, k) for an optimiser that runs past the next loss_reduce
-    host[i] = scalars[i];
+  if (i < 4 && snap) snap[i] = scalars[i];  // the step's (loss, frames, k) for an optimiser that runs past the next loss_reduce
+  if (i == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) host[k] = scalars[k];
     __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned*>(host) + kStepSeqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 // fp32 [rows, lds] -> bf16 [rows, ldd] (ldd multiple of 8): one thread per 8-column chunk, padding columns zero
@@ -1396,9 +1401,9 @@ void adam_apply(hipStream_t s, float* w, float* g, float* m, float* v, size_t n,
 }
 
 void step_finish(hipStream_t s, float* moving, float* e, size_t n, const float* scalars, float decay, float* host,
-                 float* snap) {
+                 float* snap, unsigned seq) {
   const size_t blocks = n ? (n + 255) / 256 : 1;
-  hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host, snap);
+  hipLaunchKernelGGL(step_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, moving, e, n, scalars, decay, host, snap, seq);
 }
 void to_bf16_rows(hipStream_t s, const float* src, int lds, uint16_t* dst, int ldd, int rows, int cols, int x3) {
   const size_t n = (size_t)rows * (ldd / 8);
